@@ -1,0 +1,365 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY — parity unpinned, see orc_common.h).
+Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+c_dp = C.POINTER(C.c_double)
+c_fp = C.POINTER(C.c_float)
+c_ip = C.POINTER(C.c_int)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _DIR])
+
+
+def _p(a, t):
+    if a is None:
+        return None
+    return a.ctypes.data_as(t)
+
+
+def dp(a):
+    return _p(a, c_dp)
+
+
+def fp(a):
+    return _p(a, c_fp)
+
+
+def ip(a):
+    return _p(a, c_ip)
+
+
+def u8p(a):
+    return _p(a, c_u8p)
+
+
+def lib(kind="f32"):
+    """kind: 'f32' (reference-faithful pointwise fp32), 'f64' (all-fp64 ground truth), 'fast' (timed baseline)."""
+    if kind in _LIBS:
+        return _LIBS[kind]
+    path = os.path.join(_DIR, "liboracle_%s.so" % kind)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    L.orc_trk_create.restype = C.c_void_p
+    L.orc_trk_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orc_trk_destroy.argtypes = [C.c_void_p]
+    L.orc_trk_set_ref.argtypes = [C.c_void_p, c_fp, C.c_int, c_fp, c_fp, c_fp, c_fp]
+    L.orc_trk_set_pc.argtypes = [C.c_void_p, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]
+    L.orc_trk_get_pc.argtypes = [C.c_void_p, C.c_int, c_fp, c_fp, c_fp, c_fp]
+    L.orc_trk_get_pc.restype = C.c_int
+    L.orc_trk_get_depth.argtypes = [C.c_void_p, C.c_int, c_fp, c_fp]
+    L.orc_trk_calc_res.argtypes = [C.c_void_p, c_fp, C.c_int, c_dp, c_dp, c_fp, C.c_float, c_dp]
+    L.orc_trk_calc_gs.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, c_dp, c_dp]
+    L.orc_trk_track.argtypes = [C.c_void_p, c_fp, c_dp, c_dp, c_dp, c_fp, C.c_int, c_dp, c_dp, c_dp]
+    L.orc_trk_track.restype = C.c_int
+    L.orc_trk_counter.argtypes = [C.c_void_p, C.c_int]
+    L.orc_trk_counter.restype = C.c_long
+    L.orc_make_images.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp]
+    L.orc_pyr_offset.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.orc_pyr_offset.restype = C.c_long
+    L.orc_pyr_levels.argtypes = [C.c_int, C.c_int]
+    L.orc_pyr_levels.restype = C.c_int
+    L.orc_se3_exp.argtypes = [c_dp, c_dp]
+    L.orc_se3_log.argtypes = [c_dp, c_dp]
+    L.orc_se3_mul.argtypes = [c_dp, c_dp, c_dp]
+    L.orc_se3_inv.argtypes = [c_dp, c_dp]
+    L.orc_se3_adj.argtypes = [c_dp, c_dp]
+    L.orc_ldlt_solve.argtypes = [C.c_int, c_dp, c_dp, c_dp]
+    L.orc_set_sum_mode.argtypes = [C.c_int]
+    L.orc_ba_create.restype = C.c_void_p
+    L.orc_ba_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.orc_ba_destroy.argtypes = [C.c_void_p]
+    L.orc_ba_set_frame.argtypes = [C.c_void_p, C.c_int, c_fp, c_dp, C.c_double, C.c_double, C.c_float, C.c_float, C.c_int, c_dp]
+    L.orc_ba_set_points.argtypes = [C.c_void_p, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip]
+    L.orc_ba_set_residuals.argtypes = [C.c_void_p, c_u8p]
+    L.orc_ba_set_adjoints.argtypes = [C.c_void_p]
+    L.orc_ba_set_precalc.argtypes = [C.c_void_p]
+    L.orc_ba_linearize_all.argtypes = [C.c_void_p, C.c_int]
+    L.orc_ba_linearize_all.restype = C.c_double
+    L.orc_ba_apply_res.argtypes = [C.c_void_p]
+    L.orc_ba_accumulate.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
+    L.orc_ba_accumulate_sc.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp]
+    L.orc_ba_solve_system.argtypes = [C.c_void_p, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.orc_ba_do_step.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.orc_ba_do_step.restype = C.c_int
+    L.orc_ba_optimize.argtypes = [C.c_void_p, C.c_int]
+    L.orc_ba_optimize.restype = C.c_double
+    L.orc_ba_marginalize_points.argtypes = [C.c_void_p, c_u8p, c_dp, c_dp, c_dp, c_dp]
+    L.orc_ba_get_residual.argtypes = [C.c_void_p, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_ip, c_dp, c_fp]
+    L.orc_ba_get_slots.argtypes = [C.c_void_p, C.POINTER(C.c_int8), c_u8p, c_fp, c_fp]
+    L.orc_ba_get_points.argtypes = [C.c_void_p, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
+    L.orc_ba_get_frame.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp, c_fp]
+    L.orc_ba_get_calib.argtypes = [C.c_void_p, c_dp]
+    L.orc_ba_get_precalc.argtypes = [C.c_void_p, c_fp]
+    L.orc_ba_get_adjoints.argtypes = [C.c_void_p, c_dp, c_dp, c_fp]
+    L.orc_ba_get_prior.argtypes = [C.c_void_p, c_dp, c_dp]
+    L.orc_ba_set_prior.argtypes = [C.c_void_p, c_dp, c_dp]
+    L.orc_ba_set_options.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.orc_ba_get_timers.argtypes = [C.c_void_p, c_dp]
+    L.orc_ba_counts.argtypes = [C.c_void_p, C.c_int]
+    L.orc_ba_counts.restype = C.c_int
+    L.orc_ba_set_idepth.argtypes = [C.c_void_p, c_fp]
+    L.orc_dense_bbox.argtypes = [c_fp, C.c_int, C.c_int, C.c_float, c_ip]
+    L.orc_dense_make_map.argtypes = [c_fp, c_fp, c_u8p, C.c_int, C.c_int, c_fp, C.c_float, c_ip, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, c_dp, c_ip, c_ip, c_fp, c_fp, c_u8p, c_ip]
+    L.orc_dense_make_map.restype = C.c_int
+    _LIBS[kind] = L
+    return L
+
+
+# ------------------------------------------------------------------ convenience wrappers
+def se3_exp(xi, kind="f32"):
+    T = np.zeros(12)
+    lib(kind).orc_se3_exp(dp(np.ascontiguousarray(xi, np.float64)), dp(T))
+    return T.reshape(3, 4)
+
+
+def se3_log(T, kind="f32"):
+    xi = np.zeros(6)
+    lib(kind).orc_se3_log(dp(np.ascontiguousarray(T, np.float64).reshape(-1)), dp(xi))
+    return xi
+
+
+def se3_mul(A, B, kind="f32"):
+    Cc = np.zeros(12)
+    lib(kind).orc_se3_mul(dp(np.ascontiguousarray(A, np.float64).reshape(-1)), dp(np.ascontiguousarray(B, np.float64).reshape(-1)), dp(Cc))
+    return Cc.reshape(3, 4)
+
+
+def se3_inv(A, kind="f32"):
+    Cc = np.zeros(12)
+    lib(kind).orc_se3_inv(dp(np.ascontiguousarray(A, np.float64).reshape(-1)), dp(Cc))
+    return Cc.reshape(3, 4)
+
+
+def se3_adj(A, kind="f32"):
+    Ad = np.zeros(36)
+    lib(kind).orc_se3_adj(dp(np.ascontiguousarray(A, np.float64).reshape(-1)), dp(Ad))
+    return Ad.reshape(6, 6)
+
+
+def make_images(img, levels, kind="f32"):
+    """returns (dI_all [npix,3] float32, abs_all [npix]) with pyramid levels concatenated."""
+    h, w = img.shape
+    L = lib(kind)
+    tot = L.orc_pyr_offset(w, h, levels)
+    dI = np.zeros((tot, 3), np.float32)
+    ab = np.zeros(tot, np.float32)
+    L.orc_make_images(fp(np.ascontiguousarray(img, np.float32)), w, h, levels, None, fp(dI), fp(ab))
+    return dI, ab
+
+
+class Tracker:
+    def __init__(self, w, h, levels, K, kind="f32"):
+        self.L = lib(kind)
+        self.w, self.h, self.levels = w, h, levels
+        self.h_ = self.L.orc_trk_create(w, h, levels, K[0], K[1], K[2], K[3])
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.L.orc_trk_destroy(self.h_)
+        except Exception:
+            pass
+
+    def set_ref(self, dI_ref, Ku, Kv, new_idepth, HdiF):
+        self._keep = [np.ascontiguousarray(dI_ref, np.float32)]
+        a = [np.ascontiguousarray(x, np.float32) for x in (Ku, Kv, new_idepth, HdiF)]
+        self.L.orc_trk_set_ref(self.h_, fp(self._keep[0]), len(a[0]), fp(a[0]), fp(a[1]), fp(a[2]), fp(a[3]))
+
+    def set_pc(self, dI_ref, lvl, u, v, idepth, color):
+        self._keep = [np.ascontiguousarray(dI_ref, np.float32)]
+        a = [np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color)]
+        self.L.orc_trk_set_pc(self.h_, fp(self._keep[0]), lvl, len(a[0]), fp(a[0]), fp(a[1]), fp(a[2]), fp(a[3]))
+
+    def get_pc(self, lvl):
+        n = self.L.orc_trk_get_pc(self.h_, lvl, None, None, None, None)
+        out = [np.zeros(n, np.float32) for _ in range(4)]
+        self.L.orc_trk_get_pc(self.h_, lvl, *[fp(o) for o in out])
+        return out
+
+    def get_depth(self, lvl):
+        n = (self.w >> lvl) * (self.h >> lvl)
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self.L.orc_trk_get_depth(self.h_, lvl, fp(a), fp(b))
+        return a, b
+
+    def calc_res(self, dI_new, lvl, T, affLL, cutoff):
+        T = np.ascontiguousarray(T, np.float64).reshape(3, 4)
+        R = np.ascontiguousarray(T[:, :3]).reshape(-1)
+        t = np.ascontiguousarray(T[:, 3])
+        out = np.zeros(6)
+        self.L.orc_trk_calc_res(self.h_, fp(dI_new), lvl, dp(R), dp(t), fp(np.asarray(affLL, np.float32)), cutoff, dp(out))
+        return out
+
+    def calc_gs(self, lvl, aff_a, b0):
+        H, b = np.zeros(64), np.zeros(8)
+        self.L.orc_trk_calc_gs(self.h_, lvl, aff_a, b0, dp(H), dp(b))
+        return H.reshape(8, 8), b
+
+    def track(self, dI_new, T0, aff0, ref_aff, exposures, coarsest, min_res=None):
+        T = np.ascontiguousarray(T0, np.float64).reshape(-1).copy()
+        aff = np.array(aff0, np.float64)
+        mr = np.full(5, np.nan) if min_res is None else np.asarray(min_res, np.float64)
+        lr, lf = np.zeros(5), np.zeros(3)
+        ok = self.L.orc_trk_track(self.h_, fp(dI_new), dp(T), dp(aff), dp(np.asarray(ref_aff, np.float64)),
+                                  fp(np.asarray(exposures, np.float32)), coarsest, dp(mr), dp(lr), dp(lf))
+        return ok, T.reshape(3, 4), aff, lr, lf
+
+
+class BA:
+    """Sliding-window BA oracle over a synth.Window-like description."""
+
+    def __init__(self, W, P, w, h, K, kind="f32"):
+        self.L = lib(kind)
+        self.W, self.P, self.w, self.h = W, P, w, h
+        self.n = 8 * W + 4
+        self.h_ = self.L.orc_ba_create(W, P, w, h, K[0], K[1], K[2], K[3])
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            self.L.orc_ba_destroy(self.h_)
+        except Exception:
+            pass
+
+    def set_frame(self, i, dI0, evalPT, aff=(0.0, 0.0), exposure=1.0, th=8 * 8 * 8.0, frame_id=None, state6=None):
+        self._keep[i] = np.ascontiguousarray(dI0, np.float32)
+        s6 = None if state6 is None else np.ascontiguousarray(state6, np.float64)
+        self.L.orc_ba_set_frame(self.h_, i, fp(self._keep[i]), dp(np.ascontiguousarray(evalPT, np.float64).reshape(-1)),
+                                aff[0], aff[1], exposure, th, i if frame_id is None else frame_id, dp(s6))
+
+    def set_points(self, host, u, v, idepth, color, weights, has_prior=None):
+        a = [np.ascontiguousarray(host, np.int32)] + [np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color, weights)]
+        hp = None if has_prior is None else np.ascontiguousarray(has_prior, np.int32)
+        self.L.orc_ba_set_points(self.h_, ip(a[0]), fp(a[1]), fp(a[2]), fp(a[3]), fp(a[4]), fp(a[5]), ip(hp))
+
+    def set_residuals(self, exists):
+        self.L.orc_ba_set_residuals(self.h_, u8p(np.ascontiguousarray(exists, np.uint8)))
+
+    def prepare(self):
+        self.L.orc_ba_set_adjoints(self.h_)
+        self.L.orc_ba_set_precalc(self.h_)
+
+    def linearize_all(self, fix=False):
+        return self.L.orc_ba_linearize_all(self.h_, int(fix))
+
+    def apply_res(self):
+        self.L.orc_ba_apply_res(self.h_)
+
+    def accumulate(self, mode, want13=False):
+        H, b = np.zeros(self.n * self.n), np.zeros(self.n)
+        h13 = np.zeros(self.W * self.W * 169) if want13 else None
+        self.L.orc_ba_accumulate(self.h_, mode, dp(H), dp(b), dp(h13))
+        H = H.reshape(self.n, self.n)
+        return (H, b, h13.reshape(self.W * self.W, 13, 13)) if want13 else (H, b)
+
+    def accumulate_sc(self, shift=True):
+        H, b = np.zeros(self.n * self.n), np.zeros(self.n)
+        self.L.orc_ba_accumulate_sc(self.h_, int(shift), dp(H), dp(b))
+        return H.reshape(self.n, self.n), b
+
+    def solve_system(self, iteration, lam=1e-5, debug=False):
+        x = np.zeros(self.n)
+        if debug:
+            HA, bA, Hs, bs = np.zeros(self.n ** 2), np.zeros(self.n), np.zeros(self.n ** 2), np.zeros(self.n)
+            self.L.orc_ba_solve_system(self.h_, iteration, lam, dp(x), dp(HA), dp(bA), dp(Hs), dp(bs))
+            return x, HA.reshape(self.n, self.n), bA, Hs.reshape(self.n, self.n), bs
+        self.L.orc_ba_solve_system(self.h_, iteration, lam, dp(x), None, None, None, None)
+        return x
+
+    def do_step(self, f=1.0):
+        return self.L.orc_ba_do_step(self.h_, f, f, f, f, f)
+
+    def optimize(self, its=6):
+        return self.L.orc_ba_optimize(self.h_, its)
+
+    def marginalize_points(self, flags):
+        n = self.n
+        M, Mb, Ms, Mbs = np.zeros(n * n), np.zeros(n), np.zeros(n * n), np.zeros(n)
+        self.L.orc_ba_marginalize_points(self.h_, u8p(np.ascontiguousarray(flags, np.uint8)), dp(M), dp(Mb), dp(Ms), dp(Mbs))
+        return M.reshape(n, n), Mb, Ms.reshape(n, n), Mbs
+
+    def residual(self, p, t):
+        J, jp, rtz = np.zeros(74), np.zeros(8), np.zeros(8)
+        st = np.zeros(3, np.int32)
+        en = np.zeros(3)
+        pr = np.zeros(19, np.float32)
+        self.L.orc_ba_get_residual(self.h_, p, t, dp(J), dp(jp), dp(rtz), ip(st), dp(en), fp(pr))
+        return dict(J=J, JpJdF=jp, rtz=rtz, state=st, energy=en, proj=pr)
+
+    def slots(self):
+        n = self.P * self.W
+        st = np.zeros(n, np.int8)
+        ac = np.zeros(n, np.uint8)
+        jp = np.zeros(n * 8, np.float32)
+        en = np.zeros(n, np.float32)
+        self.L.orc_ba_get_slots(self.h_, st.ctypes.data_as(C.POINTER(C.c_int8)), u8p(ac), fp(jp), fp(en))
+        return st.reshape(self.P, self.W), ac.reshape(self.P, self.W), jp.reshape(self.P, self.W, 8), en.reshape(self.P, self.W)
+
+    def points(self):
+        P = self.P
+        o = {k: np.zeros(P, np.float32) for k in ("idepth", "step", "HdiF", "bdSumF", "Hdd", "bd")}
+        o["Hcd"] = np.zeros(4 * P, np.float32)
+        o["maxRelBaseline"] = np.zeros(P, np.float32)
+        self.L.orc_ba_get_points(self.h_, fp(o["idepth"]), fp(o["step"]), fp(o["HdiF"]), fp(o["bdSumF"]), fp(o["Hdd"]), fp(o["bd"]),
+                                 fp(o["Hcd"]), fp(o["maxRelBaseline"]))
+        o["Hcd"] = o["Hcd"].reshape(P, 4)
+        return o
+
+    def frame(self, f):
+        st, w2c, ev = np.zeros(10), np.zeros(12), np.zeros(12)
+        th = C.c_float(0)
+        self.L.orc_ba_get_frame(self.h_, f, dp(st), dp(w2c), dp(ev), C.byref(th))
+        return dict(state=st, worldToCam=w2c.reshape(3, 4), evalPT=ev.reshape(3, 4), frameEnergyTH=th.value)
+
+    def calib(self):
+        v = np.zeros(4)
+        self.L.orc_ba_get_calib(self.h_, dp(v))
+        return v
+
+    def precalc(self):
+        o = np.zeros((self.W * self.W, 32), np.float32)
+        self.L.orc_ba_get_precalc(self.h_, fp(o))
+        return o
+
+    def adjoints(self):
+        n = self.W * self.W
+        a, b, d = np.zeros((n, 8, 8)), np.zeros((n, 8, 8)), np.zeros((n, 8), np.float32)
+        self.L.orc_ba_get_adjoints(self.h_, dp(a), dp(b), fp(d))
+        return a, b, d
+
+    def set_options(self, nthreads=6, never_break=False):
+        self.L.orc_ba_set_options(self.h_, nthreads, int(never_break))
+
+    def timers(self):
+        t = np.zeros(4)
+        self.L.orc_ba_get_timers(self.h_, dp(t))
+        return t
+
+    def counts(self):
+        return [self.L.orc_ba_counts(self.h_, i) for i in range(3)]
+
+
+def ba_from_window(win, kind="f32", state6=None, aff=None, th=None):
+    """Builds a BA oracle from a synth.Window (keyframes 0..W-1)."""
+    ba = BA(win.W, len(win.host), win.w, win.h, win.K, kind)
+    for i in range(win.W):
+        dI, _ = make_images(win.images[i], 1, kind)
+        ba.set_frame(i, dI, win.world_to_cam[i], aff=(0.0, 0.0) if aff is None else tuple(aff[i]),
+                     th=8 * 8 * 8.0 if th is None else th[i], state6=None if state6 is None else state6[i])
+    ba.set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights)
+    ba.set_residuals(win.exists)
+    ba.prepare()
+    return ba
