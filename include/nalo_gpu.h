@@ -1,0 +1,201 @@
+/*
+ * nalo_gpu.h — C ABI of the MI355X (gfx950) hot path of the NALO-SLAM direct photometric core.
+ *
+ * Drop-in boundary. The reference has no FFI: its hot path is plain C++ member calls.
+ * Every entry point below names the reference call site it replaces (paths relative to the reference's
+ * src/). A maintainer binds these from the reference's own FullSystem / CoarseTracker / EnergyFunctional
+ * (see INTEGRATION.md for the stubs).
+ *
+ * Conventions
+ *   - opaque nalo_ctx*, one per thread of use (the reference keeps two CoarseTracker instances and one
+ *     EnergyFunctional, FullSystem/FullSystem.h:310-311; use one ctx per such owner);
+ *   - every call returns 0 on success, <0 on error (nalo_last_error gives the message); no exceptions
+ *     cross the ABI; all calls are synchronous on return unless suffixed _async;
+ *   - plain pointers and sizes only; host buffers are caller-owned; matrices are row-major;
+ *   - SE(3) is a row-major 3x4 [R|t] of doubles; the tangent order is Sophus' [translation(3), rotation(3)];
+ *   - arithmetic is IEEE fp32 on the device exactly where the reference uses float, partial sums are
+ *     finished in fp64, stitched systems and solves are fp64 (reference: Eigen double).
+ *   - the library needs a gfx950 device; there is no CPU fallback (calls fail with NALO_ERR_NO_DEVICE).
+ */
+#ifndef NALO_GPU_H
+#define NALO_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nalo_ctx nalo_ctx;
+
+enum {
+    NALO_OK = 0,
+    NALO_ERR_ARG = -1,
+    NALO_ERR_NO_DEVICE = -2,
+    NALO_ERR_HIP = -3,
+    NALO_ERR_STATE = -4,
+    NALO_ERR_UNSUPPORTED = -5
+};
+
+#define NALO_MAX_LEVELS 6     /* PYR_LEVELS, util/settings.h:52 (tracker uses <= 5, CoarseTracker.cpp:1083) */
+#define NALO_MAX_WINDOW 16    /* frames in the BA window; reference: setting_maxFrames+1 = 8 (util/settings.cpp:88) */
+
+/* ------------------------------------------------------------------------------------------------
+ * Context.  Replaces: setGlobalCalib (util/globalCalib.cpp:45-105) + the allocations in
+ * CoarseTracker::CoarseTracker (FullSystem/CoarseTracker.cpp:58-95) / EnergyFunctional().
+ * levels <= 0 -> use the reference's level rule (halve while both dims even and area > 5000).
+ * K = {fx, fy, cx, cy} at level 0. n_slots = number of frame slots (pyramids resident in HBM).
+ * ------------------------------------------------------------------------------------------------ */
+int nalo_create(nalo_ctx** out, int device, int w, int h, int levels, const float K[4], int n_slots);
+void nalo_destroy(nalo_ctx* ctx);
+const char* nalo_last_error(nalo_ctx* ctx);
+int nalo_levels(nalo_ctx* ctx);
+int nalo_sync(nalo_ctx* ctx);
+void* nalo_stream(nalo_ctx* ctx);                 /* hipStream_t every kernel of this ctx is launched on */
+
+/* ------------------------------------------------------------------------------------------------
+ * a1  FrameHessian::makeImages (FullSystem/HessianBlocks.cpp:127-190), called at FullSystem.cpp:1065.
+ * Uploads level-0 irradiance (w*h floats, 0..255), builds all pyramid levels {I,dx,dy} + absSquaredGrad
+ * in HBM. mask (w*h floats) and bgr (3*w*h bytes) are optional (densemap=1 only); gammaB[256] optional
+ * (CalibHessian::B, HessianBlocks.h:397-406; NULL = identity).
+ * ------------------------------------------------------------------------------------------------ */
+int nalo_frame_upload(nalo_ctx* ctx, int slot, const float* irradiance, const float* mask, const uint8_t* bgr,
+                      const float* gammaB);
+/* test/inspection: level image as AoS {I,dx,dy} (3 floats/px) and absSquaredGrad (1 float/px); either may be NULL */
+int nalo_frame_download(nalo_ctx* ctx, int slot, int lvl, float* dI3, float* abs_sq_grad);
+
+/* ------------------------------------------------------------------------------------------------
+ * Front-end tracker.
+ * ------------------------------------------------------------------------------------------------ */
+/* CoarseTracker::makeK (CoarseTracker.cpp:97-141): pyramid intrinsics from the current calibration */
+int nalo_trk_make_k(nalo_ctx* ctx, float fx, float fy, float cx, float cy);
+
+/* a2  CoarseTracker::setCoarseTrackingRef -> makeCoarseDepthL0 steps 1-5 (CoarseTracker.cpp:1053-1067, 382-538),
+ * called at FullSystem.cpp:1404. One entry per IN residual targeting the reference keyframe:
+ * centerProjectedTo = (Ku, Kv, new_idepth) and the point's HdiF. Builds idepth/weight pyramids and the
+ * per-level point clouds pc_u/pc_v/pc_idepth/pc_color in raster order. */
+int nalo_trk_set_ref(nalo_ctx* ctx, int slot_ref, int n, const float* Ku, const float* Kv,
+                     const float* new_idepth, const float* HdiF);
+/* direct injection of one level's point cloud (synthetic stress windows) */
+int nalo_trk_set_pc(nalo_ctx* ctx, int slot_ref, int lvl, int n, const float* u, const float* v,
+                    const float* idepth, const float* color);
+int nalo_trk_get_pc(nalo_ctx* ctx, int lvl, int* n, float* u, float* v, float* idepth, float* color);
+int nalo_trk_get_depth(nalo_ctx* ctx, int lvl, float* idepth, float* weight_sums);
+
+/* a3+a4 fused  CoarseTracker::calcRes (CoarseTracker.cpp:891-1049) + calcGSSSE (:828-885), call sites
+ * CoarseTracker.cpp:1104,1109,1115,1184,1204. R,t = refToNew; affLL = fromToVecExposure(ref,new) as float;
+ * b0 = lastRef_aff_g2l.b. stats6 = {E, numTermsInE, shiftT/(n+.1), 0, shiftRT/(n+.1), saturatedRatio}.
+ * If want_gs: H (8x8) and b (8) as calcGSSSE returns them (divided by the PADDED count, scaled by SCALE_*). */
+int nalo_trk_eval(nalo_ctx* ctx, int slot_new, int lvl, const double R[9], const double t[3],
+                  const float affLL[2], float b0, float cutoffTH, int want_gs,
+                  double stats6[6], double H[64], double b[8]);
+
+/* CoarseTracker::trackNewestCoarse (CoarseTracker.cpp:1073-1259), call site FullSystem.cpp:594-597.
+ * T_io = lastToNew_out, aff_io = aff_g2l_out (a,b), ref_aff = lastRef_aff_g2l, exposures = {ref,new}.
+ * *ok = the bool the reference returns. n_evals (optional) = number of fused evaluations launched. */
+int nalo_trk_track(nalo_ctx* ctx, int slot_new, double T_io[12], double aff_io[2], const double ref_aff[2],
+                   const float exposures[2], int coarsestLvl, const double minResForAbort[5],
+                   double lastResiduals[5], double lastFlowIndicators[3], int* ok, int* n_evals);
+
+/* ------------------------------------------------------------------------------------------------
+ * Back-end: sliding-window photometric bundle adjustment.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct nalo_frame_state {
+    int slot;                 /* frame slot holding the pyramid (nalo_frame_upload) */
+    int frame_id;             /* FrameHessian::frameID (0 gets the gauge priors, HessianBlocks.h:321-350) */
+    double worldToCam_evalPT[12];
+    double state[10];         /* FrameHessian::state (unscaled); [0:6] relative to evalPT, [6:8] = a,b / SCALE */
+    double state_zero[10];
+    float ab_exposure;
+    float frameEnergyTH;
+} nalo_frame_state;
+
+/* EnergyFunctional::insertFrame / FullSystem::setPrecalcValues / EnergyFunctional::setAdjointsF, setDeltaF
+ * (OptimizationBackend/EnergyFunctional.cpp:429-461, 46-106, 171-194; FullSystem.cpp:1694-1704).
+ * The newest keyframe must be the last entry (frameHessians.back()). calib = {fx,fy,cx,cy} value_scaled. */
+int nalo_ba_set_window(nalo_ctx* ctx, int W, const nalo_frame_state* frames, const double calib[4],
+                       const double calib_zero[4]);
+/* EnergyFunctional::insertPoint (EnergyFunctional.cpp:462-474) for all active points: SoA, P entries.
+ * color/weights are P x 8 (PointHessian::color/weights, HessianBlocks.h:424-425). idepth_zero may be NULL (= idepth). */
+int nalo_ba_set_points(nalo_ctx* ctx, int P, const int* host, const float* u, const float* v,
+                       const float* idepth, const float* idepth_zero, const float* color, const float* weights,
+                       const int* has_depth_prior);
+/* EnergyFunctional::insertResidual (EnergyFunctional.cpp:417-428): exists[p*W + t] != 0 creates the
+ * PointFrameResidual (point p -> target frame t) in the resetOOB state (FullSystem/Residuals.h:88-94). */
+int nalo_ba_set_residuals(nalo_ctx* ctx, const uint8_t* exists);
+/* marginalisation prior HM/bM ((8W+4)^2, 8W+4), EnergyFunctional.h; NULL = zero */
+int nalo_ba_set_prior(nalo_ctx* ctx, const double* HM, const double* bM);
+int nalo_ba_get_prior(nalo_ctx* ctx, double* HM, double* bM);
+
+/* a5+a6 (+ the accumulation side of a7, a9)  FullSystem::linearizeAll(fix) + applyRes_Reductor
+ * (FullSystem/FullSystemOptimize.cpp:144-211, 90-94, call sites :436,:460,:511,:524,:562) =
+ * PointFrameResidual::linearize + applyRes + EFResidual::takeDataF (Residuals.cpp:78-274,306-328,
+ * EnergyFunctionalStructs.cpp:39-50) + setNewFrameEnergyTH (:95-143). Valid because
+ * setting_forceAceptStep=true (util/settings.cpp:71): every linearisation is committed.
+ * energy = lastEnergyP (the stats[0] sum). fix != 0 drops residuals that are not IN, as linearizeAll(true). */
+int nalo_ba_linearize(nalo_ctx* ctx, int fix, double* energy);
+/* a7+a8  EnergyFunctional::accumulateAF_MT (mode 0) / accumulateLF_MT (mode 1)  (EnergyFunctional.cpp:197-238,
+ * call sites :788,:791): stitched H ((8W+4)^2) and b. Mode 1 adds the priors (usePrior=true); linearised
+ * residuals never exist at this call in the reference flow (they live only inside flagPointsForRemoval ->
+ * marginalizePointsF, FullSystem.cpp:975-990,1453) so mode 1 carries priors only. */
+int nalo_ba_accumulate(nalo_ctx* ctx, int mode, double* H, double* b);
+/* a9+a10  EnergyFunctional::accumulateSCF_MT (EnergyFunctional.cpp:244-261, call site :795) */
+int nalo_ba_accumulate_sc(nalo_ctx* ctx, int shiftPriorToZero, double* H_sc, double* b_sc);
+/* a11+a12  EnergyFunctional::solveSystemF (EnergyFunctional.cpp:776-914, call site FullSystemOptimize.cpp:616):
+ * accumulate A, L, SC; assemble; Jacobi-scaled LDL^T; orthogonalise x for iteration >= 2; resubstituteF_MT.
+ * x_out (8W+4) optional. */
+int nalo_ba_solve_system(nalo_ctx* ctx, int iteration, double lambda, double* x_out);
+/* FullSystem::backupState + doStepFromBackup (FullSystemOptimize.cpp:304-349, 217-299) */
+int nalo_ba_backup_state(nalo_ctx* ctx);
+int nalo_ba_do_step(nalo_ctx* ctx, float stepfacC, float stepfacT, float stepfacR, float stepfacA, float stepfacD,
+                    int* canbreak);
+/* FullSystem::optimize (FullSystemOptimize.cpp:398-602, call site FullSystem.cpp:1362). never_break != 0 disables
+ * the early exit at :544 so a benchmark keyframe always runs mnumOptIts iterations. */
+int nalo_ba_optimize(nalo_ctx* ctx, int mnumOptIts, int never_break, double* rmse);
+/* a13 + a7<2> + a9  flagPointsForRemoval's relinearise/fixLinearizationF (FullSystem.cpp:975-990,
+ * EnergyFunctionalStructs.cpp:89-115) + EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:615-676).
+ * flags[p] != 0 marks PS_MARGINALIZE. Adds 0.25*(M - Msc) into HM/bM and removes the points.
+ * M, Mb, Msc, Mbsc (optional outputs) are the stitched systems. */
+int nalo_ba_marginalize_points(nalo_ctx* ctx, const uint8_t* flags, double* M, double* Mb, double* Msc, double* Mbsc);
+
+/* read-back of window state (host pointers, any may be NULL) */
+int nalo_ba_get_frames(nalo_ctx* ctx, nalo_frame_state* frames /* W */, double* worldToCam /* W x 12 PRE_worldToCam */,
+                       double calib[4]);
+int nalo_ba_get_points(nalo_ctx* ctx, float* idepth, float* step, float* HdiF, float* bdSumF, float* Hdd_accAF,
+                       float* bd_accAF, float* Hcd_accAF /* P x 4 */, float* maxRelBaseline);
+/* per residual slot [p*W + t]: state (-1 none, 0 IN, 1 OOB, 2 OUTLIER), active flag, JpJdF (8), state_NewEnergyWithOutlier,
+ * centerProjectedTo (3) */
+int nalo_ba_get_residuals(nalo_ctx* ctx, int8_t* state, uint8_t* active, float* JpJdF, float* energy_new,
+                          float* center_projected);
+/* per (host,target) bin 13x13 accumulator of the last linearisation (AccumulatorApprox::H, MatrixAccumulators.h:600),
+ * index h + t*W, fp64 */
+int nalo_ba_get_acc13(nalo_ctx* ctx, double* H13 /* W*W x 169 */);
+int nalo_ba_counts(nalo_ctx* ctx, int* resInA, int* resInL, int* resInM);
+
+/* multi-GPU: the active-point set is sharded by the caller (each rank sets only its points); the stitched
+ * buffers {H_A, b_A, H_sc, b_sc, energy, counters, energy histogram} are summed across ranks through this hook
+ * before every solve. buf is a DEVICE pointer to n doubles on nalo_stream(ctx). hook == NULL = single GPU. */
+typedef void (*nalo_allreduce_fn)(void* user, double* device_buf, int n);
+int nalo_ba_set_allreduce(nalo_ctx* ctx, nalo_allreduce_fn hook, void* user);
+
+/* ------------------------------------------------------------------------------------------------
+ * a14  DenseMapping::updateMap bbox scan + makeMap (FullSystem/MapPoint.cpp:300-310, 334-407), call site
+ * FullSystem.cpp:1494. plane = (pi1..pi4) from the caller's RANSAC. rect_out = {minx,maxx,miny,maxy}.
+ * Outputs at most cap points in raster order; *n = count; *accept = the extent test of MapPoint.cpp:403.
+ * ------------------------------------------------------------------------------------------------ */
+int nalo_dense_make_map(nalo_ctx* ctx, int slot, const float plane[4], float mask_value, const double camToWorld[12],
+                        int cap, int rect_out[4], int* out_u, int* out_v, float* out_idepth, float* out_color,
+                        uint8_t* out_bgr, int* n, int* accept);
+
+/* ------------------------------------------------------------------------------------------------
+ * Profiling: per-kernel HIP-event timing on the ctx stream. Names: "trk_eval", "ba_linearize",
+ * "ba_sc", "ba_reduce", "ba_resub", "pyramid". Enable, run, then query (sync inside).
+ * ------------------------------------------------------------------------------------------------ */
+int nalo_profile_enable(nalo_ctx* ctx, int on);
+int nalo_profile_reset(nalo_ctx* ctx);
+int nalo_profile_get(nalo_ctx* ctx, const char* kernel, double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,339 @@
+"""ctypes binding of libnalo_gpu.so (the C-ABI in include/nalo_gpu.h). The product path: it fails loudly when
+the HIP library is missing or no gfx950 device is present — there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_fp = C.POINTER(C.c_float)
+c_ip = C.POINTER(C.c_int)
+c_u8p = C.POINTER(C.c_uint8)
+c_i8p = C.POINTER(C.c_int8)
+
+
+class FrameState(C.Structure):
+    _fields_ = [("slot", C.c_int), ("frame_id", C.c_int), ("worldToCam_evalPT", C.c_double * 12), ("state", C.c_double * 10),
+                ("state_zero", C.c_double * 10), ("ab_exposure", C.c_float), ("frameEnergyTH", C.c_float)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
+
+EXPORTS = [
+    "nalo_create", "nalo_destroy", "nalo_last_error", "nalo_levels", "nalo_sync", "nalo_stream",
+    "nalo_frame_upload", "nalo_frame_download",
+    "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
+    "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
+    "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
+    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
+    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce",
+    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
+]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libnalo_gpu.so")
+
+
+def load():
+    """dlopen the in-tree library; raises if it has not been built (python nalo-slam_amd/build.py)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise RuntimeError("libnalo_gpu.so is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); no CPU fallback exists")
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.nalo_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, c_fp, C.c_int]
+    L.nalo_destroy.argtypes = [vp]
+    L.nalo_destroy.restype = None
+    L.nalo_last_error.argtypes = [vp]
+    L.nalo_last_error.restype = C.c_char_p
+    L.nalo_levels.argtypes = [vp]
+    L.nalo_sync.argtypes = [vp]
+    L.nalo_stream.argtypes = [vp]
+    L.nalo_stream.restype = vp
+    L.nalo_frame_upload.argtypes = [vp, C.c_int, c_fp, c_fp, c_u8p, c_fp]
+    L.nalo_frame_download.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp]
+    L.nalo_trk_make_k.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.nalo_trk_set_ref.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]
+    L.nalo_trk_set_pc.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]
+    L.nalo_trk_get_pc.argtypes = [vp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp]
+    L.nalo_trk_get_depth.argtypes = [vp, C.c_int, c_fp, c_fp]
+    L.nalo_trk_eval.argtypes = [vp, C.c_int, C.c_int, c_dp, c_dp, c_fp, C.c_float, C.c_float, C.c_int, c_dp, c_dp, c_dp]
+    L.nalo_trk_track.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_fp, C.c_int, c_dp, c_dp, c_dp, c_ip, c_ip]
+    L.nalo_ba_set_window.argtypes = [vp, C.c_int, C.POINTER(FrameState), c_dp, c_dp]
+    L.nalo_ba_set_points.argtypes = [vp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip]
+    L.nalo_ba_set_residuals.argtypes = [vp, c_u8p]
+    L.nalo_ba_set_prior.argtypes = [vp, c_dp, c_dp]
+    L.nalo_ba_get_prior.argtypes = [vp, c_dp, c_dp]
+    L.nalo_ba_linearize.argtypes = [vp, C.c_int, c_dp]
+    L.nalo_ba_accumulate.argtypes = [vp, C.c_int, c_dp, c_dp]
+    L.nalo_ba_accumulate_sc.argtypes = [vp, C.c_int, c_dp, c_dp]
+    L.nalo_ba_solve_system.argtypes = [vp, C.c_int, C.c_double, c_dp]
+    L.nalo_ba_backup_state.argtypes = [vp]
+    L.nalo_ba_do_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_ip]
+    L.nalo_ba_optimize.argtypes = [vp, C.c_int, C.c_int, c_dp]
+    L.nalo_ba_marginalize_points.argtypes = [vp, c_u8p, c_dp, c_dp, c_dp, c_dp]
+    L.nalo_ba_get_frames.argtypes = [vp, C.POINTER(FrameState), c_dp, c_dp]
+    L.nalo_ba_get_points.argtypes = [vp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
+    L.nalo_ba_get_residuals.argtypes = [vp, c_i8p, c_u8p, c_fp, c_fp, c_fp]
+    L.nalo_ba_get_acc13.argtypes = [vp, c_dp]
+    L.nalo_ba_counts.argtypes = [vp, c_ip, c_ip, c_ip]
+    L.nalo_ba_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.nalo_dense_make_map.argtypes = [vp, C.c_int, c_fp, C.c_float, c_dp, C.c_int, c_ip, c_ip, c_ip, c_fp, c_fp, c_u8p, c_ip, c_ip]
+    L.nalo_profile_enable.argtypes = [vp, C.c_int]
+    L.nalo_profile_reset.argtypes = [vp]
+    L.nalo_profile_get.argtypes = [vp, C.c_char_p, c_dp, c_ip]
+    _LIB = L
+    return L
+
+
+def _f(a):
+    return None if a is None else a.ctypes.data_as(c_fp)
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(c_dp)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(c_ip)
+
+
+def _u8(a):
+    return None if a is None else a.ctypes.data_as(c_u8p)
+
+
+class NaloError(RuntimeError):
+    pass
+
+
+class Context:
+    """Thin object wrapper over nalo_ctx*."""
+
+    def __init__(self, w, h, K, n_slots, levels=0, device=0):
+        self.L = load()
+        self.h_ = C.c_void_p()
+        Kf = np.asarray(K, np.float32)
+        rc = self.L.nalo_create(C.byref(self.h_), device, w, h, levels, _f(Kf), n_slots)
+        if rc != 0:
+            raise NaloError("nalo_create failed (%d): needs a gfx950 device, no CPU fallback" % rc)
+        self.w, self.h, self.K = w, h, tuple(float(k) for k in K)
+        self.levels = self.L.nalo_levels(self.h_)
+        self.W = 0
+        self.P = 0
+        self._hook = None
+
+    def close(self):
+        if self.h_:
+            self.L.nalo_destroy(self.h_)
+            self.h_ = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise NaloError("nalo error %d: %s" % (rc, self.L.nalo_last_error(self.h_).decode()))
+
+    def sync(self):
+        self._ck(self.L.nalo_sync(self.h_))
+
+    # ---- frames
+    def frame_upload(self, slot, img, mask=None, bgr=None):
+        img = np.ascontiguousarray(img, np.float32)
+        m = None if mask is None else np.ascontiguousarray(mask, np.float32)
+        b = None if bgr is None else np.ascontiguousarray(bgr, np.uint8)
+        self._ck(self.L.nalo_frame_upload(self.h_, slot, _f(img), _f(m), _u8(b), None))
+
+    def frame_download(self, slot, lvl):
+        n = (self.w >> lvl) * (self.h >> lvl)
+        dI, ab = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+        self._ck(self.L.nalo_frame_download(self.h_, slot, lvl, _f(dI), _f(ab)))
+        return dI, ab
+
+    # ---- tracker
+    def trk_set_ref(self, slot, Ku, Kv, new_idepth, HdiF):
+        a = [np.ascontiguousarray(x, np.float32) for x in (Ku, Kv, new_idepth, HdiF)]
+        self._ck(self.L.nalo_trk_set_ref(self.h_, slot, len(a[0]), *[_f(x) for x in a]))
+
+    def trk_set_pc(self, slot, lvl, u, v, idepth, color):
+        a = [np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color)]
+        self._ck(self.L.nalo_trk_set_pc(self.h_, slot, lvl, len(a[0]), *[_f(x) for x in a]))
+
+    def trk_get_pc(self, lvl):
+        n = C.c_int(0)
+        self._ck(self.L.nalo_trk_get_pc(self.h_, lvl, C.byref(n), None, None, None, None))
+        out = [np.zeros(n.value, np.float32) for _ in range(4)]
+        self._ck(self.L.nalo_trk_get_pc(self.h_, lvl, C.byref(n), *[_f(o) for o in out]))
+        return out
+
+    def trk_get_depth(self, lvl):
+        n = (self.w >> lvl) * (self.h >> lvl)
+        a, b = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        self._ck(self.L.nalo_trk_get_depth(self.h_, lvl, _f(a), _f(b)))
+        return a, b
+
+    def trk_eval(self, slot_new, lvl, T, affLL, b0, cutoff, want_gs=True):
+        T = np.ascontiguousarray(T, np.float64).reshape(3, 4)
+        R = np.ascontiguousarray(T[:, :3]).reshape(-1)
+        t = np.ascontiguousarray(T[:, 3])
+        st, H, b = np.zeros(6), np.zeros(64), np.zeros(8)
+        self._ck(self.L.nalo_trk_eval(self.h_, slot_new, lvl, _d(R), _d(t), _f(np.asarray(affLL, np.float32)), b0, cutoff,
+                                      int(want_gs), _d(st), _d(H), _d(b)))
+        return st, H.reshape(8, 8), b
+
+    def trk_track(self, slot_new, T0, aff0, ref_aff, exposures, coarsest, min_res=None):
+        T = np.ascontiguousarray(T0, np.float64).reshape(-1).copy()
+        aff = np.array(aff0, np.float64)
+        mr = np.full(5, np.nan) if min_res is None else np.asarray(min_res, np.float64)
+        lr, lf = np.zeros(5), np.zeros(3)
+        ok, ne = C.c_int(0), C.c_int(0)
+        self._ck(self.L.nalo_trk_track(self.h_, slot_new, _d(T), _d(aff), _d(np.asarray(ref_aff, np.float64)),
+                                       _f(np.asarray(exposures, np.float32)), coarsest, _d(mr), _d(lr), _d(lf), C.byref(ok), C.byref(ne)))
+        return ok.value, T.reshape(3, 4), aff, lr, lf, ne.value
+
+    # ---- BA
+    def ba_set_window(self, slots, evalPT, aff=None, exposure=None, th=None, frame_ids=None, state6=None, calib=None):
+        W = len(slots)
+        arr = (FrameState * W)()
+        for i in range(W):
+            fs = arr[i]
+            fs.slot = int(slots[i])
+            fs.frame_id = int(i if frame_ids is None else frame_ids[i])
+            e = np.ascontiguousarray(evalPT[i], np.float64).reshape(-1)
+            for k in range(12):
+                fs.worldToCam_evalPT[k] = e[k]
+            a, b = (0.0, 0.0) if aff is None else aff[i]
+            # FrameHessian::setEvalPT_scaled (HessianBlocks.h:247-255): state = [0.., a/SCALE_A, b/SCALE_B, 0, 0], state_zero = state
+            st = np.zeros(10)
+            st[6] = np.float32(1.0 / 10.0) * a
+            st[7] = np.float32(1.0 / 1000.0) * b
+            for k in range(10):
+                fs.state_zero[k] = st[k]
+            if state6 is not None:
+                st[:6] = state6[i]
+            for k in range(10):
+                fs.state[k] = st[k]
+            fs.ab_exposure = 1.0 if exposure is None else float(exposure[i])
+            fs.frameEnergyTH = 8 * 8 * 8.0 if th is None else float(th[i])
+        cal = np.asarray(self.K if calib is None else calib, np.float64)
+        self._ck(self.L.nalo_ba_set_window(self.h_, W, arr, _d(cal), _d(cal)))
+        self.W = W
+
+    def ba_set_points(self, host, u, v, idepth, color, weights, has_prior=None):
+        a = [np.ascontiguousarray(host, np.int32)] + [np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color, weights)]
+        hp = None if has_prior is None else np.ascontiguousarray(has_prior, np.int32)
+        self.P = len(a[0])
+        self._ck(self.L.nalo_ba_set_points(self.h_, self.P, _i(a[0]), _f(a[1]), _f(a[2]), _f(a[3]), None, _f(a[4]), _f(a[5]), _i(hp)))
+
+    def ba_set_residuals(self, exists):
+        self._ck(self.L.nalo_ba_set_residuals(self.h_, _u8(np.ascontiguousarray(exists, np.uint8))))
+
+    @property
+    def n(self):
+        return 8 * self.W + 4
+
+    def ba_linearize(self, fix=False):
+        e = C.c_double(0)
+        self._ck(self.L.nalo_ba_linearize(self.h_, int(fix), C.byref(e)))
+        return e.value
+
+    def ba_accumulate(self, mode):
+        H, b = np.zeros(self.n * self.n), np.zeros(self.n)
+        self._ck(self.L.nalo_ba_accumulate(self.h_, mode, _d(H), _d(b)))
+        return H.reshape(self.n, self.n), b
+
+    def ba_accumulate_sc(self, shift=True):
+        H, b = np.zeros(self.n * self.n), np.zeros(self.n)
+        self._ck(self.L.nalo_ba_accumulate_sc(self.h_, int(shift), _d(H), _d(b)))
+        return H.reshape(self.n, self.n), b
+
+    def ba_solve_system(self, iteration, lam=1e-5):
+        x = np.zeros(self.n)
+        self._ck(self.L.nalo_ba_solve_system(self.h_, iteration, lam, _d(x)))
+        return x
+
+    def ba_backup_state(self):
+        self._ck(self.L.nalo_ba_backup_state(self.h_))
+
+    def ba_do_step(self, f=1.0):
+        cb = C.c_int(0)
+        self._ck(self.L.nalo_ba_do_step(self.h_, f, f, f, f, f, C.byref(cb)))
+        return cb.value
+
+    def ba_optimize(self, its=6, never_break=False):
+        r = C.c_double(0)
+        self._ck(self.L.nalo_ba_optimize(self.h_, its, int(never_break), C.byref(r)))
+        return r.value
+
+    def ba_marginalize_points(self, flags):
+        n = self.n
+        M, Mb, Ms, Mbs = np.zeros(n * n), np.zeros(n), np.zeros(n * n), np.zeros(n)
+        self._ck(self.L.nalo_ba_marginalize_points(self.h_, _u8(np.ascontiguousarray(flags, np.uint8)), _d(M), _d(Mb), _d(Ms), _d(Mbs)))
+        return M.reshape(n, n), Mb, Ms.reshape(n, n), Mbs
+
+    def ba_get_frames(self):
+        arr = (FrameState * self.W)()
+        w2c = np.zeros((self.W, 12))
+        cal = np.zeros(4)
+        self._ck(self.L.nalo_ba_get_frames(self.h_, arr, _d(w2c), _d(cal)))
+        return arr, w2c.reshape(self.W, 3, 4), cal
+
+    def ba_get_points(self):
+        P = self.P
+        o = {k: np.zeros(P, np.float32) for k in ("idepth", "step", "HdiF", "bdSumF", "Hdd", "bd")}
+        o["Hcd"] = np.zeros((P, 4), np.float32)
+        o["maxRelBaseline"] = np.zeros(P, np.float32)
+        self._ck(self.L.nalo_ba_get_points(self.h_, _f(o["idepth"]), _f(o["step"]), _f(o["HdiF"]), _f(o["bdSumF"]), _f(o["Hdd"]),
+                                           _f(o["bd"]), _f(o["Hcd"]), _f(o["maxRelBaseline"])))
+        return o
+
+    def ba_get_residuals(self):
+        n = self.P * self.W
+        st, ac = np.zeros(n, np.int8), np.zeros(n, np.uint8)
+        jp, en, cp = np.zeros((n, 8), np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+        self._ck(self.L.nalo_ba_get_residuals(self.h_, st.ctypes.data_as(c_i8p), _u8(ac), _f(jp), _f(en), _f(cp)))
+        s = (self.P, self.W)
+        return st.reshape(s), ac.reshape(s), jp.reshape(s + (8,)), en.reshape(s), cp.reshape(s + (3,))
+
+    def ba_get_acc13(self):
+        a = np.zeros(self.W * self.W * 169)
+        self._ck(self.L.nalo_ba_get_acc13(self.h_, _d(a)))
+        return a.reshape(self.W * self.W, 13, 13)
+
+    def ba_counts(self):
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._ck(self.L.nalo_ba_counts(self.h_, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def ba_set_allreduce(self, fn):
+        """fn(device_ptr:int, n:int) sums n doubles in place across ranks."""
+        if fn is None:
+            self._hook = None
+            self._ck(self.L.nalo_ba_set_allreduce(self.h_, C.cast(None, ALLREDUCE_FN), None))
+            return
+        self._hook = ALLREDUCE_FN(lambda user, ptr, n: fn(ptr, n))
+        self._ck(self.L.nalo_ba_set_allreduce(self.h_, self._hook, None))
+
+    # ---- profiling
+    def profile_enable(self, on=True):
+        self._ck(self.L.nalo_profile_enable(self.h_, int(on)))
+
+    def profile_reset(self):
+        self._ck(self.L.nalo_profile_reset(self.h_))
+
+    def profile_get(self, name):
+        ms, n = C.c_double(0), C.c_int(0)
+        self._ck(self.L.nalo_profile_get(self.h_, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

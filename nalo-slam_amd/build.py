@@ -1,0 +1,37 @@
+"""Builds libnalo_gpu.so (HIP kernels + C-ABI) for gfx950 in-tree with hipcc. No torch involved."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = ["host_api.hip", "host_ba.hip", "kernels_pyramid.hip", "kernels_tracker.hip", "kernels_ba.hip", "kernels_dense.hip"]
+OUT = os.path.join(HERE, "libnalo_gpu.so")
+
+
+def build(force=False, verbose=False):
+    csrc = os.path.join(HERE, "csrc")
+    srcs = [os.path.join(csrc, s) for s in SRC if os.path.exists(os.path.join(csrc, s))]
+    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "nalo_gpu.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+        return OUT
+    objs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    procs = []
+    for s in srcs:
+        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        objs.append(o)
+        if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):]):
+            continue
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o, "-Wno-unused-result"]
+        if verbose:
+            cmd += ["-Rpass-analysis=kernel-resource-usage"]
+        procs.append((s, subprocess.Popen(cmd)))
+    for s, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + s)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,301 @@
+// C-ABI: context, frame pyramids, front-end tracker (host mirror of CoarseTracker, reference
+// src/FullSystem/CoarseTracker.{h,cpp}). The LM loop of trackNewestCoarse stays on the host exactly as in the
+// reference (8x8 LDL^T, SE3::exp); every calcRes/calcGSSSE pair is one fused kernel launch.
+#include "nalo_internal.h"
+
+using namespace nalo;
+
+namespace nalo { void ba_destroy(nalo_ctx* c); }
+
+static int pyr_levels_rule(int w, int h) {           // util/globalCalib.cpp:50-55
+    int wl = w, hl = h, lv = 1;
+    while (wl % 2 == 0 && hl % 2 == 0 && wl * hl > 5000 && lv < NALO_MAX_LEVELS) { wl /= 2; hl /= 2; lv++; }
+    return lv;
+}
+static void set_pyr_calib(nalo_ctx* c, float fx, float fy, float cx, float cy) {   // globalCalib.cpp:74-104 / CoarseTracker::makeK
+    c->fx[0] = fx; c->fy[0] = fy; c->cx[0] = cx; c->cy[0] = cy;
+    for (int l = 1; l < c->levels; ++l) {
+        c->fx[l] = c->fx[l - 1] * 0.5; c->fy[l] = c->fy[l - 1] * 0.5;
+        c->cx[l] = (c->cx[0] + 0.5) / ((int)1 << l) - 0.5; c->cy[l] = (c->cy[0] + 0.5) / ((int)1 << l) - 0.5;
+    }
+}
+
+extern "C" {
+
+int nalo_create(nalo_ctx** out, int device, int w, int h, int levels, const float K[4], int n_slots) {
+    if (!out || !K || w < 16 || h < 16 || n_slots < 1) return NALO_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return NALO_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return NALO_ERR_NO_DEVICE;
+    nalo_ctx* c = new nalo_ctx();
+    c->device = device; c->w = w; c->h = h;
+    c->levels = levels > 0 ? levels : pyr_levels_rule(w, h);
+    if (c->levels > NALO_MAX_LEVELS) { delete c; return NALO_ERR_ARG; }
+    for (int l = 0; l < c->levels; ++l) { c->wl[l] = w >> l; c->hl[l] = h >> l; }
+    for (int i = 0; i < 4; ++i) c->K0[i] = K[i];
+    set_pyr_calib(c, K[0], K[1], K[2], K[3]);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) { delete c; return NALO_ERR_HIP; }
+    c->slots.resize(n_slots);
+    for (auto& s : c->slots)
+        for (int l = 0; l < c->levels; ++l) {
+            const size_t npx = (size_t)c->wl[l] * c->hl[l];
+            if (hipMalloc((void**)&s.I[l], npx * 4) != hipSuccess || hipMalloc((void**)&s.dI[l], npx * 16) != hipSuccess ||
+                hipMalloc((void**)&s.absg[l], npx * 4) != hipSuccess) { nalo_destroy(c); return NALO_ERR_HIP; }
+        }
+    if (hipHostMalloc((void**)&c->trk_out_host, 64 * sizeof(double), hipHostMallocMapped) != hipSuccess) { nalo_destroy(c); return NALO_ERR_HIP; }
+    *out = c;
+    return NALO_OK;
+}
+
+void nalo_destroy(nalo_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    ba_destroy(c);
+    for (auto& s : c->slots) {
+        for (int l = 0; l < NALO_MAX_LEVELS; ++l) { if (s.I[l]) (void)hipFree(s.I[l]); if (s.dI[l]) (void)hipFree(s.dI[l]); if (s.absg[l]) (void)hipFree(s.absg[l]); }
+        if (s.mask) (void)hipFree(s.mask);
+        if (s.bgr) (void)hipFree(s.bgr);
+    }
+    for (int l = 0; l < NALO_MAX_LEVELS; ++l) {
+        c->trk_idepth[l].release(); c->trk_wsum[l].release(); c->trk_wbak[l].release();
+        c->pc_u[l].release(); c->pc_v[l].release(); c->pc_id[l].release(); c->pc_col[l].release();
+    }
+    c->trk_partial.release(); c->trk_out.release(); c->scan_tmp.release(); c->upload_tmp.release();
+    if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
+    if (c->pinned_f) (void)hipHostFree(c->pinned_f);
+    for (auto& kv : c->prof) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+}
+
+const char* nalo_last_error(nalo_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+int nalo_levels(nalo_ctx* c) { return c ? c->levels : NALO_ERR_ARG; }
+int nalo_sync(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; NALO_HIP(c, hipStreamSynchronize(c->stream)); NALO_HIP(c, hipStreamSynchronize(c->side)); return NALO_OK; }
+void* nalo_stream(nalo_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int nalo_frame_upload(nalo_ctx* c, int slot, const float* irradiance, const float* mask, const uint8_t* bgr, const float* gammaB) {
+    if (!c || !irradiance || slot < 0 || slot >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_frame_upload: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    FrameSlot& s = c->slots[slot];
+    const size_t n0 = (size_t)c->w * c->h;
+    NALO_HIP(c, hipMemcpyAsync(s.I[0], irradiance, n0 * 4, hipMemcpyHostToDevice, c->stream));
+    if (mask) { if (!s.mask) NALO_HIP(c, hipMalloc((void**)&s.mask, n0 * 4)); NALO_HIP(c, hipMemcpyAsync(s.mask, mask, n0 * 4, hipMemcpyHostToDevice, c->stream)); }
+    if (bgr) { if (!s.bgr) NALO_HIP(c, hipMalloc((void**)&s.bgr, n0 * 3)); NALO_HIP(c, hipMemcpyAsync(s.bgr, bgr, n0 * 3, hipMemcpyHostToDevice, c->stream)); }
+    const float* gdev = nullptr;
+    if (gammaB) { NALO_HIP(c, c->upload_tmp.reserve(256)); NALO_HIP(c, hipMemcpyAsync(c->upload_tmp.p, gammaB, 256 * 4, hipMemcpyHostToDevice, c->stream)); gdev = c->upload_tmp.p; }
+    int rc = pyramid_build(c, s, gdev);
+    if (rc) return rc;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));      // host buffers are caller-owned: safe to reuse on return
+    s.valid = true;
+    return NALO_OK;
+}
+
+int nalo_frame_download(nalo_ctx* c, int slot, int lvl, float* dI3, float* absg) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || lvl < 0 || lvl >= c->levels) return fail(c, NALO_ERR_ARG, "nalo_frame_download: bad argument");
+    FrameSlot& s = c->slots[slot];
+    if (!s.valid) return fail(c, NALO_ERR_STATE, "nalo_frame_download: empty slot");
+    const size_t npx = (size_t)c->wl[lvl] * c->hl[lvl];
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    if (dI3) {
+        std::vector<float4> tmp(npx);
+        NALO_HIP(c, hipMemcpy(tmp.data(), s.dI[lvl], npx * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < npx; ++i) { dI3[3 * i] = tmp[i].x; dI3[3 * i + 1] = tmp[i].y; dI3[3 * i + 2] = tmp[i].z; }
+    }
+    if (absg) NALO_HIP(c, hipMemcpy(absg, s.absg[lvl], npx * 4, hipMemcpyDeviceToHost));
+    return NALO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ tracker
+int nalo_trk_make_k(nalo_ctx* c, float fx, float fy, float cx, float cy) {
+    if (!c) return NALO_ERR_ARG;
+    set_pyr_calib(c, fx, fy, cx, cy);
+    return NALO_OK;
+}
+
+static int upload4(nalo_ctx* c, int n, const float* a, const float* b, const float* d, const float* e, float** dev) {
+    NALO_HIP(c, c->upload_tmp.reserve((size_t)4 * n + 256));
+    float* base = c->upload_tmp.p + 256;
+    const float* src[4] = {a, b, d, e};
+    for (int k = 0; k < 4; ++k) { NALO_HIP(c, hipMemcpyAsync(base + (size_t)k * n, src[k], (size_t)n * 4, hipMemcpyHostToDevice, c->stream)); dev[k] = base + (size_t)k * n; }
+    return NALO_OK;
+}
+
+int nalo_trk_set_ref(nalo_ctx* c, int slot_ref, int n, const float* Ku, const float* Kv, const float* new_idepth, const float* HdiF) {
+    if (!c || slot_ref < 0 || slot_ref >= (int)c->slots.size() || n < 0 || (n > 0 && (!Ku || !Kv || !new_idepth || !HdiF)))
+        return fail(c, NALO_ERR_ARG, "nalo_trk_set_ref: bad argument");
+    if (!c->slots[slot_ref].valid) return fail(c, NALO_ERR_STATE, "nalo_trk_set_ref: reference slot has no pyramid");
+    NALO_HIP(c, hipSetDevice(c->device));
+    c->slot_ref = slot_ref;
+    float* dev[4] = {};
+    if (n > 0) { int rc = upload4(c, n, Ku, Kv, new_idepth, HdiF, dev); if (rc) return rc; }
+    return trk_build_ref(c, n, dev[0], dev[1], dev[2], dev[3]);
+}
+
+int nalo_trk_set_pc(nalo_ctx* c, int slot_ref, int lvl, int n, const float* u, const float* v, const float* idepth, const float* color) {
+    if (!c || slot_ref < 0 || slot_ref >= (int)c->slots.size() || lvl < 0 || lvl >= c->levels || n < 0) return fail(c, NALO_ERR_ARG, "nalo_trk_set_pc: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    c->slot_ref = slot_ref;
+    const size_t cap = std::max((size_t)n, (size_t)c->wl[lvl] * c->hl[lvl]);
+    NALO_HIP(c, c->pc_u[lvl].reserve(cap)); NALO_HIP(c, c->pc_v[lvl].reserve(cap)); NALO_HIP(c, c->pc_id[lvl].reserve(cap)); NALO_HIP(c, c->pc_col[lvl].reserve(cap));
+    NALO_HIP(c, hipMemcpy(c->pc_u[lvl].p, u, (size_t)n * 4, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(c->pc_v[lvl].p, v, (size_t)n * 4, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(c->pc_id[lvl].p, idepth, (size_t)n * 4, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(c->pc_col[lvl].p, color, (size_t)n * 4, hipMemcpyHostToDevice));
+    c->pc_n[lvl] = n;
+    return NALO_OK;
+}
+
+int nalo_trk_get_pc(nalo_ctx* c, int lvl, int* n, float* u, float* v, float* idepth, float* color) {
+    if (!c || lvl < 0 || lvl >= c->levels || !n) return fail(c, NALO_ERR_ARG, "nalo_trk_get_pc: bad argument");
+    *n = c->pc_n[lvl];
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t b = (size_t)c->pc_n[lvl] * 4;
+    if (u && b) NALO_HIP(c, hipMemcpy(u, c->pc_u[lvl].p, b, hipMemcpyDeviceToHost));
+    if (v && b) NALO_HIP(c, hipMemcpy(v, c->pc_v[lvl].p, b, hipMemcpyDeviceToHost));
+    if (idepth && b) NALO_HIP(c, hipMemcpy(idepth, c->pc_id[lvl].p, b, hipMemcpyDeviceToHost));
+    if (color && b) NALO_HIP(c, hipMemcpy(color, c->pc_col[lvl].p, b, hipMemcpyDeviceToHost));
+    return NALO_OK;
+}
+
+int nalo_trk_get_depth(nalo_ctx* c, int lvl, float* idepth, float* wsum) {
+    if (!c || lvl < 0 || lvl >= c->levels) return fail(c, NALO_ERR_ARG, "nalo_trk_get_depth: bad argument");
+    if (!c->trk_idepth[lvl].p) return fail(c, NALO_ERR_STATE, "nalo_trk_get_depth: no reference set");
+    const size_t b = (size_t)c->wl[lvl] * c->hl[lvl] * 4;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    if (idepth) NALO_HIP(c, hipMemcpy(idepth, c->trk_idepth[lvl].p, b, hipMemcpyDeviceToHost));
+    if (wsum) NALO_HIP(c, hipMemcpy(wsum, c->trk_wsum[lvl].p, b, hipMemcpyDeviceToHost));
+    return NALO_OK;
+}
+
+int nalo_trk_eval(nalo_ctx* c, int slot_new, int lvl, const double R[9], const double t[3], const float affLL[2], float b0,
+                  float cutoffTH, int want_gs, double stats6[6], double H[64], double b[8]) {
+    if (!c || !R || !t || !affLL || !stats6 || lvl < 0 || lvl >= c->levels || slot_new < 0 || slot_new >= (int)c->slots.size())
+        return fail(c, NALO_ERR_ARG, "nalo_trk_eval: bad argument");
+    if (c->slot_ref < 0 || !c->slots[slot_new].valid) return fail(c, NALO_ERR_STATE, "nalo_trk_eval: no reference / empty frame slot");
+    if (want_gs && (!H || !b)) return fail(c, NALO_ERR_ARG, "nalo_trk_eval: H/b required");
+    // RKi = R.cast<float>() * Ki[lvl], t = translation.cast<float>() (CoarseTracker.cpp:907-908)
+    const float fx = c->fx[lvl], fy = c->fy[lvl], cx = c->cx[lvl], cy = c->cy[lvl];
+    const float Ki[9] = {1.0f / fx, 0, -cx / fx, 0, 1.0f / fy, -cy / fy, 0, 0, 1};
+    float Rf[9], RKi[9], tf[3];
+    for (int i = 0; i < 9; ++i) Rf[i] = (float)R[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) RKi[i * 3 + j] = Rf[i * 3] * Ki[j] + Rf[i * 3 + 1] * Ki[3 + j] + Rf[i * 3 + 2] * Ki[6 + j];
+    for (int i = 0; i < 3; ++i) tf[i] = (float)t[i];
+    const float maxEnergy = 2 * kHuberTH * cutoffTH - kHuberTH * kHuberTH;          // :916
+    double o[64];
+    int rc = trk_eval_launch(c, slot_new, lvl, RKi, tf, Ki, affLL[0], affLL[1], b0, cutoffTH, maxEnergy, o);
+    if (rc) return rc;
+    const double E = o[45], nE = o[46], nSat = o[47], nW = o[48], sT = o[49], sRT = o[50], sN = o[51];
+    stats6[0] = E; stats6[1] = nE; stats6[2] = sT / (sN + 0.1); stats6[3] = 0; stats6[4] = sRT / (sN + 0.1);
+    stats6[5] = (double)((float)nSat / (float)nE);
+    if (want_gs) {
+        const double npad = (double)(((long)nW + 3) & ~3L);          // divided by the padded count
+        const double inv = 1.0 / npad;
+        static const double sc[8] = {kScaleXiRot, kScaleXiRot, kScaleXiRot, kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleA, kScaleB};
+        double Hf[81]; int k = 0;
+        for (int r = 0; r < 9; ++r) for (int cc = r; cc < 9; ++cc) { Hf[r * 9 + cc] = Hf[cc * 9 + r] = o[k]; ++k; }
+        for (int r = 0; r < 8; ++r) { for (int cc = 0; cc < 8; ++cc) H[r * 8 + cc] = Hf[r * 9 + cc] * inv * sc[r] * sc[cc]; b[r] = Hf[r * 9 + 8] * inv * sc[r]; }
+    }
+    return NALO_OK;
+}
+
+int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2], const double ref_aff[2], const float exposures[2],
+                   int coarsestLvl, const double minResForAbort[5], double lastResiduals[5], double lastFlow[3], int* ok, int* n_evals) {
+    if (!c || !T_io || !aff_io || !ref_aff || !exposures || !ok) return fail(c, NALO_ERR_ARG, "nalo_trk_track: bad argument");
+    if (!(coarsestLvl < 5 && coarsestLvl < c->levels)) return fail(c, NALO_ERR_ARG, "nalo_trk_track: coarsestLvl out of range");   // assert at :1083
+    double lastRes[5] = {NAN, NAN, NAN, NAN, NAN}, flow[3] = {1000, 1000, 1000};
+    static const int maxIterations[5] = {10, 20, 50, 50, 50};
+    const float lambdaExtrapolationLimit = 0.001f;
+    SE3 cur = SE3::from(T_io);
+    double aff_cur[2] = {aff_io[0], aff_io[1]};
+    bool haveRepeated = false, good = true;
+    int evals = 0;
+    auto eval = [&](int lvl, const SE3& T, const double aff[2], float cutoff, double st[6], double* H, double* b, double* aLL0) -> int {
+        double aLL[2];
+        aff_from_to(exposures[0], exposures[1], ref_aff[0], ref_aff[1], aff[0], aff[1], aLL);
+        const float aLLf[2] = {(float)aLL[0], (float)aLL[1]};
+        const double R[9] = {T.R(0, 0), T.R(0, 1), T.R(0, 2), T.R(1, 0), T.R(1, 1), T.R(1, 2), T.R(2, 0), T.R(2, 1), T.R(2, 2)};
+        const double tt[3] = {T.t(0), T.t(1), T.t(2)};
+        if (aLL0) *aLL0 = aLL[0];
+        ++evals;
+        return nalo_trk_eval(c, slot_new, lvl, R, tt, aLLf, (float)ref_aff[1], cutoff, 1, st, H, b);
+    };
+    for (int lvl = coarsestLvl; lvl >= 0; --lvl) {
+        double H[64], b[8], Hn[64], bn[8], resOld[6], resNew[6];
+        float levelCutoffRepeat = 1;
+        int rc = eval(lvl, cur, aff_cur, kCoarseCutoffTH * levelCutoffRepeat, resOld, H, b, nullptr);
+        if (rc) return rc;
+        while (resOld[5] > 0.6 && levelCutoffRepeat < 50) {
+            levelCutoffRepeat *= 2;
+            rc = eval(lvl, cur, aff_cur, kCoarseCutoffTH * levelCutoffRepeat, resOld, H, b, nullptr);
+            if (rc) return rc;
+        }
+        float lambda = 0.01f;
+        for (int it = 0; it < maxIterations[lvl]; ++it) {
+            double Hl[64], nb[8], inc[8];
+            std::memcpy(Hl, H, sizeof(Hl));
+            for (int i = 0; i < 8; ++i) { Hl[i * 8 + i] *= (1 + lambda); nb[i] = -b[i]; }
+            ldlt_solve(8, Hl, nb, inc);
+            float extrapFac = 1;
+            if (lambda < lambdaExtrapolationLimit) extrapFac = std::sqrt(std::sqrt(lambdaExtrapolationLimit / lambda));
+            for (double& v : inc) v *= extrapFac;
+            double incS[8];
+            std::memcpy(incS, inc, sizeof(incS));
+            for (int i = 0; i < 3; ++i) incS[i] *= kScaleXiRot;      // labels swapped vs. tangent order in the reference (:1172-1173)
+            for (int i = 3; i < 6; ++i) incS[i] *= kScaleXiTrans;
+            incS[6] *= kScaleA; incS[7] *= kScaleB;
+            double s = 0; for (double v : incS) s += v;
+            if (!std::isfinite(s)) std::memset(incS, 0, sizeof(incS));
+            const SE3 Tn = se3_exp(incS) * cur;
+            const double aff_new[2] = {aff_cur[0] + incS[6], aff_cur[1] + incS[7]};
+            rc = eval(lvl, Tn, aff_new, kCoarseCutoffTH * levelCutoffRepeat, resNew, Hn, bn, nullptr);
+            if (rc) return rc;
+            const bool accept = (resNew[0] / resNew[1]) < (resOld[0] / resOld[1]);
+            if (accept) {
+                std::memcpy(H, Hn, sizeof(H)); std::memcpy(b, bn, sizeof(b)); std::memcpy(resOld, resNew, sizeof(resOld));
+                aff_cur[0] = aff_new[0]; aff_cur[1] = aff_new[1]; cur = Tn;
+                lambda *= 0.5f;
+            } else { lambda *= 4; if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit; }
+            double nrm = 0; for (double v : inc) nrm += v * v;
+            if (!(std::sqrt(nrm) > 1e-3)) break;
+        }
+        lastRes[lvl] = std::sqrt((float)(resOld[0] / resOld[1]));
+        flow[0] = resOld[2]; flow[1] = resOld[3]; flow[2] = resOld[4];
+        if (minResForAbort && lastRes[lvl] > 1.5 * minResForAbort[lvl]) { good = false; break; }
+        if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
+    }
+    if (lastResiduals) std::memcpy(lastResiduals, lastRes, sizeof(lastRes));
+    if (lastFlow) std::memcpy(lastFlow, flow, sizeof(flow));
+    if (n_evals) *n_evals = evals;
+    if (!good) { *ok = 0; return NALO_OK; }
+    std::memcpy(T_io, cur.m, sizeof(cur.m)); aff_io[0] = aff_cur[0]; aff_io[1] = aff_cur[1];
+    *ok = !(std::fabs((float)aff_io[0]) > 1.2f || std::fabs((float)aff_io[1]) > 200.f);   // :1243-1245 (affineOptMode != 0)
+    return NALO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ profiling
+static void prof_drain(nalo_ctx* c) {
+    for (auto& kv : c->prof) {
+        for (auto& ev : kv.second.pending) {
+            float ms = 0;
+            if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { kv.second.ms += ms; kv.second.n++; }
+            (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+int nalo_profile_enable(nalo_ctx* c, int on) { if (!c) return NALO_ERR_ARG; c->prof_on = on != 0; return NALO_OK; }
+int nalo_profile_reset(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; prof_drain(c); c->prof.clear(); return NALO_OK; }
+int nalo_profile_get(nalo_ctx* c, const char* kernel, double* total_ms, int* launches) {
+    if (!c || !kernel) return NALO_ERR_ARG;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    prof_drain(c);
+    auto it = c->prof.find(kernel);
+    if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->prof.end() ? 0 : it->second.n;
+    return NALO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+// Host-side fp64 math of the product: fixed-size matrices, SE(3) (Sophus conventions), Jacobi-scaled LDL^T,
+// symmetric eigen solver. Written for this library (no Eigen in the image); used by the host mirrors of
+// CoarseTracker::trackNewestCoarse and EnergyFunctional::solveSystemF.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace nalo {
+
+struct SE3 {                     // row-major 3x4 [R|t]
+    double m[12];
+    static SE3 identity() { SE3 s; std::memset(s.m, 0, sizeof(s.m)); s.m[0] = s.m[5] = s.m[10] = 1; return s; }
+    static SE3 from(const double* p) { SE3 s; std::memcpy(s.m, p, sizeof(s.m)); return s; }
+    double R(int i, int j) const { return m[i * 4 + j]; }
+    double t(int i) const { return m[i * 4 + 3]; }
+    SE3 operator*(const SE3& b) const {
+        SE3 c;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) c.m[i * 4 + j] = R(i, 0) * b.R(0, j) + R(i, 1) * b.R(1, j) + R(i, 2) * b.R(2, j);
+            c.m[i * 4 + 3] = R(i, 0) * b.t(0) + R(i, 1) * b.t(1) + R(i, 2) * b.t(2) + t(i);
+        }
+        return c;
+    }
+    SE3 inverse() const {
+        SE3 c;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c.m[i * 4 + j] = R(j, i);
+        for (int i = 0; i < 3; ++i) c.m[i * 4 + 3] = -(c.R(i, 0) * t(0) + c.R(i, 1) * t(1) + c.R(i, 2) * t(2));
+        return c;
+    }
+    // 6x6 adjoint [R, [t]x R; 0, R] (row-major)
+    void adjoint(double A[36]) const {
+        const double tx = t(0), ty = t(1), tz = t(2);
+        const double H[9] = {0, -tz, ty, tz, 0, -tx, -ty, tx, 0};
+        std::memset(A, 0, 36 * sizeof(double));
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            A[i * 6 + j] = R(i, j);
+            A[(i + 3) * 6 + j + 3] = R(i, j);
+            A[i * 6 + j + 3] = H[i * 3] * R(0, j) + H[i * 3 + 1] * R(1, j) + H[i * 3 + 2] * R(2, j);
+        }
+    }
+};
+
+// exp: tangent (upsilon, omega) -> SE3; rotation through the unit quaternion (cos(th/2), sin(th/2)/th * omega)
+inline SE3 se3_exp(const double xi[6]) {
+    const double wx = xi[3], wy = xi[4], wz = xi[5];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
+    double qi, qr;
+    if (th < 1e-10) { const double t4 = th2 * th2; qi = 0.5 - th2 / 48.0 + t4 / 3840.0; qr = 1.0 - 0.5 * th2 + t4 / 384.0; }
+    else { qi = std::sin(0.5 * th) / th; qr = std::cos(0.5 * th); }
+    double q[4] = {qr, qi * wx, qi * wy, qi * wz};
+    const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (double& v : q) v /= qn;
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    double Rm[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                    2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                    2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    double V[9];
+    if (th < 1e-10) std::memcpy(V, Rm, sizeof(V));
+    else {
+        const double a = (1 - std::cos(th)) / th2, b = (th - std::sin(th)) / (th2 * th);
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + b * O2[i];
+    }
+    SE3 s;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) s.m[i * 4 + j] = Rm[i * 3 + j];
+        s.m[i * 4 + 3] = V[i * 3] * xi[0] + V[i * 3 + 1] * xi[1] + V[i * 3 + 2] * xi[2];
+    }
+    return s;
+}
+
+inline void se3_log(const SE3& T, double xi[6]) {
+    // rotation -> unit quaternion (Shepperd), then the atan-based log
+    const double r00 = T.R(0, 0), r11 = T.R(1, 1), r22 = T.R(2, 2);
+    double q[4];
+    const double tr = r00 + r11 + r22;
+    if (tr > 0) { const double s = std::sqrt(tr + 1.0) * 2; q[0] = 0.25 * s; q[1] = (T.R(2, 1) - T.R(1, 2)) / s; q[2] = (T.R(0, 2) - T.R(2, 0)) / s; q[3] = (T.R(1, 0) - T.R(0, 1)) / s; }
+    else if (r00 > r11 && r00 > r22) { const double s = std::sqrt(1.0 + r00 - r11 - r22) * 2; q[0] = (T.R(2, 1) - T.R(1, 2)) / s; q[1] = 0.25 * s; q[2] = (T.R(0, 1) + T.R(1, 0)) / s; q[3] = (T.R(0, 2) + T.R(2, 0)) / s; }
+    else if (r11 > r22) { const double s = std::sqrt(1.0 + r11 - r00 - r22) * 2; q[0] = (T.R(0, 2) - T.R(2, 0)) / s; q[1] = (T.R(0, 1) + T.R(1, 0)) / s; q[2] = 0.25 * s; q[3] = (T.R(1, 2) + T.R(2, 1)) / s; }
+    else { const double s = std::sqrt(1.0 + r22 - r00 - r11) * 2; q[0] = (T.R(1, 0) - T.R(0, 1)) / s; q[1] = (T.R(0, 2) + T.R(2, 0)) / s; q[2] = (T.R(1, 2) + T.R(2, 1)) / s; q[3] = 0.25 * s; }
+    const double qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (double& v : q) v /= qn;
+    const double n2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3], n = std::sqrt(n2), w = q[0];
+    double f;
+    if (n < 1e-10) f = 2.0 / w - 2.0 * n2 / (w * w * w);
+    else if (std::fabs(w) < 1e-10) f = (w > 0 ? M_PI : -M_PI) / n;
+    else f = 2.0 * std::atan(n / w) / n;
+    const double th = f * n, ox = f * q[1], oy = f * q[2], oz = f * q[3];
+    const double O[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+    double O2[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    const double c = std::fabs(th) < 1e-10 ? 1.0 / 12.0 : (1.0 - th / (2.0 * std::tan(0.5 * th))) / (th * th);
+    for (int i = 0; i < 3; ++i) {
+        double s = 0;
+        for (int j = 0; j < 3; ++j) s += (((i == j) ? 1.0 : 0.0) - 0.5 * O[i * 3 + j] + c * O2[i * 3 + j]) * T.t(j);
+        xi[i] = s;
+    }
+    xi[3] = ox; xi[4] = oy; xi[5] = oz;
+}
+
+// AffLight::fromToVecExposure (util/NumType.h:173-185)
+inline void aff_from_to(float expF, float expT, double aF, double bF, double aT, double bT, double out[2]) {
+    if (expF == 0 || expT == 0) expT = expF = 1;
+    const double a = std::exp(aT - aF) * expT / expF;
+    out[0] = a; out[1] = bT - a * bF;
+}
+
+// Symmetric solve by LDL^T with diagonal pivoting (semi-definite safe), fp64. A is n x n row-major.
+inline void ldlt_solve(int n, const double* Ain, const double* b, double* x) {
+    std::vector<double> A(Ain, Ain + (size_t)n * n), y(n);
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    for (int k = 0; k < n; ++k) {
+        int p = k; double best = std::fabs(A[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; ++i) { const double v = std::fabs(A[(size_t)i * n + i]); if (v > best) { best = v; p = i; } }
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]);
+            for (int j = 0; j < n; ++j) std::swap(A[(size_t)j * n + k], A[(size_t)j * n + p]);
+            std::swap(perm[k], perm[p]);
+        }
+        const double d = A[(size_t)k * n + k];
+        if (d == 0.0 || !std::isfinite(d)) { for (int i = k + 1; i < n; ++i) A[(size_t)i * n + k] = 0; continue; }
+        for (int i = k + 1; i < n; ++i) A[(size_t)i * n + k] /= d;
+        for (int i = k + 1; i < n; ++i) {
+            const double lik = A[(size_t)i * n + k];
+            if (lik == 0) continue;
+            for (int j = k + 1; j <= i; ++j) A[(size_t)i * n + j] -= lik * d * A[(size_t)j * n + k];
+        }
+        for (int i = k + 1; i < n; ++i) for (int j = i + 1; j < n; ++j) A[(size_t)i * n + j] = A[(size_t)j * n + i];
+    }
+    for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] -= A[(size_t)i * n + j] * y[j];
+    for (int i = 0; i < n; ++i) { const double d = A[(size_t)i * n + i]; y[i] = (d != 0.0 && std::isfinite(d)) ? y[i] / d : 0.0; }
+    for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] -= A[(size_t)j * n + i] * y[j];
+    for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+}
+
+// cyclic Jacobi for small symmetric matrices; A destroyed, V columns = eigenvectors
+inline void sym_eig(int n, double* A, double* V, double* w) {
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);
+    for (int sweep = 0; sweep < 100; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) {
+            const double apq = A[p * n + q];
+            if (std::fabs(apq) < 1e-300) continue;
+            const double th = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1)), c = 1 / std::sqrt(t * t + 1), s = t * c;
+            for (int k = 0; k < n; ++k) { const double a = A[k * n + p], b = A[k * n + q]; A[k * n + p] = c * a - s * b; A[k * n + q] = s * a + c * b; }
+            for (int k = 0; k < n; ++k) { const double a = A[p * n + k], b = A[q * n + k]; A[p * n + k] = c * a - s * b; A[q * n + k] = s * a + c * b; }
+            for (int k = 0; k < n; ++k) { const double a = V[k * n + p], b = V[k * n + q]; V[k * n + p] = c * a - s * b; V[k * n + q] = s * a + c * b; }
+        }
+    }
+    for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+}
+
+}  // namespace nalo

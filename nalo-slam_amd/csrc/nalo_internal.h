@@ -1,0 +1,113 @@
+// Internal state of a nalo_ctx: HBM-resident frame pyramids, tracker point clouds, BA window arrays.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nalo_gpu.h"
+#include "host_math.h"
+
+namespace nalo {
+
+// reference constants (util/settings.cpp, FullSystem/HessianBlocks.h:61-68)
+constexpr float kScaleIdepth = 1.0f, kScaleXiRot = 1.0f, kScaleXiTrans = 0.5f, kScaleF = 50.0f, kScaleC = 50.0f,
+                kScaleA = 10.0f, kScaleB = 1000.0f;
+constexpr float kHuberTH = 9.0f, kCoarseCutoffTH = 20.0f, kOutlierTHSumComponent = 2500.0f;
+constexpr float kIdepthFixPrior = 2500.0f, kIdepthFixPriorMargFac = 360000.0f;
+constexpr double kInitialRotPrior = 1e11, kInitialTransPrior = 1e10, kInitialAffPrior = 1e14, kInitialCalibHessian = 5e9;
+constexpr double kAffineOptModeA = 1e12, kAffineOptModeB = 1e8, kSolverModeDelta = 1e-5, kMargWeightFac = 0.25;
+constexpr int kPatternNum = 8;
+
+template <typename T>
+struct DevBuf {                  // owning device buffer, grows on demand
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct FrameSlot {
+    float* I[NALO_MAX_LEVELS] = {};          // planar irradiance per level
+    float4* dI[NALO_MAX_LEVELS] = {};        // {I, dx, dy, 0} per level: one 16-B load per bilinear tap
+    float* absg[NALO_MAX_LEVELS] = {};       // absSquaredGrad
+    float* mask = nullptr;                   // level 0 (densemap only)
+    uint8_t* bgr = nullptr;
+    bool valid = false;
+};
+
+struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+
+// precalc record per (host,target), 32 floats: KRKi(9) Kt(3) R0(9) t0(3) aff(2) b0 thmax dp(8)... see kernels_ba.hip
+struct BAWindow;
+
+}  // namespace nalo
+
+struct nalo_ctx {
+    int device = 0;
+    int w = 0, h = 0, levels = 0;
+    int wl[NALO_MAX_LEVELS], hl[NALO_MAX_LEVELS];
+    float fx[NALO_MAX_LEVELS], fy[NALO_MAX_LEVELS], cx[NALO_MAX_LEVELS], cy[NALO_MAX_LEVELS];   // tracker pyramid intrinsics
+    float K0[4];
+    hipStream_t stream = nullptr, side = nullptr;
+    std::string err;
+    std::vector<nalo::FrameSlot> slots;
+
+    // ---- tracker
+    int slot_ref = -1;
+    nalo::DevBuf<float> trk_idepth[NALO_MAX_LEVELS], trk_wsum[NALO_MAX_LEVELS], trk_wbak[NALO_MAX_LEVELS];
+    nalo::DevBuf<float> pc_u[NALO_MAX_LEVELS], pc_v[NALO_MAX_LEVELS], pc_id[NALO_MAX_LEVELS], pc_col[NALO_MAX_LEVELS];
+    int pc_n[NALO_MAX_LEVELS] = {};
+    nalo::DevBuf<float> trk_partial;         // [blocks][64]
+    nalo::DevBuf<double> trk_out;            // 64 doubles
+    double* trk_out_host = nullptr;          // pinned
+    nalo::DevBuf<int> scan_tmp;              // compaction counts
+    nalo::DevBuf<float> upload_tmp;
+    float* pinned_f = nullptr; size_t pinned_f_cap = 0;
+
+    // ---- BA (opaque; defined in host_ba.cpp)
+    nalo::BAWindow* ba = nullptr;
+
+    // ---- profiling
+    bool prof_on = false;
+    std::map<std::string, nalo::ProfEntry> prof;
+};
+
+namespace nalo {
+
+inline int fail(nalo_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+#define NALO_HIP(ctx, expr)                                                                          \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return nalo::fail(ctx, NALO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+struct ProfScope {               // HIP-event bracket on the ctx stream (only when profiling is enabled)
+    nalo_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(nalo_ctx* ctx, const char* n) : c(ctx), name(n) {
+        if (c->prof_on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ProfScope() {
+        if (a) { (void)hipEventRecord(b, c->stream); c->prof[name].pending.emplace_back(a, b); }
+    }
+};
+
+// kernels_pyramid.hip
+int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
+// kernels_tracker.hip
+int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const float* dId, const float* dHdi);
+int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], const float t[3], const float Ki[9],
+                    float affa, float affb, float b0, float cutoff, float maxEnergy, double out64[64]);
+
+}  // namespace nalo

@@ -1,0 +1,42 @@
+// Deterministic block reduction of N per-lane fp32 values on CDNA4 (wave64):
+//   1. two DPP quad-permute adds (lanes 4k..4k+3 -> every lane of the quad holds the quad sum): no LDS, no ds_bpermute
+//   2. one lane per quad stores its N values to an LDS row (64 rows for a 256-thread block)
+//   3. thread j < N sums column j over the rows in a fixed order and writes out[j]
+// At step 3 all lanes read the same row -> consecutive LDS addresses, conflict free.
+// This replaces the reference's SSE-lane + 3-tier accumulators (OptimizationBackend/MatrixAccumulators.h) and the
+// per-thread accumulator replicas of IndexThreadReduce; the cross-block finish is fp64 in a separate kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nalo {
+
+__device__ __forceinline__ float dpp_quad_xor1(float v) {   // quad_perm [1,0,3,2]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {   // quad_perm [2,3,0,1]
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+// smem: (NT/4) * (N+1) floats. out: N floats (global or LDS). All NT threads must call.
+template <int N, int NT>
+__device__ __forceinline__ void block_reduce_cols(float (&v)[N], float* smem, float* out) {
+    constexpr int NP = N + 1;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { v[i] += dpp_quad_xor1(v[i]); v[i] += dpp_quad_xor2(v[i]); }
+    const int tid = threadIdx.x;
+    if ((tid & 3) == 0) {
+        float* row = smem + (tid >> 2) * NP;
+#pragma unroll
+        for (int i = 0; i < N; ++i) row[i] = v[i];
+    }
+    __syncthreads();
+    if (tid < N) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < NT / 4; ++r) s += smem[r * NP + tid];
+        out[tid] = s;
+    }
+    __syncthreads();
+}
+
+}  // namespace nalo

@@ -1,0 +1,105 @@
+"""GPU parity: pyramid (a1), coarse depth (a2), fused calcRes+calcGS (a3+a4), LM tracking — HIP path through the
+C-ABI vs the CPU oracle on identical seeded inputs. Tolerances are stated per check."""
+import numpy as np
+import pytest
+
+import orc
+from helpers import rel_err, tracker_inputs, true_rel_pose, pose_dist
+from nalo_slam_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(small_window):
+    win = small_window
+    c = binding.Context(win.w, win.h, win.K, n_slots=win.W + 1)
+    for i in range(win.W + 1):
+        c.frame_upload(i, win.images[i])
+    yield c
+    c.close()
+
+
+def test_pyramid_bit_exact(ctx, small_window):
+    """a1: box-mean pyramid + flat-index central differences: same fp32 operations in the same order -> bit exact."""
+    win = small_window
+    dI_ref, ab_ref = orc.make_images(win.images[2], win.levels)
+    L = orc.lib()
+    for l in range(win.levels):
+        dI, ab = ctx.frame_download(2, l)
+        o, n = L.orc_pyr_offset(win.w, win.h, l), (win.w >> l) * (win.h >> l)
+        assert np.array_equal(dI, dI_ref[o:o + n]), "level %d texels differ" % l
+        assert np.array_equal(ab, ab_ref[o:o + n])
+
+
+def test_coarse_depth_and_point_clouds(ctx, small_window):
+    """a2: scatter + sum pyramid + dilation + ordered compaction. Same raster order, values within 1 ulp-ish (1e-6 rel):
+    the scatter sums at most a handful of terms per pixel."""
+    win = small_window
+    Ku, Kv, nid, hdi = tracker_inputs(win)
+    trk = orc.Tracker(win.w, win.h, win.levels, win.K)
+    dI_ref, _ = orc.make_images(win.images[win.W - 1], win.levels)
+    trk.set_ref(dI_ref, Ku, Kv, nid, hdi)
+    ctx.trk_set_ref(win.W - 1, Ku, Kv, nid, hdi)
+    for l in range(win.levels):
+        a = trk.get_pc(l)
+        b = ctx.trk_get_pc(l)
+        assert len(a[0]) == len(b[0]) and len(a[0]) > 0
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])          # u, v: identical order
+        assert rel_err(b[2], a[2]) < 1e-6 and np.array_equal(a[3], b[3])
+        ia, wa = trk.get_depth(l)
+        ib, wb = ctx.trk_get_depth(l)
+        assert rel_err(ib, ia) < 1e-6 and rel_err(wb, wa) < 1e-6
+
+
+@pytest.mark.parametrize("lvl", [0, 1, 3])
+def test_fused_eval_matches_oracle(ctx, small_window, lvl):
+    """a3+a4: stats6, H (8x8), b (8). fp32 pointwise, fp32 block partials, fp64 finish vs the fp64-sum oracle:
+    tolerance 2e-5 relative to max|H| (SURVEY §8d expects <= 1e-5 of ||H||max for fp32 partials)."""
+    win = small_window
+    Ku, Kv, nid, hdi = tracker_inputs(win)
+    trk = orc.Tracker(win.w, win.h, win.levels, win.K)
+    dI_ref, _ = orc.make_images(win.images[win.W - 1], win.levels)
+    dI_new, _ = orc.make_images(win.images[win.W], win.levels)
+    trk.set_ref(dI_ref, Ku, Kv, nid, hdi)
+    ctx.trk_set_ref(win.W - 1, Ku, Kv, nid, hdi)
+    T = orc.se3_exp(orc.se3_log(true_rel_pose(win, win.W - 1, win.W)) * 0.9)
+    aff = np.array([0.98, 1.5], np.float32)
+    orc.lib().orc_set_sum_mode(0)
+    st_o = trk.calc_res(dI_new, lvl, T, aff, 20.0)
+    H_o, b_o = trk.calc_gs(lvl, float(aff[0]), 0.3)
+    st, H, b = ctx.trk_eval(win.W, lvl, T, aff, 0.3, 20.0)
+    assert st[1] == st_o[1] and st[1] > 100                                        # same inlier count
+    assert abs(st[0] - st_o[0]) / st_o[0] < 2e-6
+    assert abs(st[5] - st_o[5]) < 1e-7
+    if lvl == 0:
+        assert rel_err(st[[2, 4]], st_o[[2, 4]]) < 1e-5
+    assert rel_err(H, H_o) < 2e-5 and rel_err(b, b_o) < 2e-5
+    assert np.abs(H - H.T).max() == 0
+    # the reference-order fp32 oracle (SSE lanes + 3-tier) sits inside the same band
+    orc.lib().orc_set_sum_mode(1)
+    trk.calc_res(dI_new, lvl, T, aff, 20.0)
+    H_r, b_r = trk.calc_gs(lvl, float(aff[0]), 0.3)
+    orc.lib().orc_set_sum_mode(0)
+    assert rel_err(H_r, H_o) < 2e-5
+
+
+def test_track_recovers_pose_and_matches_oracle(ctx, small_window):
+    """trackNewestCoarse: LM on the host driving the fused kernel. Pose parity vs oracle: |log(T_gpu^-1 T_ref)| < 1e-5
+    (BASELINE.json target); also recovers the synthetic ground truth to < 2e-3."""
+    win = small_window
+    Ku, Kv, nid, hdi = tracker_inputs(win)
+    trk = orc.Tracker(win.w, win.h, win.levels, win.K)
+    dI_ref, _ = orc.make_images(win.images[win.W - 1], win.levels)
+    dI_new, _ = orc.make_images(win.images[win.W], win.levels)
+    trk.set_ref(dI_ref, Ku, Kv, nid, hdi)
+    ctx.trk_set_ref(win.W - 1, Ku, Kv, nid, hdi)
+    Ttrue = true_rel_pose(win, win.W - 1, win.W)
+    T0 = orc.se3_exp(orc.se3_log(Ttrue) * 0.8)
+    ok_o, T_o, aff_o, lr_o, _ = trk.track(dI_new, T0, [0, 0], [0, 0], [1, 1], win.levels - 1)
+    ok, T, aff, lr, lf, nev = ctx.trk_track(win.W, T0, [0, 0], [0, 0], [1, 1], win.levels - 1)
+    assert ok == 1 and ok_o == 1 and nev > 4
+    assert pose_dist(T, T_o) < 1e-5
+    assert np.abs(aff - aff_o).max() < 1e-3
+    assert pose_dist(T, Ttrue) < 2e-3
+    assert np.allclose(lr[:win.levels], lr_o[:win.levels], rtol=1e-4)
