@@ -1,0 +1,55 @@
+// Device-side layout of the BA window (shared by kernels_ba.hip and host_ba.hip).
+//
+// Points are sorted by host frame; every host segment is padded to a multiple of kBlk so that one 256-thread
+// block only holds points of one host (blk_host[b]). One residual slot per (target t, point d): arrays are
+// [W][Ppad], t-major, so a wave reads consecutive points of one target: coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace nalo {
+
+constexpr int kBlk = 256;            // points per linearize block
+constexpr int kTopVals = 93;         // 91 AccumulatorApprox entries + residual count + energy
+constexpr int kTopStride = 96;       // floats per (block, target) partial
+constexpr int kPreStride = 40;       // floats per (host,target) precalc record
+
+// residual slot state byte
+enum : uint8_t { RS_STATE_MASK = 3, RS_EXISTS = 4, RS_ACTIVE = 8, RS_LINEARIZED = 16 };
+// point flags
+enum : uint8_t { PT_VALID = 1, PT_MARG = 2, PT_HAS_PRIOR = 4 };
+
+// precalc record (FrameFramePrecalc, reference src/FullSystem/HessianBlocks.h:80-107 + adHTdeltaF):
+//  [0..8] PRE_KRKiTll  [9..11] PRE_KtTll  [12..20] PRE_RTll_0  [21..23] PRE_tTll_0  [24,25] PRE_aff_mode  [26] PRE_b0_mode
+//  [27..34] adHTdeltaF[h + t*W]  (EnergyFunctional.cpp:175-181)
+struct BADev {
+    int W, P, Ppad, nblocks, w, h;
+    float fxl, fyl, cxl, cyl, fxli, fyli;       // CalibHessian::value_scaledf / value_scaledi
+    float cDelta[4];                            // EnergyFunctional::cDeltaF
+    const float4* img[16];                      // level-0 {I,dx,dy,0} of every window frame
+    const float* pre;                           // [W*W][kPreStride], index h*W + t
+    float* frameTH;                             // [W] frameEnergyTH (device resident, updated by the quantile kernel)
+    const int* blk_host;                        // [nblocks]
+    // points
+    float4* pt_geo;                             // {u, v, idepth, idepth_zero}
+    const float4 *pt_col0, *pt_col1, *pt_w0, *pt_w1;
+    float* pt_prior;                            // EFPoint::priorF
+    uint8_t* pt_flags;
+    float4* pt_acc;                             // {Hdd_accAF, bd_accAF, HdiF, bdSumF}
+    float4* pt_hcd;                             // Hcd_accAF
+    uint8_t* pt_ngood;
+    float* pt_step;
+    float* pt_backup;
+    float* pt_relbs;                            // max relBS over this pass' active residuals (fix mode)
+    // residual slots [W][Ppad]
+    uint8_t* rs_state;
+    float2* rs_energy;                          // {state_energy, state_NewEnergy}
+    float4 *rs_jp0, *rs_jp1;                    // EFResidual::JpJdF
+    float4* rs_cpt;                             // {Ku, Kv, new_idepth, relBS} (centerProjectedTo), written when fix/marg
+    float* en_new;                              // [Ppad] state_NewEnergyWithOutlier of residuals targeting frame W-1 (-1 = none)
+    // partials
+    float* top_partial;                         // [nblocks][W][kTopStride]
+    float* sc_partial;                          // [nblocks][NPL*NPL]
+};
+
+}  // namespace nalo

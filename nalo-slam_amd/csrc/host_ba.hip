@@ -1,26 +1,752 @@
-// placeholder: BA window (filled in next milestone)
+// Host mirror of the back-end around the BA kernels: the parts of FullSystem::optimize / EnergyFunctional that the
+// reference keeps as tiny fp64 host work stay on the host here too (frame states, SE3, precalc, adjoints, (8W+4)^2
+// solve, nullspace projection); everything that scales with points/residuals runs in kernels_ba.hip.
+// Reference paths relative to src/.
 #include "nalo_internal.h"
-namespace nalo { struct BAWindow { int W = 0; }; void ba_destroy(nalo_ctx* c) { delete c->ba; c->ba = nullptr; } }
-#define STUB(name, ...) int name(__VA_ARGS__) { return NALO_ERR_UNSUPPORTED; }
-extern "C" {
-STUB(nalo_ba_set_window, nalo_ctx*, int, const nalo_frame_state*, const double*, const double*)
-STUB(nalo_ba_set_points, nalo_ctx*, int, const int*, const float*, const float*, const float*, const float*, const float*, const float*, const int*)
-STUB(nalo_ba_set_residuals, nalo_ctx*, const uint8_t*)
-STUB(nalo_ba_set_prior, nalo_ctx*, const double*, const double*)
-STUB(nalo_ba_get_prior, nalo_ctx*, double*, double*)
-STUB(nalo_ba_linearize, nalo_ctx*, int, double*)
-STUB(nalo_ba_accumulate, nalo_ctx*, int, double*, double*)
-STUB(nalo_ba_accumulate_sc, nalo_ctx*, int, double*, double*)
-STUB(nalo_ba_solve_system, nalo_ctx*, int, double, double*)
-STUB(nalo_ba_backup_state, nalo_ctx*)
-STUB(nalo_ba_do_step, nalo_ctx*, float, float, float, float, float, int*)
-STUB(nalo_ba_optimize, nalo_ctx*, int, int, double*)
-STUB(nalo_ba_marginalize_points, nalo_ctx*, const uint8_t*, double*, double*, double*, double*)
-STUB(nalo_ba_get_frames, nalo_ctx*, nalo_frame_state*, double*, double*)
-STUB(nalo_ba_get_points, nalo_ctx*, float*, float*, float*, float*, float*, float*, float*, float*)
-STUB(nalo_ba_get_residuals, nalo_ctx*, int8_t*, uint8_t*, float*, float*, float*)
-STUB(nalo_ba_get_acc13, nalo_ctx*, double*)
-STUB(nalo_ba_counts, nalo_ctx*, int*, int*, int*)
-STUB(nalo_ba_set_allreduce, nalo_ctx*, nalo_allreduce_fn, void*)
-STUB(nalo_dense_make_map, nalo_ctx*, int, const float*, float, const double*, int, int*, int*, int*, float*, float*, uint8_t*, int*, int*)
+#include "ba_device.h"
+
+namespace nalo {
+
+void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly);
+void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix);
+void ba_launch_reset_oob(hipStream_t s, const BADev& B);
+void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc);
+void ba_launch_stitch(hipStream_t s, const double* S, const double* M, int nb, int n1, int m, double* Tm, double* H);
+void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc);
+void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
+void ba_launch_energy_th(hipStream_t s, const BADev& B);
+
+struct HostFrame {
+    int slot = 0, frameID = 0;
+    SE3 evalPT, PRE_worldToCam, PRE_camToWorld;
+    double state[10] = {}, state_zero[10] = {}, state_scaled[10] = {}, step[10] = {}, state_backup[10] = {};
+    float ab_exposure = 1.f, frameEnergyTH = 8 * 8 * kPatternNum;
+    double prior[8] = {}, delta[8] = {}, delta_prior[8] = {};
+    double ns_pose[6][6] = {}, ns_scale[6] = {};
+};
+
+struct BAWindow {
+    int W = 0, P = 0, Ppad = 0, nblocks = 0, n = 0, n1 = 0, T = 1, NPL = 16;
+    // CalibHessian (FullSystem/HessianBlocks.h:364-395)
+    double c_value[4] = {}, c_value_zero[4] = {}, c_value_scaled[4] = {}, c_step[4] = {}, c_value_backup[4] = {};
+    float c_scaledf[4] = {}, c_scaledi[4] = {};
+    std::vector<HostFrame> frames;
+    std::vector<double> adHost, adTarget, HM, bM, lastX, Sproj;
+    std::vector<float> adHostF, adTargetF, adHTdeltaF;
+    float cDeltaF[4] = {};
+    bool proj_valid = false;
+    int resInA = 0, resInL = 0, resInM = 0;
+    // permutation: device slot d -> caller point (or -1), caller point -> device slot
+    std::vector<int> d2p, p2d, blk_host_h, host_blk_h;
+    std::vector<uint8_t> flags_h;
+    // device
+    BADev dev{};
+    DevBuf<float> pre, frameTH, pt_prior, pt_step, pt_backup, pt_relbs, en_new, top_partial, sc_partial, xad, step_partial;
+    DevBuf<float4> pt_geo, pt_col0, pt_col1, pt_w0, pt_w1, pt_acc, pt_hcd, rs_jp0, rs_jp1, rs_cpt;
+    DevBuf<float2> rs_energy;
+    DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
+    DevBuf<int> blk_host, host_blk;
+    DevBuf<double> acc13, misc, G, S_top, S_sc, Tm, stitched;     // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | scalars(8)]
+    double* stitched_host = nullptr;                                // pinned mirror
+    float* up_host = nullptr;                                       // pinned upload staging (precalc, xAd)
+    size_t up_cap = 0;
+    bool have_lin = false, have_sc = false, stitched_top = false, stitched_sc = false, points_set = false, res_set = false;
+    int sc_shift = -1;
+    nalo_allreduce_fn hook = nullptr;
+    void* hook_user = nullptr;
+    bool never_break = false;
+};
+
+void ba_destroy(nalo_ctx* c) {
+    BAWindow* w = c->ba;
+    if (!w) return;
+    w->pre.release(); w->frameTH.release(); w->pt_prior.release(); w->pt_step.release(); w->pt_backup.release(); w->pt_relbs.release();
+    w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
+    w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
+    w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
+    w->blk_host.release(); w->host_blk.release(); w->acc13.release(); w->misc.release(); w->G.release(); w->S_top.release(); w->S_sc.release();
+    w->Tm.release(); w->stitched.release();
+    if (w->stitched_host) (void)hipHostFree(w->stitched_host);
+    if (w->up_host) (void)hipHostFree(w->up_host);
+    delete w;
+    c->ba = nullptr;
 }
+
+// ---------------------------------------------------------------------------------------------- frame / calib state
+static void calib_set_value(BAWindow& w, const double v[4]) {            // CalibHessian::setValue
+    for (int i = 0; i < 4; ++i) w.c_value[i] = v[i];
+    w.c_value_scaled[0] = kScaleF * v[0]; w.c_value_scaled[1] = kScaleF * v[1]; w.c_value_scaled[2] = kScaleC * v[2]; w.c_value_scaled[3] = kScaleC * v[3];
+    for (int i = 0; i < 4; ++i) w.c_scaledf[i] = (float)w.c_value_scaled[i];
+    w.c_scaledi[0] = 1.0f / w.c_scaledf[0]; w.c_scaledi[1] = 1.0f / w.c_scaledf[1];
+    w.c_scaledi[2] = -w.c_scaledf[2] / w.c_scaledf[0]; w.c_scaledi[3] = -w.c_scaledf[3] / w.c_scaledf[1];
+}
+static void frame_set_state(HostFrame& f, const double st[10]) {          // FrameHessian::setState (HessianBlocks.h:208-222)
+    std::memcpy(f.state, st, sizeof(f.state));
+    for (int i = 0; i < 3; ++i) f.state_scaled[i] = kScaleXiTrans * st[i];
+    for (int i = 3; i < 6; ++i) f.state_scaled[i] = kScaleXiRot * st[i];
+    f.state_scaled[6] = kScaleA * st[6]; f.state_scaled[7] = kScaleB * st[7]; f.state_scaled[8] = kScaleA * st[8]; f.state_scaled[9] = kScaleB * st[9];
+    f.PRE_worldToCam = se3_exp(f.state_scaled) * f.evalPT;
+    f.PRE_camToWorld = f.PRE_worldToCam.inverse();
+}
+static void frame_set_state_zero(HostFrame& f, const double sz[10]) {     // FrameHessian::setStateZero (HessianBlocks.cpp:73-106)
+    std::memcpy(f.state_zero, sz, sizeof(f.state_zero));
+    const SE3 inv = f.evalPT.inverse();
+    for (int i = 0; i < 6; ++i) {
+        double eps[6] = {0, 0, 0, 0, 0, 0}, lp[6], lm[6];
+        eps[i] = 1e-3; const SE3 P = (f.evalPT * se3_exp(eps)) * inv;
+        eps[i] = -1e-3; const SE3 M = (f.evalPT * se3_exp(eps)) * inv;
+        se3_log(P, lp); se3_log(M, lm);
+        for (int r = 0; r < 6; ++r) f.ns_pose[i][r] = (lp[r] - lm[r]) / (2e-3);
+    }
+    SE3 P = f.evalPT, M = f.evalPT;
+    for (int i = 0; i < 3; ++i) { P.m[i * 4 + 3] *= 1.00001; M.m[i * 4 + 3] /= 1.00001; }
+    double lp[6], lm[6];
+    se3_log(P * inv, lp); se3_log(M * inv, lm);
+    for (int r = 0; r < 6; ++r) f.ns_scale[r] = (lp[r] - lm[r]) / (2e-3);
+}
+static void frame_take_data(HostFrame& f) {                               // EFFrame::takeData + FrameHessian::getPrior
+    double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (f.frameID == 0) { for (int i = 0; i < 3; ++i) p[i] = kInitialTransPrior; for (int i = 3; i < 6; ++i) p[i] = kInitialRotPrior; p[6] = kInitialAffPrior; p[7] = kInitialAffPrior; }
+    else { p[6] = kAffineOptModeA; p[7] = kAffineOptModeB; }
+    for (int i = 0; i < 8; ++i) { f.prior[i] = p[i]; f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
+}
+
+// EnergyFunctional::setAdjointsF (OptimizationBackend/EnergyFunctional.cpp:46-106) + the S matrices of the stitch
+static int set_adjoints(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    const int W = w.W, n1 = w.n1;
+    w.adHost.assign((size_t)W * W * 64, 0.0); w.adTarget.assign((size_t)W * W * 64, 0.0);
+    w.adHostF.resize((size_t)W * W * 64); w.adTargetF.resize((size_t)W * W * 64);
+    for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
+        const HostFrame &host = w.frames[h], &target = w.frames[t];
+        const SE3 h2t = target.evalPT * host.evalPT.inverse();
+        double Ad[36]; h2t.adjoint(Ad);
+        double* AH = &w.adHost[(size_t)(h + t * W) * 64];
+        double* AT = &w.adTarget[(size_t)(h + t * W) * 64];
+        for (int i = 0; i < 8; ++i) { AH[i * 8 + i] = 1; AT[i * 8 + i] = 1; }
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) AH[i * 8 + j] = -Ad[j * 6 + i];
+        double a[2];
+        aff_from_to(host.ab_exposure, target.ab_exposure, host.state_zero[6] * kScaleA, host.state_zero[7] * kScaleB,
+                    target.state_zero[6] * kScaleA, target.state_zero[7] * kScaleB, a);
+        const float affLL0 = (float)a[0];
+        AT[6 * 8 + 6] = -affLL0; AH[6 * 8 + 6] = affLL0; AT[7 * 8 + 7] = -1; AH[7 * 8 + 7] = affLL0;
+        for (int j = 0; j < 8; ++j) {
+            for (int i = 0; i < 3; ++i) { AH[i * 8 + j] *= kScaleXiTrans; AT[i * 8 + j] *= kScaleXiTrans; }
+            for (int i = 3; i < 6; ++i) { AH[i * 8 + j] *= kScaleXiRot; AT[i * 8 + j] *= kScaleXiRot; }
+            AH[6 * 8 + j] *= kScaleA; AT[6 * 8 + j] *= kScaleA; AH[7 * 8 + j] *= kScaleB; AT[7 * 8 + j] *= kScaleB;
+        }
+        for (int k = 0; k < 64; ++k) { w.adHostF[(size_t)(h + t * W) * 64 + k] = (float)AH[k]; w.adTargetF[(size_t)(h + t * W) * 64 + k] = (float)AT[k]; }
+    }
+    // S_top[bin = h + t*W][n1][13]: cols 0-3 calib, 4-11 the local (xi,a,b) block through adHost (rows of h) / adTarget (rows of t), col 12 -> row n (b vector)
+    std::vector<double> St((size_t)W * W * n1 * 13, 0.0);
+    for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
+        if (h == t) continue;
+        double* S = &St[(size_t)(h + t * W) * n1 * 13];
+        const double* AH = &w.adHost[(size_t)(h + t * W) * 64];
+        const double* AT = &w.adTarget[(size_t)(h + t * W) * 64];
+        for (int i = 0; i < 4; ++i) S[i * 13 + i] = 1;
+        for (int i = 0; i < 8; ++i) for (int k = 0; k < 8; ++k) { S[(4 + 8 * h + i) * 13 + 4 + k] = AH[i * 8 + k]; S[(4 + 8 * t + i) * 13 + 4 + k] = AT[i * 8 + k]; }
+        S[(size_t)w.n * 13 + 12] = 1;
+    }
+    // S_sc[host i][n1][NPL]: compact slot g <-> target j; rows of i get adHost[i + j*W] per slot, rows of j get adTarget[i + j*W]; Hcd cols -> calib rows; bdSum col -> row n
+    const int NPL = w.NPL;
+    std::vector<double> Ss((size_t)W * n1 * NPL, 0.0);
+    for (int i = 0; i < W; ++i) {
+        double* S = &Ss[(size_t)i * n1 * NPL];
+        for (int g = 0; g < W - 1; ++g) {
+            const int j = g < i ? g : g + 1;
+            const double* AH = &w.adHost[(size_t)(i + j * W) * 64];
+            const double* AT = &w.adTarget[(size_t)(i + j * W) * 64];
+            for (int r = 0; r < 8; ++r) for (int k = 0; k < 8; ++k) { S[(size_t)(4 + 8 * i + r) * NPL + 8 * g + k] = AH[r * 8 + k]; S[(size_t)(4 + 8 * j + r) * NPL + 8 * g + k] = AT[r * 8 + k]; }
+        }
+        for (int k = 0; k < 4; ++k) S[(size_t)k * NPL + 8 * (W - 1) + k] = 1;
+        S[(size_t)w.n * NPL + 8 * (W - 1) + 4] = 1;
+    }
+    NALO_HIP(c, w.S_top.reserve(St.size())); NALO_HIP(c, w.S_sc.reserve(Ss.size()));
+    NALO_HIP(c, hipMemcpyAsync(w.S_top.p, St.data(), St.size() * 8, hipMemcpyHostToDevice, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(w.S_sc.p, Ss.data(), Ss.size() * 8, hipMemcpyHostToDevice, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    w.proj_valid = false;
+    return NALO_OK;
+}
+
+// FullSystem::setPrecalcValues = FrameFramePrecalc::set for all pairs (HessianBlocks.cpp:192-222) + EnergyFunctional::setDeltaF (:171-194)
+static int set_precalc(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    const int W = w.W;
+    w.adHTdeltaF.resize((size_t)W * W * 8);
+    for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
+        const int idx = h + t * W;
+        float dh[8], dt[8];
+        for (int i = 0; i < 8; ++i) { dh[i] = (float)(w.frames[h].state[i] - w.frames[h].state_zero[i]); dt[i] = (float)(w.frames[t].state[i] - w.frames[t].state_zero[i]); }
+        for (int j = 0; j < 8; ++j) {
+            float s1 = 0, s2 = 0;
+            for (int i = 0; i < 8; ++i) { s1 += dh[i] * w.adHostF[(size_t)idx * 64 + i * 8 + j]; s2 += dt[i] * w.adTargetF[(size_t)idx * 64 + i * 8 + j]; }
+            w.adHTdeltaF[(size_t)idx * 8 + j] = s1 + s2;
+        }
+    }
+    for (int i = 0; i < 4; ++i) w.cDeltaF[i] = (float)(w.c_value[i] - w.c_value_zero[i]);
+    for (auto& f : w.frames) frame_take_data(f);
+    const size_t nfl = (size_t)W * W * kPreStride;
+    if (w.up_cap < nfl + 64) { if (w.up_host) (void)hipHostFree(w.up_host); NALO_HIP(c, hipHostMalloc((void**)&w.up_host, (nfl + 64 + (size_t)W * W * 8) * 4)); w.up_cap = nfl + 64; }
+    float* rec = w.up_host;
+    const float fx = w.c_scaledf[0], fy = w.c_scaledf[1], cx = w.c_scaledf[2], cy = w.c_scaledf[3];
+    const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1.0f / fx, 0, -cx / fx, 0, 1.0f / fy, -cy / fy, 0, 0, 1};
+    for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
+        float* o = rec + (size_t)(h * W + t) * kPreStride;
+        std::memset(o, 0, kPreStride * 4);
+        const HostFrame &host = w.frames[h], &target = w.frames[t];
+        const SE3 l0 = target.evalPT * host.evalPT.inverse();
+        const SE3 ll = target.PRE_worldToCam * host.PRE_camToWorld;
+        float R[9], tt[3], KR[9];
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) { o[12 + i * 3 + j] = (float)l0.R(i, j); R[i * 3 + j] = (float)ll.R(i, j); } o[21 + i] = (float)l0.t(i); tt[i] = (float)ll.t(i); }
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) KR[i * 3 + j] = K[i * 3] * R[j] + K[i * 3 + 1] * R[3 + j] + K[i * 3 + 2] * R[6 + j];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[i * 3 + j] = KR[i * 3] * Ki[j] + KR[i * 3 + 1] * Ki[3 + j] + KR[i * 3 + 2] * Ki[6 + j];
+        for (int i = 0; i < 3; ++i) o[9 + i] = K[i * 3] * tt[0] + K[i * 3 + 1] * tt[1] + K[i * 3 + 2] * tt[2];
+        double a[2];
+        aff_from_to(host.ab_exposure, target.ab_exposure, host.state_scaled[6], host.state_scaled[7], target.state_scaled[6], target.state_scaled[7], a);
+        o[24] = (float)a[0]; o[25] = (float)a[1]; o[26] = (float)(host.state_zero[7] * kScaleB);
+        for (int k = 0; k < 8; ++k) o[27 + k] = w.adHTdeltaF[(size_t)(h + t * W) * 8 + k];
+    }
+    NALO_HIP(c, w.pre.reserve(nfl));
+    NALO_HIP(c, hipMemcpyAsync(w.pre.p, rec, nfl * 4, hipMemcpyHostToDevice, c->stream));
+    w.dev.pre = w.pre.p;
+    w.dev.fxl = fx; w.dev.fyl = fy; w.dev.cxl = cx; w.dev.cyl = cy; w.dev.fxli = w.c_scaledi[0]; w.dev.fyli = w.c_scaledi[1];
+    for (int i = 0; i < 4; ++i) w.dev.cDelta[i] = w.cDeltaF[i];
+    return NALO_OK;
+}
+
+static int upload_frame_th(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    std::vector<float> th(w.W);
+    for (int i = 0; i < w.W; ++i) th[i] = w.frames[i].frameEnergyTH;
+    NALO_HIP(c, w.frameTH.reserve(w.W));
+    NALO_HIP(c, hipMemcpy(w.frameTH.p, th.data(), w.W * 4, hipMemcpyHostToDevice));
+    w.dev.frameTH = w.frameTH.p;
+    return NALO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- pipeline pieces
+static int linearize_async(nalo_ctx* c, int mode, int fix) {
+    BAWindow& w = *c->ba;
+    {
+        ProfScope ps(c, "ba_linearize");
+        ba_launch_linearize(c->stream, w.dev, mode, fix);
+    }
+    if (mode == 0) ba_launch_energy_th(c->stream, w.dev);
+    w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+static int sc_async(nalo_ctx* c, int shift, float margScale, int margOnly) {
+    BAWindow& w = *c->ba;
+    ProfScope ps(c, "ba_sc");
+    ba_launch_sc(c->stream, w.dev, w.T, shift, margScale, margOnly);
+    w.have_sc = true; w.sc_shift = shift; w.stitched_sc = false;
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+// fp64 finish + stitch of whichever system is not stitched yet; then (optionally) the cross-rank sum and the D2H copy
+static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
+    BAWindow& w = *c->ba;
+    const int n1 = w.n1, NPL = w.NPL, W = w.W;
+    const size_t blk = (size_t)n1 * n1;
+    bool did = false;
+    {
+        ProfScope ps(c, "ba_reduce");
+        const bool top = want_top && !w.stitched_top, sc = want_sc && !w.stitched_sc;
+        if (top || sc) ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.misc.p, w.G.p, top, sc);
+        if (top) { ba_launch_stitch(c->stream, w.S_top.p, w.acc13.p, W * W, n1, 13, w.Tm.p, w.stitched.p); w.stitched_top = true; did = true; }
+        if (sc) { ba_launch_stitch(c->stream, w.S_sc.p, w.G.p, W, n1, NPL, w.Tm.p, w.stitched.p + blk); w.stitched_sc = true; did = true; }
+    }
+    NALO_HIP(c, hipGetLastError());
+    if (did) {
+        // scalars: [0] = sum energy, [1] = resInA   (misc holds {count, energy} per bin)
+        // computed on the host from misc after the copy for a single GPU; with a hook the per-rank sums are appended first
+        NALO_HIP(c, hipMemcpyAsync(w.stitched.p + 2 * blk, w.misc.p, (size_t)2 * W * W * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (w.hook) {
+            NALO_HIP(c, hipStreamSynchronize(c->stream));
+            w.hook(w.hook_user, w.stitched.p, (int)(2 * blk + 2 * W * W));
+        }
+        NALO_HIP(c, hipMemcpyAsync(w.stitched_host, w.stitched.p, (2 * blk + 2 * W * W) * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    return NALO_OK;
+}
+static void unpack_system(const BAWindow& w, const double* Ht, double* H, double* b) {
+    const int n = w.n, n1 = w.n1;
+    for (int r = 0; r < n; ++r) { for (int cc = 0; cc < n; ++cc) H[(size_t)r * n + cc] = Ht[(size_t)r * n1 + cc]; b[r] = Ht[(size_t)r * n1 + n]; }
+}
+static void misc_totals(const BAWindow& w, double* energy, int* nres) {
+    const double* m = w.stitched_host + 2 * (size_t)w.n1 * w.n1;
+    double e = 0, cnt = 0;
+    for (int i = 0; i < w.W * w.W; ++i) { cnt += m[2 * i]; e += m[2 * i + 1]; }
+    if (energy) *energy = e;
+    if (nres) *nres = (int)(cnt + 0.5);
+}
+
+// orthogonalize(x) (EnergyFunctional.cpp:719-773) with the nullspaces of FullSystem::getNullspaces (FullSystemOptimize.cpp:658-712):
+// x -= U U^T x, U = left singular vectors of the normalised [pose(6) | scale] nullspace matrix above delta * sigma_max.
+static void build_projector(BAWindow& w) {
+    const int W = w.W, n = w.n, m = 7;
+    std::vector<double> N((size_t)n * m, 0.0);
+    for (int i = 0; i < 6; ++i) for (int f = 0; f < W; ++f) for (int r = 0; r < 6; ++r)
+        N[(size_t)(4 + f * 8 + r) * m + i] = w.frames[f].ns_pose[i][r] * (r < 3 ? (1.0f / kScaleXiTrans) : (1.0f / kScaleXiRot));
+    for (int f = 0; f < W; ++f) for (int r = 0; r < 6; ++r) N[(size_t)(4 + f * 8 + r) * m + 6] = w.frames[f].ns_scale[r] * (r < 3 ? (1.0f / kScaleXiTrans) : (1.0f / kScaleXiRot));
+    for (int cc = 0; cc < m; ++cc) { double s = 0; for (int r = 0; r < n; ++r) s += N[(size_t)r * m + cc] * N[(size_t)r * m + cc]; s = std::sqrt(s); if (s > 0) for (int r = 0; r < n; ++r) N[(size_t)r * m + cc] /= s; }
+    double G[49], V[49], wv[7];
+    for (int a = 0; a < m; ++a) for (int cc = 0; cc < m; ++cc) { double s = 0; for (int r = 0; r < n; ++r) s += N[(size_t)r * m + a] * N[(size_t)r * m + cc]; G[a * m + cc] = s; }
+    sym_eig(m, G, V, wv);
+    double maxSv = 0;
+    for (int i = 0; i < m; ++i) maxSv = std::max(maxSv, wv[i] > 0 ? std::sqrt(wv[i]) : 0.0);
+    w.Sproj.assign((size_t)n * m, 0.0);                 // columns u_i (zero column if dropped)
+    for (int i = 0; i < m; ++i) {
+        const double sv = wv[i] > 0 ? std::sqrt(wv[i]) : 0.0;
+        if (!(sv > kSolverModeDelta * maxSv)) continue;
+        for (int r = 0; r < n; ++r) { double s = 0; for (int cc = 0; cc < m; ++cc) s += N[(size_t)r * m + cc] * V[cc * m + i]; w.Sproj[(size_t)r * m + i] = s / sv; }
+    }
+    w.proj_valid = true;
+}
+
+static int do_accumulate_top(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    if (!w.have_lin) return fail(c, NALO_ERR_STATE, "accumulate before linearize");
+    return stitch_and_fetch(c, true, false);
+}
+static int do_accumulate_sc(nalo_ctx* c, int shift) {
+    BAWindow& w = *c->ba;
+    if (!w.have_lin) return fail(c, NALO_ERR_STATE, "accumulate_sc before linearize");
+    if (!w.have_sc || w.sc_shift != shift) { int rc = sc_async(c, shift, 1.f, 0); if (rc) return rc; }
+    return stitch_and_fetch(c, false, true);
+}
+static void prior_system(const BAWindow& w, double* H, double* b) {         // accumulateLF with usePrior (AccumulatedTopHessian.cpp:292-302)
+    const int n = w.n;
+    std::fill(H, H + (size_t)n * n, 0.0); std::fill(b, b + n, 0.0);
+    for (int i = 0; i < 4; ++i) { H[(size_t)i * n + i] += kInitialCalibHessian; b[i] += kInitialCalibHessian * (double)w.cDeltaF[i]; }
+    for (int h = 0; h < w.W; ++h) for (int i = 0; i < 8; ++i) { const int d = 4 + h * 8 + i; H[(size_t)d * n + d] += w.frames[h].prior[i]; b[d] += w.frames[h].prior[i] * w.frames[h].delta_prior[i]; }
+}
+
+static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out) {
+    BAWindow& w = *c->ba;
+    const int W = w.W, n = w.n, n1 = w.n1;
+    (void)lambda; lambda = 1e-5;                                            // SOLVER_FIX_LAMBDA (EnergyFunctional.cpp:779)
+    if (!w.have_lin) return fail(c, NALO_ERR_STATE, "solve_system before linearize");
+    if (!w.have_sc || w.sc_shift != 1) { int rc = sc_async(c, 1, 1.f, 0); if (rc) return rc; }
+    int rc = stitch_and_fetch(c, true, true);
+    if (rc) return rc;
+    std::vector<double> HA((size_t)n * n), bA(n), Hsc((size_t)n * n), bsc(n), HL((size_t)n * n), bL(n), HF((size_t)n * n), bF(n), x(n), delta(n);
+    unpack_system(w, w.stitched_host, HA.data(), bA.data());
+    unpack_system(w, w.stitched_host + (size_t)n1 * n1, Hsc.data(), bsc.data());
+    misc_totals(w, nullptr, &w.resInA);
+    prior_system(w, HL.data(), bL.data());
+    for (int i = 0; i < 4; ++i) delta[i] = (double)w.cDeltaF[i];
+    for (int h = 0; h < W; ++h) for (int i = 0; i < 8; ++i) delta[4 + 8 * h + i] = w.frames[h].delta[i];
+    for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += w.HM[(size_t)i * n + j] * delta[j]; bF[i] = bL[i] + (w.bM[i] + s) + bA[i] - bsc[i]; }
+    for (size_t i = 0; i < (size_t)n * n; ++i) HF[i] = HL[i] + w.HM[i] + HA[i];
+    for (int i = 0; i < n; ++i) HF[(size_t)i * n + i] *= (1 + lambda);
+    { const double f = 1.0 / (1 + lambda); for (size_t i = 0; i < (size_t)n * n; ++i) HF[i] -= Hsc[i] * f; }
+    std::vector<double> sv(n), Hs((size_t)n * n), bs(n);
+    for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * n + i] + 10);
+    for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = sv[i] * HF[(size_t)i * n + j] * sv[j]; bs[i] = sv[i] * bF[i]; }
+    ldlt_solve(n, Hs.data(), bs.data(), x.data());
+    for (int i = 0; i < n; ++i) x[i] *= sv[i];
+    if (iteration >= 2) {                                                   // SOLVER_ORTHOGONALIZE_X_LATER (:898-902)
+        if (!w.proj_valid) build_projector(w);
+        double coef[7];
+        for (int k = 0; k < 7; ++k) { double s = 0; for (int r = 0; r < n; ++r) s += w.Sproj[(size_t)r * 7 + k] * x[r]; coef[k] = s; }
+        for (int r = 0; r < n; ++r) { double s = 0; for (int k = 0; k < 7; ++k) s += w.Sproj[(size_t)r * 7 + k] * coef[k]; x[r] -= s; }
+    }
+    w.lastX = x;
+    if (x_out) std::memcpy(x_out, x.data(), n * 8);
+    // resubstituteF_MT (:263-289)
+    for (int i = 0; i < 4; ++i) w.c_step[i] = -x[i];
+    float* xAd = w.up_host + (size_t)W * W * kPreStride + 64;
+    float* xc = w.up_host + (size_t)W * W * kPreStride;
+    std::vector<float> xF(n);
+    for (int i = 0; i < n; ++i) xF[i] = (float)x[i];
+    for (int i = 0; i < 4; ++i) xc[i] = xF[i];
+    for (int h = 0; h < W; ++h) {
+        for (int i = 0; i < 8; ++i) w.frames[h].step[i] = -x[4 + 8 * h + i];
+        w.frames[h].step[8] = w.frames[h].step[9] = 0;
+        for (int t = 0; t < W; ++t) {
+            const float *AH = &w.adHostF[(size_t)(h + W * t) * 64], *AT = &w.adTargetF[(size_t)(h + W * t) * 64];
+            for (int j = 0; j < 8; ++j) { float s1 = 0, s2 = 0; for (int i = 0; i < 8; ++i) { s1 += xF[4 + 8 * h + i] * AH[i * 8 + j]; s2 += xF[4 + 8 * t + i] * AT[i * 8 + j]; } xAd[(size_t)(W * h + t) * 8 + j] = s1 + s2; }
+        }
+    }
+    NALO_HIP(c, w.xad.reserve((size_t)W * W * 8 + 64));
+    NALO_HIP(c, hipMemcpyAsync(w.xad.p, xc, ((size_t)W * W * 8 + 64) * 4, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, "ba_resub");
+        ba_launch_resub(c->stream, w.dev, w.xad.p + 64, w.xad.p);
+    }
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+
+static void backup_state(BAWindow& w) {
+    std::memcpy(w.c_value_backup, w.c_value, sizeof(w.c_value));
+    for (auto& f : w.frames) std::memcpy(f.state_backup, f.state, sizeof(f.state));
+}
+static int do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float fD, int* canbreak) {
+    BAWindow& w = *c->ba;
+    const double pf[10] = {fT, fT, fT, fR, fR, fR, fA, fA, fA, fA};
+    float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
+    double v[4];
+    for (int i = 0; i < 4; ++i) v[i] = w.c_value_backup[i] + fC * w.c_step[i];
+    calib_set_value(w, v);
+    for (auto& fh : w.frames) {
+        double st[10];
+        for (int i = 0; i < 10; ++i) st[i] = fh.state_backup[i] + pf[i] * fh.step[i];
+        frame_set_state(fh, st);
+        sumA += fh.step[6] * fh.step[6]; sumB += fh.step[7] * fh.step[7];
+        sumT += fh.step[0] * fh.step[0] + fh.step[1] * fh.step[1] + fh.step[2] * fh.step[2];
+        sumR += fh.step[3] * fh.step[3] + fh.step[4] * fh.step[4] + fh.step[5] * fh.step[5];
+    }
+    NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
+    double* out3 = w.stitched.p + 2 * (size_t)w.n1 * w.n1 + 2 * w.W * w.W;      // scratch tail of the stitched buffer
+    ba_launch_step(c->stream, w.dev, fD, w.step_partial.p, out3);
+    int rc = set_precalc(c);
+    if (rc) return rc;
+    double s3[3];
+    NALO_HIP(c, hipMemcpyAsync(s3, out3, 24, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    const float numID = (float)s3[2];
+    const float sumNID = numID > 0 ? (float)(s3[1] / numID) : 0.f;
+    sumA /= w.W; sumB /= w.W; sumR /= w.W; sumT /= w.W;
+    const float th = 1.2f;                                                  // setting_thOptIterations
+    if (canbreak) *canbreak = std::sqrt(sumA) < 0.0005 * th && std::sqrt(sumB) < 0.00005 * th && std::sqrt(sumR) < 0.00005 * th && std::sqrt(sumT) * sumNID < 0.00005 * th;
+    w.have_lin = false; w.have_sc = false;
+    return NALO_OK;
+}
+
+}  // namespace nalo
+
+using namespace nalo;
+
+extern "C" {
+
+int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const double calib[4], const double calib_zero[4]) {
+    if (!c || !frames || !calib || W < 2 || W > NALO_MAX_WINDOW) return fail(c, NALO_ERR_ARG, "nalo_ba_set_window: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    if (!c->ba) c->ba = new BAWindow();
+    BAWindow& w = *c->ba;
+    if (w.W != W) { w.points_set = false; w.res_set = false; }
+    w.W = W; w.n = 8 * W + 4; w.n1 = w.n + 1;
+    w.T = (8 * (W - 1) + 5 + 15) / 16; w.NPL = 16 * w.T;
+    // CalibHessian(): setValueScaled(K) then value_zero (HessianBlocks.h:347-361, 381-395)
+    double v[4], vz[4];
+    const double* cz = calib_zero ? calib_zero : calib;
+    v[0] = (1.0f / kScaleF) * calib[0]; v[1] = (1.0f / kScaleF) * calib[1]; v[2] = (1.0f / kScaleC) * calib[2]; v[3] = (1.0f / kScaleC) * calib[3];
+    vz[0] = (1.0f / kScaleF) * cz[0]; vz[1] = (1.0f / kScaleF) * cz[1]; vz[2] = (1.0f / kScaleC) * cz[2]; vz[3] = (1.0f / kScaleC) * cz[3];
+    calib_set_value(w, v);
+    for (int i = 0; i < 4; ++i) { w.c_value_scaled[i] = calib[i]; w.c_scaledf[i] = (float)calib[i]; w.c_value_zero[i] = vz[i]; }
+    w.c_scaledi[0] = 1.0f / w.c_scaledf[0]; w.c_scaledi[1] = 1.0f / w.c_scaledf[1];
+    w.c_scaledi[2] = -w.c_scaledf[2] / w.c_scaledf[0]; w.c_scaledi[3] = -w.c_scaledf[3] / w.c_scaledf[1];
+    w.frames.assign(W, HostFrame());
+    for (int i = 0; i < W; ++i) {
+        HostFrame& f = w.frames[i];
+        const nalo_frame_state& s = frames[i];
+        if (s.slot < 0 || s.slot >= (int)c->slots.size() || !c->slots[s.slot].valid) return fail(c, NALO_ERR_STATE, "nalo_ba_set_window: frame slot has no pyramid");
+        f.slot = s.slot; f.frameID = s.frame_id; f.evalPT = SE3::from(s.worldToCam_evalPT);
+        f.ab_exposure = s.ab_exposure; f.frameEnergyTH = s.frameEnergyTH;
+        double z6[10]; std::memcpy(z6, s.state_zero, sizeof(z6));
+        frame_set_state(f, s.state_zero);
+        frame_set_state_zero(f, z6);
+        frame_set_state(f, s.state);
+        frame_take_data(f);
+        w.dev.img[i] = c->slots[s.slot].dI[0];
+    }
+    w.dev.W = W; w.dev.w = c->w; w.dev.h = c->h;
+    if (w.HM.size() != (size_t)w.n * w.n) { w.HM.assign((size_t)w.n * w.n, 0.0); w.bM.assign(w.n, 0.0); }
+    w.lastX.assign(w.n, 0.0);
+    const size_t blk = (size_t)w.n1 * w.n1;
+    NALO_HIP(c, w.acc13.reserve((size_t)W * W * 169)); NALO_HIP(c, w.misc.reserve((size_t)2 * W * W));
+    NALO_HIP(c, w.G.reserve((size_t)W * w.NPL * w.NPL));
+    NALO_HIP(c, w.Tm.reserve(std::max((size_t)W * W * 13 * w.n1, (size_t)W * w.NPL * w.n1)));
+    NALO_HIP(c, w.stitched.reserve(2 * blk + 2 * W * W + 16));
+    if (w.stitched_host) { (void)hipHostFree(w.stitched_host); w.stitched_host = nullptr; }
+    NALO_HIP(c, hipHostMalloc((void**)&w.stitched_host, (2 * blk + 2 * W * W + 16) * 8));
+    int rc = upload_frame_th(c); if (rc) return rc;
+    rc = set_adjoints(c); if (rc) return rc;
+    rc = set_precalc(c); if (rc) return rc;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    w.have_lin = w.have_sc = false;
+    return NALO_OK;
+}
+
+int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, const float* v, const float* idepth, const float* idepth_zero,
+                       const float* color, const float* weights, const int* has_prior) {
+    if (!c || !c->ba || c->ba->W < 2) return fail(c, NALO_ERR_STATE, "nalo_ba_set_points: set the window first");
+    if (P < 0 || (P > 0 && (!host || !u || !v || !idepth || !color || !weights))) return fail(c, NALO_ERR_ARG, "nalo_ba_set_points: bad argument");
+    BAWindow& w = *c->ba;
+    const int W = w.W;
+    NALO_HIP(c, hipSetDevice(c->device));
+    // sort by host (stable: keeps the caller's order inside a host, i.e. the reference's frame->points iteration order), pad each host to kBlk
+    std::vector<int> cnt(W, 0);
+    for (int p = 0; p < P; ++p) { if (host[p] < 0 || host[p] >= W) return fail(c, NALO_ERR_ARG, "nalo_ba_set_points: host index out of range"); cnt[host[p]]++; }
+    w.host_blk_h.assign(W + 1, 0);
+    for (int h = 0; h < W; ++h) w.host_blk_h[h + 1] = w.host_blk_h[h] + (cnt[h] + kBlk - 1) / kBlk;
+    w.nblocks = std::max(w.host_blk_h[W], 1);
+    if (w.host_blk_h[W] == 0) w.host_blk_h[W] = 0;
+    w.Ppad = w.nblocks * kBlk; w.P = P;
+    w.blk_host_h.assign(w.nblocks, 0);
+    for (int h = 0; h < W; ++h) for (int b = w.host_blk_h[h]; b < w.host_blk_h[h + 1]; ++b) w.blk_host_h[b] = h;
+    w.d2p.assign(w.Ppad, -1); w.p2d.assign(P, -1);
+    std::vector<int> fill(W);
+    for (int h = 0; h < W; ++h) fill[h] = w.host_blk_h[h] * kBlk;
+    for (int p = 0; p < P; ++p) { const int d = fill[host[p]]++; w.d2p[d] = p; w.p2d[p] = d; }
+    const size_t N = w.Ppad;
+    std::vector<float4> geo(N, make_float4(8.f, 8.f, 1.f, 1.f)), c0(N, make_float4(0, 0, 0, 0)), c1(N, make_float4(0, 0, 0, 0)), w0(N, make_float4(0, 0, 0, 0)), w1(N, make_float4(0, 0, 0, 0));
+    std::vector<float> prior(N, 0.f);
+    w.flags_h.assign(N, 0);
+    for (size_t d = 0; d < N; ++d) {
+        const int p = w.d2p[d];
+        if (p < 0) continue;
+        geo[d] = make_float4(u[p], v[p], idepth[p], idepth_zero ? idepth_zero[p] : idepth[p]);
+        c0[d] = make_float4(color[8 * p], color[8 * p + 1], color[8 * p + 2], color[8 * p + 3]); c1[d] = make_float4(color[8 * p + 4], color[8 * p + 5], color[8 * p + 6], color[8 * p + 7]);
+        w0[d] = make_float4(weights[8 * p], weights[8 * p + 1], weights[8 * p + 2], weights[8 * p + 3]); w1[d] = make_float4(weights[8 * p + 4], weights[8 * p + 5], weights[8 * p + 6], weights[8 * p + 7]);
+        const bool hp = has_prior && has_prior[p];
+        prior[d] = hp ? kIdepthFixPrior * kScaleIdepth * kScaleIdepth : 0.f;        // EFPoint::takeData (EnergyFunctionalStructs.cpp:79-85)
+        w.flags_h[d] = PT_VALID | (hp ? PT_HAS_PRIOR : 0);
+    }
+    NALO_HIP(c, w.pt_geo.reserve(N)); NALO_HIP(c, w.pt_col0.reserve(N)); NALO_HIP(c, w.pt_col1.reserve(N)); NALO_HIP(c, w.pt_w0.reserve(N)); NALO_HIP(c, w.pt_w1.reserve(N));
+    NALO_HIP(c, w.pt_acc.reserve(N)); NALO_HIP(c, w.pt_hcd.reserve(N)); NALO_HIP(c, w.pt_prior.reserve(N)); NALO_HIP(c, w.pt_step.reserve(N)); NALO_HIP(c, w.pt_backup.reserve(N));
+    NALO_HIP(c, w.pt_relbs.reserve(N)); NALO_HIP(c, w.en_new.reserve(N)); NALO_HIP(c, w.pt_flags.reserve(N)); NALO_HIP(c, w.pt_ngood.reserve(N));
+    NALO_HIP(c, w.blk_host.reserve(w.nblocks)); NALO_HIP(c, w.host_blk.reserve(W + 1));
+    const size_t NS = (size_t)W * N;
+    NALO_HIP(c, w.rs_state.reserve(NS)); NALO_HIP(c, w.rs_energy.reserve(NS)); NALO_HIP(c, w.rs_jp0.reserve(NS)); NALO_HIP(c, w.rs_jp1.reserve(NS)); NALO_HIP(c, w.rs_cpt.reserve(NS));
+    NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * W * kTopStride)); NALO_HIP(c, w.sc_partial.reserve((size_t)w.nblocks * w.NPL * w.NPL));
+    NALO_HIP(c, hipMemcpy(w.pt_geo.p, geo.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_col0.p, c0.data(), N * 16, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(w.pt_col1.p, c1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_w0.p, w0.data(), N * 16, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(w.pt_w1.p, w1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_prior.p, prior.data(), N * 4, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(w.pt_flags.p, w.flags_h.data(), N, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(w.blk_host.p, w.blk_host_h.data(), (size_t)w.nblocks * 4, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(w.host_blk.p, w.host_blk_h.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemset(w.pt_acc.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_hcd.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_step.p, 0, N * 4));
+    NALO_HIP(c, hipMemset(w.pt_backup.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_relbs.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_ngood.p, 0, N));
+    NALO_HIP(c, hipMemset(w.rs_state.p, 0, NS)); NALO_HIP(c, hipMemset(w.rs_energy.p, 0, NS * 8)); NALO_HIP(c, hipMemset(w.rs_jp0.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.rs_jp1.p, 0, NS * 16));
+    NALO_HIP(c, hipMemset(w.rs_cpt.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.top_partial.p, 0, (size_t)w.nblocks * W * kTopStride * 4));
+    BADev& D = w.dev;
+    D.P = P; D.Ppad = w.Ppad; D.nblocks = w.nblocks; D.blk_host = w.blk_host.p;
+    D.pt_geo = w.pt_geo.p; D.pt_col0 = w.pt_col0.p; D.pt_col1 = w.pt_col1.p; D.pt_w0 = w.pt_w0.p; D.pt_w1 = w.pt_w1.p; D.pt_prior = w.pt_prior.p;
+    D.pt_flags = w.pt_flags.p; D.pt_acc = w.pt_acc.p; D.pt_hcd = w.pt_hcd.p; D.pt_ngood = w.pt_ngood.p; D.pt_step = w.pt_step.p; D.pt_backup = w.pt_backup.p; D.pt_relbs = w.pt_relbs.p;
+    D.rs_state = w.rs_state.p; D.rs_energy = w.rs_energy.p; D.rs_jp0 = w.rs_jp0.p; D.rs_jp1 = w.rs_jp1.p; D.rs_cpt = w.rs_cpt.p; D.en_new = w.en_new.p;
+    D.top_partial = w.top_partial.p; D.sc_partial = w.sc_partial.p;
+    w.points_set = true; w.res_set = false; w.have_lin = w.have_sc = false;
+    return NALO_OK;
+}
+
+int nalo_ba_set_residuals(nalo_ctx* c, const uint8_t* exists) {
+    if (!c || !c->ba || !c->ba->points_set || !exists) return fail(c, NALO_ERR_STATE, "nalo_ba_set_residuals: set window and points first");
+    BAWindow& w = *c->ba;
+    const int W = w.W;
+    std::vector<uint8_t> st((size_t)W * w.Ppad, 0);
+    for (int p = 0; p < w.P; ++p) { const int d = w.p2d[p]; for (int t = 0; t < W; ++t) if (exists[(size_t)p * W + t]) st[(size_t)t * w.Ppad + d] = RS_EXISTS; }   // state IN (0), resetOOB
+    NALO_HIP(c, hipMemcpy(w.rs_state.p, st.data(), st.size(), hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemset(w.rs_energy.p, 0, st.size() * 8));
+    w.res_set = true; w.have_lin = w.have_sc = false;
+    return NALO_OK;
+}
+
+int nalo_ba_set_prior(nalo_ctx* c, const double* HM, const double* bM) {
+    if (!c || !c->ba || c->ba->W < 2) return fail(c, NALO_ERR_STATE, "nalo_ba_set_prior: set the window first");
+    BAWindow& w = *c->ba;
+    if (HM) w.HM.assign(HM, HM + (size_t)w.n * w.n); else w.HM.assign((size_t)w.n * w.n, 0.0);
+    if (bM) w.bM.assign(bM, bM + w.n); else w.bM.assign(w.n, 0.0);
+    return NALO_OK;
+}
+int nalo_ba_get_prior(nalo_ctx* c, double* HM, double* bM) {
+    if (!c || !c->ba || c->ba->W < 2) return fail(c, NALO_ERR_STATE, "nalo_ba_get_prior: set the window first");
+    BAWindow& w = *c->ba;
+    if (HM) std::memcpy(HM, w.HM.data(), w.HM.size() * 8);
+    if (bM) std::memcpy(bM, w.bM.data(), w.bM.size() * 8);
+    return NALO_OK;
+}
+
+#define NALO_BA_READY(name)                                                                                       \
+    if (!c || !c->ba || !c->ba->points_set || !c->ba->res_set) return fail(c, NALO_ERR_STATE, name ": window/points/residuals not set"); \
+    NALO_HIP(c, hipSetDevice(c->device));                                                                         \
+    BAWindow& w = *c->ba;
+
+int nalo_ba_linearize(nalo_ctx* c, int fix, double* energy) {
+    NALO_BA_READY("nalo_ba_linearize")
+    int rc = linearize_async(c, 0, fix); if (rc) return rc;
+    rc = stitch_and_fetch(c, true, false); if (rc) return rc;
+    NALO_HIP(c, hipMemcpy(&w.frames[w.W - 1].frameEnergyTH, w.frameTH.p + (w.W - 1), 4, hipMemcpyDeviceToHost));
+    double e = 0; misc_totals(w, &e, &w.resInA);
+    if (energy) *energy = e;
+    return NALO_OK;
+}
+int nalo_ba_accumulate(nalo_ctx* c, int mode, double* H, double* b) {
+    NALO_BA_READY("nalo_ba_accumulate")
+    if (!H || !b) return fail(c, NALO_ERR_ARG, "nalo_ba_accumulate: H/b required");
+    if (mode == 0) { int rc = do_accumulate_top(c); if (rc) return rc; unpack_system(w, w.stitched_host, H, b); misc_totals(w, nullptr, &w.resInA); return NALO_OK; }
+    if (mode == 1) { prior_system(w, H, b); w.resInL = 0; return NALO_OK; }
+    return fail(c, NALO_ERR_UNSUPPORTED, "nalo_ba_accumulate: mode 2 runs inside nalo_ba_marginalize_points");
+}
+int nalo_ba_accumulate_sc(nalo_ctx* c, int shiftPriorToZero, double* H, double* b) {
+    NALO_BA_READY("nalo_ba_accumulate_sc")
+    if (!H || !b) return fail(c, NALO_ERR_ARG, "nalo_ba_accumulate_sc: H/b required");
+    int rc = do_accumulate_sc(c, shiftPriorToZero ? 1 : 0); if (rc) return rc;
+    unpack_system(w, w.stitched_host + (size_t)w.n1 * w.n1, H, b);
+    return NALO_OK;
+}
+int nalo_ba_solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out) {
+    NALO_BA_READY("nalo_ba_solve_system")
+    (void)w;
+    int rc = solve_system(c, iteration, lambda, x_out); if (rc) return rc;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    return NALO_OK;
+}
+int nalo_ba_backup_state(nalo_ctx* c) {
+    NALO_BA_READY("nalo_ba_backup_state")
+    backup_state(w);
+    return NALO_OK;
+}
+int nalo_ba_do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float fD, int* canbreak) {
+    NALO_BA_READY("nalo_ba_do_step")
+    (void)w;
+    return do_step(c, fC, fT, fR, fA, fD, canbreak);
+}
+
+int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse) {
+    NALO_BA_READY("nalo_ba_optimize")
+    const int W = w.W;
+    if (W < 3) mnumOptIts = 20;                                             // FullSystemOptimize.cpp:401-403
+    if (W < 4) mnumOptIts = 15;
+    ba_launch_reset_oob(c->stream, w.dev);                                  // :412-429
+    int rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :436 (+ applyRes :459-462)
+    double lambda = 1e-1;
+    for (int it = 0; it < mnumOptIts; ++it) {
+        backup_state(w);                                                    // :482
+        rc = solve_system(c, it, lambda, nullptr); if (rc) return rc;       // :485
+        int canbreak = 0;
+        rc = do_step(c, 1, 1, 1, 1, 1, &canbreak); if (rc) return rc;       // :501 (stepsize 1: no SOLVER_STEPMOMENTUM)
+        rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :511, accepted unconditionally (:519-532)
+        lambda *= 0.25;
+        if (canbreak && it >= 1 && !never_break) break;                     // :544, setting_minOptIterations = 1
+    }
+    HostFrame& nf = w.frames[W - 1];                                        // :550-557
+    const double nsz[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
+    nf.evalPT = nf.PRE_worldToCam;
+    frame_set_state(nf, nsz); frame_set_state_zero(nf, nsz);
+    rc = set_adjoints(c); if (rc) return rc;
+    rc = set_precalc(c); if (rc) return rc;
+    rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
+    rc = stitch_and_fetch(c, true, false); if (rc) return rc;
+    NALO_HIP(c, hipMemcpy(&nf.frameEnergyTH, w.frameTH.p + (W - 1), 4, hipMemcpyDeviceToHost));
+    double e = 0; int nres = 0; misc_totals(w, &e, &nres);
+    // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)
+    if (rmse) *rmse = std::sqrt((float)(e / (kPatternNum * (double)w.resInA)));
+    return NALO_OK;
+}
+
+int nalo_ba_marginalize_points(nalo_ctx* c, const uint8_t* flags, double* M, double* Mb, double* Msc, double* Mbsc) {
+    NALO_BA_READY("nalo_ba_marginalize_points")
+    if (!flags) return fail(c, NALO_ERR_ARG, "nalo_ba_marginalize_points: flags required");
+    const int n = w.n, n1 = w.n1, W = w.W;
+    for (int p = 0; p < w.P; ++p) { const int d = w.p2d[p]; if (flags[p] && (w.flags_h[d] & PT_VALID)) w.flags_h[d] |= PT_MARG; }
+    NALO_HIP(c, hipMemcpyAsync(w.pt_flags.p, w.flags_h.data(), w.Ppad, hipMemcpyHostToDevice, c->stream));
+    int rc = linearize_async(c, 2, 0); if (rc) return rc;                                   // relinearise + fixLinearizationF + addPoint<2>
+    rc = sc_async(c, 0, kIdepthFixPriorMargFac, 1); if (rc) return rc;                      // priorF *= margFac; addPoint(p, false)
+    rc = stitch_and_fetch(c, true, true); if (rc) return rc;
+    std::vector<double> m((size_t)n * n), mb(n), ms((size_t)n * n), mbs(n);
+    unpack_system(w, w.stitched_host, m.data(), mb.data());
+    unpack_system(w, w.stitched_host + (size_t)n1 * n1, ms.data(), mbs.data());
+    int nres = 0; misc_totals(w, nullptr, &nres); w.resInM += nres;
+    for (size_t i = 0; i < (size_t)n * n; ++i) w.HM[i] += kMargWeightFac * (m[i] - ms[i]);  // EnergyFunctional.cpp:654-669
+    for (int i = 0; i < n; ++i) w.bM[i] += kMargWeightFac * (mb[i] - mbs[i]);
+    if (M) std::memcpy(M, m.data(), m.size() * 8); if (Mb) std::memcpy(Mb, mb.data(), n * 8);
+    if (Msc) std::memcpy(Msc, ms.data(), ms.size() * 8); if (Mbsc) std::memcpy(Mbsc, mbs.data(), n * 8);
+    // removePoint: drop the points and all their residuals
+    std::vector<uint8_t> st((size_t)W * w.Ppad);
+    NALO_HIP(c, hipMemcpy(st.data(), w.rs_state.p, st.size(), hipMemcpyDeviceToHost));
+    for (int d = 0; d < w.Ppad; ++d) if (w.flags_h[d] & PT_MARG) { w.flags_h[d] = 0; for (int t = 0; t < W; ++t) st[(size_t)t * w.Ppad + d] = 0; }
+    NALO_HIP(c, hipMemcpy(w.rs_state.p, st.data(), st.size(), hipMemcpyHostToDevice));
+    NALO_HIP(c, hipMemcpy(w.pt_flags.p, w.flags_h.data(), w.Ppad, hipMemcpyHostToDevice));
+    w.have_lin = w.have_sc = false;
+    return NALO_OK;
+}
+
+int nalo_ba_get_frames(nalo_ctx* c, nalo_frame_state* frames, double* worldToCam, double calib[4]) {
+    if (!c || !c->ba || c->ba->W < 2) return fail(c, NALO_ERR_STATE, "nalo_ba_get_frames: set the window first");
+    BAWindow& w = *c->ba;
+    for (int i = 0; i < w.W; ++i) {
+        const HostFrame& f = w.frames[i];
+        if (frames) {
+            nalo_frame_state& s = frames[i];
+            s.slot = f.slot; s.frame_id = f.frameID; std::memcpy(s.worldToCam_evalPT, f.evalPT.m, 96);
+            std::memcpy(s.state, f.state, 80); std::memcpy(s.state_zero, f.state_zero, 80); s.ab_exposure = f.ab_exposure; s.frameEnergyTH = f.frameEnergyTH;
+        }
+        if (worldToCam) std::memcpy(worldToCam + 12 * i, f.PRE_worldToCam.m, 96);
+    }
+    if (calib) std::memcpy(calib, w.c_value_scaled, 32);
+    return NALO_OK;
+}
+
+int nalo_ba_get_points(nalo_ctx* c, float* idepth, float* step, float* HdiF, float* bdSumF, float* Hdd, float* bd, float* Hcd, float* maxRelBaseline) {
+    if (!c || !c->ba || !c->ba->points_set) return fail(c, NALO_ERR_STATE, "nalo_ba_get_points: no points");
+    BAWindow& w = *c->ba;
+    const size_t N = w.Ppad;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<float4> geo(N), acc(N), hcd(N);
+    std::vector<float> stp(N), rel(N);
+    NALO_HIP(c, hipMemcpy(geo.data(), w.pt_geo.p, N * 16, hipMemcpyDeviceToHost)); NALO_HIP(c, hipMemcpy(acc.data(), w.pt_acc.p, N * 16, hipMemcpyDeviceToHost));
+    NALO_HIP(c, hipMemcpy(hcd.data(), w.pt_hcd.p, N * 16, hipMemcpyDeviceToHost)); NALO_HIP(c, hipMemcpy(stp.data(), w.pt_step.p, N * 4, hipMemcpyDeviceToHost));
+    NALO_HIP(c, hipMemcpy(rel.data(), w.pt_relbs.p, N * 4, hipMemcpyDeviceToHost));
+    for (int p = 0; p < w.P; ++p) {
+        const int d = w.p2d[p];
+        if (idepth) idepth[p] = geo[d].z; if (step) step[p] = stp[d]; if (HdiF) HdiF[p] = acc[d].z; if (bdSumF) bdSumF[p] = acc[d].w;
+        if (Hdd) Hdd[p] = acc[d].x; if (bd) bd[p] = acc[d].y;
+        if (Hcd) { Hcd[4 * p] = hcd[d].x; Hcd[4 * p + 1] = hcd[d].y; Hcd[4 * p + 2] = hcd[d].z; Hcd[4 * p + 3] = hcd[d].w; }
+        if (maxRelBaseline) maxRelBaseline[p] = rel[d];
+    }
+    return NALO_OK;
+}
+
+int nalo_ba_get_residuals(nalo_ctx* c, int8_t* state, uint8_t* active, float* JpJdF, float* energy_new, float* center) {
+    if (!c || !c->ba || !c->ba->points_set) return fail(c, NALO_ERR_STATE, "nalo_ba_get_residuals: no points");
+    BAWindow& w = *c->ba;
+    const int W = w.W; const size_t NS = (size_t)W * w.Ppad;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<uint8_t> st(NS); std::vector<float4> j0(NS), j1(NS), cp(NS); std::vector<float> en(w.Ppad);
+    NALO_HIP(c, hipMemcpy(st.data(), w.rs_state.p, NS, hipMemcpyDeviceToHost));
+    if (JpJdF) { NALO_HIP(c, hipMemcpy(j0.data(), w.rs_jp0.p, NS * 16, hipMemcpyDeviceToHost)); NALO_HIP(c, hipMemcpy(j1.data(), w.rs_jp1.p, NS * 16, hipMemcpyDeviceToHost)); }
+    if (center) NALO_HIP(c, hipMemcpy(cp.data(), w.rs_cpt.p, NS * 16, hipMemcpyDeviceToHost));
+    if (energy_new) NALO_HIP(c, hipMemcpy(en.data(), w.en_new.p, (size_t)w.Ppad * 4, hipMemcpyDeviceToHost));
+    for (int p = 0; p < w.P; ++p) for (int t = 0; t < W; ++t) {
+        const size_t si = (size_t)t * w.Ppad + w.p2d[p], o = (size_t)p * W + t;
+        const uint8_t s = st[si];
+        if (state) state[o] = (s & RS_EXISTS) ? (int8_t)(s & RS_STATE_MASK) : (int8_t)-1;
+        if (active) active[o] = (s & RS_ACTIVE) ? 1 : 0;
+        if (JpJdF) { float* q = JpJdF + o * 8; q[0] = j0[si].x; q[1] = j0[si].y; q[2] = j0[si].z; q[3] = j0[si].w; q[4] = j1[si].x; q[5] = j1[si].y; q[6] = j1[si].z; q[7] = j1[si].w; }
+        if (energy_new) energy_new[o] = (t == W - 1) ? en[w.p2d[p]] : -1.f;
+        if (center) { center[o * 3] = cp[si].x; center[o * 3 + 1] = cp[si].y; center[o * 3 + 2] = cp[si].z; }
+    }
+    return NALO_OK;
+}
+
+int nalo_ba_get_acc13(nalo_ctx* c, double* H13) {
+    if (!c || !c->ba || !c->ba->have_lin || !H13) return fail(c, NALO_ERR_STATE, "nalo_ba_get_acc13: linearize first");
+    BAWindow& w = *c->ba;
+    int rc = stitch_and_fetch(c, true, false); if (rc) return rc;
+    NALO_HIP(c, hipMemcpy(H13, w.acc13.p, (size_t)w.W * w.W * 169 * 8, hipMemcpyDeviceToHost));
+    return NALO_OK;
+}
+int nalo_ba_counts(nalo_ctx* c, int* a, int* l, int* m) {
+    if (!c || !c->ba) return fail(c, NALO_ERR_STATE, "nalo_ba_counts: no window");
+    if (a) *a = c->ba->resInA; if (l) *l = c->ba->resInL; if (m) *m = c->ba->resInM;
+    return NALO_OK;
+}
+int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
+    if (!c) return NALO_ERR_ARG;
+    if (!c->ba) c->ba = new BAWindow();
+    c->ba->hook = hook; c->ba->hook_user = user;
+    return NALO_OK;
+}
+
+int nalo_dense_make_map(nalo_ctx* c, int, const float*, float, const double*, int, int*, int*, int*, float*, float*, uint8_t*, int*, int*) {
+    return fail(c, NALO_ERR_UNSUPPORTED, "nalo_dense_make_map: not built yet");
+}
+
+}  // extern "C"

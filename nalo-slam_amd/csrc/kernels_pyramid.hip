@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void pyr_grad_kernel(const float* __restrict__
             dy = 0.5f * (I[idx + wl] - I[idx - wl]);
             if (!isfinite(dx)) dx = 0.f;
             if (!isfinite(dy)) dy = 0.f;
-            ab = dx * dx + dy * dy;
+            ab = dx * dx + dy * dy;   // this file is built with -ffp-contract=off: rounds as the reference's scalar code
             if (gammaB) {                                   // HessianBlocks.h:400-406 getBGradOnly
                 int ci = (int)(c + 0.5f);
                 ci = ci < 5 ? 5 : (ci > 250 ? 250 : ci);

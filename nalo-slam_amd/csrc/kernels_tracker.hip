@@ -162,11 +162,13 @@ __global__ __launch_bounds__(256) void trk_dilate_kernel(float* __restrict__ id,
     if (i >= wl * hl - wl) return;
     if (bak[i] > 0) return;
     const int o0 = diag ? 1 + wl : 1, o1 = diag ? -1 - wl : -1, o2 = diag ? wl - 1 : wl, o3 = diag ? -wl + 1 : -wl;
+    // the reference reads one element before/after the array at the first/last pixel of this range
+    // (i-1-wl = -1, i+1+wl = w*h): those two taps are outside the image and are skipped here.
+    const int npx = wl * hl;
     float sum = 0, num = 0, numn = 0;
-    if (bak[i + o0] > 0) { sum += id[i + o0]; num += bak[i + o0]; numn++; }
-    if (bak[i + o1] > 0) { sum += id[i + o1]; num += bak[i + o1]; numn++; }
-    if (bak[i + o2] > 0) { sum += id[i + o2]; num += bak[i + o2]; numn++; }
-    if (bak[i + o3] > 0) { sum += id[i + o3]; num += bak[i + o3]; numn++; }
+#define NALO_TAP(o) { const int j = i + (o); if (j >= 0 && j < npx) { const float b = bak[j]; if (b > 0) { sum += id[j]; num += b; numn++; } } }
+    NALO_TAP(o0) NALO_TAP(o1) NALO_TAP(o2) NALO_TAP(o3)
+#undef NALO_TAP
     if (numn > 0) { id[i] = sum / numn; ws[i] = num / numn; }
 }
 // step 5 (:493-538): normalise + ordered (raster) compaction into pc_*. Pass 0 counts per block, pass 1 writes.

@@ -1,8 +1,10 @@
 // Deterministic block reduction of N per-lane fp32 values on CDNA4 (wave64):
 //   1. two DPP quad-permute adds (lanes 4k..4k+3 -> every lane of the quad holds the quad sum): no LDS, no ds_bpermute
 //   2. one lane per quad stores its N values to an LDS row (64 rows for a 256-thread block)
-//   3. thread j < N sums column j over the rows in a fixed order and writes out[j]
+//   3. thread j < N sums column j over the rows in a fixed order, IN FP64, and writes out[j] (rounded to fp32 once)
 // At step 3 all lanes read the same row -> consecutive LDS addresses, conflict free.
+// The fp64 column sum matters: the reduced BA system H_A - H_sc cancels ~100x, so fp32 running sums over 64 rows
+// (error ~5e-7) would show up as ~1e-5 in the recovered poses; with fp64 here the block partial is good to one rounding.
 // This replaces the reference's SSE-lane + 3-tier accumulators (OptimizationBackend/MatrixAccumulators.h) and the
 // per-thread accumulator replicas of IndexThreadReduce; the cross-block finish is fp64 in a separate kernel.
 #pragma once
@@ -31,10 +33,10 @@ __device__ __forceinline__ void block_reduce_cols(float (&v)[N], float* smem, fl
     }
     __syncthreads();
     if (tid < N) {
-        float s = 0.f;
+        double s = 0.0;
 #pragma unroll 8
-        for (int r = 0; r < NT / 4; ++r) s += smem[r * NP + tid];
-        out[tid] = s;
+        for (int r = 0; r < NT / 4; ++r) s += (double)smem[r * NP + tid];
+        out[tid] = (float)s;
     }
     __syncthreads();
 }

@@ -131,8 +131,9 @@ void orc_trk_set_ref(OrcTracker* t, const float* dI_ref, int n, const float* Ku,
         memcpy(bak, ws, sizeof(float)*t->w[lvl]*t->h[lvl]);
         for (int i=wl;i<wh;i++) if (bak[i] <= 0) {
             float sum=0,num=0,numn=0;
-            if (bak[i+1+wl]>0) { sum+=id[i+1+wl]; num+=bak[i+1+wl]; numn++; }
-            if (bak[i-1-wl]>0) { sum+=id[i-1-wl]; num+=bak[i-1-wl]; numn++; }
+            /* reference reads bak[w*h] / bak[-1] at the range ends (one past / before the array): skipped here */
+            if (i+1+wl<t->w[lvl]*t->h[lvl] && bak[i+1+wl]>0) { sum+=id[i+1+wl]; num+=bak[i+1+wl]; numn++; }
+            if (i-1-wl>=0 && bak[i-1-wl]>0) { sum+=id[i-1-wl]; num+=bak[i-1-wl]; numn++; }
             if (bak[i+wl-1]>0) { sum+=id[i+wl-1]; num+=bak[i+wl-1]; numn++; }
             if (bak[i-wl+1]>0) { sum+=id[i-wl+1]; num+=bak[i-wl+1]; numn++; }
             if (numn>0) { id[i]=sum/numn; ws[i]=num/numn; }

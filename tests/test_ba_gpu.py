@@ -1,0 +1,150 @@
+"""GPU parity of the sliding-window BA (a5-a13) through the C-ABI vs the CPU oracle on identical seeded windows.
+Oracle = checker only. Tolerances: per-residual values 2e-5 relative (fp32 pointwise, FMA contraction differs from the
+scalar CPU order); accumulated/stitched systems 2e-5 of max|H| (fp32 block partials, fp64 finish); solution x
+and poses as stated in each test."""
+import numpy as np
+import pytest
+
+import orc
+from helpers import rel_err, pose_dist
+from nalo_slam_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def make_ctx(win, state6=None, aff=None):
+    c = binding.Context(win.w, win.h, win.K, n_slots=win.W + 1)
+    for i in range(win.W):
+        c.frame_upload(i, win.images[i])
+    c.ba_set_window(list(range(win.W)), win.world_to_cam[:win.W], state6=state6, aff=aff)
+    c.ba_set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights)
+    c.ba_set_residuals(win.exists)
+    return c
+
+
+@pytest.fixture(scope="module")
+def pair(small_window):
+    win = small_window
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    aff = [(0.0, 0.0), (0.01, 1.0), (-0.02, -2.0), (0.015, 0.5)]
+    orc.lib().orc_set_sum_mode(0)
+    ba = orc.ba_from_window(win, "f32", state6=st6, aff=aff)
+    c = make_ctx(win, st6, aff)
+    yield win, ba, c
+    c.close()
+
+
+def test_linearize_states_and_jacobian_products(pair):
+    win, ba, c = pair
+    E_o = ba.linearize_all(False)
+    ba.apply_res()
+    E = c.ba_linearize(False)
+    st_o, ac_o, jp_o, en_o = ba.slots()
+    st, ac, jp, en, _ = c.ba_get_residuals()
+    assert np.array_equal(st, st_o), "residual states differ"
+    assert np.array_equal(ac, ac_o)
+    assert ac.sum() > 500
+    assert abs(E - E_o) / E_o < 1e-5
+    m = ac.astype(bool)
+    assert rel_err(jp[m], jp_o[m]) < 2e-5
+    nw = win.W - 1
+    mm = (en_o[:, nw] >= 0) & (win.exists[:, nw] > 0)
+    assert np.array_equal(mm, en[:, nw] >= 0)
+    assert rel_err(en[mm, nw], en_o[mm, nw]) < 2e-5
+    pts_o = ba.accumulate(0)  # fills Hdd/bd/Hcd in the oracle
+    po, pg = ba.points(), c.ba_get_points()
+    assert rel_err(pg["Hdd"], po["Hdd"]) < 2e-5 and rel_err(pg["bd"], po["bd"]) < 5e-5 and rel_err(pg["Hcd"], po["Hcd"]) < 2e-5
+    # new-frame energy threshold (exact order statistic)
+    assert abs(c.ba_get_frames()[0][win.W - 1].frameEnergyTH - ba.frame(win.W - 1)["frameEnergyTH"]) < 1e-3 * ba.frame(win.W - 1)["frameEnergyTH"]
+
+
+def test_accumulators_and_stitched_systems(pair):
+    win, ba, c = pair
+    HA_o, bA_o, h13_o = ba.accumulate(0, True)
+    Hs_o, bs_o = ba.accumulate_sc(True)
+    HL_o, bL_o = ba.accumulate(1)
+    h13 = c.ba_get_acc13()
+    for k in range(win.W * win.W):
+        if np.abs(h13_o[k]).max() > 0:
+            assert rel_err(h13[k], h13_o[k]) < 2e-5, "bin %d" % k
+    HA, bA = c.ba_accumulate(0)
+    Hs, bs = c.ba_accumulate_sc(True)
+    HL, bL = c.ba_accumulate(1)
+    assert rel_err(HA, HA_o) < 2e-5 and rel_err(bA, bA_o) < 2e-5
+    assert rel_err(Hs, Hs_o) < 2e-5 and rel_err(bs, bs_o) < 5e-5
+    assert rel_err(HL, HL_o) < 1e-12 and rel_err(bL, bL_o) < 1e-7
+    assert np.abs(HA - HA.T).max() <= 1e-12 * np.abs(HA).max()
+    assert c.ba_counts()[0] == ba.counts()[0]
+    po, pg = ba.points(), c.ba_get_points()
+    assert rel_err(pg["HdiF"], po["HdiF"]) < 2e-5 and rel_err(pg["bdSumF"], po["bdSumF"]) < 5e-5
+
+
+def test_solve_resubstitute_step(pair):
+    win, ba, c = pair
+    x_o = ba.solve_system(0)
+    c.ba_backup_state()
+    x = c.ba_solve_system(0)
+    # the reduced system is ill-conditioned along the gauge directions (400 points, 4 frames): x is compared loosely,
+    # the per-point back-substituted steps (what the update uses) tightly
+    assert rel_err(x, x_o) < 1e-2
+    po, pg = ba.points(), c.ba_get_points()
+    scale = np.abs(po["step"]).max()
+    assert np.abs(pg["step"] - po["step"]).max() < 5e-3 * scale
+
+
+@pytest.mark.parametrize("cfg", [dict(W=4, P=400, tol=None), dict(W=8, P=3000, tol=1e-5)])
+def test_optimize_matches_oracle_and_converges(cfg):
+    """Full FullSystem::optimize(6). Pose delta |log(T_gpu T_ref^-1)| vs the fp32 oracle: < 1e-5 on the KITTI-sized window
+    (BASELINE.json target). On the tiny 400-point window the problem is so weakly constrained that two valid fp32
+    evaluations differ more: there the bound is 3x the spread between the oracle's own fp32 and fp64 builds."""
+    win = synth.make_window(w=640, h=480, W=cfg["W"], P=cfg["P"], seed=7)
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    orc.lib().orc_set_sum_mode(0)
+    ba = orc.ba_from_window(win, "f32", state6=st6)
+    c = make_ctx(win, st6)
+    before = [pose_dist(ba.frame(f)["worldToCam"], win.world_to_cam[f]) for f in range(win.W)]
+    r_o = ba.optimize(6)
+    r = c.ba_optimize(6)
+    _, w2c, cal = c.ba_get_frames()
+    tol = cfg["tol"]
+    if tol is None:
+        ba64 = orc.ba_from_window(win, "f64", state6=st6)
+        ba64.optimize(6)
+        tol = max(1e-5, 3 * max(pose_dist(ba64.frame(f)["worldToCam"], ba.frame(f)["worldToCam"]) for f in range(win.W)))
+    after = []
+    for f in range(win.W):
+        assert pose_dist(w2c[f], ba.frame(f)["worldToCam"]) < tol, "frame %d" % f
+        after.append(pose_dist(w2c[f], win.world_to_cam[f]))
+    assert max(after[1:]) < 0.5 * max(before[1:])
+    assert abs(r - r_o) < 1e-3 * r_o
+    assert rel_err(cal, ba.calib()) < 1e-6
+    idp, idp_o = c.ba_get_points()["idepth"], ba.points()["idepth"]
+    assert np.median(np.abs(idp - idp_o) / np.abs(idp_o)) < 1e-5
+    st_o, ac_o, _, _ = ba.slots()
+    st, ac, _, _, _ = c.ba_get_residuals()
+    assert (st != st_o).mean() < 0.01          # borderline outlier decisions may flip on 1-ulp differences
+    c.close()
+
+
+def test_marginalize_points(small_window):
+    win = small_window
+    st6 = synth.perturbed_poses(win, sigma_t=0.002, sigma_r=0.0002)
+    orc.lib().orc_set_sum_mode(0)
+    ba = orc.ba_from_window(win, "f32", state6=st6)
+    c = make_ctx(win, st6)
+    ba.linearize_all(False); ba.apply_res()
+    c.ba_linearize(False)
+    flags = (np.arange(len(win.host)) % 5 == 0).astype(np.uint8)
+    M_o, Mb_o, Ms_o, Mbs_o = ba.marginalize_points(flags)
+    M, Mb, Ms, Mbs = c.ba_marginalize_points(flags)
+    assert rel_err(M, M_o) < 2e-5 and rel_err(Mb, Mb_o) < 1e-4
+    assert rel_err(Ms, Ms_o) < 2e-5 and rel_err(Mbs, Mbs_o) < 1e-4
+    n = 8 * win.W + 4
+    HM, bM = np.zeros(n * n), np.zeros(n)
+    c._ck(c.L.nalo_ba_get_prior(c.h_, HM.ctypes.data_as(binding.c_dp), bM.ctypes.data_as(binding.c_dp)))
+    assert rel_err(HM.reshape(n, n), 0.25 * (M_o - Ms_o)) < 5e-5
+    # the marginalised points are gone: next linearisation only sees the rest
+    E_o = ba.linearize_all(False); ba.apply_res()
+    E = c.ba_linearize(False)
+    assert abs(E - E_o) / E_o < 1e-5
+    c.close()

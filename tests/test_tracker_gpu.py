@@ -75,7 +75,7 @@ def test_fused_eval_matches_oracle(ctx, small_window, lvl):
     if lvl == 0:
         assert rel_err(st[[2, 4]], st_o[[2, 4]]) < 1e-5
     assert rel_err(H, H_o) < 2e-5 and rel_err(b, b_o) < 2e-5
-    assert np.abs(H - H.T).max() == 0
+    assert np.abs(H - H.T).max() <= 1e-12 * np.abs(H).max()
     # the reference-order fp32 oracle (SSE lanes + 3-tier) sits inside the same band
     orc.lib().orc_set_sum_mode(1)
     trk.calc_res(dI_new, lvl, T, aff, 20.0)
