@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""bench.py — keyframes/sec of the MI355X hot path (front-end tracking + sliding-window photometric BA).
+
+One step = one keyframe on a fixed synthetic window:
+  3 tracked frames x {makeImages + trackNewestCoarse}  +  setCoarseTrackingRef  +  optimize(6 GN iterations, no early exit)
+  = 1 initial linearise + 6 x {accumulate A/L/SC -> stitch -> solve -> resubstitute -> step -> linearise} + 1 fixing linearise.
+
+Workloads (config.workload):
+  kitti00_8kf   BASELINE.json configs[1]: KITTI-00-shaped 1224x368, 4 pyramid levels, W=8, P=2000 active points, dense tracker
+                reference (~8.7k residual inputs). Default. With N>1 ranks every GPU runs its own window (replicas, weak):
+                a 2k-point window is far too small to amortise an all-reduce (north_star).
+  stress250k    configs[3]: 1920x1072, 5 levels, W=8, P=250 000, R=1.75 M (Hessian-accumulation stress).
+  shard1m       configs[4]: W=12, P=1 000 000 sharded over the ranks, stitched systems all-reduced over RCCL (strong).
+
+Rank 0 prints ONE JSON line. `roofline` is measured live with HIP events on the library's stream; `cpu_baseline` times the
+oracle's -O3 -march=native build (kind "port": the reference itself cannot be built here) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import nalo_pkg  # noqa: E402
+
+nalo_pkg.load()
+from nalo_slam_amd import binding, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRACKED_PER_KF = 3             # frames tracked between two keyframes (KITTI at 10 Hz: a keyframe every ~2-4 frames)
+
+WORKLOADS = {
+    "kitti00_8kf": dict(w=1224, h=368, W=8, P=2000, trk_extra=7000),
+    "stress250k": dict(w=1920, h=1072, W=8, P=250000, trk_extra=0),
+    "shard1m": dict(w=1920, h=1072, W=12, P=1000000, trk_extra=0),
+}
+
+
+def make_inputs(name, seed=7):
+    cfg = WORKLOADS[name]
+    win = synth.make_window(w=cfg["w"], h=cfg["h"], W=cfg["W"], P=cfg["P"], seed=seed, n_extra=TRACKED_PER_KF)
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    # tracker reference: residuals that target the newest keyframe (+ dense extra inputs for dense=1)
+    rng = np.random.RandomState(11)
+    n_in = int((win.host != win.W - 1).sum()) + cfg["trk_extra"]
+    n_in = min(n_in, 300000)
+    Ku = rng.uniform(5, win.w - 6, n_in).astype(np.float32)
+    Kv = rng.uniform(5, win.h - 6, n_in).astype(np.float32)
+    d = win.depth[win.W - 1][(Kv + 0.5).astype(int), (Ku + 0.5).astype(int)]
+    ok = np.isfinite(d)
+    trk = (Ku[ok], Kv[ok], (1.0 / d[ok]).astype(np.float32), (10.0 ** rng.uniform(-6, -3, ok.sum())).astype(np.float32))
+    return win, st6, trk
+
+
+def shard(win, rank, world):
+    """Block-cyclic shard of the active-point set: points keep their residuals; frames are replicated."""
+    if world == 1:
+        return win
+    import dataclasses
+    idx = np.arange(len(win.host))[rank::world]
+    return dataclasses.replace(win, host=win.host[idx], u=win.u[idx], v=win.v[idx], idepth=win.idepth[idx],
+                               idepth_true=win.idepth_true[idx], color=win.color[idx], weights=win.weights[idx], exists=win.exists[idx])
+
+
+class GpuJob:
+    def __init__(self, win, st6, trk, device, hook=None):
+        self.win, self.trk = win, trk
+        W = win.W
+        self.ctx = binding.Context(win.w, win.h, win.K, n_slots=W + TRACKED_PER_KF, device=device)
+        for i in range(W + TRACKED_PER_KF):
+            self.ctx.frame_upload(i, win.images[i])
+        self.ctx.ba_set_window(list(range(W)), win.world_to_cam[:W], state6=st6)
+        self.ctx.ba_set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights)
+        self.ctx.ba_set_residuals(win.exists)
+        if hook is not None:
+            self.ctx.ba_set_allreduce(hook)
+        self.ctx.ba_snapshot()
+        self.ctx.trk_set_ref(W - 1, *trk)
+        self.T0 = [synth.se3_mul(win.world_to_cam[W + k], synth.se3_inv(win.world_to_cam[W - 1])) for k in range(TRACKED_PER_KF)]
+        self.evals = 0
+
+    def step(self, track=True):
+        c, W = self.ctx, self.win.W
+        c.ba_restore()
+        if track:
+            for k in range(TRACKED_PER_KF):
+                c.frame_rebuild(W + k)                                       # a1 on the HBM-resident frame
+                # constant-velocity style initial guess: 95% of the true motion
+                xi = orc_free_log(self.T0[k]) * 0.95
+                ok, T, aff, lr, lf, nev = c.trk_track(W + k, synth_exp(xi), [0, 0], [0, 0], [1, 1], c.levels - 1)
+                self.evals += nev
+            c.trk_set_ref(W - 1, *self.trk)                                  # a2 for the new keyframe
+        return c.ba_optimize(6, never_break=True)
+
+
+def synth_exp(xi):
+    """SE(3) exp on the host (numpy), translation-first tangent."""
+    R = synth.so3_exp(xi[3:])
+    th = np.linalg.norm(xi[3:])
+    K = np.array([[0, -xi[5], xi[4]], [xi[5], 0, -xi[3]], [-xi[4], xi[3], 0]])
+    V = np.eye(3) + 0.5 * K + (K @ K) / 6.0 if th < 1e-8 else np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+    return np.concatenate([R, (V @ xi[:3])[:, None]], axis=1)
+
+
+def orc_free_log(T):
+    """SE(3) log in numpy (no oracle on the product path)."""
+    R, t = T[:, :3], T[:, 3]
+    c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+    th = np.arccos(c)
+    if th < 1e-8:
+        w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / 2
+    else:
+        w = th / (2 * np.sin(th)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    Vi = np.eye(3) - 0.5 * K + (K @ K) / 12.0 if th < 1e-8 else np.eye(3) - 0.5 * K + (1 - th / (2 * np.tan(th / 2))) / th ** 2 * (K @ K)
+    return np.concatenate([Vi @ t, w])
+
+
+def cpu_baseline(win, st6, trk, budget_s=20.0, track=True):
+    """The oracle's fast build (fp32 tiers, -O3 -march=native, 6 accumulate threads, single-thread linearise: the reference's
+    own threading, util/NumType.h:42, FullSystemOptimize.cpp:154-164) timed on a bounded sample of the same keyframes."""
+    import orc
+    W = win.W
+    P_cap = 20000
+    if len(win.host) > P_cap:                     # bounded sample: the first P_cap points of the window, scaled back linearly
+        import dataclasses
+        sub = dataclasses.replace(win, host=win.host[:P_cap], u=win.u[:P_cap], v=win.v[:P_cap], idepth=win.idepth[:P_cap],
+                                  idepth_true=win.idepth_true[:P_cap], color=win.color[:P_cap], weights=win.weights[:P_cap], exists=win.exists[:P_cap])
+        scale = P_cap / float(len(win.host))
+    else:
+        sub, scale = win, 1.0
+    dIs = [orc.make_images(win.images[i], 1, "fast")[0] for i in range(W)]
+    t_total, n_kf = 0.0, 0
+    trkr = None
+    if track:
+        trkr = orc.Tracker(win.w, win.h, win.levels, win.K, "fast")
+        dref = orc.make_images(win.images[W - 1], win.levels, "fast")[0]
+        trkr.set_ref(dref, *trk)
+    while t_total < budget_s and n_kf < 50:
+        ba = orc.BA(W, len(sub.host), win.w, win.h, win.K, "fast")
+        for i in range(W):
+            ba.set_frame(i, dIs[i], win.world_to_cam[i], state6=st6[i])
+        ba.set_points(sub.host, sub.u, sub.v, sub.idepth, sub.color, sub.weights)
+        ba.set_residuals(sub.exists)
+        ba.prepare()
+        ba.set_options(nthreads=6, never_break=True)
+        t0 = time.perf_counter()
+        if track:
+            for k in range(TRACKED_PER_KF):
+                dnew = orc.make_images(win.images[W + k], win.levels, "fast")[0]
+                T0 = synth.se3_mul(win.world_to_cam[W + k], synth.se3_inv(win.world_to_cam[W - 1]))
+                trkr.track(dnew, synth_exp(orc_free_log(T0) * 0.95), [0, 0], [0, 0], [1, 1], win.levels - 1)
+            trkr.set_ref(dref, *trk)
+        ba.optimize(6)
+        t_total += time.perf_counter() - t0
+        n_kf += 1
+        del ba
+    kfs = n_kf / t_total * scale
+    sample = "%d keyframes of %s, %d of %d points%s" % (n_kf, "the same window", len(sub.host), len(win.host),
+                                                       "" if scale == 1.0 else " (KF/s scaled by the point ratio)")
+    return dict(value=kfs, unit="keyframes/s", cores=6, kind="port", sample=sample)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="kitti00_8kf", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the stress250k roofline leg appended to the kitti00 line")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    sharded = args.workload == "shard1m"
+
+    win, st6, trk = make_inputs(args.workload)
+    hook = None
+    if sharded and world > 1:
+        class _Ptr:                                       # wraps the device buffer of the stitched systems for torch
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+        def hook(ptr, n):
+            t = torch.as_tensor(_Ptr(ptr, n), device="cuda")
+            dist.all_reduce(t)                             # RCCL over xGMI; payload ~2*(8W+5)^2*8 B (latency bound)
+            torch.cuda.current_stream().synchronize()
+    job = GpuJob(shard(win, rank, world) if sharded else win, st6, trk, local_rank, hook)
+    do_track = not sharded
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        job.ctx.sync()
+
+    for _ in range(args.warmup):
+        job.step(do_track)
+    job.ctx.profile_enable(True)
+    job.ctx.profile_reset()
+    job.evals = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rm = job.step(do_track)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    job.ctx.profile_enable(False)
+    units = args.steps * (1 if sharded else world)       # replicas: every rank processed its own keyframes
+    value = units / dt
+
+    prof = {k: job.ctx.profile_get(k) for k in ("ba_linearize", "ba_sc", "ba_reduce", "ba_resub", "trk_eval", "pyramid")}
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel (ba_linearize): algorithmic bytes per launch:
+        #   424*R + 104*P  = R*(8 state/energy + 8px*4taps*12 B + 32 B JpJdF write) + P*(80 B point + 24 B Hdd/bd/Hcd write)
+        st, ac, _, _, _ = job.ctx.ba_get_residuals()
+        R = int((job.win.exists > 0).sum())
+        P = len(job.win.host)
+        ms, n = prof["ba_linearize"]
+        roof = None
+        if n > 0:
+            alg = 424.0 * R + 104.0 * P
+            ach = alg / (ms / n * 1e-3) / 1e9
+            roof = dict(kernel="ba_linearize", bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBS, 5), traffic=load_traffic(args.workload),
+                        avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg))
+        out = {
+            "metric": "keyframes/sec, KITTI-00 dense 8-KF photometric BA; pose RMSE vs ref",
+            "value": round(value, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "image": "%dx%d" % (win.w, win.h), "levels": win.levels, "window_frames": win.W,
+                       "active_points": int(len(win.host)), "residuals": int((win.exists > 0).sum()),
+                       "tracked_frames_per_keyframe": TRACKED_PER_KF if do_track else 0, "gn_iterations": 6,
+                       "multi_gpu": ("points sharded, all-reduce of stitched H,b" if sharded else "replicas (window too small to shard)")},
+            "roofline": roof,
+            "kernel_ms": {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
+            "tracker_evals_per_step": job.evals / max(args.steps, 1),
+            "fine_track_rmse": round(float(rm), 4),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(win, st6, trk, track=do_track)
+            out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 2)
+        elif world == 1:
+            out["cpu_baseline"] = None
+    # extra leg (single GPU, default workload only): the 250k-point stress window where the kernels saturate the chip
+    if rank == 0 and world == 1 and args.workload == "kitti00_8kf" and not args.no_extra:
+        job.ctx.close()
+        out["stress250k"] = stress_leg()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_traffic(workload):
+    """HBM bytes per ba_linearize launch from the committed PMC summary (profiles/traffic_*.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(workload)
+        except Exception:
+            return None
+    return None
+
+
+def stress_leg(steps=5, warmup=2):
+    win, st6, trk = make_inputs("stress250k")
+    job = GpuJob(win, st6, trk, 0)
+    for _ in range(warmup):
+        job.step(False)
+    job.ctx.profile_enable(True)
+    job.ctx.profile_reset()
+    job.ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step(False)
+    job.ctx.sync()
+    dt = time.perf_counter() - t0
+    R, P = int((win.exists > 0).sum()), len(win.host)
+    res = {"workload": "stress250k", "keyframes_per_s": round(steps / dt, 3), "ms_per_keyframe": round(dt / steps * 1e3, 3),
+           "active_points": P, "residuals": R, "note": "BA only (optimize), no front-end"}
+    for k, alg in (("ba_linearize", 424.0 * R + 104.0 * P), ("ba_sc", 32.0 * R + 56.0 * P), ("ba_resub", 32.0 * R + 24.0 * P)):
+        ms, n = job.ctx.profile_get(k)
+        if n:
+            ach = alg / (ms / n * 1e-3) / 1e9
+            res[k] = dict(avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg), achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
+    res["traffic"] = load_traffic("stress250k")
+    job.ctx.close()
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,9 @@ void* nalo_stream(nalo_ctx* ctx);                 /* hipStream_t every kernel of
  * ------------------------------------------------------------------------------------------------ */
 int nalo_frame_upload(nalo_ctx* ctx, int slot, const float* irradiance, const float* mask, const uint8_t* bgr,
                       const float* gammaB);
+/* makeImages again from the level-0 irradiance already resident in the slot (asynchronous on the ctx stream): the
+ * HBM-resident form of a1, used when the caller's frames already live on the device */
+int nalo_frame_rebuild(nalo_ctx* ctx, int slot);
 /* test/inspection: level image as AoS {I,dx,dy} (3 floats/px) and absSquaredGrad (1 float/px); either may be NULL */
 int nalo_frame_download(nalo_ctx* ctx, int slot, int lvl, float* dI3, float* abs_sq_grad);
 
@@ -171,6 +174,11 @@ int nalo_ba_get_residuals(nalo_ctx* ctx, int8_t* state, uint8_t* active, float* 
  * index h + t*W, fp64 */
 int nalo_ba_get_acc13(nalo_ctx* ctx, double* H13 /* W*W x 169 */);
 int nalo_ba_counts(nalo_ctx* ctx, int* resInA, int* resInL, int* resInM);
+
+/* bench/test utility (no reference counterpart): snapshot / restore the mutable window state (idepths, residual states,
+ * frame states, calibration, HM/bM) on the device, so the same synthetic keyframe can be replayed without host uploads */
+int nalo_ba_snapshot(nalo_ctx* ctx);
+int nalo_ba_restore(nalo_ctx* ctx);
 
 /* multi-GPU: the active-point set is sharded by the caller (each rank sets only its points); the stitched
  * buffers {H_A, b_A, H_sc, b_sc, energy, counters, energy histogram} are summed across ranks through this hook

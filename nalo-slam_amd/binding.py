@@ -26,12 +26,12 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 
 EXPORTS = [
     "nalo_create", "nalo_destroy", "nalo_last_error", "nalo_levels", "nalo_sync", "nalo_stream",
-    "nalo_frame_upload", "nalo_frame_download",
+    "nalo_frame_upload", "nalo_frame_rebuild", "nalo_frame_download",
     "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
-    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce",
+    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
 ]
 
@@ -60,6 +60,7 @@ def load():
     L.nalo_stream.argtypes = [vp]
     L.nalo_stream.restype = vp
     L.nalo_frame_upload.argtypes = [vp, C.c_int, c_fp, c_fp, c_u8p, c_fp]
+    L.nalo_frame_rebuild.argtypes = [vp, C.c_int]
     L.nalo_frame_download.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp]
     L.nalo_trk_make_k.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
     L.nalo_trk_set_ref.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]
@@ -87,6 +88,8 @@ def load():
     L.nalo_ba_get_acc13.argtypes = [vp, c_dp]
     L.nalo_ba_counts.argtypes = [vp, c_ip, c_ip, c_ip]
     L.nalo_ba_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.nalo_ba_snapshot.argtypes = [vp]
+    L.nalo_ba_restore.argtypes = [vp]
     L.nalo_dense_make_map.argtypes = [vp, C.c_int, c_fp, C.c_float, c_dp, C.c_int, c_ip, c_ip, c_ip, c_fp, c_fp, c_u8p, c_ip, c_ip]
     L.nalo_profile_enable.argtypes = [vp, C.c_int]
     L.nalo_profile_reset.argtypes = [vp]
@@ -155,6 +158,9 @@ class Context:
         m = None if mask is None else np.ascontiguousarray(mask, np.float32)
         b = None if bgr is None else np.ascontiguousarray(bgr, np.uint8)
         self._ck(self.L.nalo_frame_upload(self.h_, slot, _f(img), _f(m), _u8(b), None))
+
+    def frame_rebuild(self, slot):
+        self._ck(self.L.nalo_frame_rebuild(self.h_, slot))
 
     def frame_download(self, slot, lvl):
         n = (self.w >> lvl) * (self.h >> lvl)
@@ -316,6 +322,12 @@ class Context:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._ck(self.L.nalo_ba_counts(self.h_, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def ba_snapshot(self):
+        self._ck(self.L.nalo_ba_snapshot(self.h_))
+
+    def ba_restore(self):
+        self._ck(self.L.nalo_ba_restore(self.h_))
 
     def ba_set_allreduce(self, fn):
         """fn(device_ptr:int, n:int) sums n doubles in place across ranks."""

@@ -93,6 +93,12 @@ int nalo_frame_upload(nalo_ctx* c, int slot, const float* irradiance, const floa
     return NALO_OK;
 }
 
+int nalo_frame_rebuild(nalo_ctx* c, int slot) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size() || !c->slots[slot].valid) return fail(c, NALO_ERR_ARG, "nalo_frame_rebuild: bad slot");
+    NALO_HIP(c, hipSetDevice(c->device));
+    return pyramid_build(c, c->slots[slot], nullptr);
+}
+
 int nalo_frame_download(nalo_ctx* c, int slot, int lvl, float* dI3, float* absg) {
     if (!c || slot < 0 || slot >= (int)c->slots.size() || lvl < 0 || lvl >= c->levels) return fail(c, NALO_ERR_ARG, "nalo_frame_download: bad argument");
     FrameSlot& s = c->slots[slot];

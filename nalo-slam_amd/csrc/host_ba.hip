@@ -52,6 +52,9 @@ struct BAWindow {
     size_t up_cap = 0;
     bool have_lin = false, have_sc = false, stitched_top = false, stitched_sc = false, points_set = false, res_set = false;
     int sc_shift = -1;
+    // snapshot of the mutable window state (bench/test utility: replay the same synthetic keyframe)
+    DevBuf<float4> snap_geo; DevBuf<uint8_t> snap_state, snap_flags; DevBuf<float> snap_prior;
+    std::vector<HostFrame> snap_frames; std::vector<double> snap_HM, snap_bM; std::vector<uint8_t> snap_flags_h; double snap_calib[4] = {}; bool have_snap = false;
     nalo_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
     bool never_break = false;
@@ -65,7 +68,7 @@ void ba_destroy(nalo_ctx* c) {
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
     w->blk_host.release(); w->host_blk.release(); w->acc13.release(); w->misc.release(); w->G.release(); w->S_top.release(); w->S_sc.release();
-    w->Tm.release(); w->stitched.release();
+    w->Tm.release(); w->stitched.release(); w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
     delete w;
@@ -742,6 +745,38 @@ int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
     if (!c) return NALO_ERR_ARG;
     if (!c->ba) c->ba = new BAWindow();
     c->ba->hook = hook; c->ba->hook_user = user;
+    return NALO_OK;
+}
+
+int nalo_ba_snapshot(nalo_ctx* c) {
+    NALO_BA_READY("nalo_ba_snapshot")
+    const size_t N = w.Ppad, NS = (size_t)w.W * N;
+    NALO_HIP(c, w.snap_geo.reserve(N)); NALO_HIP(c, w.snap_state.reserve(NS)); NALO_HIP(c, w.snap_flags.reserve(N)); NALO_HIP(c, w.snap_prior.reserve(N));
+    NALO_HIP(c, hipMemcpyAsync(w.snap_geo.p, w.pt_geo.p, N * 16, hipMemcpyDeviceToDevice, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(w.snap_state.p, w.rs_state.p, NS, hipMemcpyDeviceToDevice, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(w.snap_flags.p, w.pt_flags.p, N, hipMemcpyDeviceToDevice, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(w.snap_prior.p, w.pt_prior.p, N * 4, hipMemcpyDeviceToDevice, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    w.snap_frames = w.frames; w.snap_HM = w.HM; w.snap_bM = w.bM; w.snap_flags_h = w.flags_h;
+    std::memcpy(w.snap_calib, w.c_value, sizeof(w.snap_calib));
+    w.have_snap = true;
+    return NALO_OK;
+}
+int nalo_ba_restore(nalo_ctx* c) {
+    NALO_BA_READY("nalo_ba_restore")
+    if (!w.have_snap) return fail(c, NALO_ERR_STATE, "nalo_ba_restore: no snapshot");
+    const size_t N = w.Ppad, NS = (size_t)w.W * N;
+    NALO_HIP(c, hipMemcpyAsync(w.pt_geo.p, w.snap_geo.p, N * 16, hipMemcpyDeviceToDevice, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(w.rs_state.p, w.snap_state.p, NS, hipMemcpyDeviceToDevice, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(w.pt_flags.p, w.snap_flags.p, N, hipMemcpyDeviceToDevice, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(w.pt_prior.p, w.snap_prior.p, N * 4, hipMemcpyDeviceToDevice, c->stream));
+    NALO_HIP(c, hipMemsetAsync(w.rs_energy.p, 0, NS * 8, c->stream));
+    w.frames = w.snap_frames; w.HM = w.snap_HM; w.bM = w.snap_bM; w.flags_h = w.snap_flags_h;
+    calib_set_value(w, w.snap_calib);
+    int rc = upload_frame_th(c); if (rc) return rc;
+    rc = set_adjoints(c); if (rc) return rc;
+    rc = set_precalc(c); if (rc) return rc;
+    w.have_lin = w.have_sc = false;
     return NALO_OK;
 }
 
