@@ -47,6 +47,7 @@ struct BADev {
     float4 *rs_jp0, *rs_jp1;                    // EFResidual::JpJdF
     float4* rs_cpt;                             // {Ku, Kv, new_idepth, relBS} (centerProjectedTo), written when fix/marg
     float* en_new;                              // [Ppad] state_NewEnergyWithOutlier of residuals targeting frame W-1 (-1 = none)
+    unsigned *th_hist_hi, *th_hist_lo, *th_state;   // radix-select histograms (2 x 65536) + {count, k_rem, prefix_hi}
     // partials
     float* top_partial;                         // [nblocks][W][kTopStride]
     float* sc_partial;                          // [nblocks][NPL*NPL]

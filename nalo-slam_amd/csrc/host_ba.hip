@@ -11,7 +11,7 @@ void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorSc
 void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix);
 void ba_launch_reset_oob(hipStream_t s, const BADev& B);
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc);
-void ba_launch_stitch(hipStream_t s, const double* S, const double* M, int nb, int n1, int m, double* Tm, double* H);
+void ba_launch_stitch(hipStream_t s, const int* rowptr, const int* col, const double* val, const double* M, int nb, int n1, int m, double* Tm, double* H);
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
@@ -46,7 +46,10 @@ struct BAWindow {
     DevBuf<float2> rs_energy;
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
     DevBuf<int> blk_host, host_blk;
-    DevBuf<double> acc13, misc, G, S_top, S_sc, Tm, stitched;     // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | scalars(8)]
+    DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 16
+    hipEvent_t ev_lin = nullptr, ev_th = nullptr;
+    DevBuf<double> acc13, misc, G, S_top, S_sc, Tm, stitched;     // S_*: CSR values
+    DevBuf<int> Srp_top, Sci_top, Srp_sc, Sci_sc;                   // CSR rowptr / col of the stitch matrices     // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | scalars(8)]
     double* stitched_host = nullptr;                                // pinned mirror
     float* up_host = nullptr;                                       // pinned upload staging (precalc, xAd)
     size_t up_cap = 0;
@@ -67,8 +70,10 @@ void ba_destroy(nalo_ctx* c) {
     w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
-    w->blk_host.release(); w->host_blk.release(); w->acc13.release(); w->misc.release(); w->G.release(); w->S_top.release(); w->S_sc.release();
-    w->Tm.release(); w->stitched.release(); w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
+    w->blk_host.release(); w->host_blk.release(); w->acc13.release(); w->misc.release(); w->G.release(); w->S_top.release(); w->S_sc.release(); w->Srp_top.release(); w->Sci_top.release(); w->Srp_sc.release(); w->Sci_sc.release();
+    w->Tm.release(); w->stitched.release(); w->th_hist.release();
+    if (w->ev_lin) (void)hipEventDestroy(w->ev_lin);
+    if (w->ev_th) (void)hipEventDestroy(w->ev_th); w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
     delete w;
@@ -165,10 +170,25 @@ static int set_adjoints(nalo_ctx* c) {
         for (int k = 0; k < 4; ++k) S[(size_t)k * NPL + 8 * (W - 1) + k] = 1;
         S[(size_t)w.n * NPL + 8 * (W - 1) + 4] = 1;
     }
-    NALO_HIP(c, w.S_top.reserve(St.size())); NALO_HIP(c, w.S_sc.reserve(Ss.size()));
-    NALO_HIP(c, hipMemcpyAsync(w.S_top.p, St.data(), St.size() * 8, hipMemcpyHostToDevice, c->stream));
-    NALO_HIP(c, hipMemcpyAsync(w.S_sc.p, Ss.data(), Ss.size() * 8, hipMemcpyHostToDevice, c->stream));
-    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    // dense -> CSR (row = (b, r)); the kernels only touch the non-zeros
+    auto to_csr = [&](const std::vector<double>& D, int nb, int m, DevBuf<int>& rp, DevBuf<int>& ci, DevBuf<double>& va) -> int {
+        std::vector<int> rowptr((size_t)nb * n1 + 1, 0), col;
+        std::vector<double> val;
+        for (int b = 0; b < nb; ++b) for (int r = 0; r < n1; ++r) {
+            const double* row = &D[((size_t)b * n1 + r) * m];
+            for (int k = 0; k < m; ++k) if (row[k] != 0.0) { col.push_back(k); val.push_back(row[k]); }
+            rowptr[(size_t)b * n1 + r + 1] = (int)col.size();
+        }
+        if (col.empty()) { col.push_back(0); val.push_back(0.0); }
+        NALO_HIP(c, rp.reserve(rowptr.size())); NALO_HIP(c, ci.reserve(col.size())); NALO_HIP(c, va.reserve(val.size()));
+        NALO_HIP(c, hipMemcpyAsync(rp.p, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice, c->stream));
+        NALO_HIP(c, hipMemcpyAsync(ci.p, col.data(), col.size() * 4, hipMemcpyHostToDevice, c->stream));
+        NALO_HIP(c, hipMemcpyAsync(va.p, val.data(), val.size() * 8, hipMemcpyHostToDevice, c->stream));
+        NALO_HIP(c, hipStreamSynchronize(c->stream));
+        return NALO_OK;
+    };
+    int rc = to_csr(St, W * W, 13, w.Srp_top, w.Sci_top, w.S_top); if (rc) return rc;
+    rc = to_csr(Ss, W, NPL, w.Srp_sc, w.Sci_sc, w.S_sc); if (rc) return rc;
     w.proj_valid = false;
     return NALO_OK;
 }
@@ -224,6 +244,7 @@ static int upload_frame_th(nalo_ctx* c) {
     std::vector<float> th(w.W);
     for (int i = 0; i < w.W; ++i) th[i] = w.frames[i].frameEnergyTH;
     NALO_HIP(c, w.frameTH.reserve(w.W));
+    NALO_HIP(c, hipStreamSynchronize(c->side));
     NALO_HIP(c, hipMemcpy(w.frameTH.p, th.data(), w.W * 4, hipMemcpyHostToDevice));
     w.dev.frameTH = w.frameTH.p;
     return NALO_OK;
@@ -232,11 +253,17 @@ static int upload_frame_th(nalo_ctx* c) {
 // ---------------------------------------------------------------------------------------------- pipeline pieces
 static int linearize_async(nalo_ctx* c, int mode, int fix) {
     BAWindow& w = *c->ba;
+    NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0));           // frameEnergyTH of the previous pass must have landed
     {
         ProfScope ps(c, "ba_linearize");
         ba_launch_linearize(c->stream, w.dev, mode, fix);
     }
-    if (mode == 0) ba_launch_energy_th(c->stream, w.dev);
+    if (mode == 0) {                                                   // quantile on the side stream, overlapped with SC / reduce / stitch / solve
+        NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
+        NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
+        ba_launch_energy_th(c->side, w.dev);
+        NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
+    }
     w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
@@ -259,8 +286,8 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
         ProfScope ps(c, "ba_reduce");
         const bool top = want_top && !w.stitched_top, sc = want_sc && !w.stitched_sc;
         if (top || sc) ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.misc.p, w.G.p, top, sc);
-        if (top) { ba_launch_stitch(c->stream, w.S_top.p, w.acc13.p, W * W, n1, 13, w.Tm.p, w.stitched.p); w.stitched_top = true; did = true; }
-        if (sc) { ba_launch_stitch(c->stream, w.S_sc.p, w.G.p, W, n1, NPL, w.Tm.p, w.stitched.p + blk); w.stitched_sc = true; did = true; }
+        if (top) { ba_launch_stitch(c->stream, w.Srp_top.p, w.Sci_top.p, w.S_top.p, w.acc13.p, W * W, n1, 13, w.Tm.p, w.stitched.p); w.stitched_top = true; did = true; }
+        if (sc) { ba_launch_stitch(c->stream, w.Srp_sc.p, w.Sci_sc.p, w.S_sc.p, w.G.p, W, n1, NPL, w.Tm.p, w.stitched.p + blk); w.stitched_sc = true; did = true; }
     }
     NALO_HIP(c, hipGetLastError());
     if (did) {
@@ -460,6 +487,9 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
         w.dev.img[i] = c->slots[s.slot].dI[0];
     }
     w.dev.W = W; w.dev.w = c->w; w.dev.h = c->h;
+    if (!w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming)); NALO_HIP(c, hipEventRecord(w.ev_th, c->side)); }
+    NALO_HIP(c, w.th_hist.reserve(2 * 65536 + 16)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, (2 * 65536 + 16) * 4));
+    w.dev.th_hist_hi = w.th_hist.p; w.dev.th_hist_lo = w.th_hist.p + 65536; w.dev.th_state = w.th_hist.p + 2 * 65536;
     if (w.HM.size() != (size_t)w.n * w.n) { w.HM.assign((size_t)w.n * w.n, 0.0); w.bM.assign(w.n, 0.0); }
     w.lastX.assign(w.n, 0.0);
     const size_t blk = (size_t)w.n1 * w.n1;
@@ -575,6 +605,7 @@ int nalo_ba_linearize(nalo_ctx* c, int fix, double* energy) {
     NALO_BA_READY("nalo_ba_linearize")
     int rc = linearize_async(c, 0, fix); if (rc) return rc;
     rc = stitch_and_fetch(c, true, false); if (rc) return rc;
+    NALO_HIP(c, hipStreamSynchronize(c->side));
     NALO_HIP(c, hipMemcpy(&w.frames[w.W - 1].frameEnergyTH, w.frameTH.p + (w.W - 1), 4, hipMemcpyDeviceToHost));
     double e = 0; misc_totals(w, &e, &w.resInA);
     if (energy) *energy = e;
@@ -637,6 +668,7 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
     rc = set_precalc(c); if (rc) return rc;
     rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
     rc = stitch_and_fetch(c, true, false); if (rc) return rc;
+    NALO_HIP(c, hipStreamSynchronize(c->side));
     NALO_HIP(c, hipMemcpy(&nf.frameEnergyTH, w.frameTH.p + (W - 1), 4, hipMemcpyDeviceToHost));
     double e = 0; int nres = 0; misc_totals(w, &e, &nres);
     // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)

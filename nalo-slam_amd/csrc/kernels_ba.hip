@@ -226,7 +226,10 @@ __global__ __launch_bounds__(kBlk) void ba_linearize_kernel(BADev B) {
                 }
             }
         }
-        if (t == W - 1) B.en_new[d] = enew;
+        if (t == W - 1) {
+            B.en_new[d] = enew;
+            if (MODE == 0 && enew >= 0.f) atomicAdd(&B.th_hist_hi[__float_as_uint(enew) >> 16], 1u);   // integer atomics: order independent
+        }
         block_reduce_cols<kTopVals, kBlk>(v, smem, B.top_partial + ((size_t)b * W + t) * kTopStride);
     }
     if (h == W - 1) B.en_new[d] = -1.f;
@@ -394,33 +397,36 @@ void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NP
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)
-// S: [nb][n1][m] (n1 = 8W+5: the last row selects the residual/bdSum column so H~[:,n1-1] is the b vector), M: [nb][m][m].
-__global__ __launch_bounds__(256) void ba_stitch_a_kernel(const double* __restrict__ S, const double* __restrict__ M, int n1, int m, double* __restrict__ Tm) {
-    const int b = blockIdx.x;
-    const double *Sb = S + (size_t)b * n1 * m, *Mb = M + (size_t)b * m * m;
-    double* Tb = Tm + (size_t)b * m * n1;
-    for (int e = threadIdx.x; e < m * n1; e += blockDim.x) {
-        const int k = e / n1, c = e - k * n1;
-        double s = 0;
-        for (int l = 0; l < m; ++l) s += Mb[k * m + l] * Sb[c * m + l];
-        Tb[e] = s;
-    }
-}
-__global__ __launch_bounds__(256) void ba_stitch_b_kernel(const double* __restrict__ S, const double* __restrict__ Tm, int nb, int n1, int m, double* __restrict__ H) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n1 * n1) return;
-    const int r = e / n1, c = e - r * n1;
+// S_b ((8W+5) x m) is sparse: a frame row carries one 8-wide adjoint block per slot it takes part in. It is kept in CSR
+// (rowptr over [b][row], col, val), built on the host from adHost/adTarget. The last row (index 8W+4) selects the
+// residual / bdSum column, so column 8W+4 of H~ is the b vector.
+//   step A  T_b[k][c] = sum_{(l,v) in row c of S_b} M_b[k][l] * v        one thread per (b,k,c)
+//   step B  H~[r][c]  = sum_b sum_{(k,v) in row r of S_b} v * T_b[k][c]    one block per row r, fixed order: deterministic
+__global__ __launch_bounds__(256) void ba_stitch_a_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                          const double* __restrict__ M, int n1, int m, double* __restrict__ Tm) {
+    const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * n1) return;
+    const int k = e / n1, c = e - k * n1;
+    const double* Mk = M + ((size_t)b * m + k) * m;
     double s = 0;
-    for (int b = 0; b < nb; ++b) {
-        const double* Sr = S + ((size_t)b * n1 + r) * m;
-        const double* Tb = Tm + (size_t)b * m * n1 + c;
-        for (int k = 0; k < m; ++k) { const double sv = Sr[k]; if (sv != 0.0) s += sv * Tb[(size_t)k * n1]; }
-    }
-    H[e] = s;
+    for (int q = rowptr[b * n1 + c]; q < rowptr[b * n1 + c + 1]; ++q) s += Mk[col[q]] * val[q];
+    Tm[(size_t)b * m * n1 + e] = s;
 }
-void ba_launch_stitch(hipStream_t s, const double* S, const double* M, int nb, int n1, int m, double* Tm, double* H) {
-    ba_stitch_a_kernel<<<nb, 256, 0, s>>>(S, M, n1, m, Tm);
-    ba_stitch_b_kernel<<<(n1 * n1 + 255) / 256, 256, 0, s>>>(S, Tm, nb, n1, m, H);
+__global__ __launch_bounds__(128) void ba_stitch_b_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                          const double* __restrict__ Tm, int nb, int n1, int m, double* __restrict__ H) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < n1; c += blockDim.x) {
+        double s = 0;
+        for (int b = 0; b < nb; ++b) {
+            const double* Tb = Tm + (size_t)b * m * n1 + c;
+            for (int q = rowptr[b * n1 + r]; q < rowptr[b * n1 + r + 1]; ++q) s += val[q] * Tb[(size_t)col[q] * n1];
+        }
+        H[(size_t)r * n1 + c] = s;
+    }
+}
+void ba_launch_stitch(hipStream_t s, const int* rowptr, const int* col, const double* val, const double* M, int nb, int n1, int m, double* Tm, double* H) {
+    ba_stitch_a_kernel<<<dim3((m * n1 + 255) / 256, nb), 256, 0, s>>>(rowptr, col, val, M, n1, m, Tm);
+    ba_stitch_b_kernel<<<n1, 128, 0, s>>>(rowptr, col, val, Tm, nb, n1, m, H);
 }
 
 // ------------------------------------------------------------------------------------------------ a12 + step
@@ -459,12 +465,15 @@ __global__ __launch_bounds__(256) void ba_step_kernel(BADev B, float stepfacD, f
     }
     block_reduce_cols<3, 256>(v, smem, partial + (size_t)blockIdx.x * 4);
 }
-__global__ __launch_bounds__(64) void ba_sum_partials_kernel(const float* __restrict__ partial, int nblocks, int stride, int nvals, double* __restrict__ out) {
-    const int j = threadIdx.x;
-    if (j >= nvals) return;
+// out[j] = sum_b partial[b*stride + j] in fp64: 16 groups of 64 lanes stride over the blocks, then a fixed-order LDS combine
+__global__ __launch_bounds__(1024) void ba_sum_partials_kernel(const float* __restrict__ partial, int nblocks, int stride, int nvals, double* __restrict__ out) {
+    __shared__ double part[16][64];
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * stride + j];
-    out[j] = s;
+    if (j < nvals) for (int b = g; b < nblocks; b += 16) s += (double)partial[(size_t)b * stride + j];
+    part[g][j] = s;
+    __syncthreads();
+    if (g == 0 && j < nvals) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; out[j] = t; }
 }
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc) {
     ba_resub_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc);
@@ -472,56 +481,68 @@ void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const floa
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3) {
     const int nb = (B.Ppad + 255) / 256;
     ba_step_kernel<<<nb, 256, 0, s>>>(B, stepfacD, partial);
-    ba_sum_partials_kernel<<<1, 64, 0, s>>>(partial, nb, 4, 3, out3);
+    ba_sum_partials_kernel<<<1, 1024, 0, s>>>(partial, nb, 4, 3, out3);
 }
 
 // ------------------------------------------------------------------------------------------------ setNewFrameEnergyTH
-// Exact n-th element (nthIdx = (int)(0.7f * n)) of the non-negative energies by a 4-pass byte radix select in one block,
-// then the threshold formula of FullSystemOptimize.cpp:117-133; writes frameTH[W-1].
-__global__ __launch_bounds__(1024) void ba_energy_th_kernel(const float* __restrict__ en, int n, float* __restrict__ frameTH_new) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_k, s_count;
+// Exact n-th element (nthIdx = (int)(0.7f * n), FullSystemOptimize.cpp:117-122) of the non-negative energies of the residuals
+// that target the newest frame, by a two-level 16+16-bit radix select on the float bit patterns (monotone for x >= 0):
+// the high-half histogram is filled by ba_linearize_kernel itself (integer atomics), then find-hi -> low-half histogram of the
+// matching entries -> find-lo + the threshold formula (:130-133). Runs on the side stream, overlapped with SC/reduce/stitch.
+__global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new) {
+    __shared__ unsigned part[1024];
+    __shared__ unsigned s_sel, s_run;
     const int tid = threadIdx.x;
-    if (tid == 0) s_count = 0;
+    unsigned loc[64], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) { loc[i] = hist[tid * 64 + i]; sum += loc[i]; }
+    part[tid] = sum;
     __syncthreads();
-    unsigned cnt = 0;
-    for (int i = tid; i < n; i += blockDim.x) cnt += (en[i] >= 0.f) ? 1u : 0u;
-    atomicAdd(&s_count, cnt);
-    __syncthreads();
-    const unsigned total = s_count;
-    if (total == 0) { if (tid == 0) *frameTH_new = 12.f * 12.f * (float)kPatternNum; return; }
-    if (tid == 0) { s_prefix = 0; s_k = (unsigned)(int)(0.7f * (float)total); }
-    __syncthreads();
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        const unsigned prefix = s_prefix, himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = tid; i < n; i += blockDim.x) {
-            const float f = en[i];
-            if (!(f >= 0.f)) continue;
-            const unsigned u = __float_as_uint(f);
-            if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned k = s_k, run = 0; int bsel = 255;
-            for (int bkt = 0; bkt < 256; ++bkt) { if (run + hist[bkt] > k) { bsel = bkt; break; } run += hist[bkt]; }
-            s_k = k - run; s_prefix = prefix | ((unsigned)bsel << shift);
-        }
-        __syncthreads();
-    }
     if (tid == 0) {
-        const float nthElement = sqrtf(__uint_as_float(s_prefix));
-        float th = nthElement * 1.5f;                                   // setting_frameEnergyTHFacMedian
-        th = 26.0f * 0.5f + th * (1.f - 0.5f);                          // setting_frameEnergyTHConstWeight
-        th = th * th;
-        th *= 1.0f * 1.0f;                                              // setting_overallEnergyTHWeight^2
-        *frameTH_new = th;
+        unsigned total = 0;
+        for (int i = 0; i < 1024; ++i) total += part[i];
+        unsigned k;
+        if (level == 0) { state[0] = total; k = (unsigned)(int)(0.7f * (float)total); } else k = state[1];
+        unsigned run = 0; int sel = 1023;
+        for (int i = 0; i < 1024; ++i) { if (run + part[i] > k) { sel = i; break; } run += part[i]; }
+        s_sel = (unsigned)sel; s_run = run;
+        if (level == 0 && total == 0) state[3] = 1; else if (level == 0) state[3] = 0;
     }
+    __syncthreads();
+    if (tid == (int)s_sel) {
+        const unsigned k = (level == 0) ? (unsigned)(int)(0.7f * (float)state[0]) : state[1];
+        unsigned run = s_run; int bsel = 63;
+        for (int i = 0; i < 64; ++i) { if (run + loc[i] > k) { bsel = i; break; } run += loc[i]; }
+        const unsigned bin = (unsigned)(tid * 64 + bsel);
+        if (level == 0) { state[1] = k - run; state[2] = bin; }
+        else {
+            float th;
+            if (state[3]) th = 12.f * 12.f * (float)kPatternNum;                        // no residual on the newest frame (:110-114)
+            else {
+                const float nthElement = sqrtf(__uint_as_float((state[2] << 16) | bin));
+                th = nthElement * 1.5f;                                                 // setting_frameEnergyTHFacMedian
+                th = 26.0f * 0.5f + th * (1.f - 0.5f);                                  // setting_frameEnergyTHConstWeight
+                th = th * th;                                                           // setting_overallEnergyTHWeight = 1
+            }
+            *frameTH_new = th;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64; ++i) hist[tid * 64 + i] = 0;                                // ready for the next pass
+}
+__global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float f = en[i];
+    if (!(f >= 0.f)) return;
+    const unsigned u = __float_as_uint(f);
+    if ((u >> 16) == state[2]) atomicAdd(&hist_lo[u & 0xFFFFu], 1u);
 }
 void ba_launch_energy_th(hipStream_t s, const BADev& B) {
-    ba_energy_th_kernel<<<1, 1024, 0, s>>>(B.en_new, B.Ppad, B.frameTH + (B.W - 1));
+    ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr);
+    ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo);
+    ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1));
 }
 
 }  // namespace nalo

@@ -99,12 +99,14 @@ __global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* _
 }
 
 // fp64 finish: out[j] = sum_b partial[b][j]; written straight into host-mapped pinned memory
-__global__ __launch_bounds__(64) void trk_finish_kernel(const float* __restrict__ partial, int nblocks, double* __restrict__ out) {
-    const int j = threadIdx.x;
-    if (j >= kTrkVals) return;
+__global__ __launch_bounds__(1024) void trk_finish_kernel(const float* __restrict__ partial, int nblocks, double* __restrict__ out) {
+    __shared__ double part[16][64];
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * 64 + j];
-    out[j] = s;
+    if (j < kTrkVals) for (int b = g; b < nblocks; b += 16) s += (double)partial[(size_t)b * 64 + j];
+    part[g][j] = s;
+    __syncthreads();
+    if (g == 0 && j < kTrkVals) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; out[j] = t; }
 }
 
 int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], const float t[3], const float Ki[9],
@@ -118,7 +120,7 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
     for (int i = 0; i < 3; ++i) P.t[i] = t[i];
     P.affa = affa; P.affb = affb; P.b0 = b0; P.cutoff = cutoff; P.maxEnergy = maxEnergy;
     int nblocks = (P.n + 255) / 256;
-    nblocks = nblocks < 1 ? 1 : (nblocks > 2048 ? 2048 : nblocks);
+    nblocks = nblocks < 1 ? 1 : (nblocks > 512 ? 512 : nblocks);
     NALO_HIP(c, c->trk_partial.reserve((size_t)2048 * 64));
     {
         ProfScope ps(c, "trk_eval");
@@ -126,7 +128,7 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
     }
     double* dout = nullptr;
     NALO_HIP(c, hipHostGetDevicePointer((void**)&dout, c->trk_out_host, 0));
-    trk_finish_kernel<<<1, 64, 0, c->stream>>>(c->trk_partial.p, nblocks, dout);
+    trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, dout);
     NALO_HIP(c, hipGetLastError());
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(out64, c->trk_out_host, sizeof(double) * kTrkVals);
