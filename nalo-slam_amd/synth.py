@@ -65,12 +65,12 @@ class Window:
 
 
 class Scene:
-    def __init__(self, seed: int = 20240601, wall_z: float = 40.0, ground_y: float = 1.6, amp: float = 50.0):
+    def __init__(self, seed: int = 20240601, wall_z: float = 40.0, ground_y: float = 1.6, amp: float = 50.0, freq_scale: float = 1.0):
         rng = np.random.RandomState(seed)
         self.wall_z, self.ground_y, self.amp = wall_z, ground_y, amp
-        self.fg = rng.uniform(2.0, 14.0, size=(6, 2))     # ground freqs (rad/m)
+        self.fg = rng.uniform(2.0, 14.0, size=(6, 2)) * freq_scale     # ground freqs (rad/m)
         self.pg = rng.uniform(0, 2 * np.pi, size=(6, 2))
-        self.fw = rng.uniform(1.0, 8.0, size=(6, 2))      # wall freqs
+        self.fw = rng.uniform(1.0, 8.0, size=(6, 2)) * freq_scale      # wall freqs
         self.pw = rng.uniform(0, 2 * np.pi, size=(6, 2))
 
     def _tex(self, a, b, f, p):
@@ -101,10 +101,10 @@ class Scene:
 
 
 def make_window(w=640, h=480, W=8, P=2000, seed=7, n_extra=1, idepth_noise=0.01, f=None,
-                step_z=0.8, yaw_deg=0.5, full_graph=True, pose_seed_scene=20240601, min_grad2=50.0) -> Window:
+                step_z=0.8, yaw_deg=0.5, full_graph=True, pose_seed_scene=20240601, min_grad2=50.0, freq_scale=1.0) -> Window:
     f = float(f if f is not None else 0.52 * w)
     K = (f, f, (w - 1) / 2.0, (h - 1) / 2.0)
-    scene = Scene(pose_seed_scene)
+    scene = Scene(pose_seed_scene, freq_scale=freq_scale)
     F = W + n_extra
     w2c = np.zeros((F, 3, 4))
     for i in range(F):

@@ -1,0 +1,75 @@
+"""Regenerates tests/golden/*.npz from the CPU oracle (fp32-pointwise build, fp64 sums) on tiny seeded windows.
+The reference ships no golden vectors for this path (parity unpinned); these fixtures pin the ORACLE's behaviour so that
+any later change to oracle or kernels is caught, and let the GPU tests run against committed data only.
+Run:  python tests/golden/make_golden.py"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import nalo_pkg  # noqa: E402
+
+nalo_pkg.load()
+import orc  # noqa: E402
+from helpers import tracker_inputs, true_rel_pose  # noqa: E402
+from nalo_slam_amd import synth  # noqa: E402
+
+GOLDEN_WINDOW = dict(w=320, h=240, W=3, P=64, seed=11)
+
+
+def main():
+    orc.lib().orc_set_sum_mode(0)
+    win = synth.make_window(**GOLDEN_WINDOW)
+    out = {}
+    # a1: pyramid checksums + a few texels
+    dI, ab = orc.make_images(win.images[1], win.levels)
+    out["pyr_sum"] = np.array([dI[:, k].astype(np.float64).sum() for k in range(3)] + [ab.astype(np.float64).sum()])
+    out["pyr_texels"] = dI[[1000, 5000, 20000, 76800 + 100, 76800 + 19200 + 50]]
+    # a2-a4: tracker
+    Ku, Kv, nid, hdi = tracker_inputs(win, n=800, seed=2)
+    trk = orc.Tracker(win.w, win.h, win.levels, win.K)
+    dref = orc.make_images(win.images[win.W - 1], win.levels)[0]
+    dnew = orc.make_images(win.images[win.W], win.levels)[0]
+    trk.set_ref(dref, Ku, Kv, nid, hdi)
+    out["trk_in"] = np.stack([Ku, Kv, nid, hdi])
+    out["pc_n"] = np.array([len(trk.get_pc(l)[0]) for l in range(win.levels)])
+    out["pc0_head"] = np.stack([a[:16] for a in trk.get_pc(0)])
+    T = orc.se3_exp(orc.se3_log(true_rel_pose(win, win.W - 1, win.W)) * 0.9)
+    aff = np.array([0.97, 2.0], np.float32)
+    out["trk_T"], out["trk_aff"] = T, aff
+    for lvl in (0, 2):
+        out["trk_stats%d" % lvl] = trk.calc_res(dnew, lvl, T, aff, 20.0)
+        H, b = trk.calc_gs(lvl, float(aff[0]), 0.5)
+        out["trk_H%d" % lvl], out["trk_b%d" % lvl] = H, b
+    ok, Tt, afft, lr, lf = trk.track(dnew, T, [0, 0], [0, 0], [1, 1], win.levels - 1)
+    out["trk_track_T"], out["trk_track_aff"], out["trk_track_ok"] = Tt, afft, np.array([ok])
+    # a5-a13: BA
+    st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
+    out["ba_state6"] = st6
+    ba = orc.ba_from_window(win, "f32", state6=st6)
+    out["ba_energy"] = np.array([ba.linearize_all(False)])
+    ba.apply_res()
+    st, ac, jp, en = ba.slots()
+    out["ba_state"], out["ba_active"], out["ba_JpJdF"] = st, ac, jp
+    HA, bA, h13 = ba.accumulate(0, True)
+    Hs, bs = ba.accumulate_sc(True)
+    out["ba_HA"], out["ba_bA"], out["ba_Hsc"], out["ba_bsc"], out["ba_acc13"] = HA, bA, Hs, bs, h13
+    out["ba_J16"] = np.stack([ba.residual(p, t)["J"] for p, t in zip(*np.nonzero(ac)) if True][:16])
+    out["ba_x0"] = ba.solve_system(0)
+    out["ba_step"] = ba.points()["step"]
+    ba2 = orc.ba_from_window(win, "f32", state6=st6)
+    out["ba_opt_rmse"] = np.array([ba2.optimize(6)])
+    out["ba_opt_w2c"] = np.stack([ba2.frame(f)["worldToCam"] for f in range(win.W)])
+    out["ba_opt_idepth"] = ba2.points()["idepth"]
+    out["ba_opt_calib"] = ba2.calib()
+    np.savez_compressed(os.path.join(HERE, "golden_r01.npz"), **out)
+    print("wrote golden_r01.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "golden_r01.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

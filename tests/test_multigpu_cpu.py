@@ -1,0 +1,62 @@
+"""world_size-2 gloo test of the N>1 path: the active-point set is sharded block-cyclically over the ranks,
+every rank stitches its own partial systems, one all-reduce(SUM, fp64) of {H_A, b_A, H_sc, b_sc, energy, count} gives
+every rank the window's systems. No GPU here, so the per-shard compute is the oracle (test infrastructure); the sharding
+helper, the buffer packing and the hook contract are the product's (bench.shard / nalo_ba_set_allreduce)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nalo_pkg
+    nalo_pkg.load()
+    import bench
+    import orc
+    from nalo_slam_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    win = synth.make_window(w=320, h=240, W=3, P=96, seed=5)
+    st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
+    orc.lib().orc_set_sum_mode(0)
+    part = bench.shard(win, rank, world)
+    ba = orc.ba_from_window(part, "f32", state6=st6)
+    E = ba.linearize_all(False)
+    ba.apply_res()
+    HA, bA = ba.accumulate(0)
+    Hs, bs = ba.accumulate_sc(True)
+    buf = torch.from_numpy(np.concatenate([HA.ravel(), bA, Hs.ravel(), bs, [E, ba.counts()[0]]]))
+    dist.all_reduce(buf)                      # the hook's contract: in-place SUM of n doubles
+    if rank == 0:
+        full = orc.ba_from_window(win, "f32", state6=st6)
+        E0 = full.linearize_all(False)
+        full.apply_res()
+        HA0, bA0 = full.accumulate(0)
+        Hs0, bs0 = full.accumulate_sc(True)
+        ref = np.concatenate([HA0.ravel(), bA0, Hs0.ravel(), bs0, [E0, full.counts()[0]]])
+        got = buf.numpy()
+        n = HA0.size
+        ret["err_HA"] = float(np.abs(got[:n] - ref[:n]).max() / np.abs(ref[:n]).max())
+        ret["err_all"] = float(np.abs(got - ref).max() / np.abs(ref).max())
+        ret["count"] = (float(got[-1]), float(ref[-1]))
+        ret["shard_sizes"] = len(part.host)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_systems_sum_to_the_window_system():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret["err_HA"] < 1e-12 and ret["err_all"] < 1e-12      # fp64 sums of disjoint point sets: only rounding order differs
+    assert ret["count"][0] == ret["count"][1] and ret["shard_sizes"] == 48

@@ -1,0 +1,299 @@
+"""CPU tests of the oracle itself (parity unpinned by the reference: these are the pins we do have).
+ - SE(3): the element list of the reference's vendored Sophus test (thirdparty/Sophus/sophus/test_se3.cpp:41-60) as KATs
+   for exp/log/Adj/group identities;
+ - oracle-free cross-checks: finite differences of the residual Jacobians, the Schur identity of accumulate+SC+stitch
+   against a dense J^T J assembled in numpy, LM recovery of a known synthetic pose, BA convergence;
+ - reference-order fp32 accumulators (SSE lanes + 3-tier shiftUp) stay inside a stated band of the fp64 sums."""
+import numpy as np
+import pytest
+
+import orc
+from helpers import rel_err, tracker_inputs, true_rel_pose, pose_dist
+from nalo_slam_amd import synth
+
+
+def _so3(w):
+    return synth.so3_exp(np.asarray(w, float))
+
+
+def _se3(R, t):
+    return np.concatenate([R, np.asarray(t, float)[:, None]], axis=1)
+
+
+def sophus_elements():
+    I = np.eye(3)
+    e = [
+        _se3(_so3([0.2, 0.5, 0.0]), [0, 0, 0]),
+        _se3(_so3([0.2, 0.5, -1.0]), [10, 0, 0]),
+        _se3(_so3([0.0, 0.0, 0.0]), [0, 100, 5]),
+        _se3(_so3([0.0, 0.0, 0.00001]), [0, 0, 0]),
+        _se3(_so3([0.0, 0.0, 0.00001]), [0, -0.00000001, 0.0000000001]),
+        _se3(_so3([0.0, 0.0, 0.00001]), [0.01, 0, 0]),
+        _se3(_so3([np.pi, 0, 0]), [4, -5, 0]),
+    ]
+    e.append(synth.se3_mul(synth.se3_mul(_se3(_so3([0.2, 0.5, 0.0]), [0, 0, 0]), _se3(_so3([np.pi, 0, 0]), [0, 0, 0])),
+                           _se3(_so3([-0.2, -0.5, -0.0]), [0, 0, 0])))
+    e.append(synth.se3_mul(synth.se3_mul(_se3(_so3([0.3, 0.5, 0.1]), [2, 0, -7]), _se3(_so3([np.pi, 0, 0]), [0, 0, 0])),
+                           _se3(_so3([-0.3, -0.5, -0.1]), [0, 6, 0])))
+    return e
+
+
+def test_se3_sophus_kats():
+    for T in sophus_elements():
+        xi = orc.se3_log(T)
+        T2 = orc.se3_exp(xi)
+        assert np.abs(T2 - T).max() < 1e-9 * max(1.0, np.abs(T).max())
+        Ti = orc.se3_inv(T)
+        assert np.abs(orc.se3_mul(T, Ti) - _se3(np.eye(3), [0, 0, 0])).max() < 1e-9
+        # Adj(T) x = vee(T hat(x) T^-1): check through exp on a small tangent
+        x = np.array([1e-4, -2e-4, 3e-4, 2e-4, 1e-4, -3e-4])
+        lhs = orc.se3_log(orc.se3_mul(orc.se3_mul(T, orc.se3_exp(x)), Ti))
+        assert np.abs(lhs - orc.se3_adj(T) @ x).max() < 1e-6 * max(1.0, np.abs(orc.se3_adj(T)).max())
+    for xi in ([0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0], [0, 0, 1, 0.1, 0, 0], [0, -5, 10, 0, 0, 0], [-1, 1, 0, 0, 0, 1], [20, -1, 0, -1, 1, 0],
+               [30, 5, -1, 20, -1, 0]):
+        xi = np.array(xi, float)
+        T = orc.se3_exp(xi)
+        R = T[:, :3]
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-12
+        if np.linalg.norm(xi[3:]) < np.pi:
+            assert np.abs(orc.se3_log(T) - xi).max() < 1e-9 * max(1, np.abs(xi).max())
+
+
+def test_ldlt_against_numpy():
+    rng = np.random.RandomState(0)
+    L = orc.lib()
+    for n in (8, 36, 68):
+        A = rng.randn(n, n)
+        A = A @ A.T + 1e-3 * np.eye(n)
+        S = np.diag(10.0 ** rng.uniform(-3, 3, n))
+        A = S @ A @ S
+        b, x = rng.randn(n), np.zeros(n)
+        L.orc_ldlt_solve(n, orc.dp(np.ascontiguousarray(A).reshape(-1)), orc.dp(b), orc.dp(x))
+        assert np.abs(x - np.linalg.solve(A, b)).max() <= 1e-9 * np.abs(x).max()
+
+
+def test_pyramid_properties(small_window):
+    win = small_window
+    dI, ab = orc.make_images(win.images[0], win.levels)
+    L = orc.lib()
+    assert win.levels == L.orc_pyr_levels(win.w, win.h) == 4
+    I0 = dI[:win.w * win.h, 0].reshape(win.h, win.w)
+    assert np.array_equal(I0, win.images[0])
+    o1 = L.orc_pyr_offset(win.w, win.h, 1)
+    I1 = dI[o1:o1 + (win.w // 2) * (win.h // 2), 0].reshape(win.h // 2, win.w // 2)
+    box = 0.25 * (I0[0::2, 0::2] + I0[0::2, 1::2] + I0[1::2, 0::2] + I0[1::2, 1::2])
+    assert np.abs(I1 - box).max() < 1e-4
+    dx = dI[:win.w * win.h, 1].reshape(win.h, win.w)
+    assert np.abs(dx[5, 5] - 0.5 * (I0[5, 6] - I0[5, 4])) < 1e-6
+    assert np.all(dx[0] == 0) and np.all(dx[-1] == 0)                       # rows the reference leaves uninitialised
+    assert abs(dx[3, 0] - 0.5 * (I0[3, 1] - I0[2, -1])) < 1e-6              # flat-index wrap at x = 0
+
+
+def _tracker(win, kind="f32"):
+    Ku, Kv, nid, hdi = tracker_inputs(win)
+    trk = orc.Tracker(win.w, win.h, win.levels, win.K, kind)
+    dI_ref, _ = orc.make_images(win.images[win.W - 1], win.levels, kind)
+    dI_new, _ = orc.make_images(win.images[win.W], win.levels, kind)
+    trk.set_ref(dI_ref, Ku, Kv, nid, hdi)
+    return trk, dI_new
+
+
+def test_tracker_gradient_matches_finite_differences(small_window):
+    """b (Vec8) is the gradient of the mean energy w.r.t. the scaled left increment: compare with central differences of
+    calcRes' energy (Huber inactive region dominates; image gradients are interpolated, not exact): 10% + absolute floor."""
+    win = small_window
+    trk, dI_new = _tracker(win)
+    T = orc.se3_exp(orc.se3_log(true_rel_pose(win, win.W - 1, win.W)) * 0.97)
+    aff = np.array([1.0, 0.0], np.float32)
+    lvl = 1
+    st = trk.calc_res(dI_new, lvl, T, aff, 1e9)
+    H, b = trk.calc_gs(lvl, 1.0, 0.0)
+    n = st[1]
+    npad = (int(n) + 3) // 4 * 4
+    sc = np.array([1, 1, 1, 0.5, 0.5, 0.5, 10, 1000.0])
+    g = np.zeros(6)
+    for k in range(6):
+        eps = 2e-4
+        d = np.zeros(6)
+        d[k] = eps
+        Ep = trk.calc_res(dI_new, lvl, synth.se3_mul(orc.se3_exp(d * sc[k]), T), aff, 1e9)
+        Em = trk.calc_res(dI_new, lvl, synth.se3_mul(orc.se3_exp(-d * sc[k]), T), aff, 1e9)
+        if Ep[1] != n or Em[1] != n:
+            g[k] = np.nan
+            continue
+        g[k] = (Ep[0] - Em[0]) / (2 * eps) / (2 * npad)
+    ok = np.isfinite(g)
+    assert ok.sum() >= 4
+    scale = np.abs(b[:6]).max()
+    assert np.abs(g[ok] - b[:6][ok]).max() < 0.1 * scale
+    assert np.all(np.linalg.eigvalsh(H) > -1e-9 * np.abs(H).max())          # PSD
+
+
+def test_tracker_lm_recovers_known_pose(small_window):
+    win = small_window
+    trk, dI_new = _tracker(win)
+    Ttrue = true_rel_pose(win, win.W - 1, win.W)
+    ok, T, aff, lr, lf = trk.track(dI_new, orc.se3_exp(orc.se3_log(Ttrue) * 0.8), [0, 0], [0, 0], [1, 1], win.levels - 1)
+    assert ok == 1 and pose_dist(T, Ttrue) < 2e-3
+    assert lr[0] < lr[win.levels - 1] * 2 and np.isnan(lr[4])
+
+
+def test_tracker_reference_order_band(small_window):
+    """SSE-lane + 3-tier fp32 accumulation (the reference's order) vs plain fp64 sums: H within 2e-5 of max|H|."""
+    win = small_window
+    trk, dI_new = _tracker(win)
+    T = true_rel_pose(win, win.W - 1, win.W)
+    aff = np.array([1.0, 0.0], np.float32)
+    L = orc.lib()
+    L.orc_set_sum_mode(0)
+    s0 = trk.calc_res(dI_new, 0, T, aff, 20.0)
+    H0, b0 = trk.calc_gs(0, 1.0, 0.0)
+    L.orc_set_sum_mode(1)
+    s1 = trk.calc_res(dI_new, 0, T, aff, 20.0)
+    H1, b1 = trk.calc_gs(0, 1.0, 0.0)
+    L.orc_set_sum_mode(0)
+    assert s0[1] == s1[1] and abs(s0[0] - s1[0]) < 1e-5 * s0[0]
+    assert rel_err(H1, H0) < 2e-5 and rel_err(b1, b0) < 1e-4
+
+
+def _dense_system(win, ba):
+    """numpy J^T J over all active residuals, in the global parametrisation [calib(4) | frames(8 each) | idepths]."""
+    W, P, n = win.W, len(win.host), 8 * win.W + 4
+    st, ac, jp, en = ba.slots()
+    adH, adT, _ = ba.adjoints()
+    rows, rhs = [], []
+    for p in range(P):
+        for t in range(W):
+            if not ac[p, t]:
+                continue
+            J = ba.residual(p, t)["J"]
+            resF, Jx, Jy, Cx, Cy, dd = J[0:8], J[8:14], J[14:20], J[20:24], J[24:28], J[28:30]
+            JI0, JI1, Ja, Jb = J[30:38], J[38:46], J[46:54], J[54:62]
+            h = win.host[p]
+            k = h + t * W
+            for i in range(8):
+                loc = np.concatenate([JI0[i] * Jx + JI1[i] * Jy, [Ja[i], Jb[i]]])
+                row = np.zeros(n + P)
+                row[0:4] = JI0[i] * Cx + JI1[i] * Cy
+                row[4 + 8 * h:12 + 8 * h] += adH[k] @ loc
+                row[4 + 8 * t:12 + 8 * t] += adT[k] @ loc
+                row[n + p] = JI0[i] * dd[0] + JI1[i] * dd[1]
+                rows.append(row)
+                rhs.append(resF[i])
+    Jf, rf = np.array(rows), np.array(rhs)
+    return Jf.T @ Jf, Jf.T @ rf
+
+
+@pytest.mark.parametrize("kind", ["f32", "f64"])
+def test_ba_schur_identity(kind):
+    """accumulate(A) + accumulateSC + both stitches == dense J^T J with the idepths eliminated (oracle-free check)."""
+    win = synth.make_window(w=320, h=240, W=3, P=90, seed=3)
+    st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
+    orc.lib(kind).orc_set_sum_mode(0)
+    ba = orc.ba_from_window(win, kind, state6=st6)
+    ba.linearize_all(False)
+    ba.apply_res()
+    HA, bA = ba.accumulate(0)
+    Hs, bs = ba.accumulate_sc(True)
+    n = 8 * win.W + 4
+    Hf, bf = _dense_system(win, ba)
+    Hdd = np.diag(Hf[n:, n:]).copy()
+    Hdi = np.where(Hdd > 0, 1.0 / np.maximum(Hdd, 1e-10), 0)
+    Hpd = Hf[:n, n:]
+    tol = 1e-6 if kind == "f32" else 1e-7        # EFPoint fields (HdiF, Hcd...) are float in both builds
+    assert rel_err(HA, Hf[:n, :n]) < tol and rel_err(bA, bf[:n]) < tol
+    assert rel_err(Hs, (Hpd * Hdi) @ Hpd.T) < tol and rel_err(bs, (Hpd * Hdi) @ bf[n:]) < 10 * tol
+    assert np.abs(HA - HA.T).max() <= 1e-12 * np.abs(HA).max()
+
+
+def test_residual_jacobian_finite_differences():
+    """d resF / d idepth and d resF / d (target pose) against central differences of the residual itself."""
+    # band-limited texture (freq_scale): the reference's J uses interpolated central differences, which only equal the
+    # derivative of the bilinear interpolant on smooth images
+    win = synth.make_window(w=320, h=240, W=3, P=60, seed=4, freq_scale=0.2, min_grad2=4.0)
+    kind = "f64"
+    ba = orc.ba_from_window(win, kind)
+    ba.linearize_all(False)
+    ba.apply_res()
+    st, ac, _, _ = ba.slots()
+    checked = 0
+    fds, ans = [], []
+    for p in range(len(win.host)):
+        for t in range(win.W):
+            if not ac[p, t] or checked >= 12:
+                continue
+            r0 = ba.residual(p, t)["J"]
+            resF, dd, JI0, JI1, hw0 = r0[0:8], r0[28:30], r0[30:38], r0[38:46], r0[54:62]
+            if np.abs(resF).max() > 6:              # keep away from the Huber kink
+                continue
+            eps = 1e-4 * win.idepth[p]
+            out = []
+            for s in (+1, -1):
+                idp = win.idepth.copy()
+                idp[p] += s * eps
+                b2 = orc.ba_from_window(win, kind)
+                b2.L.orc_ba_set_idepth(b2.h_, orc.fp(idp))
+                b2.prepare()
+                b2.linearize_all(False)
+                b2.apply_res()
+                Jp = b2.residual(p, t)["J"]
+                out.append(Jp[0:8] / Jp[54:62])         # un-weighted residual: resF / hw (JabF[1] = hw)
+            fd = (out[0] - out[1]) / (2 * eps)
+            an = (JI0 * dd[0] + JI1 * dd[1]) / hw0      # the weights' own derivative is not part of the reference's J
+            fds.append(fd)
+            ans.append(an)
+            checked += 1
+    assert checked >= 6
+    # central-difference image gradients vs the exact slope of the bilinear interpolant: equal up to the texture's curvature,
+    # so the check is statistical: slope 1 +- 10 %, correlation > 0.98 over all (residual, pattern pixel) pairs
+    fds, ans = np.concatenate(fds), np.concatenate(ans)
+    slope = (fds @ ans) / (ans @ ans)
+    assert abs(slope - 1) < 0.1 and np.corrcoef(fds, ans)[0, 1] > 0.98
+
+
+def test_ba_optimize_converges_and_reference_order_band():
+    win = synth.make_window(w=640, h=480, W=4, P=400, seed=7)
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    res = {}
+    for name, kind, mode in (("f32", "f32", 0), ("ref", "f32", 1), ("f64", "f64", 0)):
+        orc.lib(kind).orc_set_sum_mode(mode)
+        ba = orc.ba_from_window(win, kind, state6=st6)
+        before = max(pose_dist(ba.frame(f)["worldToCam"], win.world_to_cam[f]) for f in range(win.W))
+        ba.optimize(6)
+        res[name] = [ba.frame(f)["worldToCam"] for f in range(win.W)]
+        orc.lib(kind).orc_set_sum_mode(0)
+        after = max(pose_dist(res[name][f], win.world_to_cam[f]) for f in range(win.W))
+        assert after < 0.5 * before
+    # the reference's own fp32 summation order moves the poses by ~1e-5: that is the noise floor of "the reference"
+    d_ref = max(pose_dist(res["ref"][f], res["f32"][f]) for f in range(win.W))
+    d_64 = max(pose_dist(res["f64"][f], res["f32"][f]) for f in range(win.W))
+    assert d_ref < 1e-4 and d_64 < 1e-5
+
+
+def test_dense_make_map_oracle():
+    L = orc.lib()
+    w, h = 160, 120
+    rng = np.random.RandomState(0)
+    mask = np.zeros((h, w), np.float32)
+    mask[30:90, 40:130] = 7.0
+    mask[35:40, 50:60] = 3.0
+    dI = rng.rand(h * w, 3).astype(np.float32)
+    bgr = rng.randint(0, 255, (h * w, 3)).astype(np.uint8)
+    rect = np.zeros(4, np.int32)
+    L.orc_dense_bbox(orc.fp(mask), w, h, 7.0, orc.ip(rect))
+    assert list(rect) == [40, 129, 30, 89]
+    plane = np.array([0.0, 1.0, 0.0, -1.6], np.float32)
+    fx = fy = 100.0
+    cx, cy = 79.5, 59.5
+    c2w = np.concatenate([np.eye(3), np.zeros((3, 1))], 1)
+    cap = w * h
+    ou, ov = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    oid, oc, ob = np.zeros(cap, np.float32), np.zeros(cap, np.float32), np.zeros((cap, 3), np.uint8)
+    acc = np.zeros(1, np.int32)
+    n = L.orc_dense_make_map(orc.fp(mask), orc.fp(dI), orc.u8p(bgr), w, h, orc.fp(plane), 7.0, orc.ip(rect), 1 / fx, 1 / fy, cx, cy,
+                             orc.dp(c2w), orc.ip(ou), orc.ip(ov), orc.fp(oid), orc.fp(oc), orc.u8p(ob), orc.ip(acc))
+    sel = [(i, j) for i in range(30, 89) for j in range(40, 129) if mask[i, j] == 7.0 and (i % 3 == 0 or j % 3 == 0)]
+    assert n == len(sel) and (ov[0], ou[0]) == sel[0] and (ov[n - 1], ou[n - 1]) == sel[-1]
+    i, j = sel[10]
+    depth = 1.6 / ((i - cy) / fy)
+    assert abs(1 / oid[10] - depth) < 1e-4 * abs(depth)
