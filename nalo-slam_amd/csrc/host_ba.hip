@@ -812,8 +812,5 @@ int nalo_ba_restore(nalo_ctx* c) {
     return NALO_OK;
 }
 
-int nalo_dense_make_map(nalo_ctx* c, int, const float*, float, const double*, int, int*, int*, int*, float*, float*, uint8_t*, int*, int*) {
-    return fail(c, NALO_ERR_UNSUPPORTED, "nalo_dense_make_map: not built yet");
-}
 
 }  // extern "C"

@@ -1,0 +1,195 @@
+// a14 — DenseMapping::updateMap bounding-box scan (reference src/FullSystem/MapPoint.cpp:300-310) and
+// DenseMapping::makeMap pixel loop (MapPoint.cpp:362-404) on gfx950.
+//   bbox     : integer atomicMin/Max over the mask (order independent)
+//   make_map : per pixel of the rect with mask == value and (i%3==0 || j%3==0): plane depth, colour, world point;
+//              ordered (raster) stream compaction = count / scan / write, same scheme as the tracker point clouds
+//   extent   : the accept test of :403 INCLUDING the reference's order-dependent typos:
+//              maxy/maxz are "the last point whose y (z) is strictly above the running minimum", maxima are seeded with
+//              FLT_MIN. Done with an in-order prefix-min scan in one block, so the decision equals the serial loop's.
+#include <cfloat>
+#include <climits>
+#include "nalo_internal.h"
+
+namespace nalo {
+
+__global__ __launch_bounds__(256) void dense_bbox_kernel(const float* __restrict__ mask, int w, int h, float value, int* __restrict__ rect /* minx,maxx,miny,maxy */) {
+    const int iw = w - 4, total = iw * (h - 4);
+    int minx = INT_MAX, maxx = INT_MIN, miny = INT_MAX, maxy = INT_MIN;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int y = e / iw + 2, x = e % iw + 2;
+        if (mask[x + y * w] != value) continue;
+        minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
+    }
+    if (minx != INT_MAX) { atomicMin(&rect[0], minx); atomicMax(&rect[1], maxx); atomicMin(&rect[2], miny); atomicMax(&rect[3], maxy); }
+}
+
+struct DenseParams {
+    const float* mask; const float4* dI; const uint8_t* bgr;
+    int w, rx0, ry0, rw, rh;
+    float p0, p1, p2, p3, pcolor, fxi, fyi, cx, cy;
+    double c2w[12];
+};
+constexpr int kDenseChunk = 2048;
+
+template <int WRITE>
+__global__ __launch_bounds__(256) void dense_map_kernel(DenseParams P, int* __restrict__ counts, const int* __restrict__ offsets, int cap,
+                                                        int* __restrict__ ou, int* __restrict__ ov, float* __restrict__ oid, float* __restrict__ ocol,
+                                                        uint8_t* __restrict__ obgr, double* __restrict__ world /* [cap][3] */) {
+    __shared__ int wave_cnt[4];
+    __shared__ int running;
+    const int total = P.rw * P.rh, base = blockIdx.x * kDenseChunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) running = WRITE ? offsets[blockIdx.x] : 0;
+    __syncthreads();
+    for (int r = 0; r < kDenseChunk / 256; ++r) {
+        const int e = base + r * 256 + threadIdx.x;
+        bool keep = false; int i = 0, j = 0; float idepth = 0.f;
+        if (e < total) {
+            i = P.ry0 + e / P.rw; j = P.rx0 + e % P.rw;
+            if (P.mask[j + i * P.w] == P.pcolor && (i % 3 == 0 || j % 3 == 0)) {
+                const float ddepth = P.p0 * (j * P.fxi - P.cx * P.fxi) + P.p1 * (i * P.fyi - P.cy * P.fyi) + P.p2;   // MapPoint.cpp:377
+                if (ddepth != 0.f) { const float depth = -P.p3 / ddepth; if (depth != 0.f) { idepth = 1.f / depth; keep = true; } }
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = running;
+        for (int k = 0; k < wave; ++k) off += wave_cnt[k];
+        if (WRITE && keep && off + rank < cap) {
+            const int o = off + rank, px = j + i * P.w;
+            ou[o] = j; ov[o] = i; oid[o] = idepth; ocol[o] = P.dI[px].x;
+            if (P.bgr) { obgr[3 * o] = P.bgr[3 * px]; obgr[3 * o + 1] = P.bgr[3 * px + 1]; obgr[3 * o + 2] = P.bgr[3 * px + 2]; }
+            // cP = Ki * (j,i,1) / idepth (float), mP = camToWorld * cP (double)  (:390-394)
+            float c0 = P.fxi * j + (-P.cx * P.fxi), c1 = P.fyi * i + (-P.cy * P.fyi), c2 = 1.f;
+            c0 /= idepth; c1 /= idepth; c2 /= idepth;
+            for (int q = 0; q < 3; ++q) world[3 * (size_t)o + q] = P.c2w[q * 4] * (double)c0 + P.c2w[q * 4 + 1] * (double)c1 + P.c2w[q * 4 + 2] * (double)c2 + P.c2w[q * 4 + 3];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (!WRITE && threadIdx.x == 0) counts[blockIdx.x] = running;
+}
+
+__global__ __launch_bounds__(1024) void dense_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int nb) {
+    __shared__ int part[1024];
+    const int per = (nb + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, nb);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; } offsets[nb] = run; }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+}
+
+// out6 = {minx, maxx, miny, maxy, minz, maxz} exactly as the serial loop of MapPoint.cpp:362-397 leaves them
+__global__ __launch_bounds__(1024) void dense_extent_kernel(const double* __restrict__ world, int n, float* __restrict__ out6) {
+    __shared__ float s_min[3][1024], s_max0[1024];
+    __shared__ int s_last[2][1024];
+    const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(t * per, n), hi = min(lo + per, n);
+    // the reference keeps float extrema and compares the double coordinate against them
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx0 = FLT_MIN;
+    for (int k = lo; k < hi; ++k) for (int q = 0; q < 3; ++q) { const double v = world[3 * (size_t)k + q]; if (v < (double)mn[q]) mn[q] = (float)v; if (q == 0 && v > (double)mx0) mx0 = (float)v; }
+    for (int q = 0; q < 3; ++q) s_min[q][t] = mn[q];
+    s_max0[t] = mx0;
+    __syncthreads();
+    if (t == 0) {            // exclusive prefix min over the chunks (serial: 1024 steps)
+        float run[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rmx = FLT_MIN;
+        for (int i = 0; i < 1024; ++i) {
+            for (int q = 0; q < 3; ++q) { const float v = s_min[q][i]; s_min[q][i] = run[q]; run[q] = fminf(run[q], v); }
+            rmx = fmaxf(rmx, s_max0[i]);
+        }
+        out6[0] = run[0]; out6[1] = rmx; out6[2] = run[1]; out6[4] = run[2];
+    }
+    __syncthreads();
+    // last index whose y (z) is strictly above the running minimum AFTER the minimum update of that same point
+    int last[2] = {-1, -1};
+    float run1 = s_min[1][t], run2 = s_min[2][t];
+    for (int k = lo; k < hi; ++k) {
+        const double y = world[3 * (size_t)k + 1], z = world[3 * (size_t)k + 2];
+        if (y < (double)run1) run1 = (float)y;
+        if (y > (double)run1) last[0] = k;
+        if (z < (double)run2) run2 = (float)z;
+        if (z > (double)run2) last[1] = k;
+    }
+    s_last[0][t] = last[0]; s_last[1][t] = last[1];
+    __syncthreads();
+    if (t == 0) {
+        int l0 = -1, l1 = -1;
+        for (int i = 0; i < 1024; ++i) { l0 = max(l0, s_last[0][i]); l1 = max(l1, s_last[1][i]); }
+        out6[3] = l0 >= 0 ? (float)world[3 * (size_t)l0 + 1] : FLT_MIN;
+        out6[5] = l1 >= 0 ? (float)world[3 * (size_t)l1 + 2] : FLT_MIN;
+    }
+}
+
+}  // namespace nalo
+
+using namespace nalo;
+
+extern "C" int nalo_dense_make_map(nalo_ctx* c, int slot, const float plane[4], float mask_value, const double camToWorld[12], int cap,
+                                   int rect_out[4], int* out_u, int* out_v, float* out_idepth, float* out_color, uint8_t* out_bgr, int* n_out, int* accept) {
+    if (!c || !plane || !camToWorld || !n_out || !accept || cap < 0 || slot < 0 || slot >= (int)c->slots.size())
+        return fail(c, NALO_ERR_ARG, "nalo_dense_make_map: bad argument");
+    FrameSlot& s = c->slots[slot];
+    if (!s.valid || !s.mask) return fail(c, NALO_ERR_STATE, "nalo_dense_make_map: slot has no pyramid / mask (nalo_frame_upload with mask)");
+    NALO_HIP(c, hipSetDevice(c->device));
+    *n_out = 0; *accept = 0;
+    // ---- bbox scan (MapPoint.cpp:287-310)
+    NALO_HIP(c, c->scan_tmp.reserve(8));
+    const int init[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+    NALO_HIP(c, hipMemcpyAsync(c->scan_tmp.p, init, 16, hipMemcpyHostToDevice, c->stream));
+    const int total0 = (c->w - 4) * (c->h - 4);
+    dense_bbox_kernel<<<std::min((total0 + 255) / 256, 2048), 256, 0, c->stream>>>(s.mask, c->w, c->h, mask_value, c->scan_tmp.p);
+    int rect[4];
+    NALO_HIP(c, hipMemcpyAsync(rect, c->scan_tmp.p, 16, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    if (rect_out) std::memcpy(rect_out, rect, 16);
+    if (mask_value == 0.f) return NALO_OK;                                   // `if(pcolor==0) return;` (:355-357)
+    const int rw = rect[1] - rect[0], rh = rect[3] - rect[2];
+    float ext[6] = {FLT_MAX, FLT_MIN, FLT_MAX, FLT_MIN, FLT_MAX, FLT_MIN};
+    int n = 0;
+    if (rect[0] != INT_MAX && rw > 0 && rh > 0) {
+        DenseParams P;
+        P.mask = s.mask; P.dI = s.dI[0]; P.bgr = s.bgr; P.w = c->w; P.rx0 = rect[0]; P.ry0 = rect[2]; P.rw = rw; P.rh = rh;
+        P.p0 = plane[0]; P.p1 = plane[1]; P.p2 = plane[2]; P.p3 = plane[3]; P.pcolor = mask_value;
+        P.fxi = 1.0f / c->fx[0]; P.fyi = 1.0f / c->fy[0]; P.cx = c->cx[0]; P.cy = c->cy[0];            // DenseMapping::makeK level 0
+        std::memcpy(P.c2w, camToWorld, sizeof(P.c2w));
+        const int total = rw * rh, nb = (total + kDenseChunk - 1) / kDenseChunk;
+        NALO_HIP(c, c->scan_tmp.reserve((size_t)2 * nb + 2));
+        int *counts = c->scan_tmp.p, *offsets = counts + nb;
+        const size_t capz = (size_t)std::max(cap, 1);
+        // scratch: u,v (int), idepth,color (float), bgr, world(double) carved from upload_tmp
+        const size_t words = capz * (4 + 1 + 6) + 64;
+        NALO_HIP(c, c->upload_tmp.reserve(words));
+        int* du = (int*)c->upload_tmp.p; int* dv = du + capz; float* did = (float*)(dv + capz); float* dcol = did + capz;
+        uint8_t* dbgr = (uint8_t*)(dcol + capz);
+        double* dworld = (double*)(c->upload_tmp.p + capz * 5 + (capz * 5 % 2));
+        dense_map_kernel<0><<<nb, 256, 0, c->stream>>>(P, counts, nullptr, cap, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        dense_scan_kernel<<<1, 1024, 0, c->stream>>>(counts, offsets, nb);
+        dense_map_kernel<1><<<nb, 256, 0, c->stream>>>(P, nullptr, offsets, cap, du, dv, did, dcol, dbgr, dworld);
+        NALO_HIP(c, hipMemcpyAsync(&n, offsets + nb, 4, hipMemcpyDeviceToHost, c->stream));
+        NALO_HIP(c, hipStreamSynchronize(c->stream));
+        if (n > cap) return fail(c, NALO_ERR_ARG, "nalo_dense_make_map: cap too small");
+        if (n > 0) {
+            float* d6 = (float*)(dworld + 3 * capz);
+            NALO_HIP(c, c->trk_partial.reserve(16));
+            dense_extent_kernel<<<1, 1024, 0, c->stream>>>(dworld, n, c->trk_partial.p);
+            (void)d6;
+            NALO_HIP(c, hipMemcpyAsync(ext, c->trk_partial.p, 24, hipMemcpyDeviceToHost, c->stream));
+            if (out_u) NALO_HIP(c, hipMemcpyAsync(out_u, du, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            if (out_v) NALO_HIP(c, hipMemcpyAsync(out_v, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            if (out_idepth) NALO_HIP(c, hipMemcpyAsync(out_idepth, did, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            if (out_color) NALO_HIP(c, hipMemcpyAsync(out_color, dcol, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+            if (out_bgr && s.bgr) NALO_HIP(c, hipMemcpyAsync(out_bgr, dbgr, (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
+            NALO_HIP(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    NALO_HIP(c, hipGetLastError());
+    *n_out = n;
+    *accept = (ext[1] - ext[0] < 30 && ext[3] - ext[2] < 30 && ext[5] - ext[4] < 30) ? 1 : 0;       // :403
+    return NALO_OK;
+}
