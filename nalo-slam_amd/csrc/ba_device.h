@@ -45,12 +45,13 @@ struct BADev {
     uint8_t* rs_state;
     float2* rs_energy;                          // {state_energy, state_NewEnergy}
     float4 *rs_jp0, *rs_jp1;                    // EFResidual::JpJdF
+    float4* rs_pp0; float2* rs_pp1;             // per-slot share of the point sums: {bd, Hdd, Hcd0, Hcd1}, {Hcd2, Hcd3}
     float4* rs_cpt;                             // {Ku, Kv, new_idepth, relBS} (centerProjectedTo), written when fix/marg
     float* en_new;                              // [Ppad] state_NewEnergyWithOutlier of residuals targeting frame W-1 (-1 = none)
     unsigned *th_hist_hi, *th_hist_lo, *th_state;   // radix-select histograms (2 x 65536) + {count, k_rem, prefix_hi}
     // partials
-    float* top_partial;                         // [nblocks][W][kTopStride]
-    float* sc_partial;                          // [nblocks][NPL*NPL]
+    double* top_partial;                        // [nblocks][W][kTopStride]  (fp64: one rounding less before the cancelling H_A - H_sc)
+    double* sc_partial;                         // [nblocks][NPL*NPL]
 };
 
 }  // namespace nalo

@@ -14,6 +14,7 @@ void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NP
 void ba_launch_stitch(hipStream_t s, const int* rowptr, const int* col, const double* val, const double* M, int nb, int n1, int m, double* Tm, double* H);
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
+void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
 
 struct HostFrame {
@@ -41,9 +42,12 @@ struct BAWindow {
     std::vector<uint8_t> flags_h;
     // device
     BADev dev{};
-    DevBuf<float> pre, frameTH, pt_prior, pt_step, pt_backup, pt_relbs, en_new, top_partial, sc_partial, xad, step_partial;
+    DevBuf<float> pre, frameTH, pt_prior, pt_step, pt_backup, pt_relbs, en_new, xad, step_partial;
+    DevBuf<double> top_partial, sc_partial;
+    unsigned long long pub_seq = 0; bool step_pending = false; int last_canbreak = 0; float st_sumA = 0, st_sumB = 0, st_sumT = 0, st_sumR = 0;
     DevBuf<float4> pt_geo, pt_col0, pt_col1, pt_w0, pt_w1, pt_acc, pt_hcd, rs_jp0, rs_jp1, rs_cpt;
-    DevBuf<float2> rs_energy;
+    DevBuf<float2> rs_energy, rs_pp1;
+    DevBuf<float4> rs_pp0;
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
     DevBuf<int> blk_host, host_blk;
     DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 16
@@ -69,7 +73,7 @@ void ba_destroy(nalo_ctx* c) {
     w->pre.release(); w->frameTH.release(); w->pt_prior.release(); w->pt_step.release(); w->pt_backup.release(); w->pt_relbs.release();
     w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
-    w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
+    w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
     w->blk_host.release(); w->host_blk.release(); w->acc13.release(); w->misc.release(); w->G.release(); w->S_top.release(); w->S_sc.release(); w->Srp_top.release(); w->Sci_top.release(); w->Srp_sc.release(); w->Sci_sc.release();
     w->Tm.release(); w->stitched.release(); w->th_hist.release();
     if (w->ev_lin) (void)hipEventDestroy(w->ev_lin);
@@ -254,6 +258,7 @@ static int upload_frame_th(nalo_ctx* c) {
 static int linearize_async(nalo_ctx* c, int mode, int fix) {
     BAWindow& w = *c->ba;
     NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0));           // frameEnergyTH of the previous pass must have landed
+    if (fix || mode == 2) NALO_HIP(c, hipMemsetAsync(w.pt_relbs.p, 0, (size_t)w.Ppad * 4, c->stream));
     {
         ProfScope ps(c, "ba_linearize");
         ba_launch_linearize(c->stream, w.dev, mode, fix);
@@ -296,12 +301,34 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
         NALO_HIP(c, hipMemcpyAsync(w.stitched.p + 2 * blk, w.misc.p, (size_t)2 * W * W * 8, hipMemcpyDeviceToDevice, c->stream));
         if (w.hook) {
             NALO_HIP(c, hipStreamSynchronize(c->stream));
-            w.hook(w.hook_user, w.stitched.p, (int)(2 * blk + 2 * W * W));
+            w.hook(w.hook_user, w.stitched.p, (int)(2 * blk + 2 * W * W + 3));     // + the step sums (sumID, sumNID, numID)
         }
-        NALO_HIP(c, hipMemcpyAsync(w.stitched_host, w.stitched.p, (2 * blk + 2 * W * W) * 8, hipMemcpyDeviceToHost, c->stream));
+        // [H~_A | H~_sc | misc (2 W^2) | step sums (3)] -> host-mapped pinned memory, completion by a polled sequence number
+        const int npub = (int)(2 * blk + 2 * W * W + 3);
+        double* dmap = nullptr;
+        NALO_HIP(c, hipHostGetDevicePointer((void**)&dmap, w.stitched_host, 0));
+        const double seq = (double)(++w.pub_seq);
+        ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
+        NALO_HIP(c, hipGetLastError());
+        if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
+        if (w.step_pending) {                                   // finish doStepFromBackup's break test with the sums of the last step
+            const double* s3 = w.stitched_host + 2 * blk + 2 * W * W;
+            const float numID = (float)s3[2];
+            const float sumNID = numID > 0 ? (float)(s3[1] / numID) : 0.f;
+            const float th = 1.2f;                              // setting_thOptIterations
+            w.last_canbreak = std::sqrt(w.st_sumA) < 0.0005 * th && std::sqrt(w.st_sumB) < 0.00005 * th && std::sqrt(w.st_sumR) < 0.00005 * th &&
+                              std::sqrt(w.st_sumT) * sumNID < 0.00005 * th;
+            w.step_pending = false;
+        }
+        return NALO_OK;
     }
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     return NALO_OK;
+}
+static int stitch_and_fetch_for_break(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    if (!w.have_sc || w.sc_shift != 1) { int rc = sc_async(c, 1, 1.f, 0); if (rc) return rc; }
+    return stitch_and_fetch(c, true, true);
 }
 static void unpack_system(const BAWindow& w, const double* Ht, double* H, double* b) {
     const int n = w.n, n1 = w.n1;
@@ -437,15 +464,18 @@ static int do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float fD
     ba_launch_step(c->stream, w.dev, fD, w.step_partial.p, out3);
     int rc = set_precalc(c);
     if (rc) return rc;
-    double s3[3];
-    NALO_HIP(c, hipMemcpyAsync(s3, out3, 24, hipMemcpyDeviceToHost, c->stream));
-    NALO_HIP(c, hipStreamSynchronize(c->stream));
-    const float numID = (float)s3[2];
-    const float sumNID = numID > 0 ? (float)(s3[1] / numID) : 0.f;
     sumA /= w.W; sumB /= w.W; sumR /= w.W; sumT /= w.W;
-    const float th = 1.2f;                                                  // setting_thOptIterations
-    if (canbreak) *canbreak = std::sqrt(sumA) < 0.0005 * th && std::sqrt(sumB) < 0.00005 * th && std::sqrt(sumR) < 0.00005 * th && std::sqrt(sumT) * sumNID < 0.00005 * th;
+    w.st_sumA = sumA; w.st_sumB = sumB; w.st_sumT = sumT; w.st_sumR = sumR;
     w.have_lin = false; w.have_sc = false;
+    if (canbreak) {                                                         // the API call wants the answer now: fetch the point sums
+        double s3[3];
+        NALO_HIP(c, hipMemcpyAsync(s3, out3, 24, hipMemcpyDeviceToHost, c->stream));
+        NALO_HIP(c, hipStreamSynchronize(c->stream));
+        const float numID = (float)s3[2];
+        const float sumNID = numID > 0 ? (float)(s3[1] / numID) : 0.f;
+        const float th = 1.2f;                                              // setting_thOptIterations
+        *canbreak = std::sqrt(sumA) < 0.0005 * th && std::sqrt(sumB) < 0.00005 * th && std::sqrt(sumR) < 0.00005 * th && std::sqrt(sumT) * sumNID < 0.00005 * th;
+    } else w.step_pending = true;                                           // optimize(): the sums ride along with the next fetch (no extra sync)
     return NALO_OK;
 }
 
@@ -498,7 +528,8 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     NALO_HIP(c, w.Tm.reserve(std::max((size_t)W * W * 13 * w.n1, (size_t)W * w.NPL * w.n1)));
     NALO_HIP(c, w.stitched.reserve(2 * blk + 2 * W * W + 16));
     if (w.stitched_host) { (void)hipHostFree(w.stitched_host); w.stitched_host = nullptr; }
-    NALO_HIP(c, hipHostMalloc((void**)&w.stitched_host, (2 * blk + 2 * W * W + 16) * 8));
+    NALO_HIP(c, hipHostMalloc((void**)&w.stitched_host, (2 * blk + 2 * W * W + 16) * 8, hipHostMallocMapped));
+    w.stitched_host[2 * blk + 2 * W * W + 3] = -1.0; w.pub_seq = 0;
     int rc = upload_frame_th(c); if (rc) return rc;
     rc = set_adjoints(c); if (rc) return rc;
     rc = set_precalc(c); if (rc) return rc;
@@ -525,9 +556,17 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     w.blk_host_h.assign(w.nblocks, 0);
     for (int h = 0; h < W; ++h) for (int b = w.host_blk_h[h]; b < w.host_blk_h[h + 1]; ++b) w.blk_host_h[b] = h;
     w.d2p.assign(w.Ppad, -1); w.p2d.assign(P, -1);
+    // inside a host: Morton order of the 8x8-pixel tile, so the 64 lanes of a wave gather neighbouring texels (cache-line reuse
+    // in L1/L2 instead of 64 scattered lines per load instruction). Sums are order independent up to rounding.
+    auto morton = [](unsigned x, unsigned y) { unsigned long long r = 0; for (int i = 0; i < 16; ++i) r |= ((unsigned long long)((x >> i) & 1) << (2 * i)) | ((unsigned long long)((y >> i) & 1) << (2 * i + 1)); return r; };
+    std::vector<int> order(P);
+    for (int p = 0; p < P; ++p) order[p] = p;
+    std::vector<unsigned long long> key(P);
+    for (int p = 0; p < P; ++p) key[p] = ((unsigned long long)host[p] << 40) | morton((unsigned)std::max(0.f, u[p]) >> 3, (unsigned)std::max(0.f, v[p]) >> 3);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
     std::vector<int> fill(W);
     for (int h = 0; h < W; ++h) fill[h] = w.host_blk_h[h] * kBlk;
-    for (int p = 0; p < P; ++p) { const int d = fill[host[p]]++; w.d2p[d] = p; w.p2d[p] = d; }
+    for (int q = 0; q < P; ++q) { const int p = order[q]; const int d = fill[host[p]]++; w.d2p[d] = p; w.p2d[p] = d; }
     const size_t N = w.Ppad;
     std::vector<float4> geo(N, make_float4(8.f, 8.f, 1.f, 1.f)), c0(N, make_float4(0, 0, 0, 0)), c1(N, make_float4(0, 0, 0, 0)), w0(N, make_float4(0, 0, 0, 0)), w1(N, make_float4(0, 0, 0, 0));
     std::vector<float> prior(N, 0.f);
@@ -547,7 +586,7 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     NALO_HIP(c, w.pt_relbs.reserve(N)); NALO_HIP(c, w.en_new.reserve(N)); NALO_HIP(c, w.pt_flags.reserve(N)); NALO_HIP(c, w.pt_ngood.reserve(N));
     NALO_HIP(c, w.blk_host.reserve(w.nblocks)); NALO_HIP(c, w.host_blk.reserve(W + 1));
     const size_t NS = (size_t)W * N;
-    NALO_HIP(c, w.rs_state.reserve(NS)); NALO_HIP(c, w.rs_energy.reserve(NS)); NALO_HIP(c, w.rs_jp0.reserve(NS)); NALO_HIP(c, w.rs_jp1.reserve(NS)); NALO_HIP(c, w.rs_cpt.reserve(NS));
+    NALO_HIP(c, w.rs_state.reserve(NS)); NALO_HIP(c, w.rs_energy.reserve(NS)); NALO_HIP(c, w.rs_jp0.reserve(NS)); NALO_HIP(c, w.rs_jp1.reserve(NS)); NALO_HIP(c, w.rs_cpt.reserve(NS)); NALO_HIP(c, w.rs_pp0.reserve(NS)); NALO_HIP(c, w.rs_pp1.reserve(NS));
     NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * W * kTopStride)); NALO_HIP(c, w.sc_partial.reserve((size_t)w.nblocks * w.NPL * w.NPL));
     NALO_HIP(c, hipMemcpy(w.pt_geo.p, geo.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_col0.p, c0.data(), N * 16, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.pt_col1.p, c1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_w0.p, w0.data(), N * 16, hipMemcpyHostToDevice));
@@ -558,12 +597,12 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     NALO_HIP(c, hipMemset(w.pt_acc.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_hcd.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_step.p, 0, N * 4));
     NALO_HIP(c, hipMemset(w.pt_backup.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_relbs.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_ngood.p, 0, N));
     NALO_HIP(c, hipMemset(w.rs_state.p, 0, NS)); NALO_HIP(c, hipMemset(w.rs_energy.p, 0, NS * 8)); NALO_HIP(c, hipMemset(w.rs_jp0.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.rs_jp1.p, 0, NS * 16));
-    NALO_HIP(c, hipMemset(w.rs_cpt.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.top_partial.p, 0, (size_t)w.nblocks * W * kTopStride * 4));
+    NALO_HIP(c, hipMemset(w.rs_cpt.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.top_partial.p, 0, (size_t)w.nblocks * W * kTopStride * 8));
     BADev& D = w.dev;
     D.P = P; D.Ppad = w.Ppad; D.nblocks = w.nblocks; D.blk_host = w.blk_host.p;
     D.pt_geo = w.pt_geo.p; D.pt_col0 = w.pt_col0.p; D.pt_col1 = w.pt_col1.p; D.pt_w0 = w.pt_w0.p; D.pt_w1 = w.pt_w1.p; D.pt_prior = w.pt_prior.p;
     D.pt_flags = w.pt_flags.p; D.pt_acc = w.pt_acc.p; D.pt_hcd = w.pt_hcd.p; D.pt_ngood = w.pt_ngood.p; D.pt_step = w.pt_step.p; D.pt_backup = w.pt_backup.p; D.pt_relbs = w.pt_relbs.p;
-    D.rs_state = w.rs_state.p; D.rs_energy = w.rs_energy.p; D.rs_jp0 = w.rs_jp0.p; D.rs_jp1 = w.rs_jp1.p; D.rs_cpt = w.rs_cpt.p; D.en_new = w.en_new.p;
+    D.rs_state = w.rs_state.p; D.rs_energy = w.rs_energy.p; D.rs_jp0 = w.rs_jp0.p; D.rs_jp1 = w.rs_jp1.p; D.rs_cpt = w.rs_cpt.p; D.rs_pp0 = w.rs_pp0.p; D.rs_pp1 = w.rs_pp1.p; D.en_new = w.en_new.p;
     D.top_partial = w.top_partial.p; D.sc_partial = w.sc_partial.p;
     w.points_set = true; w.res_set = false; w.have_lin = w.have_sc = false;
     return NALO_OK;
@@ -654,11 +693,15 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
     for (int it = 0; it < mnumOptIts; ++it) {
         backup_state(w);                                                    // :482
         rc = solve_system(c, it, lambda, nullptr); if (rc) return rc;       // :485
-        int canbreak = 0;
-        rc = do_step(c, 1, 1, 1, 1, 1, &canbreak); if (rc) return rc;       // :501 (stepsize 1: no SOLVER_STEPMOMENTUM)
+        rc = do_step(c, 1, 1, 1, 1, 1, nullptr); if (rc) return rc;         // :501 (stepsize 1: no SOLVER_STEPMOMENTUM)
         rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :511, accepted unconditionally (:519-532)
         lambda *= 0.25;
-        if (canbreak && it >= 1 && !never_break) break;                     // :544, setting_minOptIterations = 1
+        // :544 `if(canbreak && iteration >= setting_minOptIterations) break;` — the step sums arrive with the next fetch, so the
+        // test is made there; a loop that must break only costs one discarded accumulate+stitch, the state is untouched
+        if (!never_break && it >= 1 && it + 1 < mnumOptIts) {
+            rc = stitch_and_fetch_for_break(c); if (rc) return rc;
+            if (w.last_canbreak) break;
+        }
     }
     HostFrame& nf = w.frames[W - 1];                                        // :550-557
     const double nsz[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
@@ -723,6 +766,7 @@ int nalo_ba_get_points(nalo_ctx* c, float* idepth, float* step, float* HdiF, flo
     if (!c || !c->ba || !c->ba->points_set) return fail(c, NALO_ERR_STATE, "nalo_ba_get_points: no points");
     BAWindow& w = *c->ba;
     const size_t N = w.Ppad;
+    if (w.have_lin && !w.have_sc) { int rc = sc_async(c, 1, 1.f, 0); if (rc) return rc; }    // Hdd/bd/Hcd/HdiF are produced by the SC pass
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<float4> geo(N), acc(N), hcd(N);
     std::vector<float> stp(N), rel(N);

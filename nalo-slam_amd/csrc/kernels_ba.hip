@@ -24,223 +24,7 @@
 
 namespace nalo {
 
-__device__ __forceinline__ float4 ba_bilinear(const float4* __restrict__ img, float x, float y, int width) {
-    const int ix = (int)x, iy = (int)y;                 // util/globalFuncs.h:75-89
-    const float dx = x - ix, dy = y - iy, dxdy = dx * dy;
-    const float4* bp = img + ix + iy * width;
-    const float4 p00 = bp[0], p10 = bp[1], p01 = bp[width], p11 = bp[1 + width];
-    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-    float4 r;
-    r.x = w11 * p11.x + w01 * p01.x + w10 * p10.x + w00 * p00.x;
-    r.y = w11 * p11.y + w01 * p01.y + w10 * p10.y + w00 * p00.y;
-    r.z = w11 * p11.z + w01 * p01.z + w10 * p10.z + w00 * p00.z;
-    r.w = 0.f;
-    return r;
-}
-
-// MODE 0: active residuals (optimize). MODE 2: marginalisation of the flagged points (resApprox = res_toZeroF).
-// FIX: linearizeAll(true) semantics — residuals that do not end IN are dropped, centerProjectedTo/relBS are stored.
-template <int MODE, int FIX>
-__global__ __launch_bounds__(kBlk) void ba_linearize_kernel(BADev B) {
-    __shared__ float smem[(kBlk / 4) * (kTopVals + 1)];
-    const int b = blockIdx.x, tid = threadIdx.x, d = b * kBlk + tid;
-    const int h = B.blk_host[b], W = B.W;
-    const uint8_t pf = B.pt_flags[d];
-    const bool pvalid = (pf & PT_VALID) && (MODE == 0 || (pf & PT_MARG));
-    const float4 geo = B.pt_geo[d];
-    const float pu = geo.x, pv = geo.y, idepth = geo.z, idz = geo.w;
-    float color[8], wgt[8];
-    {
-        const float4 c0 = B.pt_col0[d], c1 = B.pt_col1[d], w0 = B.pt_w0[d], w1 = B.pt_w1[d];
-        color[0] = c0.x; color[1] = c0.y; color[2] = c0.z; color[3] = c0.w; color[4] = c1.x; color[5] = c1.y; color[6] = c1.z; color[7] = c1.w;
-        wgt[0] = w0.x; wgt[1] = w0.y; wgt[2] = w0.z; wgt[3] = w0.w; wgt[4] = w1.x; wgt[5] = w1.y; wgt[6] = w1.z; wgt[7] = w1.w;
-    }
-    const float wM3G = (float)(B.w - 3), hM3G = (float)(B.h - 3);
-    const float thH = B.frameTH[h];
-    float Hdd_acc = 0.f, bd_acc = 0.f, Hcd_acc[4] = {0.f, 0.f, 0.f, 0.f}, relbs_max = 0.f;
-    int ngood = 0;
-    const float KliP0 = (pu - B.cxl) * B.fxli, KliP1 = (pv - B.cyl) * B.fyli;     // ResidualProjections.h:70-73
-    const float dd = idepth - idz;                                                  // EFPoint::deltaF
-
-    for (int t = 0; t < W; ++t) {
-        if (t == h) continue;
-        const size_t si = (size_t)t * B.Ppad + d;
-        const float* pc = B.pre + (size_t)(h * W + t) * kPreStride;                 // block-uniform: scalar loads
-        uint8_t st = B.rs_state[si];
-        const bool exists = pvalid && (st & RS_EXISTS) && (MODE == 2 || !(st & RS_LINEARIZED));
-        float v[kTopVals];
-#pragma unroll
-        for (int i = 0; i < kTopVals; ++i) v[i] = 0.f;
-        float enew = -1.f;
-        if (exists) {
-            float2 en = B.rs_energy[si];
-            int state = st & RS_STATE_MASK;
-            if (MODE == 2) { en.x = 0.f; en.y = 0.f; state = 0; st &= ~RS_LINEARIZED; }        // resetOOB + isLinearized=false (FullSystem.cpp:978-981)
-            int newState = 2;
-            float energy = en.x;
-            bool full = false;
-            float Jpdxi0[6], Jpdxi1[6], Jpdc0[4], Jpdc1[4], Jpdd0 = 0.f, Jpdd1 = 0.f, cKu = 0.f, cKv = 0.f, cId = 0.f;
-            float a = 0.f, bb = 0.f, c = 0.f, jab00 = 0.f, jab01 = 0.f, jab10 = 0.f, jab11 = 0.f, ab00 = 0.f, ab01 = 0.f, ab11 = 0.f;
-            float JIr0 = 0.f, JIr1 = 0.f, Jabr0 = 0.f, Jabr1 = 0.f, rr = 0.f;
-            if (state == 1) { newState = 1; }                                                     // Residuals.cpp:82-83
-            else {
-                // ---- centre projection at idepth_zero (projectPoint, ResidualProjections.h:61-87)
-                const float p0 = pc[12] * KliP0 + pc[13] * KliP1 + pc[14] + pc[21] * idz;
-                const float p1 = pc[15] * KliP0 + pc[16] * KliP1 + pc[17] + pc[22] * idz;
-                const float p2 = pc[18] * KliP0 + pc[19] * KliP1 + pc[20] + pc[23] * idz;
-                const float drescale = 1.0f / p2, new_idepth = idz * drescale;
-                const float u = p0 * drescale, vv = p1 * drescale;
-                const float Ku0 = u * B.fxl + B.cxl, Kv0 = vv * B.fyl + B.cyl;
-                bool ok = (drescale > 0.f) && Ku0 > 1.1f && Kv0 > 1.1f && Ku0 < wM3G && Kv0 < hM3G;
-                // ---- the 8 pattern pixels at the current idepth (projectPoint, ResidualProjections.h:47-57)
-                float Kus[8], Kvs[8];
-                const int pdx[8] = {0, -1, 1, -2, 0, 2, -1, 0}, pdy[8] = {-2, -1, -1, 0, 0, 0, 1, 2};   // util/settings.cpp:297
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float x = pu + (float)pdx[k], y = pv + (float)pdy[k];
-                    const float q0 = pc[0] * x + pc[1] * y + pc[2] + pc[9] * idepth;
-                    const float q1 = pc[3] * x + pc[4] * y + pc[5] + pc[10] * idepth;
-                    const float q2 = pc[6] * x + pc[7] * y + pc[8] + pc[11] * idepth;
-                    Kus[k] = q0 / q2; Kvs[k] = q1 / q2;
-                    ok = ok && Kus[k] > 1.1f && Kvs[k] > 1.1f && Kus[k] < wM3G && Kvs[k] < hM3G;
-                }
-                if (!ok) { newState = 1; }
-                else {
-                    cKu = Ku0; cKv = Kv0; cId = new_idepth;
-                    const float t0x = pc[21], t0y = pc[22], t0z = pc[23];
-                    Jpdd0 = drescale * (t0x - t0z * u) * kScaleIdepth * B.fxl;                         // Residuals.cpp:116-117
-                    Jpdd1 = drescale * (t0y - t0z * vv) * kScaleIdepth * B.fyl;
-                    Jpdc0[2] = drescale * (pc[18] * u - pc[12]);                                     // :123-131
-                    Jpdc0[3] = B.fxl * drescale * (pc[19] * u - pc[13]) * B.fyli;
-                    Jpdc0[0] = KliP0 * Jpdc0[2]; Jpdc0[1] = KliP1 * Jpdc0[3];
-                    Jpdc1[2] = B.fyl * drescale * (pc[18] * vv - pc[15]) * B.fxli;
-                    Jpdc1[3] = drescale * (pc[19] * vv - pc[16]);
-                    Jpdc1[0] = KliP0 * Jpdc1[2]; Jpdc1[1] = KliP1 * Jpdc1[3];
-                    Jpdc0[0] = (Jpdc0[0] + u) * kScaleF; Jpdc0[1] *= kScaleF; Jpdc0[2] = (Jpdc0[2] + 1) * kScaleC; Jpdc0[3] *= kScaleC;   // :133-141
-                    Jpdc1[0] *= kScaleF; Jpdc1[1] = (Jpdc1[1] + vv) * kScaleF; Jpdc1[2] *= kScaleC; Jpdc1[3] = (Jpdc1[3] + 1) * kScaleC;
-                    Jpdxi0[0] = new_idepth * B.fxl; Jpdxi0[1] = 0.f; Jpdxi0[2] = -new_idepth * u * B.fxl;   // :144-156
-                    Jpdxi0[3] = -u * vv * B.fxl; Jpdxi0[4] = (1 + u * u) * B.fxl; Jpdxi0[5] = -vv * B.fxl;
-                    Jpdxi1[0] = 0.f; Jpdxi1[1] = new_idepth * B.fyl; Jpdxi1[2] = -new_idepth * vv * B.fyl;
-                    Jpdxi1[3] = -(1 + vv * vv) * B.fyl; Jpdxi1[4] = u * vv * B.fyl; Jpdxi1[5] = u * B.fyl;
-                    float jx = 0.f, jy = 0.f;
-                    if (MODE == 2) {                                                                 // Jp*delta (EnergyFunctionalStructs.cpp:94-99)
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) { jx += Jpdxi0[i] * pc[27 + i]; jy += Jpdxi1[i] * pc[27 + i]; }
-                        float cxs = 0.f, cys = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { cxs += Jpdc0[i] * B.cDelta[i]; cys += Jpdc1[i] * B.cDelta[i]; }
-                        jx = jx + cxs + Jpdd0 * dd; jy = jy + cys + Jpdd1 * dd;
-                    }
-                    const float affLL0 = pc[24], affLL1 = pc[25], b0 = pc[26];
-                    const float4* img = B.img[t];
-                    float energyLeft = 0.f, wJI2_sum = 0.f;
-                    bool finite_ok = true;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {                                                    // :183-245
-                        float4 hit = ba_bilinear(img, Kus[k], Kvs[k], B.w);
-                        const float residual = hit.x - (affLL0 * color[k] + affLL1);
-                        const float drdA = color[k] - b0;
-                        finite_ok = finite_ok && isfinite(hit.x);
-                        float wgt_k = sqrtf(kOutlierTHSumComponent / (kOutlierTHSumComponent + (hit.y * hit.y + hit.z * hit.z)));
-                        wgt_k = 0.5f * (wgt_k + wgt[k]);
-                        const float ar = fabsf(residual);
-                        float hw = ar < kHuberTH ? 1.f : kHuberTH / ar;
-                        energyLeft += wgt_k * wgt_k * hw * residual * residual * (2.f - hw);
-                        if (hw < 1.f) hw = sqrtf(hw);
-                        hw = hw * wgt_k;
-                        const float jI0 = hit.y * hw, jI1 = hit.z * hw, resF = residual * hw, jA = drdA * hw, jB = hw;
-                        a += jI0 * jI0; c += jI1 * jI1; bb += jI0 * jI1;
-                        jab00 += jA * jI0; jab01 += jA * jI1; jab10 += jB * jI0; jab11 += jB * jI1;
-                        ab00 += jA * jA; ab01 += jA * jB; ab11 += jB * jB;
-                        wJI2_sum += hw * hw * (jI0 * jI0 + jI1 * jI1);      // on the already hw-scaled gradient, as Residuals.cpp:215-239
-                        float ra = resF;                                                             // mode 2: res_toZeroF (:103-111)
-                        if (MODE == 2) ra = resF - jI0 * jx - jI1 * jy - jA * pc[33] - jB * pc[34];
-                        JIr0 += ra * jI0; JIr1 += ra * jI1; Jabr0 += ra * jA; Jabr1 += ra * jB; rr += ra * ra;
-                    }
-                    if (!finite_ok) { newState = 1; }
-                    else {
-                        full = true;
-                        enew = energyLeft;
-                        const float th = fmaxf(thH, B.frameTH[t]);
-                        if (energyLeft > th || wJI2_sum < 2.f) { energyLeft = th; newState = 2; } else newState = 0;   // :262-270
-                        en.y = energyLeft;
-                        energy = energyLeft;
-                    }
-                }
-            }
-            // ---- applyRes(true) (Residuals.cpp:306-328)
-            bool active = false;
-            if (state != 1) {
-                active = (newState == 0);
-                state = newState;
-                en.x = en.y;
-            }
-            st = (uint8_t)((st & ~(RS_STATE_MASK | RS_ACTIVE)) | state | (active ? RS_ACTIVE : 0));
-            if (MODE == 2 && active) st |= RS_LINEARIZED;
-            if (FIX && !active) st &= ~(RS_EXISTS | RS_ACTIVE);                                      // toRemove (FullSystemOptimize.cpp:81-84,184-205)
-            B.rs_state[si] = st;
-            B.rs_energy[si] = en;
-            v[92] = energy;
-            if (active && full) {
-                ngood++;
-                // ---- takeDataF (EnergyFunctionalStructs.cpp:39-50)
-                const float a0 = a * Jpdd0 + bb * Jpdd1, a1 = bb * Jpdd0 + c * Jpdd1;
-                float4 j0, j1;
-                j0.x = Jpdxi0[0] * a0 + Jpdxi1[0] * a1; j0.y = Jpdxi0[1] * a0 + Jpdxi1[1] * a1; j0.z = Jpdxi0[2] * a0 + Jpdxi1[2] * a1;
-                j0.w = Jpdxi0[3] * a0 + Jpdxi1[3] * a1; j1.x = Jpdxi0[4] * a0 + Jpdxi1[4] * a1; j1.y = Jpdxi0[5] * a0 + Jpdxi1[5] * a1;
-                j1.z = jab00 * Jpdd0 + jab01 * Jpdd1; j1.w = jab10 * Jpdd0 + jab11 * Jpdd1;
-                B.rs_jp0[si] = j0; B.rs_jp1[si] = j1;
-                // ---- AccumulatorApprox::update / updateTopRight / updateBotRight (AccumulatedTopHessian.cpp:115-129)
-                float x[10], y[10], ax[10], cy[10];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { x[i] = Jpdc0[i]; y[i] = Jpdc1[i]; }
-#pragma unroll
-                for (int i = 0; i < 6; ++i) { x[4 + i] = Jpdxi0[i]; y[4 + i] = Jpdxi1[i]; }
-#pragma unroll
-                for (int i = 0; i < 10; ++i) { ax[i] = a * x[i] + bb * y[i]; cy[i] = bb * x[i] + c * y[i]; }
-                int idx = 0;
-#pragma unroll
-                for (int r = 0; r < 10; ++r)
-#pragma unroll
-                    for (int cc = r; cc < 10; ++cc) { v[idx] = ax[r] * x[cc] + cy[r] * y[cc]; ++idx; }
-#pragma unroll
-                for (int i = 0; i < 10; ++i) {
-                    v[55 + 3 * i + 0] = x[i] * jab00 + y[i] * jab01;
-                    v[55 + 3 * i + 1] = x[i] * jab10 + y[i] * jab11;
-                    v[55 + 3 * i + 2] = x[i] * JIr0 + y[i] * JIr1;
-                }
-                v[85] = ab00; v[86] = ab01; v[87] = Jabr0; v[88] = ab11; v[89] = Jabr1; v[90] = rr;
-                v[91] = 1.f;
-                bd_acc += JIr0 * Jpdd0 + JIr1 * Jpdd1;                                               // :132-135
-                Hdd_acc += a0 * Jpdd0 + a1 * Jpdd1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) Hcd_acc[i] += Jpdc0[i] * a0 + Jpdc1[i] * a1;
-                if (FIX || MODE == 2) {
-                    // relBS of FullSystemOptimize.cpp:69-71 + centerProjectedTo (makeCoarseDepthL0 input)
-                    const float i0 = pc[0] * pu + pc[1] * pv + pc[2], i1 = pc[3] * pu + pc[4] * pv + pc[5], i2 = pc[6] * pu + pc[7] * pv + pc[8];
-                    const float q0 = i0 + pc[9] * idepth, q1 = i1 + pc[10] * idepth, q2 = i2 + pc[11] * idepth;
-                    const float ex = i0 / i2 - q0 / q2, ey = i1 / i2 - q1 / q2;
-                    const float relBS = 0.01f * sqrtf(ex * ex + ey * ey);
-                    relbs_max = fmaxf(relbs_max, relBS);
-                    B.rs_cpt[si] = make_float4(cKu, cKv, cId, relBS);
-                }
-            }
-        }
-        if (t == W - 1) {
-            B.en_new[d] = enew;
-            if (MODE == 0 && enew >= 0.f) atomicAdd(&B.th_hist_hi[__float_as_uint(enew) >> 16], 1u);   // integer atomics: order independent
-        }
-        block_reduce_cols<kTopVals, kBlk>(v, smem, B.top_partial + ((size_t)b * W + t) * kTopStride);
-    }
-    if (h == W - 1) B.en_new[d] = -1.f;
-    // per-point sums: EFPoint::{Hdd,bd,Hcd}_accAF (mode 0) / _accLF (mode 2, AF zeroed: AccumulatedTopHessian.cpp:140-157)
-    if (pvalid) {
-        B.pt_acc[d] = make_float4(Hdd_acc, bd_acc, 0.f, 0.f);
-        B.pt_hcd[d] = make_float4(Hcd_acc[0], Hcd_acc[1], Hcd_acc[2], Hcd_acc[3]);
-        B.pt_ngood[d] = (uint8_t)ngood;
-        if (FIX || MODE == 2) B.pt_relbs[d] = relbs_max;
-    }
-}
+// ba_linearize_kernel lives in kernels_ba_lin.hip
 
 // resetOOB for every active residual at the start of optimize() (FullSystemOptimize.cpp:412-429, Residuals.h:88-94)
 __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__ rs_state, float2* __restrict__ rs_energy, size_t n) {
@@ -255,13 +39,49 @@ __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__
 template <int T>
 __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
     constexpr int NPL = 16 * T, SUB = 64;
-    __shared__ float A[SUB * NPL];
-    __shared__ float Wt[SUB];
+    __shared__ __attribute__((aligned(16))) float A[SUB * NPL];
+    __shared__ __attribute__((aligned(16))) float4 Hc[kBlk];
+    __shared__ float Wt[kBlk], Bd[kBlk];
     const int b = blockIdx.x, tid = threadIdx.x, h = B.blk_host[b], W = B.W;
     const int ty = tid >> 4, tx = tid & 15;
-    // fp32 products and short fp32 runs (16 points), flushed into fp64: keeps the block partial good to ~1e-7 so the
-    // cancellation in H_A - H_sc does not amplify summation noise into the poses
-    constexpr int RUN = 16;
+    {   // ---- per point (AccumulatedSCHessian.cpp:36-57): EFPoint::{Hdd,bd,Hcd}_acc = sum over the point's active residuals in
+        //      target order (AccumulatedTopHessian.cpp:132-157), then HdiF, bdSumF
+        const int d = b * kBlk + tid;
+        const uint8_t pf = B.pt_flags[d];
+        const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
+        float wgt = 0.f, bds = 0.f;
+        float4 hc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pvalid) {
+            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+            int ngood = 0;
+            for (int t = 0; t < W; ++t) {
+                if (t == h) continue;
+                const size_t si = (size_t)t * B.Ppad + d;
+                if (!(B.rs_state[si] & RS_ACTIVE)) continue;
+                const float4 q0 = B.rs_pp0[si]; const float2 q1 = B.rs_pp1[si];
+                pa.y += q0.x; pa.x += q0.y; hc.x += q0.z; hc.y += q0.w; hc.z += q1.x; hc.w += q1.y;
+                ++ngood;
+            }
+            B.pt_hcd[d] = hc; B.pt_ngood[d] = (uint8_t)ngood;
+            if (ngood == 0) { pa.z = 0.f; pa.w = 0.f; }
+            else {
+                float prior = B.pt_prior[d];
+                if (margOnly) { prior *= priorScaleMarg; B.pt_prior[d] = prior; }          // EnergyFunctional.cpp:630
+                float Hs = pa.x + prior;                                                    // Hdd_accAF + Hdd_accLF + priorF (only one of AF/LF is live)
+                if (Hs < 1e-10f) Hs = 1e-10f;
+                pa.z = (float)(1.0 / (double)Hs);
+                pa.w = pa.y;
+                if (shiftPriorToZero) { const float4 geo = B.pt_geo[d]; pa.w += prior * (geo.z - geo.w); }
+                wgt = pa.z;
+            }
+            B.pt_acc[d] = pa;
+            bds = pa.w;
+        }
+        Wt[tid] = wgt; Bd[tid] = bds; Hc[tid] = hc;
+    }
+    // fp32 products in short runs (8 points) flushed into fp64: the block partial is good to ~1e-8, so the ~100x cancellation in
+    // H_A - H_sc does not amplify summation noise into the poses
+    constexpr int RUN = 8;
     float acc[T][T];
     double acc64[T][T];
 #pragma unroll
@@ -270,52 +90,28 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
         for (int j = 0; j < T; ++j) { acc[i][j] = 0.f; acc64[i][j] = 0.0; }
     for (int sub = 0; sub < kBlk / SUB; ++sub) {
         const int d0 = b * kBlk + sub * SUB;
+        __syncthreads();
         // ---- stage SUB operand rows: [JpJdF(t != h) (8 each) | Hcd (4) | bdSum | 0..]
         for (int e = tid; e < SUB * (NPL / 4); e += 256) {
             const int r = e / (NPL / 4), q = e - r * (NPL / 4);       // q-th float4 of row r
             const int d = d0 + r;
-            const uint8_t pf = B.pt_flags[d];
-            const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
             float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
             const int g = q >> 1;                                     // compact target slot
-            if (pvalid && g < W - 1) {
+            if (g < W - 1) {
                 const int t = g < h ? g : g + 1;
                 const size_t si = (size_t)t * B.Ppad + d;
-                if (B.rs_state[si] & RS_ACTIVE) val = (q & 1) ? B.rs_jp1[si] : B.rs_jp0[si];
-            } else if (pvalid && q == 2 * (W - 1)) {
-                val = B.pt_hcd[d];
-            }
+                const uint8_t pf = B.pt_flags[d];
+                const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
+                if (pvalid && (B.rs_state[si] & RS_ACTIVE)) val = (q & 1) ? B.rs_jp1[si] : B.rs_jp0[si];
+            } else if (q == 2 * (W - 1)) val = Hc[sub * SUB + r];
+            else if (q == 2 * (W - 1) + 1) val = make_float4(Bd[sub * SUB + r], 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&A[r * NPL + 4 * q]) = val;
         }
         __syncthreads();
-        if (tid < SUB) {                                              // per point: AccumulatedSCHessian.cpp:36-57
-            const int d = d0 + tid;
-            const uint8_t pf = B.pt_flags[d];
-            const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
-            float wgt = 0.f;
-            if (pvalid) {
-                float4 pa = B.pt_acc[d];
-                if (B.pt_ngood[d] == 0) { pa.z = 0.f; pa.w = 0.f; }
-                else {
-                    float prior = B.pt_prior[d];
-                    if (margOnly) { prior *= priorScaleMarg; B.pt_prior[d] = prior; }          // EnergyFunctional.cpp:630
-                    float Hs = pa.x + prior;                          // Hdd_accAF + Hdd_accLF + priorF (only one of AF/LF is live)
-                    if (Hs < 1e-10f) Hs = 1e-10f;
-                    pa.z = (float)(1.0 / (double)Hs);
-                    pa.w = pa.y;
-                    if (shiftPriorToZero) { const float4 geo = B.pt_geo[d]; pa.w += prior * (geo.z - geo.w); }
-                    wgt = pa.z;
-                }
-                B.pt_acc[d] = pa;
-                A[tid * NPL + 8 * (W - 1) + 4] = pa.w;                // bdSum column
-            }
-            Wt[tid] = wgt;
-        }
-        __syncthreads();
         for (int k0 = 0; k0 < SUB; k0 += RUN) {
-#pragma unroll 4
+#pragma unroll
             for (int k = k0; k < k0 + RUN; ++k) {
-                const float wk = Wt[k];
+                const float wk = Wt[sub * SUB + k];
                 float ai[T], aj[T];
 #pragma unroll
                 for (int i = 0; i < T; ++i) { ai[i] = wk * A[k * NPL + ty * T + i]; aj[i] = A[k * NPL + tx * T + i]; }
@@ -329,13 +125,12 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
 #pragma unroll
                 for (int j = 0; j < T; ++j) { acc64[i][j] += (double)acc[i][j]; acc[i][j] = 0.f; }
         }
-        __syncthreads();
     }
-    float* out = B.sc_partial + (size_t)b * NPL * NPL;
+    double* out = B.sc_partial + (size_t)b * NPL * NPL;
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j) out[(ty * T + i) * NPL + tx * T + j] = (float)acc64[i][j];
+        for (int j = 0; j < T; ++j) out[(ty * T + i) * NPL + tx * T + j] = acc64[i][j];
 }
 
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
@@ -350,11 +145,6 @@ void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorSc
         default: ba_sc_kernel<8><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
     }
 }
-void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix) {
-    if (mode == 2) ba_linearize_kernel<2, 0><<<B.nblocks, kBlk, 0, s>>>(B);
-    else if (fix) ba_linearize_kernel<0, 1><<<B.nblocks, kBlk, 0, s>>>(B);
-    else ba_linearize_kernel<0, 0><<<B.nblocks, kBlk, 0, s>>>(B);
-}
 void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
     const size_t n = (size_t)B.W * B.Ppad;
     ba_reset_oob_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(B.rs_state, B.rs_energy, n);
@@ -362,13 +152,13 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 
 // ------------------------------------------------------------------------------------------------ fp64 finish of the partials
 // acc13[(h + t*W)][169] (full symmetric 13x13, AccumulatorApprox::finish layout MatrixAccumulators.h:626-647), misc[h+t*W] = {count, energy}
-__global__ __launch_bounds__(128) void ba_reduce_top_kernel(const float* __restrict__ top_partial, const int* __restrict__ host_blk /* [W+1] */,
+__global__ __launch_bounds__(128) void ba_reduce_top_kernel(const double* __restrict__ top_partial, const int* __restrict__ host_blk /* [W+1] */,
                                                             int W, double* __restrict__ acc13, double* __restrict__ misc) {
     __shared__ double sums[kTopVals];
     const int h = blockIdx.x % W, t = blockIdx.x / W, j = threadIdx.x;
     if (j < kTopVals) {
         double s = 0;
-        if (h != t) for (int b = host_blk[h]; b < host_blk[h + 1]; ++b) s += (double)top_partial[((size_t)b * W + t) * kTopStride + j];
+        if (h != t) for (int b = host_blk[h]; b < host_blk[h + 1]; ++b) s += top_partial[((size_t)b * W + t) * kTopStride + j];
         sums[j] = s;
     }
     __syncthreads();
@@ -384,11 +174,11 @@ __global__ __launch_bounds__(128) void ba_reduce_top_kernel(const float* __restr
     }
     if (j == 0) { misc[2 * (h + t * W)] = sums[91]; misc[2 * (h + t * W) + 1] = sums[92]; }
 }
-__global__ __launch_bounds__(256) void ba_reduce_sc_kernel(const float* __restrict__ sc_partial, const int* __restrict__ host_blk, int NPL2, double* __restrict__ G) {
+__global__ __launch_bounds__(256) void ba_reduce_sc_kernel(const double* __restrict__ sc_partial, const int* __restrict__ host_blk, int NPL2, double* __restrict__ G) {
     const int h = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= NPL2) return;
     double s = 0;
-    for (int b = host_blk[h]; b < host_blk[h + 1]; ++b) s += (double)sc_partial[(size_t)b * NPL2 + e];
+    for (int b = host_blk[h]; b < host_blk[h + 1]; ++b) s += sc_partial[(size_t)b * NPL2 + e];
     G[(size_t)h * NPL2 + e] = s;
 }
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc) {
@@ -474,6 +264,16 @@ __global__ __launch_bounds__(1024) void ba_sum_partials_kernel(const float* __re
     part[g][j] = s;
     __syncthreads();
     if (g == 0 && j < nvals) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; out[j] = t; }
+}
+// copies the stitched systems into host-mapped pinned memory and publishes a sequence number the host polls on
+__global__ __launch_bounds__(1024) void ba_publish_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, double seq) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&dst[n], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq) {
+    ba_publish_kernel<<<1, 1024, 0, s>>>(src, dst_mapped, n, seq);
 }
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc) {
     ba_resub_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc);

@@ -99,14 +99,18 @@ __global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* _
 }
 
 // fp64 finish: out[j] = sum_b partial[b][j]; written straight into host-mapped pinned memory
-__global__ __launch_bounds__(1024) void trk_finish_kernel(const float* __restrict__ partial, int nblocks, double* __restrict__ out) {
+// out = host-mapped pinned memory; out[63] carries the sequence number of this evaluation, published after the data with
+// system-scope fences so the host can poll it instead of paying a stream synchronisation per LM iteration
+__global__ __launch_bounds__(1024) void trk_finish_kernel(const float* __restrict__ partial, int nblocks, double* __restrict__ out, double seq) {
     __shared__ double part[16][64];
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
     double s = 0;
     if (j < kTrkVals) for (int b = g; b < nblocks; b += 16) s += (double)partial[(size_t)b * 64 + j];
     part[g][j] = s;
     __syncthreads();
-    if (g == 0 && j < kTrkVals) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; out[j] = t; }
+    if (g == 0 && j < kTrkVals) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; out[j] = t; __threadfence_system(); }
+    __syncthreads();
+    if (threadIdx.x == 0) { __hip_atomic_store(&out[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
 int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], const float t[3], const float Ki[9],
@@ -128,9 +132,10 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
     }
     double* dout = nullptr;
     NALO_HIP(c, hipHostGetDevicePointer((void**)&dout, c->trk_out_host, 0));
-    trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, dout);
+    const double seq = (double)(++c->trk_seq);
+    trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, dout, seq);
     NALO_HIP(c, hipGetLastError());
-    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    if (!poll_flag(c, &c->trk_out_host[63], seq)) return NALO_ERR_HIP;
     std::memcpy(out64, c->trk_out_host, sizeof(double) * kTrkVals);
     return NALO_OK;
 }
@@ -246,18 +251,20 @@ int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const 
         const int cnt = npx - 2 * c->wl[l];
         if (cnt > 0) trk_dilate_kernel<<<(cnt + 255) / 256, 256, 0, c->stream>>>(c->trk_idepth[l].p, c->trk_wsum[l].p, c->trk_wbak[l].p, c->wl[l], c->hl[l], l < 2 ? 1 : 0);
     }
+    size_t scan_off[NALO_MAX_LEVELS + 1] = {0};
+    for (int l = 0; l < L; ++l) scan_off[l + 1] = scan_off[l] + 2 * (size_t)(((c->wl[l] - 4) * (c->hl[l] - 4) + kCompactChunk - 1) / kCompactChunk) + 2;
+    NALO_HIP(c, c->scan_tmp.reserve(scan_off[L]));
     for (int l = 0; l < L; ++l) {
         const int total = (c->wl[l] - 4) * (c->hl[l] - 4);
         const int nb = (total + kCompactChunk - 1) / kCompactChunk;
-        NALO_HIP(c, c->scan_tmp.reserve((size_t)2 * nb + 2));
-        int* counts = c->scan_tmp.p; int* offsets = counts + nb;
+        int* counts = c->scan_tmp.p + scan_off[l]; int* offsets = counts + nb;
         const float4* dIref = c->slots[c->slot_ref].dI[l];
         trk_compact_kernel<0><<<nb, 256, 0, c->stream>>>(c->trk_idepth[l].p, c->trk_wsum[l].p, dIref, c->wl[l], c->hl[l], counts, nullptr, nullptr, nullptr, nullptr, nullptr);
         scan_counts_kernel<<<1, 1024, 0, c->stream>>>(counts, offsets, nb);
         trk_compact_kernel<1><<<nb, 256, 0, c->stream>>>(c->trk_idepth[l].p, c->trk_wsum[l].p, dIref, c->wl[l], c->hl[l], nullptr, offsets, c->pc_u[l].p, c->pc_v[l].p, c->pc_id[l].p, c->pc_col[l].p);
         NALO_HIP(c, hipMemcpyAsync(&c->pc_n[l], offsets + nb, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        NALO_HIP(c, hipStreamSynchronize(c->stream));     // scan_tmp is reused by the next level
     }
+    NALO_HIP(c, hipStreamSynchronize(c->stream));         // one synchronisation for all levels (pc_n is needed on the host)
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }

@@ -70,7 +70,8 @@ struct nalo_ctx {
     int pc_n[NALO_MAX_LEVELS] = {};
     nalo::DevBuf<float> trk_partial;         // [blocks][64]
     nalo::DevBuf<double> trk_out;            // 64 doubles
-    double* trk_out_host = nullptr;          // pinned
+    double* trk_out_host = nullptr;          // pinned, host-mapped: results + sequence flag
+    unsigned long long trk_seq = 0;
     nalo::DevBuf<int> scan_tmp;              // compaction counts
     nalo::DevBuf<float> upload_tmp;
     float* pinned_f = nullptr; size_t pinned_f_cap = 0;
@@ -92,6 +93,20 @@ inline int fail(nalo_ctx* c, int code, const std::string& msg) { if (c) c->err =
         if (e__ != hipSuccess)                                                                       \
             return nalo::fail(ctx, NALO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
+
+// Wait for a kernel to publish `seq` into host-mapped memory (system-scope release on the device side). Spinning on the
+// flag costs a few microseconds; hipStreamSynchronize costs tens. Falls back to a stream sync after 5 s (kernel fault).
+inline bool poll_flag(nalo_ctx* c, volatile double* flag, double seq) {
+    for (unsigned long long spins = 0;; ++spins) {
+        if (*flag == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; }
+        if ((spins & 0xFFFFF) == 0xFFFFF) {
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e != hipSuccess && e != hipErrorNotReady) { c->err = std::string("kernel failed: ") + hipGetErrorString(e); return false; }
+            if (spins > (1ull << 34)) { c->err = "timeout waiting for the device"; return false; }
+        }
+        __builtin_ia32_pause();
+    }
+}
 
 struct ProfScope {               // HIP-event bracket on the ctx stream (only when profiling is enabled)
     nalo_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
