@@ -24,6 +24,7 @@ def build(force=False, verbose=False):
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):]):
             continue
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o, "-Wno-unused-result"]
+        cmd += os.environ.get("NALO_CXXFLAGS", "").split()
         if os.path.basename(s) in NO_CONTRACT:
             cmd += ["-ffp-contract=off"]
         if verbose:

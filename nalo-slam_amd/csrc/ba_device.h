@@ -30,6 +30,8 @@ struct BADev {
     const float* pre;                           // [W*W][kPreStride], index h*W + t
     float* frameTH;                             // [W] frameEnergyTH (device resident, updated by the quantile kernel)
     const int* blk_host;                        // [nblocks]
+    const int* blk_order;                       // [8][xcd_len]: point blocks an XCD walks (spatial eighth of every host), -1 = none
+    int xcd_len;
     // points
     float4* pt_geo;                             // {u, v, idepth, idepth_zero}
     const float4 *pt_col0, *pt_col1, *pt_w0, *pt_w1;

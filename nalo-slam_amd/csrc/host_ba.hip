@@ -49,7 +49,7 @@ struct BAWindow {
     DevBuf<float2> rs_energy, rs_pp1;
     DevBuf<float4> rs_pp0;
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
-    DevBuf<int> blk_host, host_blk;
+    DevBuf<int> blk_host, host_blk, blk_order;
     DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 16
     hipEvent_t ev_lin = nullptr, ev_th = nullptr;
     DevBuf<double> acc13, misc, G, S_top, S_sc, Tm, stitched;     // S_*: CSR values
@@ -74,7 +74,7 @@ void ba_destroy(nalo_ctx* c) {
     w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
-    w->blk_host.release(); w->host_blk.release(); w->acc13.release(); w->misc.release(); w->G.release(); w->S_top.release(); w->S_sc.release(); w->Srp_top.release(); w->Sci_top.release(); w->Srp_sc.release(); w->Sci_sc.release();
+    w->blk_host.release(); w->host_blk.release(); w->blk_order.release(); w->acc13.release(); w->misc.release(); w->G.release(); w->S_top.release(); w->S_sc.release(); w->Srp_top.release(); w->Sci_top.release(); w->Srp_sc.release(); w->Sci_sc.release();
     w->Tm.release(); w->stitched.release(); w->th_hist.release();
     if (w->ev_lin) (void)hipEventDestroy(w->ev_lin);
     if (w->ev_th) (void)hipEventDestroy(w->ev_th); w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
@@ -594,6 +594,27 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     NALO_HIP(c, hipMemcpy(w.pt_flags.p, w.flags_h.data(), N, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.blk_host.p, w.blk_host_h.data(), (size_t)w.nblocks * 4, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.host_blk.p, w.host_blk_h.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice));
+    {   // XCD walk lists: list x = the x-th eighth (in Morton = spatial order) of every host's blocks
+        std::vector<std::vector<int>> lists(8);
+        for (int h = 0; h < W; ++h) {
+            const int b0 = w.host_blk_h[h], nb = w.host_blk_h[h + 1] - b0;
+            for (int k = 0; k < nb; ++k) lists[std::min(7, (int)((long long)k * 8 / std::max(nb, 1)))].push_back(b0 + k);
+        }
+        // balance: an XCD with a short list would idle; move tail blocks from the longest to the shortest list
+        for (;;) {
+            int lo = 0, hi = 0;
+            for (int x = 1; x < 8; ++x) { if (lists[x].size() < lists[lo].size()) lo = x; if (lists[x].size() > lists[hi].size()) hi = x; }
+            if (lists[hi].size() <= lists[lo].size() + 1) break;
+            lists[lo].push_back(lists[hi].back()); lists[hi].pop_back();
+        }
+        size_t len = 1;
+        for (auto& l : lists) len = std::max(len, l.size());
+        std::vector<int> order(8 * len, -1);
+        for (int x = 0; x < 8; ++x) for (size_t k = 0; k < lists[x].size(); ++k) order[x * len + k] = lists[x][k];
+        NALO_HIP(c, w.blk_order.reserve(order.size()));
+        NALO_HIP(c, hipMemcpy(w.blk_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+        w.dev.blk_order = w.blk_order.p; w.dev.xcd_len = (int)len;
+    }
     NALO_HIP(c, hipMemset(w.pt_acc.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_hcd.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_step.p, 0, N * 4));
     NALO_HIP(c, hipMemset(w.pt_backup.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_relbs.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_ngood.p, 0, N));
     NALO_HIP(c, hipMemset(w.rs_state.p, 0, NS)); NALO_HIP(c, hipMemset(w.rs_energy.p, 0, NS * 8)); NALO_HIP(c, hipMemset(w.rs_jp0.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.rs_jp1.p, 0, NS * 16));

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__
 // Block = the same 256 points as the linearize block. Thread (ty,tx) of a 16x16 grid owns a TxT tile of G (NPL = 16T columns).
 template <int T>
 __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
-    constexpr int NPL = 16 * T, SUB = 64;
+    // rows staged per pass: the whole block when it fits (<= 64 KiB of LDS), so all operand loads of a block are in flight at once
+    constexpr int NPL = 16 * T, SUB = T <= 4 ? 256 : (T <= 6 ? 128 : 64);
     __shared__ __attribute__((aligned(16))) float A[SUB * NPL];
     __shared__ __attribute__((aligned(16))) float4 Hc[kBlk];
     __shared__ float Wt[kBlk], Bd[kBlk];
@@ -57,8 +58,9 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
             for (int t = 0; t < W; ++t) {
                 if (t == h) continue;
                 const size_t si = (size_t)t * B.Ppad + d;
-                if (!(B.rs_state[si] & RS_ACTIVE)) continue;
-                const float4 q0 = B.rs_pp0[si]; const float2 q1 = B.rs_pp1[si];
+                const uint8_t rs = B.rs_state[si];
+                const float4 q0 = B.rs_pp0[si]; const float2 q1 = B.rs_pp1[si];     // unconditional loads, selected below
+                if (!(rs & RS_ACTIVE)) continue;
                 pa.y += q0.x; pa.x += q0.y; hc.x += q0.z; hc.y += q0.w; hc.z += q1.x; hc.w += q1.y;
                 ++ngood;
             }
@@ -100,9 +102,10 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
             if (g < W - 1) {
                 const int t = g < h ? g : g + 1;
                 const size_t si = (size_t)t * B.Ppad + d;
-                const uint8_t pf = B.pt_flags[d];
+                const uint8_t pf = B.pt_flags[d], rs = B.rs_state[si];
+                const float4 jv = (q & 1) ? B.rs_jp1[si] : B.rs_jp0[si];          // unconditional: no dependent round trip
                 const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
-                if (pvalid && (B.rs_state[si] & RS_ACTIVE)) val = (q & 1) ? B.rs_jp1[si] : B.rs_jp0[si];
+                if (pvalid && (rs & RS_ACTIVE)) val = jv;
             } else if (q == 2 * (W - 1)) val = Hc[sub * SUB + r];
             else if (q == 2 * (W - 1) + 1) val = make_float4(Bd[sub * SUB + r], 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(&A[r * NPL + 4 * q]) = val;
@@ -152,18 +155,19 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 
 // ------------------------------------------------------------------------------------------------ fp64 finish of the partials
 // acc13[(h + t*W)][169] (full symmetric 13x13, AccumulatorApprox::finish layout MatrixAccumulators.h:626-647), misc[h+t*W] = {count, energy}
-__global__ __launch_bounds__(128) void ba_reduce_top_kernel(const double* __restrict__ top_partial, const int* __restrict__ host_blk /* [W+1] */,
-                                                            int W, double* __restrict__ acc13, double* __restrict__ misc) {
-    __shared__ double sums[kTopVals];
-    const int h = blockIdx.x % W, t = blockIdx.x / W, j = threadIdx.x;
-    if (j < kTopVals) {
-        double s = 0;
-        if (h != t) for (int b = host_blk[h]; b < host_blk[h + 1]; ++b) s += top_partial[((size_t)b * W + t) * kTopStride + j];
-        sums[j] = s;
-    }
+__global__ __launch_bounds__(1024) void ba_reduce_top_kernel(const double* __restrict__ top_partial, const int* __restrict__ host_blk /* [W+1] */,
+                                                             int W, double* __restrict__ acc13, double* __restrict__ misc) {
+    __shared__ double part[8][128];
+    __shared__ double sums[128];
+    const int h = blockIdx.x % W, t = blockIdx.x / W, j = threadIdx.x & 127, g = threadIdx.x >> 7;     // 8 groups stride over the blocks
+    double s = 0;
+    if (j < kTopVals && h != t) for (int b = host_blk[h] + g; b < host_blk[h + 1]; b += 8) s += top_partial[((size_t)b * W + t) * kTopStride + j];
+    part[g][j] = s;
+    __syncthreads();
+    if (g == 0) { double tt = 0; for (int k = 0; k < 8; ++k) tt += part[k][j]; sums[j] = tt; }
     __syncthreads();
     double* H = acc13 + (size_t)(h + t * W) * 169;
-    for (int e = j; e < 169; e += blockDim.x) {
+    for (int e = threadIdx.x; e < 169; e += blockDim.x) {
         int r = e / 13, c = e % 13;
         if (r > c) { const int tmp = r; r = c; c = tmp; }
         int idx;
@@ -172,18 +176,21 @@ __global__ __launch_bounds__(128) void ba_reduce_top_kernel(const double* __rest
         else { static const int br[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}}; idx = 85 + br[r - 10][c - 10]; }
         H[e] = sums[idx];
     }
-    if (j == 0) { misc[2 * (h + t * W)] = sums[91]; misc[2 * (h + t * W) + 1] = sums[92]; }
+    if (threadIdx.x == 0) { misc[2 * (h + t * W)] = sums[91]; misc[2 * (h + t * W) + 1] = sums[92]; }
 }
+// G[h][e] = sum over the host's blocks: 4 lane-groups per entry stride over the blocks, combined in a fixed order
 __global__ __launch_bounds__(256) void ba_reduce_sc_kernel(const double* __restrict__ sc_partial, const int* __restrict__ host_blk, int NPL2, double* __restrict__ G) {
-    const int h = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= NPL2) return;
+    __shared__ double part[4][64];
+    const int h = blockIdx.y, j = threadIdx.x & 63, g = threadIdx.x >> 6, e = blockIdx.x * 64 + j;
     double s = 0;
-    for (int b = host_blk[h]; b < host_blk[h + 1]; ++b) s += sc_partial[(size_t)b * NPL2 + e];
-    G[(size_t)h * NPL2 + e] = s;
+    if (e < NPL2) for (int b = host_blk[h] + g; b < host_blk[h + 1]; b += 4) s += sc_partial[(size_t)b * NPL2 + e];
+    part[g][j] = s;
+    __syncthreads();
+    if (g == 0 && e < NPL2) G[(size_t)h * NPL2 + e] = part[0][j] + part[1][j] + part[2][j] + part[3][j];
 }
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc) {
-    if (top) ba_reduce_top_kernel<<<B.W * B.W, 128, 0, s>>>(B.top_partial, host_blk, B.W, acc13, misc);
-    if (sc) ba_reduce_sc_kernel<<<dim3((NPL * NPL + 255) / 256, B.W), 256, 0, s>>>(B.sc_partial, host_blk, NPL * NPL, G);
+    if (top) ba_reduce_top_kernel<<<B.W * B.W, 1024, 0, s>>>(B.top_partial, host_blk, B.W, acc13, misc);
+    if (sc) ba_reduce_sc_kernel<<<dim3((NPL * NPL + 63) / 64, B.W), 256, 0, s>>>(B.sc_partial, host_blk, NPL * NPL, G);
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)

@@ -6,7 +6,7 @@
 //                                                                       MatrixAccumulators.h:754-915)
 //   EFResidual::fixLinearizationF (MODE 2)                             (EnergyFunctionalStructs.cpp:89-115)
 //
-// Grid = (point block, target), TARGET-MAJOR: all CUs gather from the same target image at a time, so its 16-byte texels
+// Grid = (point block, target), TARGET-MAJOR and XCD-aware: all CUs gather from the same target image at a time, so its 16-byte texels
 // stay resident in the XCD L2s / Infinity Cache. One block = 256 points of ONE host and ONE target: the FrameFramePrecalc
 // record is block-uniform (scalar loads), and the 91-entry AccumulatorApprox block of the (host,target) bin is reduced once
 // per block. Register diet for 2 waves/SIMD: the 93 reduced values are streamed (4 at a time: 2 DPP quad adds + one 16-byte LDS
@@ -15,6 +15,10 @@
 #include "nalo_internal.h"
 #include "ba_device.h"
 #include "reduce.h"
+
+#ifndef NALO_LIN_WAVES
+#define NALO_LIN_WAVES 3      // waves per SIMD the register allocator must leave room for (142 VGPRs, no scratch)
+#endif
 
 namespace nalo {
 
@@ -54,10 +58,15 @@ struct QuadStream {
 // MODE 0: active residuals (optimize). MODE 2: marginalisation of the flagged points (resApprox = res_toZeroF).
 // FIX: linearizeAll(true) — residuals that do not end IN are dropped; centerProjectedTo / relBS are stored.
 template <int MODE, int FIX>
-__global__ __launch_bounds__(kBlk, 2) void ba_linearize_kernel(BADev B) {
+__global__ __launch_bounds__(kBlk, NALO_LIN_WAVES) void ba_linearize_kernel(BADev B) {
     __shared__ __attribute__((aligned(16))) float smem[(kBlk / 4) * kTopStride];
     const int W = B.W, tid = threadIdx.x;
-    const int b = blockIdx.x % B.nblocks, t = blockIdx.x / B.nblocks;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so launch index j of a target runs on the XCD group
+    // j % 8. Group x walks blk_order[x][*] = the x-th spatial eighth (Morton range) of every host's points, so each XCD's
+    // private 4 MiB L2 only ever sees ~1/8 of the target image instead of all of it (speed only, never correctness).
+    const int per_t = 8 * B.xcd_len, t = blockIdx.x / per_t, j = blockIdx.x - t * per_t;
+    const int b = B.blk_order[(j & 7) * B.xcd_len + (j >> 3)];
+    if (b < 0) return;
     const int d = b * kBlk + tid, h = B.blk_host[b];
     if (t == h) {                                                       // no self residuals; the newest frame's own points have no entry
         if (MODE == 0 && t == W - 1) B.en_new[d] = -1.f;
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(kBlk, 2) void ba_linearize_kernel(BADev B) {
 }
 
 void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix) {
-    const unsigned grid = (unsigned)B.nblocks * (unsigned)B.W;
+    const unsigned grid = 8u * (unsigned)B.xcd_len * (unsigned)B.W;
     if (mode == 2) ba_linearize_kernel<2, 0><<<grid, kBlk, 0, s>>>(B);
     else if (fix) ba_linearize_kernel<0, 1><<<grid, kBlk, 0, s>>>(B);
     else ba_linearize_kernel<0, 0><<<grid, kBlk, 0, s>>>(B);
