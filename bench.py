@@ -42,6 +42,10 @@ WORKLOADS = {
 }
 
 
+def log(msg):
+    print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
+
+
 def make_inputs(name, seed=7):
     cfg = WORKLOADS[name]
     win = synth.make_window(w=cfg["w"], h=cfg["h"], W=cfg["W"], P=cfg["P"], seed=seed, n_extra=TRACKED_PER_KF)
@@ -190,16 +194,7 @@ def main():
     sharded = args.workload == "shard1m"
 
     win, st6, trk = make_inputs(args.workload)
-    hook = None
-    if sharded and world > 1:
-        class _Ptr:                                       # wraps the device buffer of the stitched systems for torch
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
-
-        def hook(ptr, n):
-            t = torch.as_tensor(_Ptr(ptr, n), device="cuda")
-            dist.all_reduce(t)                             # RCCL over xGMI; payload ~2*(8W+5)^2*8 B (latency bound)
-            torch.cuda.current_stream().synchronize()
+    hook = make_hook(dist, torch) if (sharded and world > 1) else None
     job = GpuJob(shard(win, rank, world) if sharded else win, st6, trk, local_rank, hook)
     do_track = not sharded
 
@@ -263,15 +258,90 @@ def main():
             out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 2)
         elif world == 1:
             out["cpu_baseline"] = None
-    # extra leg (single GPU, default workload only): the 250k-point stress window where the kernels saturate the chip
-    if rank == 0 and world == 1 and args.workload == "kitti00_8kf" and not args.no_extra:
+    # extra legs of the default run (same JSON line):
+    #  shard1m    configs[4]: the 1M-point 12-KF window sharded over ALL ranks with the RCCL all-reduce (strong scaling, every N)
+    #  stress250k configs[3]: single GPU only, where the kernels saturate the chip
+    if args.workload == "kitti00_8kf" and not args.no_extra:
+        log("main leg done: %.1f keyframes/s; starting the shard1m leg" % value)
         job.ctx.close()
-        out["stress250k"] = stress_leg()
+        try:
+            res = shard_leg(rank, world, local_rank, dist, torch)
+        except Exception as e:                      # never lose the main line to the extra leg
+            res = {"error": repr(e)}
+        log("shard1m leg: %s" % (res,))
+        if rank == 0:
+            out["shard1m"] = res
+            if world == 1:
+                out["stress250k"] = stress_leg()
+                log("stress250k leg done")
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+    try:
+        import torch.distributed as d2
+        if d2.is_initialized():
+            d2.destroy_process_group()
+    except Exception:
+        pass
+
+
+def make_hook(dist, torch):
+    """All-reduce hook for nalo_ba_set_allreduce: SUM n doubles in place on the device over RCCL (torch.distributed 'nccl')."""
+    class _Ptr:                                           # wraps the library's device buffer for torch, zero copy
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+    def hook(ptr, n):
+        t = torch.as_tensor(_Ptr(ptr, n), device="cuda")
+        dist.all_reduce(t)                                 # payload ~2*(8W+5)^2*8 B = 163 KB at W=12: latency bound over xGMI
+        torch.cuda.current_stream().synchronize()
+    return hook
+
+
+def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1):
+    """configs[4]: 1M active points, 12-KF window; the point set is sharded block-cyclically over the ranks, frames are
+    replicated, every GN iteration all-reduces the stitched systems. Strong scaling: the window is fixed, N varies."""
+    own_group = False
+    if dist is None:                                       # N=1: still go through RCCL with a 1-rank group, so the hook path is exercised
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 300), rank=0, world_size=1,
+                                device_id=torch.device("cuda", local_rank))
+        own_group = True
+    log("shard1m: generating the 1M-point window")
+    win, st6, trk = make_inputs("shard1m")
+    part = shard(win, rank, world)
+    log("shard1m: uploading %d points" % len(part.host))
+    job = GpuJob(part, st6, trk, local_rank, make_hook(dist, torch))
+    for _ in range(warmup):
+        job.step(False)
+    job.ctx.profile_enable(True)
+    job.ctx.profile_reset()
+    dist.barrier()
+    torch.cuda.synchronize()
+    job.ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step(False)
+    job.ctx.sync()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    R, P = int((part.exists > 0).sum()), len(part.host)
+    res = {"workload": "shard1m", "scaling": "strong", "n_gpus": world, "keyframes_per_s": round(steps / dt, 3),
+           "ms_per_keyframe": round(dt / steps * 1e3, 3), "window_frames": win.W, "active_points": int(len(win.host)),
+           "residuals": int((win.exists > 0).sum()), "points_per_rank": P, "allreduce_doubles": 2 * (8 * win.W + 5) ** 2 + 2 * win.W ** 2 + 5}
+    ms, n = job.ctx.profile_get("ba_linearize")
+    if n:
+        alg = 424.0 * R + 104.0 * P
+        ach = alg / (ms / n * 1e-3) / 1e9
+        res["ba_linearize"] = dict(avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg), achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
+    job.ctx.close()
+    return res
 
 
 def load_traffic(workload):

@@ -15,6 +15,7 @@ void ba_launch_stitch(hipStream_t s, const int* rowptr, const int* col, const do
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq);
+void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
 
 struct HostFrame {
@@ -300,17 +301,31 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
         // computed on the host from misc after the copy for a single GPU; with a hook the per-rank sums are appended first
         NALO_HIP(c, hipMemcpyAsync(w.stitched.p + 2 * blk, w.misc.p, (size_t)2 * W * W * 8, hipMemcpyDeviceToDevice, c->stream));
         if (w.hook) {
+            // sharded window: tail = {step sums (3), this rank's frameEnergyTH of the newest frame, 1.0}. After the SUM over ranks the
+            // host installs the MEAN of the per-shard 70 % quantiles as the common threshold (every rank then classifies with the
+            // same value; the exact global order statistic would need the histograms all-reduced: SURVEY 8e, next round).
+            NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0));
+            ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
             NALO_HIP(c, hipStreamSynchronize(c->stream));
-            w.hook(w.hook_user, w.stitched.p, (int)(2 * blk + 2 * W * W + 3));     // + the step sums (sumID, sumNID, numID)
+            w.hook(w.hook_user, w.stitched.p, (int)(2 * blk + 2 * W * W + 5));
         }
-        // [H~_A | H~_sc | misc (2 W^2) | step sums (3)] -> host-mapped pinned memory, completion by a polled sequence number
-        const int npub = (int)(2 * blk + 2 * W * W + 3);
+        // [H~_A | H~_sc | misc (2 W^2) | step sums (3) | TH sum, rank count] -> host-mapped pinned memory, polled sequence number
+        const int npub = (int)(2 * blk + 2 * W * W + 5);
         double* dmap = nullptr;
         NALO_HIP(c, hipHostGetDevicePointer((void**)&dmap, w.stitched_host, 0));
         const double seq = (double)(++w.pub_seq);
         ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
         NALO_HIP(c, hipGetLastError());
         if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
+        if (w.hook) {
+            const double* tl = w.stitched_host + 2 * blk + 2 * W * W + 3;
+            if (tl[1] > 1.5) {                                  // more than one rank: install the common threshold
+                const float th = (float)(tl[0] / tl[1]);
+                NALO_HIP(c, hipStreamSynchronize(c->side));
+                NALO_HIP(c, hipMemcpyAsync(w.frameTH.p + (W - 1), &th, 4, hipMemcpyHostToDevice, c->stream));
+                NALO_HIP(c, hipStreamSynchronize(c->stream));
+            }
+        }
         if (w.step_pending) {                                   // finish doStepFromBackup's break test with the sums of the last step
             const double* s3 = w.stitched_host + 2 * blk + 2 * W * W;
             const float numID = (float)s3[2];
@@ -529,7 +544,7 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     NALO_HIP(c, w.stitched.reserve(2 * blk + 2 * W * W + 16));
     if (w.stitched_host) { (void)hipHostFree(w.stitched_host); w.stitched_host = nullptr; }
     NALO_HIP(c, hipHostMalloc((void**)&w.stitched_host, (2 * blk + 2 * W * W + 16) * 8, hipHostMallocMapped));
-    w.stitched_host[2 * blk + 2 * W * W + 3] = -1.0; w.pub_seq = 0;
+    w.stitched_host[2 * blk + 2 * W * W + 5] = -1.0; w.pub_seq = 0;
     int rc = upload_frame_th(c); if (rc) return rc;
     rc = set_adjoints(c); if (rc) return rc;
     rc = set_precalc(c); if (rc) return rc;

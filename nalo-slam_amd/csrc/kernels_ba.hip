@@ -40,7 +40,8 @@ template <int T>
 __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
     // rows staged per pass: the whole block when it fits (<= 64 KiB of LDS), so all operand loads of a block are in flight at once
     constexpr int NPL = 16 * T, SUB = T <= 4 ? 256 : (T <= 6 ? 128 : 64);
-    __shared__ __attribute__((aligned(16))) float A[SUB * NPL];
+    constexpr int NPLP = NPL + 4;            // padded LDS row: lanes = consecutive rows, so the row stride must not be a multiple of 32 banks
+    __shared__ __attribute__((aligned(16))) float A[SUB * NPLP];
     __shared__ __attribute__((aligned(16))) float4 Hc[kBlk];
     __shared__ float Wt[kBlk], Bd[kBlk];
     const int b = blockIdx.x, tid = threadIdx.x, h = B.blk_host[b], W = B.W;
@@ -94,21 +95,33 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
         const int d0 = b * kBlk + sub * SUB;
         __syncthreads();
         // ---- stage SUB operand rows: [JpJdF(t != h) (8 each) | Hcd (4) | bdSum | 0..]
-        for (int e = tid; e < SUB * (NPL / 4); e += 256) {
-            const int r = e / (NPL / 4), q = e - r * (NPL / 4);       // q-th float4 of row r
-            const int d = d0 + r;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int g = q >> 1;                                     // compact target slot
-            if (g < W - 1) {
-                const int t = g < h ? g : g + 1;
-                const size_t si = (size_t)t * B.Ppad + d;
-                const uint8_t pf = B.pt_flags[d], rs = B.rs_state[si];
-                const float4 jv = (q & 1) ? B.rs_jp1[si] : B.rs_jp0[si];          // unconditional: no dependent round trip
-                const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
-                if (pvalid && (rs & RS_ACTIVE)) val = jv;
-            } else if (q == 2 * (W - 1)) val = Hc[sub * SUB + r];
-            else if (q == 2 * (W - 1) + 1) val = make_float4(Bd[sub * SUB + r], 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(&A[r * NPL + 4 * q]) = val;
+        // lane <-> point (coalesced 16-byte loads from the [target][point] arrays), the NQ float4 columns of a row are split over
+        // the 256/SUB threads that share a point; the loop is fully unrolled so every load of the pass is in flight at once.
+        {
+            constexpr int NQ = NPL / 4, PARTS = kBlk / SUB;
+            const int r = tid % SUB, part = tid / SUB, d = d0 + r;
+            const uint8_t pf = B.pt_flags[d];
+            const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
+            float4 vals[(NQ + PARTS - 1) / PARTS];
+#pragma unroll
+            for (int qi = 0; qi < (NQ + PARTS - 1) / PARTS; ++qi) {
+                const int q = part + qi * PARTS, g = q >> 1;          // q-th float4 of the row, compact target slot g
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < NQ && g < W - 1) {
+                    const int t = g < h ? g : g + 1;
+                    const size_t si = (size_t)t * B.Ppad + d;
+                    const uint8_t rs = B.rs_state[si];
+                    const float4 jv = (q & 1) ? B.rs_jp1[si] : B.rs_jp0[si];      // unconditional: no dependent round trip
+                    if (pvalid && (rs & RS_ACTIVE)) val = jv;
+                } else if (q == 2 * (W - 1)) val = Hc[sub * SUB + r];
+                else if (q == 2 * (W - 1) + 1) val = make_float4(Bd[sub * SUB + r], 0.f, 0.f, 0.f);
+                vals[qi] = val;
+            }
+#pragma unroll
+            for (int qi = 0; qi < (NQ + PARTS - 1) / PARTS; ++qi) {
+                const int q = part + qi * PARTS;
+                if (q < NQ) *reinterpret_cast<float4*>(&A[r * NPLP + 4 * q]) = vals[qi];
+            }
         }
         __syncthreads();
         for (int k0 = 0; k0 < SUB; k0 += RUN) {
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
                 const float wk = Wt[sub * SUB + k];
                 float ai[T], aj[T];
 #pragma unroll
-                for (int i = 0; i < T; ++i) { ai[i] = wk * A[k * NPL + ty * T + i]; aj[i] = A[k * NPL + tx * T + i]; }
+                for (int i = 0; i < T; ++i) { ai[i] = wk * A[k * NPLP + ty * T + i]; aj[i] = A[k * NPLP + tx * T + i]; }
 #pragma unroll
                 for (int i = 0; i < T; ++i)
 #pragma unroll
@@ -279,6 +292,8 @@ __global__ __launch_bounds__(1024) void ba_publish_kernel(const double* __restri
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&dst[n], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ void ba_th_tail_kernel(const float* __restrict__ th, double* __restrict__ tail2) { tail2[0] = (double)th[0]; tail2[1] = 1.0; }
+void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2) { ba_th_tail_kernel<<<1, 1, 0, s>>>(th, tail2); }
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq) {
     ba_publish_kernel<<<1, 1024, 0, s>>>(src, dst_mapped, n, seq);
 }

@@ -157,3 +157,27 @@ def test_marginalize_points(small_window):
     E = c.ba_linearize(False)
     assert abs(E - E_o) / E_o < 1e-5
     c.close()
+
+
+@pytest.mark.parametrize("W,P", [(3, 300), (7, 900), (12, 1800)])
+def test_window_sizes(W, P):
+    """every SYRK tile width (T = 2, 4, 6) and odd/even window sizes: stitched systems vs the oracle, partial residual graph."""
+    win = synth.make_window(w=640, h=480, W=W, P=P, seed=21, full_graph=False)
+    st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
+    orc.lib().orc_set_sum_mode(0)
+    ba = orc.ba_from_window(win, "f32", state6=st6)
+    c = make_ctx(win, st6)
+    E_o = ba.linearize_all(False)
+    ba.apply_res()
+    E = c.ba_linearize(False)
+    assert abs(E - E_o) < 1e-5 * E_o
+    HA_o, bA_o = ba.accumulate(0)
+    Hs_o, bs_o = ba.accumulate_sc(True)
+    HA, bA = c.ba_accumulate(0)
+    Hs, bs = c.ba_accumulate_sc(True)
+    assert rel_err(HA, HA_o) < 2e-5 and rel_err(bA, bA_o) < 5e-5
+    assert rel_err(Hs, Hs_o) < 2e-5 and rel_err(bs, bs_o) < 1e-4
+    st_o, ac_o, _, _ = ba.slots()
+    st, ac, _, _, _ = c.ba_get_residuals()
+    assert np.array_equal(st, st_o) and np.array_equal(ac, ac_o)
+    c.close()
