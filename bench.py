@@ -230,7 +230,7 @@ def main():
     units = args.steps * (1 if sharded else world)       # replicas: every rank processed its own keyframes
     value = units / dt
 
-    prof = {k: job.ctx.profile_get(k) for k in ("ba_linearize", "ba_sc", "ba_reduce", "ba_resub", "trk_eval", "pyramid")}
+    prof = {k: job.ctx.profile_get(k) for k in ("ba_linearize", "ba_sc", "ba_reduce", "ba_resub", "trk_eval", "trk_lm", "pyramid")}
     out = None
     if rank == 0:
         # roofline of the dominant kernel (ba_linearize): algorithmic bytes per launch:

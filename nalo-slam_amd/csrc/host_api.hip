@@ -2,8 +2,11 @@
 // src/FullSystem/CoarseTracker.{h,cpp}). The LM loop of trackNewestCoarse stays on the host exactly as in the
 // reference (8x8 LDL^T, SE3::exp); every calcRes/calcGSSSE pair is one fused kernel launch.
 #include "nalo_internal.h"
+#include <cstdlib>
 
 using namespace nalo;
+
+namespace nalo { int trk_lm_launch(nalo_ctx* c, int slot_new, const double T0[12], const double aff0[2], const double ref_aff[2], const float exposures[2], int coarsest, int stop_lvl, const double* minRes, double out24[32]); }
 
 namespace nalo { void ba_destroy(nalo_ctx* c); }
 
@@ -43,13 +46,14 @@ int nalo_create(nalo_ctx** out, int device, int w, int h, int levels, const floa
             if (hipMalloc((void**)&s.I[l], npx * 4) != hipSuccess || hipMalloc((void**)&s.dI[l], npx * 16) != hipSuccess ||
                 hipMalloc((void**)&s.absg[l], npx * 4) != hipSuccess) { nalo_destroy(c); return NALO_ERR_HIP; }
         }
-    if (hipHostMalloc((void**)&c->trk_out_host, 64 * sizeof(double), hipHostMallocMapped) != hipSuccess) { nalo_destroy(c); return NALO_ERR_HIP; }
+    if (hipHostMalloc((void**)&c->trk_out_host, 128 * sizeof(double), hipHostMallocMapped) != hipSuccess) { nalo_destroy(c); return NALO_ERR_HIP; }
     *out = c;
     return NALO_OK;
 }
 
 void nalo_destroy(nalo_ctx* c) {
     if (!c) return;
+    if (std::getenv("NALO_HOST_TIMING")) for (auto& kv : c->host_t) fprintf(stderr, "[nalo host] %-28s calls=%6ld total=%10.1f us  avg=%8.2f us\n", kv.first.c_str(), kv.second.second, kv.second.first, kv.second.first / std::max(1L, kv.second.second));
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     ba_destroy(c);
@@ -96,6 +100,7 @@ int nalo_frame_upload(nalo_ctx* c, int slot, const float* irradiance, const floa
 int nalo_frame_rebuild(nalo_ctx* c, int slot) {
     if (!c || slot < 0 || slot >= (int)c->slots.size() || !c->slots[slot].valid) return fail(c, NALO_ERR_ARG, "nalo_frame_rebuild: bad slot");
     NALO_HIP(c, hipSetDevice(c->device));
+    HostTimer ht(c, "frame_rebuild");
     return pyramid_build(c, c->slots[slot], nullptr);
 }
 
@@ -134,6 +139,7 @@ int nalo_trk_set_ref(nalo_ctx* c, int slot_ref, int n, const float* Ku, const fl
         return fail(c, NALO_ERR_ARG, "nalo_trk_set_ref: bad argument");
     if (!c->slots[slot_ref].valid) return fail(c, NALO_ERR_STATE, "nalo_trk_set_ref: reference slot has no pyramid");
     NALO_HIP(c, hipSetDevice(c->device));
+    HostTimer ht(c, "trk_set_ref");
     c->slot_ref = slot_ref;
     float* dev[4] = {};
     if (n > 0) { int rc = upload4(c, n, Ku, Kv, new_idepth, HdiF, dev); if (rc) return rc; }
@@ -210,14 +216,42 @@ int nalo_trk_eval(nalo_ctx* c, int slot_new, int lvl, const double R[9], const d
 int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2], const double ref_aff[2], const float exposures[2],
                    int coarsestLvl, const double minResForAbort[5], double lastResiduals[5], double lastFlow[3], int* ok, int* n_evals) {
     if (!c || !T_io || !aff_io || !ref_aff || !exposures || !ok) return fail(c, NALO_ERR_ARG, "nalo_trk_track: bad argument");
-    if (!(coarsestLvl < 5 && coarsestLvl < c->levels)) return fail(c, NALO_ERR_ARG, "nalo_trk_track: coarsestLvl out of range");   // assert at :1083
+    if (!(coarsestLvl < 5 && coarsestLvl < c->levels)) return fail(c, NALO_ERR_ARG, "nalo_trk_track: coarsestLvl out of range");
+    HostTimer ht(c, "trk_track");   // assert at :1083
     double lastRes[5] = {NAN, NAN, NAN, NAN, NAN}, flow[3] = {1000, 1000, 1000};
-    static const int maxIterations[5] = {10, 20, 50, 50, 50};
-    const float lambdaExtrapolationLimit = 0.001f;
     SE3 cur = SE3::from(T_io);
     double aff_cur[2] = {aff_io[0], aff_io[1]};
     bool haveRepeated = false, good = true;
-    int evals = 0;
+    int evals = 0, start_lvl = coarsestLvl;
+    // Coarse levels (point clouds of <= 8192 points) run in ONE persistent device kernel (kernels_trk_lm.hip): no host round trip
+    // per LM iteration. The fine levels continue below with the multi-block evaluation kernel. NALO_TRK_HOST_LM=1 disables it.
+    {
+        static const bool force_host = std::getenv("NALO_TRK_HOST_LM") != nullptr;
+        int stop = coarsestLvl + 1;
+        while (stop > 0 && c->pc_n[stop - 1] <= 8192) --stop;           // levels coarsestLvl..stop on the device
+        if (!force_host && stop <= coarsestLvl) {
+            if (c->slot_ref < 0 || slot_new < 0 || slot_new >= (int)c->slots.size() || !c->slots[slot_new].valid)
+                return fail(c, NALO_ERR_STATE, "nalo_trk_track: no reference / empty frame slot");
+            double o[32];
+            int rc = trk_lm_launch(c, slot_new, T_io, aff_io, ref_aff, exposures, coarsestLvl, stop, minResForAbort, o);
+            if (rc) return rc;
+            for (int l = stop; l <= coarsestLvl && l < 5; ++l) lastRes[l] = o[14 + l];
+            flow[0] = o[19]; flow[1] = o[20]; flow[2] = o[21];
+            evals = (int)o[23];
+            if ((int)o[22] == 0) {                                          // aborted on minResForAbort (:1227): outputs untouched
+                if (lastResiduals) std::memcpy(lastResiduals, lastRes, sizeof(lastRes));
+                if (lastFlow) std::memcpy(lastFlow, flow, sizeof(flow));
+                if (n_evals) *n_evals = evals;
+                *ok = 0;
+                return NALO_OK;
+            }
+            cur = SE3::from(o); aff_cur[0] = o[12]; aff_cur[1] = o[13];
+            haveRepeated = o[25] != 0.0;
+            start_lvl = (int)o[24];                                         // next level to process (-1: pyramid finished)
+        }
+    }
+    static const int maxIterations[5] = {10, 20, 50, 50, 50};
+    const float lambdaExtrapolationLimit = 0.001f;
     auto eval = [&](int lvl, const SE3& T, const double aff[2], float cutoff, double st[6], double* H, double* b, double* aLL0) -> int {
         double aLL[2];
         aff_from_to(exposures[0], exposures[1], ref_aff[0], ref_aff[1], aff[0], aff[1], aLL);
@@ -228,7 +262,7 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
         ++evals;
         return nalo_trk_eval(c, slot_new, lvl, R, tt, aLLf, (float)ref_aff[1], cutoff, 1, st, H, b);
     };
-    for (int lvl = coarsestLvl; lvl >= 0; --lvl) {
+    for (int lvl = start_lvl; lvl >= 0; --lvl) {
         double H[64], b[8], Hn[64], bn[8], resOld[6], resNew[6];
         float levelCutoffRepeat = 1;
         int rc = eval(lvl, cur, aff_cur, kCoarseCutoffTH * levelCutoffRepeat, resOld, H, b, nullptr);

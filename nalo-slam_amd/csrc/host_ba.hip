@@ -127,6 +127,7 @@ static void frame_take_data(HostFrame& f) {                               // EFF
 // EnergyFunctional::setAdjointsF (OptimizationBackend/EnergyFunctional.cpp:46-106) + the S matrices of the stitch
 static int set_adjoints(nalo_ctx* c) {
     BAWindow& w = *c->ba;
+    HostTimer ht(c, "ba.set_adjoints");
     const int W = w.W, n1 = w.n1;
     w.adHost.assign((size_t)W * W * 64, 0.0); w.adTarget.assign((size_t)W * W * 64, 0.0);
     w.adHostF.resize((size_t)W * W * 64); w.adTargetF.resize((size_t)W * W * 64);
@@ -201,6 +202,7 @@ static int set_adjoints(nalo_ctx* c) {
 // FullSystem::setPrecalcValues = FrameFramePrecalc::set for all pairs (HessianBlocks.cpp:192-222) + EnergyFunctional::setDeltaF (:171-194)
 static int set_precalc(nalo_ctx* c) {
     BAWindow& w = *c->ba;
+    HostTimer ht(c, "ba.set_precalc");
     const int W = w.W;
     w.adHTdeltaF.resize((size_t)W * W * 8);
     for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
@@ -400,12 +402,15 @@ static void prior_system(const BAWindow& w, double* H, double* b) {         // a
 
 static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out) {
     BAWindow& w = *c->ba;
+    HostTimer ht(c, "ba.solve_system");
     const int W = w.W, n = w.n, n1 = w.n1;
     (void)lambda; lambda = 1e-5;                                            // SOLVER_FIX_LAMBDA (EnergyFunctional.cpp:779)
     if (!w.have_lin) return fail(c, NALO_ERR_STATE, "solve_system before linearize");
     if (!w.have_sc || w.sc_shift != 1) { int rc = sc_async(c, 1, 1.f, 0); if (rc) return rc; }
-    int rc = stitch_and_fetch(c, true, true);
+    int rc;
+    { HostTimer h2(c, "ba.solve.fetch_wait"); rc = stitch_and_fetch(c, true, true); }
     if (rc) return rc;
+    HostTimer h3(c, "ba.solve.host_math");
     std::vector<double> HA((size_t)n * n), bA(n), Hsc((size_t)n * n), bsc(n), HL((size_t)n * n), bL(n), HF((size_t)n * n), bF(n), x(n), delta(n);
     unpack_system(w, w.stitched_host, HA.data(), bA.data());
     unpack_system(w, w.stitched_host + (size_t)n1 * n1, Hsc.data(), bsc.data());
@@ -461,6 +466,7 @@ static void backup_state(BAWindow& w) {
 }
 static int do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float fD, int* canbreak) {
     BAWindow& w = *c->ba;
+    HostTimer ht(c, "ba.do_step");
     const double pf[10] = {fT, fT, fT, fR, fR, fR, fA, fA, fA, fA};
     float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
     double v[4];
@@ -720,6 +726,7 @@ int nalo_ba_do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float f
 
 int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse) {
     NALO_BA_READY("nalo_ba_optimize")
+    HostTimer ht(c, "ba_optimize");
     const int W = w.W;
     if (W < 3) mnumOptIts = 20;                                             // FullSystemOptimize.cpp:401-403
     if (W < 4) mnumOptIts = 15;
@@ -876,6 +883,7 @@ int nalo_ba_snapshot(nalo_ctx* c) {
 }
 int nalo_ba_restore(nalo_ctx* c) {
     NALO_BA_READY("nalo_ba_restore")
+    HostTimer ht(c, "ba_restore");
     if (!w.have_snap) return fail(c, NALO_ERR_STATE, "nalo_ba_restore: no snapshot");
     const size_t N = w.Ppad, NS = (size_t)w.W * N;
     NALO_HIP(c, hipMemcpyAsync(w.pt_geo.p, w.snap_geo.p, N * 16, hipMemcpyDeviceToDevice, c->stream));

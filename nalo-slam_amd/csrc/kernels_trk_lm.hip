@@ -1,0 +1,369 @@
+// Device-resident CoarseTracker::trackNewestCoarse (reference src/FullSystem/CoarseTracker.cpp:1073-1259) for gfx950.
+//
+// The reference's LM loop does up to ~180 calcRes/calcGSSSE evaluations per frame with an 8x8 solve and an SE3::exp in
+// between. Driven from the host every evaluation costs a launch + a completion round trip (~25-30 us) although the kernel
+// itself runs ~10 us on a KITTI-sized point cloud: the loop is latency bound. Here ONE persistent workgroup (1024 lanes,
+// one CU) runs the whole pyramid descent: fused calcRes+calcGS over the level's points, block reduction (DPP quad adds ->
+// LDS rows -> fp64 column sums), then lane 0 plays the host: fp64 LDL^T, SE3::exp, accept/reject, lambda schedule, level
+// cutoff repeat — exactly the control flow of the host mirror in host_api.hip. One CU only has the memory parallelism for a few
+// thousand points, so this kernel takes the COARSE levels (n <= 8192: most of the iterations happen there) and hands the state
+// (pose, affine, haveRepeated) back; the host mirror continues on the fine levels with the multi-block trk_eval kernel.
+// NALO_TRK_HOST_LM=1 forces the host loop for every level. Every wave reaches every barrier: the loop state lives
+// in LDS and all branches on it are block-uniform.
+#include "nalo_internal.h"
+#include "reduce.h"
+
+namespace nalo {
+
+#ifndef NALO_LM_THREADS
+#define NALO_LM_THREADS 512
+#endif
+#ifndef NALO_LM_G
+#define NALO_LM_G 2
+#endif
+constexpr int kLmThreads = NALO_LM_THREADS;
+constexpr int kLmVals = 52;                  // 45 H entries + E, nE, nSat, nWarped, sT, sRT, sN (same order as trk_eval_kernel)
+constexpr int kLmStride = 56;
+
+struct TrkLmLevel { const float *u, *v, *id, *col; const float4* dI; int n, wl, hl; float fx, fy, cx, cy; };
+struct TrkLmParams {
+    TrkLmLevel lv[NALO_MAX_LEVELS];
+    double T0[12], aff0[2], ref_aff[2], minRes[5];
+    float expRef, expNew;
+    int coarsest, has_minres, stop_lvl, have_repeated_in;   // levels coarsest..stop_lvl run here; the caller continues below
+    double* out;                             // host-mapped: T(12) aff(2) lastRes(5) flow(3) ok evals | seq at [31]
+    double seq;
+};
+
+struct LmState {                             // lives in LDS; written by lane 0 only, read by everyone after a barrier
+    double T[12], aff[2];                    // accepted estimate
+    double Tn[12], affn[2];                  // candidate
+    double H[64], b[8], resOld[6], resNew[6];
+    double lastRes[5], flow[3];
+    float RKi[9], t[3], Ki[9], affa, affb, b0, cutoff, maxEnergy;
+    float lambda, levelCutoffRepeat;
+    int lvl, it, phase, haveRepeated, good, evals, done, break_pending, next_lvl;
+};
+
+// ---- fp64 helpers for lane 0 -------------------------------------------------------------------------------------------
+__device__ void lm_se3_exp(const double xi[6], double T[12]) {               // Sophus SE3::exp (se3.hpp:407-428), quaternion form
+    const double wx = xi[3], wy = xi[4], wz = xi[5];
+    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
+    double qi, qr;
+    if (th < 1e-10) { const double t4 = th2 * th2; qi = 0.5 - th2 / 48.0 + t4 / 3840.0; qr = 1.0 - 0.5 * th2 + t4 / 384.0; }
+    else { qi = sin(0.5 * th) / th; qr = cos(0.5 * th); }
+    double q[4] = {qr, qi * wx, qi * wy, qi * wz};
+    const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; ++i) q[i] /= qn;
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+    const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double O2[9], V[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    if (th < 1e-10) { for (int i = 0; i < 9; ++i) V[i] = R[i]; }
+    else { const double a = (1 - cos(th)) / th2, bq = (th - sin(th)) / (th2 * th); for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + bq * O2[i]; }
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j]; T[i * 4 + 3] = V[i * 3] * xi[0] + V[i * 3 + 1] * xi[1] + V[i * 3 + 2] * xi[2]; }
+}
+__device__ void lm_se3_mul(const double A[12], const double B[12], double C[12]) {
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) C[i * 4 + j] = A[i * 4] * B[j] + A[i * 4 + 1] * B[4 + j] + A[i * 4 + 2] * B[8 + j];
+        C[i * 4 + 3] = A[i * 4] * B[3] + A[i * 4 + 1] * B[7] + A[i * 4 + 2] * B[11] + A[i * 4 + 3];
+    }
+}
+struct LmScratch { double A[64], y[8], Hl[64], nb[8], inc[8], incS[8], E[12], Hn[64], bn[8]; int perm[8]; };   // lane 0's work arrays, in LDS (not scratch memory)
+
+__device__ void lm_ldlt8(LmScratch& W, const double* Ain, const double* rhs, double* x) {    // pivoted LDL^T, same algorithm as host_math.h
+    double* A = W.A; double* y = W.y; int* perm = W.perm;
+    for (int i = 0; i < 64; ++i) A[i] = Ain[i];
+    for (int i = 0; i < 8; ++i) perm[i] = i;
+    for (int k = 0; k < 8; ++k) {
+        int p = k; double best = fabs(A[k * 8 + k]);
+        for (int i = k + 1; i < 8; ++i) { const double v = fabs(A[i * 8 + i]); if (v > best) { best = v; p = i; } }
+        if (p != k) {
+            for (int j = 0; j < 8; ++j) { const double tmp = A[k * 8 + j]; A[k * 8 + j] = A[p * 8 + j]; A[p * 8 + j] = tmp; }
+            for (int j = 0; j < 8; ++j) { const double tmp = A[j * 8 + k]; A[j * 8 + k] = A[j * 8 + p]; A[j * 8 + p] = tmp; }
+            const int ti = perm[k]; perm[k] = perm[p]; perm[p] = ti;
+        }
+        const double d = A[k * 8 + k];
+        if (d == 0.0 || !isfinite(d)) { for (int i = k + 1; i < 8; ++i) A[i * 8 + k] = 0; continue; }
+        for (int i = k + 1; i < 8; ++i) A[i * 8 + k] /= d;
+        for (int i = k + 1; i < 8; ++i) { const double lik = A[i * 8 + k]; if (lik == 0) continue; for (int j = k + 1; j <= i; ++j) A[i * 8 + j] -= lik * d * A[j * 8 + k]; }
+        for (int i = k + 1; i < 8; ++i) for (int j = i + 1; j < 8; ++j) A[i * 8 + j] = A[j * 8 + i];
+    }
+    for (int i = 0; i < 8; ++i) y[i] = rhs[perm[i]];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < i; ++j) y[i] -= A[i * 8 + j] * y[j];
+    for (int i = 0; i < 8; ++i) { const double d = A[i * 8 + i]; y[i] = (d != 0.0 && isfinite(d)) ? y[i] / d : 0.0; }
+    for (int i = 7; i >= 0; --i) for (int j = i + 1; j < 8; ++j) y[i] -= A[j * 8 + i] * y[j];
+    for (int i = 0; i < 8; ++i) x[perm[i]] = y[i];
+}
+
+// lane 0: prepare the float parameters of an evaluation at (T, aff) for level lvl (CoarseTracker.cpp:907-916)
+__device__ void lm_prepare_eval(LmState& S, const TrkLmParams& P, const double T[12], const double aff[2]) {
+    const TrkLmLevel& L = P.lv[S.lvl];
+    float expF = P.expRef, expT = P.expNew;
+    if (expF == 0 || expT == 0) expT = expF = 1;                                        // AffLight::fromToVecExposure, util/NumType.h:173-185
+    const double a = exp(aff[0] - P.ref_aff[0]) * expT / expF, bq = aff[1] - a * P.ref_aff[1];
+    S.affa = (float)a; S.affb = (float)bq; S.b0 = (float)P.ref_aff[1];
+    const float Ki[9] = {1.0f / L.fx, 0, -L.cx / L.fx, 0, 1.0f / L.fy, -L.cy / L.fy, 0, 0, 1};
+    float Rf[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rf[i * 3 + j] = (float)T[i * 4 + j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) S.RKi[i * 3 + j] = Rf[i * 3] * Ki[j] + Rf[i * 3 + 1] * Ki[3 + j] + Rf[i * 3 + 2] * Ki[6 + j];
+    for (int i = 0; i < 9; ++i) S.Ki[i] = Ki[i];
+    for (int i = 0; i < 3; ++i) S.t[i] = (float)T[i * 4 + 3];
+    S.cutoff = kCoarseCutoffTH * S.levelCutoffRepeat;
+    S.maxEnergy = 2 * kHuberTH * S.cutoff - kHuberTH * kHuberTH;
+}
+// lane 0: sums (52 doubles) -> stats6 + scaled H,b (CoarseTracker.cpp:1040-1046, 869-884)
+__device__ void lm_finish_eval(const double* o, double st[6], double* H, double* b) {
+    const double E = o[45], nE = o[46], nSat = o[47], nW = o[48], sT = o[49], sRT = o[50], sN = o[51];
+    st[0] = E; st[1] = nE; st[2] = sT / (sN + 0.1); st[3] = 0; st[4] = sRT / (sN + 0.1); st[5] = (double)((float)nSat / (float)nE);
+    const double npad = (double)(((long)nW + 3) & ~3L), inv = 1.0 / npad;
+    const double sc[8] = {kScaleXiRot, kScaleXiRot, kScaleXiRot, kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleA, kScaleB};
+    for (int r = 0; r < 8; ++r) {
+        for (int cc = 0; cc < 8; ++cc) {
+            const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;
+            H[r * 8 + cc] = o[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] * inv * sc[r] * sc[cc];       // upper-triangular index of the 9x9
+        }
+        b[r] = o[r * 9 - r * (r - 1) / 2 + (8 - r)] * inv * sc[r];
+    }
+}
+
+__global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
+    __shared__ float rows[(kLmThreads / 4) * kLmStride];
+    __shared__ double sums[64];
+    __shared__ double part[kLmThreads / 64][64];
+    __shared__ LmState S;
+    __shared__ LmScratch WK;
+    const int tid = threadIdx.x;
+    const int maxIterations[5] = {10, 20, 50, 50, 50};
+    const float lambdaExtrapolationLimit = 0.001f;
+
+    if (tid == 0) {
+        for (int i = 0; i < 12; ++i) S.T[i] = P.T0[i];
+        S.aff[0] = P.aff0[0]; S.aff[1] = P.aff0[1];
+        for (int i = 0; i < 5; ++i) S.lastRes[i] = NAN;
+        S.flow[0] = S.flow[1] = S.flow[2] = 1000;
+        S.lvl = P.coarsest; S.it = 0; S.phase = 0; S.next_lvl = -1; S.haveRepeated = P.have_repeated_in; S.good = 1; S.evals = 0; S.done = 0; S.break_pending = 0;
+        S.levelCutoffRepeat = 1; S.lambda = 0.01f;
+        lm_prepare_eval(S, P, S.T, S.aff);
+    }
+    __syncthreads();
+
+    // phase 0: first evaluation of a level at the accepted estimate (with the cutoff-repeat loop, :1104-1115)
+    // phase 1: evaluation of an LM candidate (:1184)
+    for (int guard = 0; guard < 4096; ++guard) {
+        if (S.done) break;
+        // ------------------------------------------------------------- fused calcRes + calcGS over this level's points
+        const TrkLmLevel& L = P.lv[S.lvl];
+        float acc[kLmVals];
+#pragma unroll
+        for (int k = 0; k < kLmVals; ++k) acc[k] = 0.f;
+        {
+            const float wlm3 = (float)(L.wl - 3), hlm3 = (float)(L.hl - 3);
+            const float affa = S.affa, affb = S.affb, b0 = S.b0, cutoff = S.cutoff, maxEnergy = S.maxEnergy;
+            const int lvl = S.lvl;
+            float RK[9], Kq[9], tt[3];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { RK[q] = S.RKi[q]; Kq[q] = S.Ki[q]; }
+            tt[0] = S.t[0]; tt[1] = S.t[1]; tt[2] = S.t[2];
+            // software pipeline, 4 points per lane per round: 16 point loads, then 16 texel gathers in flight, then the arithmetic.
+            // A single in-order wave would otherwise pay two dependent memory round trips per point.
+            constexpr int G = NALO_LM_G;
+            for (int base = tid; base < L.n; base += G * kLmThreads) {
+                float id[G], x[G], y[G], rc[G], Ku[G], Kv[G], uu[G], vv[G], nid[G];
+                bool inb[G], ok[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int i = base + g * kLmThreads;
+                    inb[g] = i < L.n;
+                    const int ii = inb[g] ? i : 0;
+                    id[g] = L.id[ii]; x[g] = L.u[ii]; y[g] = L.v[ii]; rc[g] = L.col[ii];
+                }
+                float4 p00[G], p10[G], p01[G], p11[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float pt0 = RK[0] * x[g] + RK[1] * y[g] + RK[2] + tt[0] * id[g];
+                    const float pt1 = RK[3] * x[g] + RK[4] * y[g] + RK[5] + tt[1] * id[g];
+                    const float pt2 = RK[6] * x[g] + RK[7] * y[g] + RK[8] + tt[2] * id[g];
+                    uu[g] = pt0 / pt2; vv[g] = pt1 / pt2;
+                    Ku[g] = L.fx * uu[g] + L.cx; Kv[g] = L.fy * vv[g] + L.cy;
+                    nid[g] = id[g] / pt2;
+                    ok[g] = inb[g] && (Ku[g] > 2.f && Kv[g] > 2.f && Ku[g] < wlm3 && Kv[g] < hlm3 && nid[g] > 0.f);        // :981
+                    const int ix = ok[g] ? (int)Ku[g] : 2, iy = ok[g] ? (int)Kv[g] : 2;
+                    const float4* bp = L.dI + ix + iy * L.wl;
+                    p00[g] = bp[0]; p10[g] = bp[1]; p01[g] = bp[L.wl]; p11[g] = bp[1 + L.wl];
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int i = base + g * kLmThreads;
+                    if (inb[g] && lvl == 0 && (i & 31) == 0) {                   // flow indicators (:948-979)
+                        const float a0 = Kq[0] * x[g] + Kq[1] * y[g] + Kq[2], a1 = Kq[3] * x[g] + Kq[4] * y[g] + Kq[5], a2 = Kq[6] * x[g] + Kq[7] * y[g] + Kq[8];
+                        const float T2 = a2 + tt[2] * id[g], U2 = a2 - tt[2] * id[g], r2 = RK[6] * x[g] + RK[7] * y[g] + RK[8] - tt[2] * id[g];
+                        const float KuT = L.fx * ((a0 + tt[0] * id[g]) / T2) + L.cx, KvT = L.fy * ((a1 + tt[1] * id[g]) / T2) + L.cy;
+                        const float KuT2 = L.fx * ((a0 - tt[0] * id[g]) / U2) + L.cx, KvT2 = L.fy * ((a1 - tt[1] * id[g]) / U2) + L.cy;
+                        const float Ku3 = L.fx * ((RK[0] * x[g] + RK[1] * y[g] + RK[2] - tt[0] * id[g]) / r2) + L.cx;
+                        const float Kv3 = L.fy * ((RK[3] * x[g] + RK[4] * y[g] + RK[5] - tt[1] * id[g]) / r2) + L.cy;
+                        acc[49] += (KuT - x[g]) * (KuT - x[g]) + (KvT - y[g]) * (KvT - y[g]);
+                        acc[49] += (KuT2 - x[g]) * (KuT2 - x[g]) + (KvT2 - y[g]) * (KvT2 - y[g]);
+                        acc[50] += (Ku[g] - x[g]) * (Ku[g] - x[g]) + (Kv[g] - y[g]) * (Kv[g] - y[g]);
+                        acc[50] += (Ku3 - x[g]) * (Ku3 - x[g]) + (Kv3 - y[g]) * (Kv3 - y[g]);
+                        acc[51] += 2.f;
+                    }
+                    if (!ok[g]) continue;
+                    const float dx = Ku[g] - (int)Ku[g], dy = Kv[g] - (int)Kv[g], dxdy = dx * dy;     // getInterpolatedElement33
+                    const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+                    const float hI = w11 * p11[g].x + w01 * p01[g].x + w10 * p10[g].x + w00 * p00[g].x;
+                    const float hx = w11 * p11[g].y + w01 * p01[g].y + w10 * p10[g].y + w00 * p00[g].y;
+                    const float hy = w11 * p11[g].z + w01 * p01[g].z + w10 * p10[g].z + w00 * p00[g].z;
+                    if (!isfinite(hI)) continue;
+                    const float residual = hI - (affa * rc[g] + affb);
+                    const float ar = fabsf(residual);
+                    const float hw = ar < kHuberTH ? 1.f : kHuberTH / ar;
+                    acc[46] += 1.f;
+                    if (ar > cutoff) { acc[45] += maxEnergy; acc[47] += 1.f; }
+                    else {
+                        acc[45] += hw * residual * residual * (2.f - hw);
+                        acc[48] += 1.f;
+                        const float gx = hx * L.fx, gy = hy * L.fy, u = uu[g], v = vv[g];
+                        float J[9];
+                        J[0] = nid[g] * gx; J[1] = nid[g] * gy; J[2] = -(nid[g] * (u * gx + v * gy));
+                        J[3] = -(u * v * gx + gy * (1.f + v * v)); J[4] = u * v * gy + gx * (1.f + u * u); J[5] = u * gy - v * gx;
+                        J[6] = affa * (b0 - rc[g]); J[7] = -1.f; J[8] = residual;
+                        int k = 0;
+#pragma unroll
+                        for (int r = 0; r < 9; ++r) {
+                            const float Jw = J[r] * hw;
+#pragma unroll
+                            for (int c2 = r; c2 < 9; ++c2) { acc[k] += Jw * J[c2]; ++k; }
+                        }
+                    }
+                }
+            }
+        }
+        // ------------------------------------------------------------- block reduction (same scheme as reduce.h, 1024 lanes)
+#pragma unroll
+        for (int k = 0; k < kLmVals; ++k) { acc[k] += dpp_quad_xor1(acc[k]); acc[k] += dpp_quad_xor2(acc[k]); }
+        if ((tid & 3) == 0) {
+            float* row = rows + (tid >> 2) * kLmStride;
+#pragma unroll
+            for (int k = 0; k < kLmVals; ++k) row[k] = acc[k];
+        }
+        __syncthreads();
+        {                                                    // fp64 column sums over the 256 quad rows: 16 lane groups x 16 rows, fixed order
+            const int j = tid & 63, g = tid >> 6;
+            double s = 0;
+            if (j < kLmVals) for (int r = g * 16; r < g * 16 + 16; ++r) s += (double)rows[r * kLmStride + j];   // (T/64) groups x 16 rows = T/4 rows
+            part[g][j] = s;
+        }
+        __syncthreads();
+        if (tid < kLmVals) { double s = 0; for (int g = 0; g < kLmThreads / 64; ++g) s += part[g][tid]; sums[tid] = s; }
+        __syncthreads();
+        // ------------------------------------------------------------- lane 0 = the host of the reference
+        if (tid == 0) {
+            S.evals++;
+            int next_action;                                 // 0 = evaluate again (parameters prepared), 1 = propose, 2 = finish level
+            if (S.phase == 0) {
+                lm_finish_eval(sums, S.resOld, S.H, S.b);
+                if (S.resOld[5] > 0.6 && S.levelCutoffRepeat < 50) {                          // :1106-1113
+                    S.levelCutoffRepeat *= 2;
+                    lm_prepare_eval(S, P, S.T, S.aff);
+                    next_action = 0;
+                } else { S.lambda = 0.01f; S.it = 0; S.break_pending = 0; next_action = 1; }
+            } else {
+                double* Hn = WK.Hn; double* bn = WK.bn;
+                lm_finish_eval(sums, S.resNew, Hn, bn);
+                const bool accept = (S.resNew[0] / S.resNew[1]) < (S.resOld[0] / S.resOld[1]);  // :1186
+                if (accept) {                                                                  // :1202-1209
+                    for (int i = 0; i < 64; ++i) S.H[i] = Hn[i];
+                    for (int i = 0; i < 8; ++i) S.b[i] = bn[i];
+                    for (int i = 0; i < 6; ++i) S.resOld[i] = S.resNew[i];
+                    for (int i = 0; i < 12; ++i) S.T[i] = S.Tn[i];
+                    S.aff[0] = S.affn[0]; S.aff[1] = S.affn[1];
+                    S.lambda *= 0.5f;
+                } else { S.lambda *= 4; if (S.lambda < lambdaExtrapolationLimit) S.lambda = lambdaExtrapolationLimit; }
+                S.it++;
+                next_action = S.break_pending ? 2 : 1;                                         // `if(!(inc.norm() > 1e-3)) break;` (:1216-1221)
+            }
+            if (next_action == 1) {
+                if (S.it < maxIterations[S.lvl]) {                                             // :1133-1184
+                    double* Hl = WK.Hl; double* nb = WK.nb; double* inc = WK.inc;
+                    for (int i = 0; i < 64; ++i) Hl[i] = S.H[i];
+                    for (int i = 0; i < 8; ++i) { Hl[i * 8 + i] *= (1 + S.lambda); nb[i] = -S.b[i]; }
+                    lm_ldlt8(WK, Hl, nb, inc);
+                    float extrapFac = 1;
+                    if (S.lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / S.lambda));
+                    for (int i = 0; i < 8; ++i) inc[i] *= extrapFac;
+                    double* incS = WK.incS;
+                    for (int i = 0; i < 8; ++i) incS[i] = inc[i];
+                    for (int i = 0; i < 3; ++i) incS[i] *= kScaleXiRot;                       // labels swapped vs tangent order (:1172-1173)
+                    for (int i = 3; i < 6; ++i) incS[i] *= kScaleXiTrans;
+                    incS[6] *= kScaleA; incS[7] *= kScaleB;
+                    double ssum = 0; for (int i = 0; i < 8; ++i) ssum += incS[i];
+                    if (!isfinite(ssum)) for (int i = 0; i < 8; ++i) incS[i] = 0;
+                    double* E12 = WK.E;
+                    lm_se3_exp(incS, E12);
+                    lm_se3_mul(E12, S.T, S.Tn);
+                    S.affn[0] = S.aff[0] + incS[6]; S.affn[1] = S.aff[1] + incS[7];
+                    double nrm = 0; for (int i = 0; i < 8; ++i) nrm += inc[i] * inc[i];
+                    S.break_pending = !(sqrt(nrm) > 1e-3);
+                    lm_prepare_eval(S, P, S.Tn, S.affn);
+                    S.phase = 1;
+                } else next_action = 2;
+            }
+            if (next_action == 2) {                                                            // level finished (:1225-1235)
+                S.lastRes[S.lvl] = (double)sqrtf((float)(S.resOld[0] / S.resOld[1]));
+                S.flow[0] = S.resOld[2]; S.flow[1] = S.resOld[3]; S.flow[2] = S.resOld[4];
+                if (P.has_minres && S.lastRes[S.lvl] > 1.5 * P.minRes[S.lvl]) { S.good = 0; S.done = 1; }
+                else {
+                    int next = S.lvl - 1;
+                    if (S.levelCutoffRepeat > 1 && !S.haveRepeated) { next = S.lvl; S.haveRepeated = 1; }   // repeat this level once
+                    if (next < P.stop_lvl) { S.done = 1; S.next_lvl = next; }
+                    else { S.lvl = next; S.levelCutoffRepeat = 1; S.phase = 0; lm_prepare_eval(S, P, S.T, S.aff); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double* o = P.out;
+        int ok = S.good;
+        for (int i = 0; i < 12; ++i) o[i] = S.T[i];
+        o[12] = S.aff[0]; o[13] = S.aff[1];
+        for (int i = 0; i < 5; ++i) o[14 + i] = S.lastRes[i];
+        for (int i = 0; i < 3; ++i) o[19 + i] = S.flow[i];
+        if (ok && (fabsf((float)S.aff[0]) > 1.2f || fabsf((float)S.aff[1]) > 200.f)) ok = 2;   // :1243-1245: pose is still written, return false
+        o[22] = (double)ok; o[23] = (double)S.evals; o[24] = (double)S.next_lvl; o[25] = (double)S.haveRepeated;
+        __threadfence_system();
+        __hip_atomic_store(&o[31], P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int trk_lm_launch(nalo_ctx* c, int slot_new, const double T0[12], const double aff0[2], const double ref_aff[2], const float exposures[2],
+                  int coarsest, int stop_lvl, const double* minRes, double out24[32]) {
+    TrkLmParams P;
+    std::memset(&P, 0, sizeof(P));
+    for (int l = 0; l < c->levels; ++l) {
+        TrkLmLevel& L = P.lv[l];
+        L.u = c->pc_u[l].p; L.v = c->pc_v[l].p; L.id = c->pc_id[l].p; L.col = c->pc_col[l].p; L.dI = c->slots[slot_new].dI[l];
+        L.n = c->pc_n[l]; L.wl = c->wl[l]; L.hl = c->hl[l]; L.fx = c->fx[l]; L.fy = c->fy[l]; L.cx = c->cx[l]; L.cy = c->cy[l];
+    }
+    std::memcpy(P.T0, T0, sizeof(P.T0)); P.aff0[0] = aff0[0]; P.aff0[1] = aff0[1]; P.ref_aff[0] = ref_aff[0]; P.ref_aff[1] = ref_aff[1];
+    P.expRef = exposures[0]; P.expNew = exposures[1]; P.coarsest = coarsest; P.stop_lvl = stop_lvl; P.have_repeated_in = 0;
+    P.has_minres = 0;
+    if (minRes) { P.has_minres = 1; for (int i = 0; i < 5; ++i) { P.minRes[i] = minRes[i]; } }
+    double* dout = nullptr;
+    NALO_HIP(c, hipHostGetDevicePointer((void**)&dout, c->trk_out_host, 0));
+    P.out = dout + 64;                                   // second half of the mapped buffer (first half: per-eval results)
+    P.seq = (double)(++c->trk_seq);
+    {
+        ProfScope ps(c, "trk_lm");
+        trk_lm_kernel<<<1, kLmThreads, 0, c->stream>>>(P);
+    }
+    NALO_HIP(c, hipGetLastError());
+    if (!poll_flag(c, &c->trk_out_host[64 + 31], P.seq)) return NALO_ERR_HIP;
+    std::memcpy(out24, c->trk_out_host + 64, sizeof(double) * 26);
+    return NALO_OK;
+}
+
+}  // namespace nalo

@@ -7,6 +7,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <chrono>
 
 #include "../../include/nalo_gpu.h"
 #include "host_math.h"
@@ -79,6 +80,9 @@ struct nalo_ctx {
     // ---- BA (opaque; defined in host_ba.cpp)
     nalo::BAWindow* ba = nullptr;
 
+    // ---- host wall-clock accounting (NALO_HOST_TIMING=1 prints it at nalo_destroy)
+    std::map<std::string, std::pair<double, long>> host_t;
+
     // ---- profiling
     bool prof_on = false;
     std::map<std::string, nalo::ProfEntry> prof;
@@ -107,6 +111,12 @@ inline bool poll_flag(nalo_ctx* c, volatile double* flag, double seq) {
         __builtin_ia32_pause();
     }
 }
+
+struct HostTimer {                // wall-clock scope, accumulated per name
+    nalo_ctx* c; const char* name; std::chrono::steady_clock::time_point t0;
+    HostTimer(nalo_ctx* ctx, const char* n) : c(ctx), name(n), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { auto& e = c->host_t[name]; e.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); e.second++; }
+};
 
 struct ProfScope {               // HIP-event bracket on the ctx stream (only when profiling is enabled)
     nalo_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
