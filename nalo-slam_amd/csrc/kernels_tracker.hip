@@ -86,12 +86,11 @@ __global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* _
             J[6] = P.affa * (P.b0 - refColor);
             J[7] = -1.f;
             J[8] = residual;
-            int k = 0;
 #pragma unroll
-            for (int r = 0; r < 9; ++r) {
+            for (int r = 0; r < 9; ++r) {                    // constant indices after unrolling: acc[] stays in VGPRs (a running `k++` index sent it to scratch)
                 const float Jw = J[r] * hw;
 #pragma unroll
-                for (int c2 = r; c2 < 9; ++c2) { acc[k] += Jw * J[c2]; ++k; }
+                for (int c2 = r; c2 < 9; ++c2) acc[r * 9 - r * (r - 1) / 2 + (c2 - r)] += Jw * J[c2];
             }
         }
     }

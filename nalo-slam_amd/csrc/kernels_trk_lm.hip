@@ -16,10 +16,13 @@
 namespace nalo {
 
 #ifndef NALO_LM_THREADS
-#define NALO_LM_THREADS 512
+#define NALO_LM_THREADS 256
 #endif
 #ifndef NALO_LM_G
-#define NALO_LM_G 2
+#define NALO_LM_G 1
+#endif
+#ifndef NALO_LM_MAX_BLOCKS
+#define NALO_LM_MAX_BLOCKS 128
 #endif
 constexpr int kLmThreads = NALO_LM_THREADS;
 constexpr int kLmVals = 52;                  // 45 H entries + E, nE, nSat, nWarped, sT, sRT, sN (same order as trk_eval_kernel)
@@ -33,6 +36,9 @@ struct TrkLmParams {
     int coarsest, has_minres, stop_lvl, have_repeated_in;   // levels coarsest..stop_lvl run here; the caller continues below
     double* out;                             // host-mapped: T(12) aff(2) lastRes(5) flow(3) ok evals | seq at [31]
     double seq;
+    double* partial;                         // [2][gridDim.x][64] block partials, double-buffered by evaluation parity
+    int light;                               // 1: partials travel as agent-scope atomics, no L2 writeback/invalidate at the barrier
+    unsigned* bar;                           // [0] grid barrier counter, [1] exit counter (both 0 between launches)
 };
 
 struct LmState {                             // lives in LDS; written by lane 0 only, read by everyone after a barrier
@@ -114,31 +120,69 @@ __device__ void lm_prepare_eval(LmState& S, const TrkLmParams& P, const double T
     S.cutoff = kCoarseCutoffTH * S.levelCutoffRepeat;
     S.maxEnergy = 2 * kHuberTH * S.cutoff - kHuberTH * kHuberTH;
 }
+__device__ __forceinline__ double lm_scale(int r) { return r < 3 ? (double)kScaleXiRot : r < 6 ? (double)kScaleXiTrans : r == 6 ? (double)kScaleA : (double)kScaleB; }
+__device__ __forceinline__ int lm_max_iterations(int lvl) { return lvl == 0 ? 10 : lvl == 1 ? 20 : 50; }      // maxIterations[] (:1085)
 // lane 0: sums (52 doubles) -> stats6 + scaled H,b (CoarseTracker.cpp:1040-1046, 869-884)
 __device__ void lm_finish_eval(const double* o, double st[6], double* H, double* b) {
     const double E = o[45], nE = o[46], nSat = o[47], nW = o[48], sT = o[49], sRT = o[50], sN = o[51];
     st[0] = E; st[1] = nE; st[2] = sT / (sN + 0.1); st[3] = 0; st[4] = sRT / (sN + 0.1); st[5] = (double)((float)nSat / (float)nE);
     const double npad = (double)(((long)nW + 3) & ~3L), inv = 1.0 / npad;
-    const double sc[8] = {kScaleXiRot, kScaleXiRot, kScaleXiRot, kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleA, kScaleB};
     for (int r = 0; r < 8; ++r) {
         for (int cc = 0; cc < 8; ++cc) {
             const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;
-            H[r * 8 + cc] = o[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] * inv * sc[r] * sc[cc];       // upper-triangular index of the 9x9
+            H[r * 8 + cc] = o[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] * inv * lm_scale(r) * lm_scale(cc);       // upper-triangular index of the 9x9
         }
-        b[r] = o[r * 9 - r * (r - 1) / 2 + (8 - r)] * inv * sc[r];
+        b[r] = o[r * 9 - r * (r - 1) / 2 + (8 - r)] * inv * lm_scale(r);
     }
 }
 
+// Grid barrier for the persistent LM kernel: every block adds 1 (agent-scope release) and spins (agent-scope acquire) until the
+// monotonically increasing counter reaches `target`. The grid is small (<= kLmMaxBlocks workgroups of 256 lanes, far below the
+// 256 CUs), so all blocks are co-resident; the spin is bounded anyway so a lost block ends the kernel with an error instead of
+// hanging the device. __threadfence() on both sides makes the block partials (plain stores) visible across the XCD L2s.
+__device__ __forceinline__ bool lm_grid_barrier(unsigned* bar, unsigned target, int* lds_flag, int light) {
+    if (light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // partial stores (agent-scope atomics, write-through) have completed
+    else __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (light) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        unsigned spins = 0;
+        while ((light ? __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) { ok = 0; break; }
+        }
+        *lds_flag = ok;
+    }
+    __syncthreads();
+    if (!light) __threadfence();
+    return *lds_flag != 0;
+}
+
+// NALO_LM_TICKS: per-phase shader-clock accounting of block 0 (debug builds only), reported in out[26..30]
+#ifdef NALO_LM_TICKS
+#define LM_TICK(i) do { if (tid == 0) { const long long now__ = clock64(); if ((i) > 0) tick_sum[(i) - 1] += now__ - tick_last; else if (tick_last) tick_sum[4] += now__ - tick_last; tick_last = now__; } } while (0)
+#else
+#define LM_TICK(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
+#ifdef NALO_LM_TICKS
+    long long tick_sum[5] = {0, 0, 0, 0, 0}, tick_last = 0;
+#endif
     __shared__ float rows[(kLmThreads / 4) * kLmStride];
     __shared__ double sums[64];
     __shared__ double part[kLmThreads / 64][64];
     __shared__ LmState S;
     __shared__ LmScratch WK;
-    const int tid = threadIdx.x;
-    const int maxIterations[5] = {10, 20, 50, 50, 50};
+    __shared__ int bar_ok;
+    const int tid = threadIdx.x, blk = blockIdx.x, NB = gridDim.x;
     const float lambdaExtrapolationLimit = 0.001f;
+    unsigned bar_target = 0;
+    int timed_out = 0;
 
+    // every block keeps its own copy of the LM state and advances it with the same inputs (the summed partials): the control flow is
+    // replicated, not broadcast, which saves a second grid barrier per evaluation
     if (tid == 0) {
         for (int i = 0; i < 12; ++i) S.T[i] = P.T0[i];
         S.aff[0] = P.aff0[0]; S.aff[1] = P.aff0[1];
@@ -154,6 +198,7 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
     // phase 1: evaluation of an LM candidate (:1184)
     for (int guard = 0; guard < 4096; ++guard) {
         if (S.done) break;
+        LM_TICK(0);
         // ------------------------------------------------------------- fused calcRes + calcGS over this level's points
         const TrkLmLevel& L = P.lv[S.lvl];
         float acc[kLmVals];
@@ -167,15 +212,15 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) { RK[q] = S.RKi[q]; Kq[q] = S.Ki[q]; }
             tt[0] = S.t[0]; tt[1] = S.t[1]; tt[2] = S.t[2];
-            // software pipeline, 4 points per lane per round: 16 point loads, then 16 texel gathers in flight, then the arithmetic.
-            // A single in-order wave would otherwise pay two dependent memory round trips per point.
+            // G points per lane per round in flight (point loads, then the texel gathers, then the arithmetic); the rounds stride over the grid
             constexpr int G = NALO_LM_G;
-            for (int base = tid; base < L.n; base += G * kLmThreads) {
+            const int gthreads = NB * kLmThreads;
+            for (int base = blk * kLmThreads + tid; base < L.n; base += G * gthreads) {
                 float id[G], x[G], y[G], rc[G], Ku[G], Kv[G], uu[G], vv[G], nid[G];
                 bool inb[G], ok[G];
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const int i = base + g * kLmThreads;
+                    const int i = base + g * gthreads;
                     inb[g] = i < L.n;
                     const int ii = inb[g] ? i : 0;
                     id[g] = L.id[ii]; x[g] = L.u[ii]; y[g] = L.v[ii]; rc[g] = L.col[ii];
@@ -196,7 +241,7 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
                 }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const int i = base + g * kLmThreads;
+                    const int i = base + g * gthreads;
                     if (inb[g] && lvl == 0 && (i & 31) == 0) {                   // flow indicators (:948-979)
                         const float a0 = Kq[0] * x[g] + Kq[1] * y[g] + Kq[2], a1 = Kq[3] * x[g] + Kq[4] * y[g] + Kq[5], a2 = Kq[6] * x[g] + Kq[7] * y[g] + Kq[8];
                         const float T2 = a2 + tt[2] * id[g], U2 = a2 - tt[2] * id[g], r2 = RK[6] * x[g] + RK[7] * y[g] + RK[8] - tt[2] * id[g];
@@ -230,35 +275,55 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
                         J[0] = nid[g] * gx; J[1] = nid[g] * gy; J[2] = -(nid[g] * (u * gx + v * gy));
                         J[3] = -(u * v * gx + gy * (1.f + v * v)); J[4] = u * v * gy + gx * (1.f + u * u); J[5] = u * gy - v * gx;
                         J[6] = affa * (b0 - rc[g]); J[7] = -1.f; J[8] = residual;
-                        int k = 0;
 #pragma unroll
                         for (int r = 0; r < 9; ++r) {
                             const float Jw = J[r] * hw;
 #pragma unroll
-                            for (int c2 = r; c2 < 9; ++c2) { acc[k] += Jw * J[c2]; ++k; }
+                            for (int c2 = r; c2 < 9; ++c2) acc[r * 9 - r * (r - 1) / 2 + (c2 - r)] += Jw * J[c2];
                         }
                     }
                 }
             }
         }
-        // ------------------------------------------------------------- block reduction (same scheme as reduce.h, 1024 lanes)
+        LM_TICK(1);
+        // ------------------------------------------------------------- block reduction (same scheme as reduce.h), then the grid sum
+        const int nbl = min(NB, (L.n + kLmThreads - 1) / kLmThreads);          // blocks that own points of this level
+        if (blk < nbl) {
 #pragma unroll
-        for (int k = 0; k < kLmVals; ++k) { acc[k] += dpp_quad_xor1(acc[k]); acc[k] += dpp_quad_xor2(acc[k]); }
-        if ((tid & 3) == 0) {
-            float* row = rows + (tid >> 2) * kLmStride;
+            for (int k = 0; k < kLmVals; ++k) { acc[k] += dpp_quad_xor1(acc[k]); acc[k] += dpp_quad_xor2(acc[k]); }
+            if ((tid & 3) == 0) {
+                float* row = rows + (tid >> 2) * kLmStride;
 #pragma unroll
-            for (int k = 0; k < kLmVals; ++k) row[k] = acc[k];
+                for (int k = 0; k < kLmVals; ++k) row[k] = acc[k];
+            }
+            __syncthreads();
+            {                                                // fp64 column sums over the quad rows: (T/64) lane groups x 16 rows, fixed order
+                const int j = tid & 63, g = tid >> 6;
+                double s = 0;
+                if (j < kLmVals) for (int r = g * 16; r < g * 16 + 16; ++r) s += (double)rows[r * kLmStride + j];
+                part[g][j] = s;
+            }
+            __syncthreads();
+            if (tid < kLmVals) {
+                double s = 0; for (int g = 0; g < kLmThreads / 64; ++g) s += part[g][tid];
+                if (NB == 1) sums[tid] = s;
+                else __hip_atomic_store(&P.partial[((size_t)(S.evals & 1) * NB + blk) * 64 + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        __syncthreads();
-        {                                                    // fp64 column sums over the 256 quad rows: 16 lane groups x 16 rows, fixed order
+        LM_TICK(2);
+        if (NB > 1) {                                        // block partials -> every block sums them in the same fixed order
+            bar_target += NB;
+            if (!lm_grid_barrier(P.bar, bar_target, &bar_ok, P.light)) { timed_out = 1; break; }
             const int j = tid & 63, g = tid >> 6;
+            const double* pp = P.partial + (size_t)(S.evals & 1) * NB * 64;
             double s = 0;
-            if (j < kLmVals) for (int r = g * 16; r < g * 16 + 16; ++r) s += (double)rows[r * kLmStride + j];   // (T/64) groups x 16 rows = T/4 rows
+            if (j < kLmVals) for (int b2 = g; b2 < nbl; b2 += kLmThreads / 64) s += __hip_atomic_load(&pp[(size_t)b2 * 64 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             part[g][j] = s;
+            __syncthreads();
+            if (tid < kLmVals) { double t2 = 0; for (int g2 = 0; g2 < kLmThreads / 64; ++g2) t2 += part[g2][tid]; sums[tid] = t2; }
         }
         __syncthreads();
-        if (tid < kLmVals) { double s = 0; for (int g = 0; g < kLmThreads / 64; ++g) s += part[g][tid]; sums[tid] = s; }
-        __syncthreads();
+        LM_TICK(3);
         // ------------------------------------------------------------- lane 0 = the host of the reference
         if (tid == 0) {
             S.evals++;
@@ -286,7 +351,7 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
                 next_action = S.break_pending ? 2 : 1;                                         // `if(!(inc.norm() > 1e-3)) break;` (:1216-1221)
             }
             if (next_action == 1) {
-                if (S.it < maxIterations[S.lvl]) {                                             // :1133-1184
+                if (S.it < lm_max_iterations(S.lvl)) {                                             // :1133-1184
                     double* Hl = WK.Hl; double* nb = WK.nb; double* inc = WK.inc;
                     for (int i = 0; i < 64; ++i) Hl[i] = S.H[i];
                     for (int i = 0; i < 8; ++i) { Hl[i * 8 + i] *= (1 + S.lambda); nb[i] = -S.b[i]; }
@@ -324,8 +389,16 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
             }
         }
         __syncthreads();
+        LM_TICK(4);
     }
-    if (tid == 0) {
+    if (NB > 1 && tid == 0) {                                // the last block out re-arms the barrier for the next launch
+        const unsigned old = __hip_atomic_fetch_add(P.bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)NB - 1u) {
+            __hip_atomic_store(P.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.bar + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (blk == 0 && tid == 0) {
         double* o = P.out;
         int ok = S.good;
         for (int i = 0; i < 12; ++i) o[i] = S.T[i];
@@ -333,6 +406,10 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
         for (int i = 0; i < 5; ++i) o[14 + i] = S.lastRes[i];
         for (int i = 0; i < 3; ++i) o[19 + i] = S.flow[i];
         if (ok && (fabsf((float)S.aff[0]) > 1.2f || fabsf((float)S.aff[1]) > 200.f)) ok = 2;   // :1243-1245: pose is still written, return false
+        if (timed_out) ok = -1;
+#ifdef NALO_LM_TICKS
+        for (int i = 0; i < 5; ++i) o[26 + i] = (double)tick_sum[i];
+#endif
         o[22] = (double)ok; o[23] = (double)S.evals; o[24] = (double)S.next_lvl; o[25] = (double)S.haveRepeated;
         __threadfence_system();
         __hip_atomic_store(&o[31], P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -356,13 +433,30 @@ int trk_lm_launch(nalo_ctx* c, int slot_new, const double T0[12], const double a
     NALO_HIP(c, hipHostGetDevicePointer((void**)&dout, c->trk_out_host, 0));
     P.out = dout + 64;                                   // second half of the mapped buffer (first half: per-eval results)
     P.seq = (double)(++c->trk_seq);
+    int maxn = 1;
+    for (int l = stop_lvl; l <= coarsest; ++l) maxn = std::max(maxn, c->pc_n[l]);
+    static const int max_blocks = [] { const char* e = std::getenv("NALO_LM_BLOCKS"); const int v = e ? std::atoi(e) : NALO_LM_MAX_BLOCKS; return std::min(std::max(v, 1), 256); }();
+    const int NB = std::min(max_blocks, (maxn + kLmThreads - 1) / kLmThreads);
+    if (!c->lm_bar.p) { NALO_HIP(c, c->lm_bar.reserve(4)); NALO_HIP(c, hipMemsetAsync(c->lm_bar.p, 0, 16, c->stream)); }
+    NALO_HIP(c, c->lm_partial.reserve((size_t)2 * 256 * 64));
+    P.partial = c->lm_partial.p; P.bar = c->lm_bar.p;
+    static const int light = [] { const char* e = std::getenv("NALO_LM_LIGHT"); return e ? std::atoi(e) : 1; }();
+    P.light = light;
     {
         ProfScope ps(c, "trk_lm");
-        trk_lm_kernel<<<1, kLmThreads, 0, c->stream>>>(P);
+        trk_lm_kernel<<<NB, kLmThreads, 0, c->stream>>>(P);
     }
     NALO_HIP(c, hipGetLastError());
     if (!poll_flag(c, &c->trk_out_host[64 + 31], P.seq)) return NALO_ERR_HIP;
     std::memcpy(out24, c->trk_out_host + 64, sizeof(double) * 26);
+#ifdef NALO_LM_TICKS
+    { const double* t = c->trk_out_host + 64 + 26; fprintf(stderr, "[lm ticks] evals=%d eval=%.0f blockred=%.0f gridsum=%.0f lane0=%.0f (shader clocks per eval)\n", (int)out24[23], t[0] / out24[23], t[1] / out24[23], t[2] / out24[23], t[3] / out24[23]); }
+#endif
+    if (out24[22] < 0) {                                 // a block never reached the grid barrier: re-arm and report
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemset(c->lm_bar.p, 0, 8);
+        return fail(c, NALO_ERR_HIP, "trk_lm_kernel: grid barrier timed out");
+    }
     return NALO_OK;
 }
 

@@ -1,10 +1,6 @@
 #!/bin/bash
-# times the kitti00 keyframe with several shapes of the device-resident LM kernel (round-1 tuning aid)
-set -e
-for cfg in "1024 2" "1024 1" "512 4" "512 2" "256 4"; do
-  set -- $cfg
-  NALO_CXXFLAGS="-DNALO_LM_THREADS=$1 -DNALO_LM_G=$2" python nalo-slam_amd/build.py --force > /dev/null
-  echo "== threads=$1 G=$2"
-  python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k:round(v['total_ms']/max(v['launches'],1)*1e3,1) for k,v in d['kernel_ms'].items() if v['launches']})"
+# sweeps the persistent LM kernel's grid size / barrier flavour on the GPU box (run through gpurun)
+for cfg in "NALO_LM_BLOCKS=1" "NALO_LM_BLOCKS=4" "NALO_LM_BLOCKS=16 NALO_LM_LIGHT=0" "NALO_LM_BLOCKS=16" "NALO_LM_BLOCKS=128 NALO_LM_LIGHT=0" "NALO_LM_BLOCKS=128" "NALO_TRK_HOST_LM=1"; do
+  echo "== $cfg"
+  env $cfg NALO_HOST_TIMING=1 timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra 2>&1 | grep -oE "\"value\": [0-9.]+|\"trk_lm\": \{[^}]*\}|nalo host\] trk_track.*" || exit 1
 done
