@@ -56,4 +56,13 @@ struct BADev {
     double* sc_partial;                         // [nblocks][NPL*NPL]
 };
 
+// Stitch operands (kernels_ba.hip ba_stitch_kernel)
+struct StitchDev {
+    const double* AD;                           // [adHost (W*W*64) | adTarget (W*W*64)], index (h + t*W)*64 + i*8 + k
+    const double *M_top, *M_sc;                 // acc13 [W*W][169], G [W][NPL*NPL]
+    double* H;                                  // [H~_A (n1*n1) | H~_sc (n1*n1) | tail]
+    unsigned* ticket;
+    int W, n1, NPL;
+};
+
 }  // namespace nalo

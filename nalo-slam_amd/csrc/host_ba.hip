@@ -11,7 +11,7 @@ void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorSc
 void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix);
 void ba_launch_reset_oob(hipStream_t s, const BADev& B);
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc);
-void ba_launch_stitch(hipStream_t s, const int* rowptr, const int* col, const double* val, const double* M, int nb, int n1, int m, double* Tm, double* H);
+int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq);
@@ -53,8 +53,11 @@ struct BAWindow {
     DevBuf<int> blk_host, host_blk, blk_order;
     DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 16
     hipEvent_t ev_lin = nullptr, ev_th = nullptr;
-    DevBuf<double> acc13, misc, G, S_top, S_sc, Tm, stitched;     // S_*: CSR values
-    DevBuf<int> Srp_top, Sci_top, Srp_sc, Sci_sc;                   // CSR rowptr / col of the stitch matrices     // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | scalars(8)]
+    DevBuf<double> acc13, G, AD, stitched;                      // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | misc (2 W^2) | step sums (3) | TH sum, ranks]
+    DevBuf<unsigned> st_ticket;
+    StitchDev sd{};
+    double* ad_host = nullptr; size_t ad_cap = 0;                   // pinned staging of AD
+    hipEvent_t ev_ad = nullptr;
     double* stitched_host = nullptr;                                // pinned mirror
     float* up_host = nullptr;                                       // pinned upload staging (precalc, xAd)
     size_t up_cap = 0;
@@ -75,12 +78,14 @@ void ba_destroy(nalo_ctx* c) {
     w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
-    w->blk_host.release(); w->host_blk.release(); w->blk_order.release(); w->acc13.release(); w->misc.release(); w->G.release(); w->S_top.release(); w->S_sc.release(); w->Srp_top.release(); w->Sci_top.release(); w->Srp_sc.release(); w->Sci_sc.release();
-    w->Tm.release(); w->stitched.release(); w->th_hist.release();
+    w->blk_host.release(); w->host_blk.release(); w->blk_order.release(); w->acc13.release(); w->G.release(); w->AD.release(); w->st_ticket.release();
+    w->stitched.release(); w->th_hist.release();
     if (w->ev_lin) (void)hipEventDestroy(w->ev_lin);
     if (w->ev_th) (void)hipEventDestroy(w->ev_th); w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
+    if (w->ad_host) (void)hipHostFree(w->ad_host);
+    if (w->ev_ad) (void)hipEventDestroy(w->ev_ad);
     delete w;
     c->ba = nullptr;
 }
@@ -124,7 +129,7 @@ static void frame_take_data(HostFrame& f) {                               // EFF
     for (int i = 0; i < 8; ++i) { f.prior[i] = p[i]; f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
 }
 
-// EnergyFunctional::setAdjointsF (OptimizationBackend/EnergyFunctional.cpp:46-106) + the S matrices of the stitch
+// EnergyFunctional::setAdjointsF (OptimizationBackend/EnergyFunctional.cpp:46-106); the values feed the stitch matrices
 static int set_adjoints(nalo_ctx* c) {
     BAWindow& w = *c->ba;
     HostTimer ht(c, "ba.set_adjoints");
@@ -151,50 +156,19 @@ static int set_adjoints(nalo_ctx* c) {
         }
         for (int k = 0; k < 64; ++k) { w.adHostF[(size_t)(h + t * W) * 64 + k] = (float)AH[k]; w.adTargetF[(size_t)(h + t * W) * 64 + k] = (float)AT[k]; }
     }
-    // S_top[bin = h + t*W][n1][13]: cols 0-3 calib, 4-11 the local (xi,a,b) block through adHost (rows of h) / adTarget (rows of t), col 12 -> row n (b vector)
-    std::vector<double> St((size_t)W * W * n1 * 13, 0.0);
-    for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
-        if (h == t) continue;
-        double* S = &St[(size_t)(h + t * W) * n1 * 13];
-        const double* AH = &w.adHost[(size_t)(h + t * W) * 64];
-        const double* AT = &w.adTarget[(size_t)(h + t * W) * 64];
-        for (int i = 0; i < 4; ++i) S[i * 13 + i] = 1;
-        for (int i = 0; i < 8; ++i) for (int k = 0; k < 8; ++k) { S[(4 + 8 * h + i) * 13 + 4 + k] = AH[i * 8 + k]; S[(4 + 8 * t + i) * 13 + 4 + k] = AT[i * 8 + k]; }
-        S[(size_t)w.n * 13 + 12] = 1;
-    }
-    // S_sc[host i][n1][NPL]: compact slot g <-> target j; rows of i get adHost[i + j*W] per slot, rows of j get adTarget[i + j*W]; Hcd cols -> calib rows; bdSum col -> row n
-    const int NPL = w.NPL;
-    std::vector<double> Ss((size_t)W * n1 * NPL, 0.0);
-    for (int i = 0; i < W; ++i) {
-        double* S = &Ss[(size_t)i * n1 * NPL];
-        for (int g = 0; g < W - 1; ++g) {
-            const int j = g < i ? g : g + 1;
-            const double* AH = &w.adHost[(size_t)(i + j * W) * 64];
-            const double* AT = &w.adTarget[(size_t)(i + j * W) * 64];
-            for (int r = 0; r < 8; ++r) for (int k = 0; k < 8; ++k) { S[(size_t)(4 + 8 * i + r) * NPL + 8 * g + k] = AH[r * 8 + k]; S[(size_t)(4 + 8 * j + r) * NPL + 8 * g + k] = AT[r * 8 + k]; }
-        }
-        for (int k = 0; k < 4; ++k) S[(size_t)k * NPL + 8 * (W - 1) + k] = 1;
-        S[(size_t)w.n * NPL + 8 * (W - 1) + 4] = 1;
-    }
-    // dense -> CSR (row = (b, r)); the kernels only touch the non-zeros
-    auto to_csr = [&](const std::vector<double>& D, int nb, int m, DevBuf<int>& rp, DevBuf<int>& ci, DevBuf<double>& va) -> int {
-        std::vector<int> rowptr((size_t)nb * n1 + 1, 0), col;
-        std::vector<double> val;
-        for (int b = 0; b < nb; ++b) for (int r = 0; r < n1; ++r) {
-            const double* row = &D[((size_t)b * n1 + r) * m];
-            for (int k = 0; k < m; ++k) if (row[k] != 0.0) { col.push_back(k); val.push_back(row[k]); }
-            rowptr[(size_t)b * n1 + r + 1] = (int)col.size();
-        }
-        if (col.empty()) { col.push_back(0); val.push_back(0.0); }
-        NALO_HIP(c, rp.reserve(rowptr.size())); NALO_HIP(c, ci.reserve(col.size())); NALO_HIP(c, va.reserve(val.size()));
-        NALO_HIP(c, hipMemcpyAsync(rp.p, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice, c->stream));
-        NALO_HIP(c, hipMemcpyAsync(ci.p, col.data(), col.size() * 4, hipMemcpyHostToDevice, c->stream));
-        NALO_HIP(c, hipMemcpyAsync(va.p, val.data(), val.size() * 8, hipMemcpyHostToDevice, c->stream));
-        NALO_HIP(c, hipStreamSynchronize(c->stream));
-        return NALO_OK;
-    };
-    int rc = to_csr(St, W * W, 13, w.Srp_top, w.Sci_top, w.S_top); if (rc) return rc;
-    rc = to_csr(Ss, W, NPL, w.Srp_sc, w.Sci_sc, w.S_sc); if (rc) return rc;
+    // the stitch kernel reads the fp64 adjoints: AD = [adHost | adTarget]
+    const size_t nad = (size_t)2 * W * W * 64;
+    if (w.ad_cap < nad) { if (w.ad_host) (void)hipHostFree(w.ad_host); NALO_HIP(c, hipHostMalloc((void**)&w.ad_host, nad * 8)); w.ad_cap = nad; }
+    if (!w.ev_ad) NALO_HIP(c, hipEventCreateWithFlags(&w.ev_ad, hipEventDisableTiming));
+    else NALO_HIP(c, hipEventSynchronize(w.ev_ad));                  // the previous upload has left the staging buffer
+    std::memcpy(w.ad_host, w.adHost.data(), (size_t)W * W * 64 * 8);
+    std::memcpy(w.ad_host + (size_t)W * W * 64, w.adTarget.data(), (size_t)W * W * 64 * 8);
+    NALO_HIP(c, w.AD.reserve(nad));
+    NALO_HIP(c, hipMemcpyAsync(w.AD.p, w.ad_host, nad * 8, hipMemcpyHostToDevice, c->stream));
+    NALO_HIP(c, hipEventRecord(w.ev_ad, c->stream));
+    w.sd.AD = w.AD.p;
+    if (!w.st_ticket.p) { NALO_HIP(c, w.st_ticket.reserve(4)); NALO_HIP(c, hipMemset(w.st_ticket.p, 0, 16)); }
+    w.sd.ticket = w.st_ticket.p; w.sd.W = W; w.sd.n1 = n1; w.sd.NPL = w.NPL;
     w.proj_valid = false;
     return NALO_OK;
 }
@@ -290,18 +264,27 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
     const int n1 = w.n1, NPL = w.NPL, W = w.W;
     const size_t blk = (size_t)n1 * n1;
     bool did = false;
+    static const bool sep_publish = std::getenv("NALO_BA_SEPARATE_PUBLISH") != nullptr;
+    const int npub = (int)(2 * blk + 2 * W * W + 5);                 // [H~_A | H~_sc | misc (2 W^2) | step sums (3) | TH sum, rank count]
+    const double seq = (double)(w.pub_seq + 1);
+    double* dmap = nullptr;
+    NALO_HIP(c, hipHostGetDevicePointer((void**)&dmap, w.stitched_host, 0));
     {
         ProfScope ps(c, "ba_reduce");
         const bool top = want_top && !w.stitched_top, sc = want_sc && !w.stitched_sc;
-        if (top || sc) ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.misc.p, w.G.p, top, sc);
-        if (top) { ba_launch_stitch(c->stream, w.Srp_top.p, w.Sci_top.p, w.S_top.p, w.acc13.p, W * W, n1, 13, w.Tm.p, w.stitched.p); w.stitched_top = true; did = true; }
-        if (sc) { ba_launch_stitch(c->stream, w.Srp_sc.p, w.Sci_sc.p, w.S_sc.p, w.G.p, W, n1, NPL, w.Tm.p, w.stitched.p + blk); w.stitched_sc = true; did = true; }
+        if (top || sc) {
+            // misc {count, energy} per bin lands in the tail of the stitched buffer; without a cross-rank hook step B publishes
+            // rows + tail + sequence number straight into host-mapped memory
+            ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.stitched.p + 2 * blk, w.G.p, top, sc);
+            if (ba_launch_stitch(c->stream, w.sd, top, sc, (w.hook || sep_publish) ? nullptr : dmap, npub - (int)(2 * blk), seq)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
+            if (top) w.stitched_top = true;
+            if (sc) w.stitched_sc = true;
+            did = true;
+        }
     }
     NALO_HIP(c, hipGetLastError());
     if (did) {
-        // scalars: [0] = sum energy, [1] = resInA   (misc holds {count, energy} per bin)
-        // computed on the host from misc after the copy for a single GPU; with a hook the per-rank sums are appended first
-        NALO_HIP(c, hipMemcpyAsync(w.stitched.p + 2 * blk, w.misc.p, (size_t)2 * W * W * 8, hipMemcpyDeviceToDevice, c->stream));
+        ++w.pub_seq;
         if (w.hook) {
             // sharded window: tail = {step sums (3), this rank's frameEnergyTH of the newest frame, 1.0}. After the SUM over ranks the
             // host installs the MEAN of the per-shard 70 % quantiles as the common threshold (every rank then classifies with the
@@ -309,15 +292,10 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
             NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0));
             ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
             NALO_HIP(c, hipStreamSynchronize(c->stream));
-            w.hook(w.hook_user, w.stitched.p, (int)(2 * blk + 2 * W * W + 5));
-        }
-        // [H~_A | H~_sc | misc (2 W^2) | step sums (3) | TH sum, rank count] -> host-mapped pinned memory, polled sequence number
-        const int npub = (int)(2 * blk + 2 * W * W + 5);
-        double* dmap = nullptr;
-        NALO_HIP(c, hipHostGetDevicePointer((void**)&dmap, w.stitched_host, 0));
-        const double seq = (double)(++w.pub_seq);
-        ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
-        NALO_HIP(c, hipGetLastError());
+            w.hook(w.hook_user, w.stitched.p, npub);
+            ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
+            NALO_HIP(c, hipGetLastError());
+        } else if (sep_publish) ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
         if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
         if (w.hook) {
             const double* tl = w.stitched_host + 2 * blk + 2 * W * W + 3;
@@ -544,10 +522,11 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     if (w.HM.size() != (size_t)w.n * w.n) { w.HM.assign((size_t)w.n * w.n, 0.0); w.bM.assign(w.n, 0.0); }
     w.lastX.assign(w.n, 0.0);
     const size_t blk = (size_t)w.n1 * w.n1;
-    NALO_HIP(c, w.acc13.reserve((size_t)W * W * 169)); NALO_HIP(c, w.misc.reserve((size_t)2 * W * W));
+    NALO_HIP(c, w.acc13.reserve((size_t)W * W * 169));
     NALO_HIP(c, w.G.reserve((size_t)W * w.NPL * w.NPL));
-    NALO_HIP(c, w.Tm.reserve(std::max((size_t)W * W * 13 * w.n1, (size_t)W * w.NPL * w.n1)));
     NALO_HIP(c, w.stitched.reserve(2 * blk + 2 * W * W + 16));
+    NALO_HIP(c, hipMemsetAsync(w.stitched.p, 0, (2 * blk + 2 * W * W + 16) * 8, c->stream));
+    w.sd.M_top = w.acc13.p; w.sd.M_sc = w.G.p; w.sd.H = w.stitched.p;
     if (w.stitched_host) { (void)hipHostFree(w.stitched_host); w.stitched_host = nullptr; }
     NALO_HIP(c, hipHostMalloc((void**)&w.stitched_host, (2 * blk + 2 * W * W + 16) * 8, hipHostMallocMapped));
     w.stitched_host[2 * blk + 2 * W * W + 5] = -1.0; w.pub_seq = 0;

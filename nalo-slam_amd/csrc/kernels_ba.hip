@@ -167,76 +167,297 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 }
 
 // ------------------------------------------------------------------------------------------------ fp64 finish of the partials
-// acc13[(h + t*W)][169] (full symmetric 13x13, AccumulatorApprox::finish layout MatrixAccumulators.h:626-647), misc[h+t*W] = {count, energy}
-__global__ __launch_bounds__(1024) void ba_reduce_top_kernel(const double* __restrict__ top_partial, const int* __restrict__ host_blk /* [W+1] */,
-                                                             int W, double* __restrict__ acc13, double* __restrict__ misc) {
-    __shared__ double part[8][128];
+// ONE launch for both systems (blocks [0, W*W) = top bins, the rest = SC tiles of 64 entries per host):
+//   acc13[(h + t*W)][169] (full symmetric 13x13, AccumulatorApprox::finish layout MatrixAccumulators.h:626-647), misc[h+t*W] = {count, energy}
+//   G[h][e] = sum over the host's blocks of the weighted SYRK partials
+// Lane groups stride over the host's blocks and are combined in a fixed order: deterministic.
+__global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
+                                                         const int* __restrict__ host_blk /* [W+1] */, int W, int NPL2, int sc_tiles, int mask,
+                                                         double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G) {
+    __shared__ double part[16][64];
     __shared__ double sums[128];
-    const int h = blockIdx.x % W, t = blockIdx.x / W, j = threadIdx.x & 127, g = threadIdx.x >> 7;     // 8 groups stride over the blocks
-    double s = 0;
-    if (j < kTopVals && h != t) for (int b = host_blk[h] + g; b < host_blk[h + 1]; b += 8) s += top_partial[((size_t)b * W + t) * kTopStride + j];
-    part[g][j] = s;
-    __syncthreads();
-    if (g == 0) { double tt = 0; for (int k = 0; k < 8; ++k) tt += part[k][j]; sums[j] = tt; }
-    __syncthreads();
-    double* H = acc13 + (size_t)(h + t * W) * 169;
-    for (int e = threadIdx.x; e < 169; e += blockDim.x) {
-        int r = e / 13, c = e % 13;
-        if (r > c) { const int tmp = r; r = c; c = tmp; }
-        int idx;
-        if (c < 10) idx = r * 10 - r * (r - 1) / 2 + (c - r);                 // upper triangle of the 10x10, row-major r<=c
-        else if (r < 10) idx = 55 + 3 * r + (c - 10);                         // TopRight 10x3
-        else { static const int br[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}}; idx = 85 + br[r - 10][c - 10]; }
-        H[e] = sums[idx];
+    if ((int)blockIdx.x < W * W) {
+        if (!(mask & 1)) return;
+        double (*part8)[128] = reinterpret_cast<double (*)[128]>(&part[0][0]);
+        const int h = blockIdx.x % W, t = blockIdx.x / W, j = threadIdx.x & 127, g = threadIdx.x >> 7;     // 8 groups stride over the blocks
+        double s = 0;
+        if (j < kTopVals && h != t) for (int b = host_blk[h] + g; b < host_blk[h + 1]; b += 8) s += top_partial[((size_t)b * W + t) * kTopStride + j];
+        part8[g][j] = s;
+        __syncthreads();
+        if (g == 0) { double tt = 0; for (int k = 0; k < 8; ++k) tt += part8[k][j]; sums[j] = tt; }
+        __syncthreads();
+        double* H = acc13 + (size_t)(h + t * W) * 169;
+        for (int e = threadIdx.x; e < 169; e += blockDim.x) {
+            int r = e / 13, c = e % 13;
+            if (r > c) { const int tmp = r; r = c; c = tmp; }
+            int idx;
+            if (c < 10) idx = r * 10 - r * (r - 1) / 2 + (c - r);                 // upper triangle of the 10x10, row-major r<=c
+            else if (r < 10) idx = 55 + 3 * r + (c - 10);                         // TopRight 10x3
+            else { const int rr = r - 10, cc = c - 10; idx = 85 + (rr == 0 ? cc : rr + cc + 1); }   // BotRight: 00 01 02 11 12 22
+            H[e] = sums[idx];
+        }
+        if (threadIdx.x == 0) { misc[2 * (h + t * W)] = sums[91]; misc[2 * (h + t * W) + 1] = sums[92]; }
+        return;
     }
-    if (threadIdx.x == 0) { misc[2 * (h + t * W)] = sums[91]; misc[2 * (h + t * W) + 1] = sums[92]; }
-}
-// G[h][e] = sum over the host's blocks: 4 lane-groups per entry stride over the blocks, combined in a fixed order
-__global__ __launch_bounds__(256) void ba_reduce_sc_kernel(const double* __restrict__ sc_partial, const int* __restrict__ host_blk, int NPL2, double* __restrict__ G) {
-    __shared__ double part[4][64];
-    const int h = blockIdx.y, j = threadIdx.x & 63, g = threadIdx.x >> 6, e = blockIdx.x * 64 + j;
+    if (!(mask & 2)) return;
+    const int q = blockIdx.x - W * W, h = q / sc_tiles, tile = q - h * sc_tiles;
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6, e = tile * 64 + j;
     double s = 0;
-    if (e < NPL2) for (int b = host_blk[h] + g; b < host_blk[h + 1]; b += 4) s += sc_partial[(size_t)b * NPL2 + e];
+    if (e < NPL2) for (int b = host_blk[h] + g; b < host_blk[h + 1]; b += 16) s += sc_partial[(size_t)b * NPL2 + e];
     part[g][j] = s;
     __syncthreads();
-    if (g == 0 && e < NPL2) G[(size_t)h * NPL2 + e] = part[0][j] + part[1][j] + part[2][j] + part[3][j];
+    if (g == 0 && e < NPL2) { double tt = 0; for (int k = 0; k < 16; ++k) tt += part[k][j]; G[(size_t)h * NPL2 + e] = tt; }
 }
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc) {
-    if (top) ba_reduce_top_kernel<<<B.W * B.W, 1024, 0, s>>>(B.top_partial, host_blk, B.W, acc13, misc);
-    if (sc) ba_reduce_sc_kernel<<<dim3((NPL * NPL + 63) / 64, B.W), 256, 0, s>>>(B.sc_partial, host_blk, NPL * NPL, G);
+    const int tiles = (NPL * NPL + 63) / 64;
+    ba_reduce_kernel<<<B.W * B.W + B.W * tiles, 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0), acc13, misc, G);
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)
-// S_b ((8W+5) x m) is sparse: a frame row carries one 8-wide adjoint block per slot it takes part in. It is kept in CSR
-// (rowptr over [b][row], col, val), built on the host from adHost/adTarget. The last row (index 8W+4) selects the
-// residual / bdSum column, so column 8W+4 of H~ is the b vector.
-//   step A  T_b[k][c] = sum_{(l,v) in row c of S_b} M_b[k][l] * v        one thread per (b,k,c)
-//   step B  H~[r][c]  = sum_b sum_{(k,v) in row r of S_b} v * T_b[k][c]    one block per row r, fixed order: deterministic
-__global__ __launch_bounds__(256) void ba_stitch_a_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
-                                                          const double* __restrict__ M, int n1, int m, double* __restrict__ Tm) {
-    const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= m * n1) return;
-    const int k = e / n1, c = e - k * n1;
-    const double* Mk = M + ((size_t)b * m + k) * m;
-    double s = 0;
-    for (int q = rowptr[b * n1 + c]; q < rowptr[b * n1 + c + 1]; ++q) s += Mk[col[q]] * val[q];
-    Tm[(size_t)b * m * n1 + e] = s;
-}
-__global__ __launch_bounds__(128) void ba_stitch_b_kernel(const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
-                                                          const double* __restrict__ Tm, int nb, int n1, int m, double* __restrict__ H) {
-    const int r = blockIdx.x;
-    for (int c = threadIdx.x; c < n1; c += blockDim.x) {
-        double s = 0;
-        for (int b = 0; b < nb; ++b) {
-            const double* Tb = Tm + (size_t)b * m * n1 + c;
-            for (int q = rowptr[b * n1 + r]; q < rowptr[b * n1 + r + 1]; ++q) s += val[q] * Tb[(size_t)col[q] * n1];
+// AccumulatedTopHessian::stitchDoubleInternal (AccumulatedTopHessian.cpp:243-330) and AccumulatedSCHessian::stitchDoubleInternal
+// (AccumulatedSCHessian.cpp:117-180) as ONE launch. H~ is (8W+5)^2: row/col 0-3 calib, 4+8f.. frame f, and 8W+4 = the b vector.
+//   top: bin b = (h,t) holds M_b (13x13: calib 4 | local 8 | residual 1); rows of frame h see it through adHost[b], rows of t through adTarget[b]
+//   SC : host i holds G_i (NPL x NPL: 8 columns per compact target slot | Hcd 4 | bdSum 1); rows of i see slot g through adHost[i,j_g], rows of
+//        target j see their slot through adTarget[i,j]
+// One workgroup per (system, frame a) computes the 8 rows of frame a: phase 1 U = L_a M (the frame's adjoints times the accumulator rows, into
+// LDS), phase 2 H~[rows a][c] = U L_c^T with direct block addressing (fixed-trip 8-wide loops: no index lists, no dependent loads). The calib/b
+// rows are the mirror of the calib/b columns (H~ is symmetric, as in the reference which copies the transposed blocks) plus a 5x5 corner done by
+// one more workgroup per system. Fixed summation order: deterministic. The kernel also publishes: every workgroup stores its rows into
+// host-mapped pinned memory, the last one to take a ticket adds the scalar tail and the sequence number the host polls on.
+// SC rows of frame a. FAST: every operand is staged in LDS with coalesced single-pass loads (phase 1: G_a, the slot rows of the other hosts'
+// G_i and frame a's adjoints; phase 2: all adjoints, over the same region) so the inner 8-wide loops run on ds_read with no global latency
+// in the dependency chain. The generic path (large windows, LDS too small) reads G and the adjoints through L2.
+#ifdef NALO_STITCH_TICKS
+#define STITCH_TICK(i) do { __syncthreads(); tk[i] = clock64(); } while (0)
+#else
+#define STITCH_TICK(i) do { } while (0)
+#endif
+constexpr int kAdRow = 9, kAdMat = 73;        // padded 8x8 adjoint in LDS
+template <bool FAST, typename Put>
+__device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, int a, Put put) {
+    const int W = D.W, n1 = D.n1, n = n1 - 1, NPL = D.NPL, tid = threadIdx.x, NT = blockDim.x, cb = 8 * (W - 1);
+#ifdef NALO_STITCH_TICKS
+    long long tk[5] = {0, 0, 0, 0, 0};
+#endif
+    double* U = lds;                                           // [W][8][NPL]
+    double* R = U + W * 8 * NPL;                               // staging region (FAST)
+    STITCH_TICK(0);
+    if constexpr (FAST) {
+        double* Ga = R;                                        // [NPL][NPL]
+        double* Gi = Ga + NPL * NPL;                           // [W][8][NPL]: rows of slot g_i(a) of host i != a
+        double* Ah = Gi + W * 8 * NPL;                         // [W][64] adHost(a, j)
+        double* At = Ah + W * 64;                              // [W][64] adTarget(i, a)
+        const double* __restrict__ Gsrc = D.M_sc;
+        for (int e = tid; e < NPL * NPL; e += NT) Ga[e] = Gsrc[(size_t)a * NPL * NPL + e];
+        for (int e = tid; e < W * 8 * NPL; e += NT) {
+            const int i = e / (8 * NPL), o = e - i * 8 * NPL;
+            if (i != a) Gi[e] = Gsrc[(size_t)i * NPL * NPL + (size_t)(8 * (a < i ? a : a - 1)) * NPL + o];
         }
-        H[(size_t)r * n1 + c] = s;
+        for (int e = tid; e < W * 64; e += NT) {
+            const int f = e >> 6, o = e & 63;
+            if (f != a) { Ah[e] = D.AD[(size_t)(a + f * W) * 64 + o]; At[e] = D.AD[(size_t)W * W * 64 + (size_t)(f + a * W) * 64 + o]; }
+        }
+        __syncthreads();
+        STITCH_TICK(1);
+        for (int e = tid; e < W * 8 * NPL; e += NT) {
+            const int i = e / (8 * NPL), o = e - i * 8 * NPL, r = o / NPL, l = o - r * NPL;
+            double s = 0;
+            if (i == a) {
+                for (int g2 = 0; g2 < W - 1; ++g2) {
+                    const double* A = Ah + (g2 < a ? g2 : g2 + 1) * 64 + r * 8;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s += A[k] * Ga[(8 * g2 + k) * NPL + l];
+                }
+            } else {
+                const double* A = At + i * 64 + r * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += A[k] * Gi[(i * 8 + k) * NPL + l];
+            }
+            U[e] = s;
+        }
+        __syncthreads();
+        STITCH_TICK(2);
+        // padded copy of all adjoints: row stride 9, matrix stride 73 doubles -> the (cp, j) pattern of phase 2 spreads over the LDS banks
+        for (int e = tid; e < 2 * W * W * 64; e += NT) R[(e >> 6) * kAdMat + ((e >> 3) & 7) * kAdRow + (e & 7)] = D.AD[e];
+        __syncthreads();
+        STITCH_TICK(3);
+    } else {
+        for (int e = tid; e < W * 8 * NPL; e += NT) {
+            const int i = e / (8 * NPL), o = e - i * 8 * NPL, r = o / NPL, l = o - r * NPL;
+            const double* __restrict__ G = D.M_sc + (size_t)i * NPL * NPL;
+            double s = 0;
+            if (i == a) {
+                for (int g2 = 0; g2 < W - 1; ++g2) {
+                    const double* __restrict__ A = D.AD + (size_t)(a + (g2 < a ? g2 : g2 + 1) * W) * 64 + r * 8;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s += A[k] * G[(size_t)(8 * g2 + k) * NPL + l];
+                }
+            } else {
+                const double* __restrict__ A = D.AD + (size_t)W * W * 64 + (size_t)(i + a * W) * 64 + r * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += A[k] * G[(size_t)(8 * (a < i ? a : a - 1) + k) * NPL + l];
+            }
+            U[e] = s;
+        }
+        __syncthreads();
+    }
+    auto phase2 = [&](const double* adH, const double* adT, const int MS, const int RS) {
+        for (int e = tid; e < 8 * n1; e += NT) {
+            const int r = e / n1, c = e - r * n1;
+            double s = 0;
+            if (c < 4) { for (int i = 0; i < W; ++i) s += U[(i * 8 + r) * NPL + cb + c]; }
+            else if (c == n) { for (int i = 0; i < W; ++i) s += U[(i * 8 + r) * NPL + cb + 4]; }
+            else {
+                // two uniform passes (no lane divergence between the 56-term own-host sum and the 8-term sums of the other hosts)
+                const int j = (c - 4) >> 3, cp = (c - 4) & 7;
+                const double* Uj = U + (j * 8 + r) * NPL;
+                double s4[4] = {0, 0, 0, 0};                                   // four chains: fp64 FMA latency is 4x its issue rate
+                for (int g2 = 0; g2 < W - 1; ++g2) {                           // host j itself: every slot of its G, through adHost(j, .)
+                    const double* A = adH + (j + (g2 < j ? g2 : g2 + 1) * W) * MS + cp * RS;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s4[k & 3] += Uj[8 * g2 + k] * A[k];
+                }
+                for (int i = 0; i < W; ++i) {                                  // the other hosts: frame j's slot, through adTarget(i, j)
+                    if (i == j) continue;
+                    const double* Ui = U + (i * 8 + r) * NPL + 8 * (j < i ? j : j - 1);
+                    const double* A = adT + (i + j * W) * MS + cp * RS;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s4[k & 3] += Ui[k] * A[k];
+                }
+                s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            }
+            put(4 + 8 * a + r, c, s);
+            if (c < 4 || c == n) put(c, 4 + 8 * a + r, s);
+        }
+    };
+    if constexpr (FAST) phase2(R, R + W * W * kAdMat, kAdMat, kAdRow); else phase2(D.AD, D.AD + (size_t)W * W * 64, 64, 8);
+    STITCH_TICK(4);
+#ifdef NALO_STITCH_TICKS
+    if (tid == 0) printf("sc a=%d stage1=%lld ph1=%lld stage2=%lld ph2=%lld\n", a, tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2], tk[4] - tk[3]);
+#endif
+}
+
+__global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, int ad_in_lds, double* mapped, int ntail, double seq) {
+    extern __shared__ double lds[];
+    __shared__ int is_last;
+    const int W = D.W, n1 = D.n1, n = n1 - 1, NPL = D.NPL, tid = threadIdx.x, NT = blockDim.x;
+    const int sys = blockIdx.x / (W + 1), g = blockIdx.x - sys * (W + 1);
+    const double* __restrict__ adH = D.AD;
+    const double* __restrict__ adT = D.AD + (size_t)W * W * 64;
+    double* Hs = D.H + (size_t)sys * n1 * n1;
+    double* Ms = mapped ? mapped + (size_t)sys * n1 * n1 : nullptr;
+    auto put = [&](int r, int c, double v) {
+        Hs[(size_t)r * n1 + c] = v;
+        if (Ms) __hip_atomic_store(&Ms[(size_t)r * n1 + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    if ((mask >> sys) & 1) {
+        if (sys == 0 && g < W) {
+            const int a = g, nb = 2 * (W - 1);                 // bins with frame a: q < W-1 -> (a,t) [a is host], q >= W-1 -> (h,a) [a is target]
+            double* Mb = lds;                                  // [nb][169]
+            double* As = Mb + nb * 169;                        // [nb][kAdMat] adjoint of a's own role in the bin (padded rows: bank spread)
+            double* Ao = As + nb * kAdMat;                     // [nb][kAdMat] adjoint of the other frame's role
+            double* U = Ao + nb * kAdMat;                      // [nb][8][13]
+            auto bin_of = [&](int q) { const int o = q < W - 1 ? q : q - (W - 1), f = o < a ? o : o + 1; return q < W - 1 ? a + f * W : f + a * W; };
+            for (int e = tid; e < nb * 169; e += NT) { const int q = e / 169; Mb[e] = D.M_top[(size_t)bin_of(q) * 169 + (e - q * 169)]; }
+            for (int e = tid; e < nb * 64; e += NT) {
+                const int q = e >> 6, o = e & 63, bin = bin_of(q);
+                const bool host_role = q < W - 1;
+                As[q * kAdMat + (o >> 3) * kAdRow + (o & 7)] = (host_role ? adH : adT)[(size_t)bin * 64 + o];
+                Ao[q * kAdMat + (o >> 3) * kAdRow + (o & 7)] = (host_role ? adT : adH)[(size_t)bin * 64 + o];
+            }
+            __syncthreads();
+            for (int e = tid; e < nb * 104; e += NT) {
+                const int q = e / 104, o = e - q * 104, r = o / 13, l = o - r * 13;
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += As[q * kAdMat + r * kAdRow + k] * Mb[q * 169 + (4 + k) * 13 + l];
+                U[e] = s;
+            }
+            __syncthreads();
+            for (int e = tid; e < 8 * n1; e += NT) {
+                const int r = e / n1, c = e - r * n1;
+                double s = 0;
+                if (c < 4) { for (int q = 0; q < nb; ++q) s += U[q * 104 + r * 13 + c]; }
+                else if (c == n) { for (int q = 0; q < nb; ++q) s += U[q * 104 + r * 13 + 12]; }
+                else {
+                    const int j = (c - 4) >> 3, cp = (c - 4) & 7;
+                    if (j == a) {
+                        for (int q = 0; q < nb; ++q)
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) s += U[q * 104 + r * 13 + 4 + k] * As[q * kAdMat + cp * kAdRow + k];
+                    } else {
+                        const int jj = j < a ? j : j - 1, q1 = jj, q2 = W - 1 + jj;          // bins (a,j) and (j,a)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) s += U[q1 * 104 + r * 13 + 4 + k] * Ao[q1 * kAdMat + cp * kAdRow + k];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) s += U[q2 * 104 + r * 13 + 4 + k] * Ao[q2 * kAdMat + cp * kAdRow + k];
+                    }
+                }
+                put(4 + 8 * a + r, c, s);
+                if (c < 4 || c == n) put(c, 4 + 8 * a + r, s);
+            }
+        } else if (sys == 0) {                                 // 5x5 corner {calib, b}: all bins' entries in one parallel pass, then a fixed-order sum
+            for (int e = tid; e < W * W * 25; e += NT) {
+                const int bin = e / 25, o = e - bin * 25, ri = o / 5, ci = o - ri * 5;
+                lds[e] = (bin % W != bin / W) ? D.M_top[(size_t)bin * 169 + (ri < 4 ? ri : 12) * 13 + (ci < 4 ? ci : 12)] : 0.0;
+            }
+            __syncthreads();
+            for (int e = tid; e < 25; e += NT) {
+                const int ri = e / 5, ci = e - ri * 5;
+                double s = 0;
+                for (int bin = 0; bin < W * W; ++bin) s += lds[bin * 25 + e];
+                put(ri < 4 ? ri : n, ci < 4 ? ci : n, s);
+            }
+        } else if (g < W) {
+            if (ad_in_lds) stitch_sc_rows<true>(D, lds, g, put); else stitch_sc_rows<false>(D, lds, g, put);
+        } else {
+            const int cb = 8 * (W - 1);
+            for (int e = tid; e < W * 25; e += NT) {
+                const int i = e / 25, o = e - i * 25, ri = o / 5, ci = o - ri * 5;
+                lds[e] = D.M_sc[(size_t)i * NPL * NPL + (size_t)(cb + ri) * NPL + cb + ci];
+            }
+            __syncthreads();
+            for (int e = tid; e < 25; e += NT) {
+                const int ri = e / 5, ci = e - ri * 5;
+                double s = 0;
+                for (int i = 0; i < W; ++i) s += lds[i * 25 + e];
+                put(ri < 4 ? ri : n, ci < 4 ? ci : n, s);
+            }
+        }
+    }
+    if (!mapped) return;
+    // the row stores have been acknowledged (release fence = s_waitcnt) before this workgroup's ticket; the flag follows the last ticket
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) is_last = __hip_atomic_fetch_add(D.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (!is_last) return;
+    const size_t t0 = (size_t)2 * n1 * n1;
+    for (int i = tid; i < ntail; i += NT) __hip_atomic_store(&mapped[t0 + i], D.H[t0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(D.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 // re-armed for the next (stream-ordered) launch
+        __hip_atomic_store(&mapped[t0 + ntail], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-void ba_launch_stitch(hipStream_t s, const int* rowptr, const int* col, const double* val, const double* M, int nb, int n1, int m, double* Tm, double* H) {
-    ba_stitch_a_kernel<<<dim3((m * n1 + 255) / 256, nb), 256, 0, s>>>(rowptr, col, val, M, n1, m, Tm);
-    ba_stitch_b_kernel<<<n1, 128, 0, s>>>(rowptr, col, val, Tm, nb, n1, m, H);
+int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq) {
+    const int mask = (top ? 1 : 0) | (sc ? 2 : 0);
+    const size_t lds_top = (size_t)2 * (D.W - 1) * (169 + 2 * kAdMat + 104) * 8, lds_ad = (size_t)2 * D.W * D.W * kAdMat * 8;
+    size_t lds_sc = (size_t)D.W * 8 * D.NPL * 8;
+    const size_t lds_p1 = ((size_t)D.NPL * D.NPL + (size_t)D.W * 8 * D.NPL + (size_t)2 * D.W * 64) * 8;
+    const size_t lds_stage = lds_p1 > lds_ad ? lds_p1 : lds_ad;
+    const int ad_in_lds = lds_sc + lds_stage <= 156 * 1024;                 // FAST path of stitch_sc_rows
+    if (ad_in_lds) lds_sc += lds_stage;
+    size_t lds = lds_top > lds_sc ? lds_top : lds_sc;
+    if (lds < (size_t)D.W * D.W * 25 * 8) lds = (size_t)D.W * D.W * 25 * 8;
+    static size_t lds_allowed = 48 * 1024;
+    if (lds > lds_allowed) {
+        if (hipFuncSetAttribute((const void*)ba_stitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        lds_allowed = lds;
+    }
+    ba_stitch_kernel<<<2 * (D.W + 1), 1024, lds, s>>>(D, mask, ad_in_lds, mapped, ntail, seq);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ a12 + step
