@@ -53,7 +53,8 @@ struct BADev {
     unsigned *th_hist_hi, *th_hist_lo, *th_state;   // radix-select histograms (2 x 65536) + {count, k_rem, prefix_hi}
     // partials
     double* top_partial;                        // [nblocks][W][kTopStride]  (fp64: one rounding less before the cancelling H_A - H_sc)
-    double* sc_partial;                         // [nblocks][NPL*NPL]
+    double* sc_partial;                         // [nblocks * sc_split][NPL*NPL]
+    int sc_split;                               // 1 or 4 workgroups per point block in ba_sc_kernel (4 for small windows)
 };
 
 // Stitch operands (kernels_ba.hip ba_stitch_kernel)

@@ -33,7 +33,8 @@ struct BAWindow {
     double c_value[4] = {}, c_value_zero[4] = {}, c_value_scaled[4] = {}, c_step[4] = {}, c_value_backup[4] = {};
     float c_scaledf[4] = {}, c_scaledi[4] = {};
     std::vector<HostFrame> frames;
-    std::vector<double> adHost, adTarget, HM, bM, lastX, Sproj;
+    std::vector<double> adHost, adTarget, HM, bM, lastX, Sproj, solve_scratch;
+    std::vector<int> solve_perm;
     std::vector<float> adHostF, adTargetF, adHTdeltaF;
     float cDeltaF[4] = {};
     bool proj_valid = false;
@@ -389,21 +390,32 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     { HostTimer h2(c, "ba.solve.fetch_wait"); rc = stitch_and_fetch(c, true, true); }
     if (rc) return rc;
     HostTimer h3(c, "ba.solve.host_math");
-    std::vector<double> HA((size_t)n * n), bA(n), Hsc((size_t)n * n), bsc(n), HL((size_t)n * n), bL(n), HF((size_t)n * n), bF(n), x(n), delta(n);
-    unpack_system(w, w.stitched_host, HA.data(), bA.data());
-    unpack_system(w, w.stitched_host + (size_t)n1 * n1, Hsc.data(), bsc.data());
+    // H = (HL + HM + HA) with the diagonal * (1+lambda), minus Hsc/(1+lambda); b = bL + (bM + HM delta) + bA - bsc   (:795-868), one pass
+    // over the published systems; then the Jacobi-scaled LDL^T (:872-885). Scratch lives in the window: no allocation per iteration.
+    w.solve_scratch.resize((size_t)n * n + 4 * (size_t)n); w.solve_perm.resize(n);
+    double* HF = w.solve_scratch.data(); double* bF = HF + (size_t)n * n; double* sv = bF + n; double* yv = sv + n; double* delta = yv + n;
+    std::vector<double>& x = w.lastX; x.resize(n);
+    const double* HAp = w.stitched_host; const double* HSp = w.stitched_host + (size_t)n1 * n1;
     misc_totals(w, nullptr, &w.resInA);
-    prior_system(w, HL.data(), bL.data());
     for (int i = 0; i < 4; ++i) delta[i] = (double)w.cDeltaF[i];
     for (int h = 0; h < W; ++h) for (int i = 0; i < 8; ++i) delta[4 + 8 * h + i] = w.frames[h].delta[i];
-    for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += w.HM[(size_t)i * n + j] * delta[j]; bF[i] = bL[i] + (w.bM[i] + s) + bA[i] - bsc[i]; }
-    for (size_t i = 0; i < (size_t)n * n; ++i) HF[i] = HL[i] + w.HM[i] + HA[i];
-    for (int i = 0; i < n; ++i) HF[(size_t)i * n + i] *= (1 + lambda);
-    { const double f = 1.0 / (1 + lambda); for (size_t i = 0; i < (size_t)n * n; ++i) HF[i] -= Hsc[i] * f; }
-    std::vector<double> sv(n), Hs((size_t)n * n), bs(n);
+    const double fsc = 1.0 / (1 + lambda);
+    for (int r = 0; r < n; ++r) {
+        double HLd, bLr;                                                    // accumulateLF with usePrior (AccumulatedTopHessian.cpp:292-302): diagonal only
+        if (r < 4) { HLd = kInitialCalibHessian; bLr = kInitialCalibHessian * (double)w.cDeltaF[r]; }
+        else { const HostFrame& f = w.frames[(r - 4) >> 3]; const int i = (r - 4) & 7; HLd = f.prior[i]; bLr = f.prior[i] * f.delta_prior[i]; }
+        const double* hm = &w.HM[(size_t)r * n]; const double* ha = HAp + (size_t)r * n1; const double* hs = HSp + (size_t)r * n1;
+        double* hf = HF + (size_t)r * n;
+        double sdot = 0;
+        for (int cc = 0; cc < n; ++cc) { hf[cc] = (0.0 + hm[cc]) + ha[cc]; sdot += hm[cc] * delta[cc]; }
+        hf[r] = (HLd + hm[r]) + ha[r];
+        hf[r] *= (1 + lambda);
+        for (int cc = 0; cc < n; ++cc) hf[cc] -= hs[cc] * fsc;
+        bF[r] = bLr + (w.bM[r] + sdot) + ha[n] - hs[n];
+    }
     for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * n + i] + 10);
-    for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) Hs[(size_t)i * n + j] = sv[i] * HF[(size_t)i * n + j] * sv[j]; bs[i] = sv[i] * bF[i]; }
-    ldlt_solve(n, Hs.data(), bs.data(), x.data());
+    for (int i = 0; i < n; ++i) { double* hf = HF + (size_t)i * n; const double si = sv[i]; for (int j = 0; j < n; ++j) hf[j] = si * hf[j] * sv[j]; bF[i] *= si; }
+    ldlt_solve_inplace(n, HF, bF, x.data(), yv, w.solve_perm.data());
     for (int i = 0; i < n; ++i) x[i] *= sv[i];
     if (iteration >= 2) {                                                   // SOLVER_ORTHOGONALIZE_X_LATER (:898-902)
         if (!w.proj_valid) build_projector(w);
@@ -411,7 +423,6 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
         for (int k = 0; k < 7; ++k) { double s = 0; for (int r = 0; r < n; ++r) s += w.Sproj[(size_t)r * 7 + k] * x[r]; coef[k] = s; }
         for (int r = 0; r < n; ++r) { double s = 0; for (int k = 0; k < 7; ++k) s += w.Sproj[(size_t)r * 7 + k] * coef[k]; x[r] -= s; }
     }
-    w.lastX = x;
     if (x_out) std::memcpy(x_out, x.data(), n * 8);
     // resubstituteF_MT (:263-289)
     for (int i = 0; i < 4; ++i) w.c_step[i] = -x[i];
@@ -587,7 +598,8 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     NALO_HIP(c, w.blk_host.reserve(w.nblocks)); NALO_HIP(c, w.host_blk.reserve(W + 1));
     const size_t NS = (size_t)W * N;
     NALO_HIP(c, w.rs_state.reserve(NS)); NALO_HIP(c, w.rs_energy.reserve(NS)); NALO_HIP(c, w.rs_jp0.reserve(NS)); NALO_HIP(c, w.rs_jp1.reserve(NS)); NALO_HIP(c, w.rs_cpt.reserve(NS)); NALO_HIP(c, w.rs_pp0.reserve(NS)); NALO_HIP(c, w.rs_pp1.reserve(NS));
-    NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * W * kTopStride)); NALO_HIP(c, w.sc_partial.reserve((size_t)w.nblocks * w.NPL * w.NPL));
+    NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * W * kTopStride)); w.dev.sc_split = w.nblocks <= 256 ? 4 : 1;
+    NALO_HIP(c, w.sc_partial.reserve((size_t)w.nblocks * w.dev.sc_split * w.NPL * w.NPL));
     NALO_HIP(c, hipMemcpy(w.pt_geo.p, geo.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_col0.p, c0.data(), N * 16, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.pt_col1.p, c1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_w0.p, w0.data(), N * 16, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.pt_w1.p, w1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_prior.p, prior.data(), N * 4, hipMemcpyHostToDevice));

@@ -109,34 +109,44 @@ inline void aff_from_to(float expF, float expT, double aF, double bF, double aT,
     out[0] = a; out[1] = bT - a * bF;
 }
 
-// Symmetric solve by LDL^T with diagonal pivoting (semi-definite safe), fp64. A is n x n row-major.
-inline void ldlt_solve(int n, const double* Ain, const double* b, double* x) {
-    std::vector<double> A(Ain, Ain + (size_t)n * n), y(n);
-    std::vector<int> perm(n);
+// Symmetric solve by LDL^T with diagonal pivoting (semi-definite safe), fp64. A is n x n row-major (full symmetric storage).
+// Right-looking, row-contiguous updates: after the pivot swap row k holds d*L[.][k] (symmetry), so the trailing update is
+// A[i][j] -= l_i * A[k][j] over whole rows (vectorisable); both triangles are kept current, no mirror pass.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target_clones("arch=haswell", "default")))   // the .so is built on one machine and run on another: dispatch at load time
+#endif
+inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, double* y /* n */, int* perm /* n */) {
     for (int i = 0; i < n; ++i) perm[i] = i;
     for (int k = 0; k < n; ++k) {
         int p = k; double best = std::fabs(A[(size_t)k * n + k]);
         for (int i = k + 1; i < n; ++i) { const double v = std::fabs(A[(size_t)i * n + i]); if (v > best) { best = v; p = i; } }
         if (p != k) {
-            for (int j = 0; j < n; ++j) std::swap(A[(size_t)k * n + j], A[(size_t)p * n + j]);
+            double* rk = A + (size_t)k * n; double* rp = A + (size_t)p * n;
+            for (int j = 0; j < n; ++j) std::swap(rk[j], rp[j]);
             for (int j = 0; j < n; ++j) std::swap(A[(size_t)j * n + k], A[(size_t)j * n + p]);
             std::swap(perm[k], perm[p]);
         }
         const double d = A[(size_t)k * n + k];
         if (d == 0.0 || !std::isfinite(d)) { for (int i = k + 1; i < n; ++i) A[(size_t)i * n + k] = 0; continue; }
-        for (int i = k + 1; i < n; ++i) A[(size_t)i * n + k] /= d;
+        const double* rk = A + (size_t)k * n;
         for (int i = k + 1; i < n; ++i) {
-            const double lik = A[(size_t)i * n + k];
+            double* ri = A + (size_t)i * n;
+            const double lik = ri[k] / d;
+            ri[k] = lik;
             if (lik == 0) continue;
-            for (int j = k + 1; j <= i; ++j) A[(size_t)i * n + j] -= lik * d * A[(size_t)j * n + k];
+            for (int j = k + 1; j < n; ++j) ri[j] -= lik * rk[j];
         }
-        for (int i = k + 1; i < n; ++i) for (int j = i + 1; j < n; ++j) A[(size_t)i * n + j] = A[(size_t)j * n + i];
     }
     for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
-    for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] -= A[(size_t)i * n + j] * y[j];
+    for (int i = 0; i < n; ++i) { const double* ri = A + (size_t)i * n; double s = y[i]; for (int j = 0; j < i; ++j) s -= ri[j] * y[j]; y[i] = s; }
     for (int i = 0; i < n; ++i) { const double d = A[(size_t)i * n + i]; y[i] = (d != 0.0 && std::isfinite(d)) ? y[i] / d : 0.0; }
-    for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) y[i] -= A[(size_t)j * n + i] * y[j];
+    for (int i = n - 1; i >= 0; --i) { const double yi = y[i]; for (int j = 0; j < i; ++j) y[j] -= A[(size_t)i * n + j] * yi; }
     for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+}
+inline void ldlt_solve(int n, const double* Ain, const double* b, double* x) {
+    std::vector<double> A(Ain, Ain + (size_t)n * n), y(n);
+    std::vector<int> perm(n);
+    ldlt_solve_inplace(n, A.data(), b, x, y.data(), perm.data());
 }
 
 // cyclic Jacobi for small symmetric matrices; A destroyed, V columns = eigenvectors

@@ -36,19 +36,23 @@ __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__
 
 // ------------------------------------------------------------------------------------------------ a9: per-host weighted SYRK
 // Block = the same 256 points as the linearize block. Thread (ty,tx) of a 16x16 grid owns a TxT tile of G (NPL = 16T columns).
-template <int T>
+// KS > 1 splits a block's points over KS workgroups (small windows: a KITTI-sized window has ~12 point blocks for 256 CUs, and the
+// k-loop of a whole block is a 20 us serial chain); the partials are [nblocks * KS][NPL * NPL].
+template <int T, int KS>
 __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
-    // rows staged per pass: the whole block when it fits (<= 64 KiB of LDS), so all operand loads of a block are in flight at once
-    constexpr int NPL = 16 * T, SUB = T <= 4 ? 256 : (T <= 6 ? 128 : 64);
+    // rows staged per pass: the whole share when it fits (<= 64 KiB of LDS), so all operand loads of a block are in flight at once
+    constexpr int NPL = 16 * T, ROWS = kBlk / KS, SUB0 = T <= 4 ? 256 : (T <= 6 ? 128 : 64), SUB = SUB0 < ROWS ? SUB0 : ROWS;
     constexpr int NPLP = NPL + 4;            // padded LDS row: lanes = consecutive rows, so the row stride must not be a multiple of 32 banks
     __shared__ __attribute__((aligned(16))) float A[SUB * NPLP];
-    __shared__ __attribute__((aligned(16))) float4 Hc[kBlk];
-    __shared__ float Wt[kBlk], Bd[kBlk];
-    const int b = blockIdx.x, tid = threadIdx.x, h = B.blk_host[b], W = B.W;
+    __shared__ __attribute__((aligned(16))) float4 Hc[ROWS];
+    __shared__ float Wt[ROWS], Bd[ROWS];
+    const int b = blockIdx.x / KS, ks = blockIdx.x - b * KS, tid = threadIdx.x, h = B.blk_host[b], W = B.W;
     const int ty = tid >> 4, tx = tid & 15;
+    const int dbase = b * kBlk + ks * ROWS;
+    if (tid < ROWS)
     {   // ---- per point (AccumulatedSCHessian.cpp:36-57): EFPoint::{Hdd,bd,Hcd}_acc = sum over the point's active residuals in
         //      target order (AccumulatedTopHessian.cpp:132-157), then HdiF, bdSumF
-        const int d = b * kBlk + tid;
+        const int d = dbase + tid;
         const uint8_t pf = B.pt_flags[d];
         const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
         float wgt = 0.f, bds = 0.f;
@@ -91,8 +95,8 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
     for (int i = 0; i < T; ++i)
 #pragma unroll
         for (int j = 0; j < T; ++j) { acc[i][j] = 0.f; acc64[i][j] = 0.0; }
-    for (int sub = 0; sub < kBlk / SUB; ++sub) {
-        const int d0 = b * kBlk + sub * SUB;
+    for (int sub = 0; sub < ROWS / SUB; ++sub) {
+        const int d0 = dbase + sub * SUB;
         __syncthreads();
         // ---- stage SUB operand rows: [JpJdF(t != h) (8 each) | Hcd (4) | bdSum | 0..]
         // lane <-> point (coalesced 16-byte loads from the [target][point] arrays), the NQ float4 columns of a row are split over
@@ -142,24 +146,30 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
                 for (int j = 0; j < T; ++j) { acc64[i][j] += (double)acc[i][j]; acc[i][j] = 0.f; }
         }
     }
-    double* out = B.sc_partial + (size_t)b * NPL * NPL;
+    double* out = B.sc_partial + (size_t)blockIdx.x * NPL * NPL;
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
         for (int j = 0; j < T; ++j) out[(ty * T + i) * NPL + tx * T + j] = acc64[i][j];
 }
 
-void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
+template <int KS>
+static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
+    const int grid = B.nblocks * KS;
     switch (T) {
-        case 1: ba_sc_kernel<1><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 2: ba_sc_kernel<2><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 3: ba_sc_kernel<3><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 4: ba_sc_kernel<4><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 5: ba_sc_kernel<5><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 6: ba_sc_kernel<6><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 7: ba_sc_kernel<7><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        default: ba_sc_kernel<8><<<B.nblocks, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 1: ba_sc_kernel<1, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 2: ba_sc_kernel<2, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 3: ba_sc_kernel<3, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 4: ba_sc_kernel<4, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 5: ba_sc_kernel<5, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 6: ba_sc_kernel<6, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 7: ba_sc_kernel<7, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        default: ba_sc_kernel<8, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
     }
+}
+void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
+    if (B.sc_split == 4) launch_sc_ks<4>(s, B, T, shift, priorScaleMarg, margOnly);
+    else launch_sc_ks<1>(s, B, T, shift, priorScaleMarg, margOnly);
 }
 void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
     const size_t n = (size_t)B.W * B.Ppad;
@@ -172,7 +182,7 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 //   G[h][e] = sum over the host's blocks of the weighted SYRK partials
 // Lane groups stride over the host's blocks and are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
-                                                         const int* __restrict__ host_blk /* [W+1] */, int W, int NPL2, int sc_tiles, int mask,
+                                                         const int* __restrict__ host_blk /* [W+1] */, int W, int NPL2, int sc_tiles, int mask, int KS,
                                                          double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G) {
     __shared__ double part[16][64];
     __shared__ double sums[128];
@@ -203,14 +213,14 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
     const int q = blockIdx.x - W * W, h = q / sc_tiles, tile = q - h * sc_tiles;
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6, e = tile * 64 + j;
     double s = 0;
-    if (e < NPL2) for (int b = host_blk[h] + g; b < host_blk[h + 1]; b += 16) s += sc_partial[(size_t)b * NPL2 + e];
+    if (e < NPL2) for (int b = host_blk[h] * KS + g; b < host_blk[h + 1] * KS; b += 16) s += sc_partial[(size_t)b * NPL2 + e];
     part[g][j] = s;
     __syncthreads();
     if (g == 0 && e < NPL2) { double tt = 0; for (int k = 0; k < 16; ++k) tt += part[k][j]; G[(size_t)h * NPL2 + e] = tt; }
 }
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc) {
     const int tiles = (NPL * NPL + 63) / 64;
-    ba_reduce_kernel<<<B.W * B.W + B.W * tiles, 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0), acc13, misc, G);
+    ba_reduce_kernel<<<B.W * B.W + B.W * tiles, 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0), B.sc_split, acc13, misc, G);
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)
