@@ -66,7 +66,7 @@ void nalo_destroy(nalo_ctx* c) {
         c->trk_idepth[l].release(); c->trk_wsum[l].release(); c->trk_wbak[l].release();
         c->pc_u[l].release(); c->pc_v[l].release(); c->pc_id[l].release(); c->pc_col[l].release();
     }
-    c->trk_partial.release(); c->trk_out.release(); c->lm_partial.release(); c->lm_bar.release(); c->scan_tmp.release(); c->upload_tmp.release();
+    c->trk_partial.release(); c->trk_out.release(); c->lm_partial.release(); c->scan_tmp.release(); c->upload_tmp.release();
     if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
     if (c->pinned_f) (void)hipHostFree(c->pinned_f);
     for (auto& kv : c->prof) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -223,11 +223,11 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
     double aff_cur[2] = {aff_io[0], aff_io[1]};
     bool haveRepeated = false, good = true;
     int evals = 0, start_lvl = coarsestLvl;
-    // NALO_TRK_DEVICE_LM=1: the whole pyramid descent runs in ONE persistent multi-block kernel (kernels_trk_lm.hip, grid barrier per
-    // evaluation). Measured on MI355X it is not faster than this host-driven loop (one fused eval+finish launch and a polled flag per
-    // evaluation, ~12-18 us): the serial fp64 solve on one GPU lane costs more than the launch it saves. Kept as an option.
+    // The whole pyramid descent runs in ONE persistent multi-block kernel (kernels_trk_lm.hip): ~10 us per LM evaluation against ~19 us for
+    // the host-driven loop below (a launch, a finish kernel and a polled flag per evaluation). NALO_TRK_HOST_LM=1 selects the host loop,
+    // which is also what a caller gets by driving nalo_trk_eval itself.
     {
-        static const bool force_host = std::getenv("NALO_TRK_DEVICE_LM") == nullptr;      // default: host-driven LM (measured faster)
+        static const bool force_host = std::getenv("NALO_TRK_HOST_LM") != nullptr;
         static const int dev_max_n = [] { const char* e = std::getenv("NALO_TRK_DEV_MAXN"); return e ? std::atoi(e) : (1 << 30); }();
         int stop = coarsestLvl + 1;
         while (stop > 0 && c->pc_n[stop - 1] <= dev_max_n) --stop;      // levels coarsestLvl..stop on the device

@@ -737,6 +737,7 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
             if (w.last_canbreak) break;
         }
     }
+    HostTimer hte(c, "ba.opt.epilogue");
     HostFrame& nf = w.frames[W - 1];                                        // :550-557
     const double nsz[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
     nf.evalPT = nf.PRE_worldToCam;

@@ -543,27 +543,32 @@ void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partia
 // the high-half histogram is filled by ba_linearize_kernel itself (integer atomics), then find-hi -> low-half histogram of the
 // matching entries -> find-lo + the threshold formula (:130-133). Runs on the side stream, overlapped with SC/reduce/stitch.
 __global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new) {
-    __shared__ unsigned part[1024];
+    __shared__ unsigned wsum[16], wpre[17];
     __shared__ unsigned s_sel, s_run;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned loc[64], sum = 0;
+    const uint4* h4 = reinterpret_cast<const uint4*>(hist + tid * 64);
 #pragma unroll
-    for (int i = 0; i < 64; ++i) { loc[i] = hist[tid * 64 + i]; sum += loc[i]; }
-    part[tid] = sum;
+    for (int i = 0; i < 16; ++i) { const uint4 q = h4[i]; loc[4 * i] = q.x; loc[4 * i + 1] = q.y; loc[4 * i + 2] = q.z; loc[4 * i + 3] = q.w; sum += q.x + q.y + q.z + q.w; }
+    // block-wide inclusive scan of the 1024 per-thread counts: shuffles inside a wave, then the 16 wave totals
+    unsigned v = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned nb = __shfl_up(v, off); if (lane >= off) v += nb; }
+    if (lane == 63) wsum[wave] = v;
+    if (tid == 0) s_sel = 0xFFFFFFFFu;
+    __syncthreads();
+    if (tid == 0) { unsigned r = 0; for (int i = 0; i < 16; ++i) { wpre[i] = r; r += wsum[i]; } wpre[16] = r; }
+    __syncthreads();
+    const unsigned incl = v + wpre[wave], excl = incl - sum, total = wpre[16];
+    const unsigned k = (level == 0) ? (unsigned)(int)(0.7f * (float)total) : state[1];
+    if (excl <= k && k < incl) { s_sel = (unsigned)tid; s_run = excl; }          // the first thread whose running count passes k (unique)
     __syncthreads();
     if (tid == 0) {
-        unsigned total = 0;
-        for (int i = 0; i < 1024; ++i) total += part[i];
-        unsigned k;
-        if (level == 0) { state[0] = total; k = (unsigned)(int)(0.7f * (float)total); } else k = state[1];
-        unsigned run = 0; int sel = 1023;
-        for (int i = 0; i < 1024; ++i) { if (run + part[i] > k) { sel = i; break; } run += part[i]; }
-        s_sel = (unsigned)sel; s_run = run;
-        if (level == 0 && total == 0) state[3] = 1; else if (level == 0) state[3] = 0;
+        if (level == 0) { state[0] = total; state[3] = total == 0 ? 1u : 0u; }
+        if (s_sel == 0xFFFFFFFFu) { s_sel = 1023u; s_run = total; }               // k beyond the last entry (empty histogram): last bin
     }
     __syncthreads();
     if (tid == (int)s_sel) {
-        const unsigned k = (level == 0) ? (unsigned)(int)(0.7f * (float)state[0]) : state[1];
         unsigned run = s_run; int bsel = 63;
         for (int i = 0; i < 64; ++i) { if (run + loc[i] > k) { bsel = i; break; } run += loc[i]; }
         const unsigned bin = (unsigned)(tid * 64 + bsel);
@@ -580,9 +585,9 @@ __global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__
             *frameTH_new = th;
         }
     }
-    __syncthreads();
+    uint4* z4 = reinterpret_cast<uint4*>(hist + tid * 64);
 #pragma unroll
-    for (int i = 0; i < 64; ++i) hist[tid * 64 + i] = 0;                                // ready for the next pass
+    for (int i = 0; i < 16; ++i) z4[i] = make_uint4(0u, 0u, 0u, 0u);                    // ready for the next pass
 }
 __global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

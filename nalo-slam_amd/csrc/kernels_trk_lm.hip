@@ -22,7 +22,7 @@ namespace nalo {
 #define NALO_LM_G 1
 #endif
 #ifndef NALO_LM_MAX_BLOCKS
-#define NALO_LM_MAX_BLOCKS 128
+#define NALO_LM_MAX_BLOCKS 64
 #endif
 constexpr int kLmThreads = NALO_LM_THREADS;
 constexpr int kLmVals = 52;                  // 45 H entries + E, nE, nSat, nWarped, sT, sRT, sN (same order as trk_eval_kernel)
@@ -36,9 +36,8 @@ struct TrkLmParams {
     int coarsest, has_minres, stop_lvl, have_repeated_in;   // levels coarsest..stop_lvl run here; the caller continues below
     double* out;                             // host-mapped: T(12) aff(2) lastRes(5) flow(3) ok evals | seq at [31]
     double seq;
-    double* partial;                         // [2][gridDim.x][64] block partials, double-buffered by evaluation parity
-    int light;                               // 1: partials travel as agent-scope atomics, no L2 writeback/invalidate at the barrier
-    unsigned* bar;                           // [0] grid barrier counter, [1] exit counter (both 0 between launches)
+    unsigned long long* partial;             // [2][gridDim.x][64] block partials {fp32 value, tag}, double-buffered by evaluation parity
+    unsigned tag0;                           // launch sequence << 12: tags of this launch are tag0 + evaluation number
 };
 
 struct LmState {                             // lives in LDS; written by lane 0 only, read by everyone after a barrier
@@ -52,113 +51,129 @@ struct LmState {                             // lives in LDS; written by lane 0 
 };
 
 // ---- fp64 helpers for lane 0 -------------------------------------------------------------------------------------------
-__device__ void lm_se3_exp(const double xi[6], double T[12]) {               // Sophus SE3::exp (se3.hpp:407-428), quaternion form
+__device__ __forceinline__ void lm_se3_exp(const double (&xi)[8], double (&T)[12]) {   // Sophus SE3::exp (se3.hpp:407-428), quaternion form
     const double wx = xi[3], wy = xi[4], wz = xi[5];
     const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
-    double qi, qr;
+    double qi, qr, sh = 0, ch = 1;
     if (th < 1e-10) { const double t4 = th2 * th2; qi = 0.5 - th2 / 48.0 + t4 / 3840.0; qr = 1.0 - 0.5 * th2 + t4 / 384.0; }
-    else { qi = sin(0.5 * th) / th; qr = cos(0.5 * th); }
+    else { sincos(0.5 * th, &sh, &ch); qi = sh / th; qr = ch; }
     double q[4] = {qr, qi * wx, qi * wy, qi * wz};
     const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
     for (int i = 0; i < 4; ++i) q[i] /= qn;
     const double w = q[0], x = q[1], y = q[2], z = q[3];
     const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                          2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
     const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
     double O2[9], V[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
-    if (th < 1e-10) { for (int i = 0; i < 9; ++i) V[i] = R[i]; }
-    else { const double a = (1 - cos(th)) / th2, bq = (th - sin(th)) / (th2 * th); for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + bq * O2[i]; }
-    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j]; T[i * 4 + 3] = V[i * 3] * xi[0] + V[i * 3 + 1] * xi[1] + V[i * 3 + 2] * xi[2]; }
-}
-__device__ void lm_se3_mul(const double A[12], const double B[12], double C[12]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+    if (th < 1e-10) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) V[i] = R[i];
+    } else {
+        // 1 - cos(th) = 2 sin^2(th/2), sin(th) = 2 sin(th/2) cos(th/2): one sincos for the whole exponential
+        const double a = (2.0 * sh * sh) / th2, bq = (th - 2.0 * sh * ch) / (th2 * th);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + bq * O2[i];
+    }
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = V[i * 3] * xi[0] + V[i * 3 + 1] * xi[1] + V[i * 3 + 2] * xi[2];
+    }
+}
+__device__ __forceinline__ void lm_se3_mul(const double (&A)[12], const double (&B)[12], double (&C)[12]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
         for (int j = 0; j < 3; ++j) C[i * 4 + j] = A[i * 4] * B[j] + A[i * 4 + 1] * B[4 + j] + A[i * 4 + 2] * B[8 + j];
         C[i * 4 + 3] = A[i * 4] * B[3] + A[i * 4 + 1] * B[7] + A[i * 4 + 2] * B[11] + A[i * 4 + 3];
     }
 }
-struct LmScratch { double A[64], y[8], Hl[64], nb[8], inc[8], incS[8], E[12], Hn[64], bn[8]; int perm[8]; };   // lane 0's work arrays, in LDS (not scratch memory)
-
-__device__ void lm_ldlt8(LmScratch& W, const double* Ain, const double* rhs, double* x) {    // pivoted LDL^T, same algorithm as host_math.h
-    double* A = W.A; double* y = W.y; int* perm = W.perm;
-    for (int i = 0; i < 64; ++i) A[i] = Ain[i];
-    for (int i = 0; i < 8; ++i) perm[i] = i;
+// ---- wave-level helpers: the serial part of an LM iteration runs on wave 0, uniform scalars computed redundantly by every lane
+__device__ __forceinline__ double lm_bcast(double v, int srclane) {              // srclane is wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void lm_wave_sync() {                                  // LDS written by one lane, read by another lane of the same wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// 8x8 symmetric solve, one matrix row per lane (lanes 0..7; a[] = row `lane`, rhs = b[lane]); returns x[lane]. LDL^T without pivoting:
+// the LM system H + lambda diag(H) is positive definite, and a zero/non-finite pivot zeroes its column and its unknown exactly like the
+// host's pivoted variant does for an empty system. Row k / the solved unknowns travel through v_readlane: no LDS, no dependent memory.
+__device__ __forceinline__ double lm_ldlt8_wave(double (&a)[8], double rhs, int lane) {
+    double dd = 0;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-        int p = k; double best = fabs(A[k * 8 + k]);
-        for (int i = k + 1; i < 8; ++i) { const double v = fabs(A[i * 8 + i]); if (v > best) { best = v; p = i; } }
-        if (p != k) {
-            for (int j = 0; j < 8; ++j) { const double tmp = A[k * 8 + j]; A[k * 8 + j] = A[p * 8 + j]; A[p * 8 + j] = tmp; }
-            for (int j = 0; j < 8; ++j) { const double tmp = A[j * 8 + k]; A[j * 8 + k] = A[j * 8 + p]; A[j * 8 + p] = tmp; }
-            const int ti = perm[k]; perm[k] = perm[p]; perm[p] = ti;
+        double rk[8];
+#pragma unroll
+        for (int j = k; j < 8; ++j) rk[j] = lm_bcast(a[j], k);
+        const double d = rk[k];
+        const bool ok = d != 0.0 && isfinite(d);
+        if (lane == k) dd = d;
+        const double l = ok ? a[k] / d : 0.0;
+        if (lane > k) {
+#pragma unroll
+            for (int j = k + 1; j < 8; ++j) a[j] -= l * rk[j];
+            a[k] = l;
         }
-        const double d = A[k * 8 + k];
-        if (d == 0.0 || !isfinite(d)) { for (int i = k + 1; i < 8; ++i) A[i * 8 + k] = 0; continue; }
-        for (int i = k + 1; i < 8; ++i) A[i * 8 + k] /= d;
-        for (int i = k + 1; i < 8; ++i) { const double lik = A[i * 8 + k]; if (lik == 0) continue; for (int j = k + 1; j <= i; ++j) A[i * 8 + j] -= lik * d * A[j * 8 + k]; }
-        for (int i = k + 1; i < 8; ++i) for (int j = i + 1; j < 8; ++j) A[i * 8 + j] = A[j * 8 + i];
     }
-    for (int i = 0; i < 8; ++i) y[i] = rhs[perm[i]];
-    for (int i = 0; i < 8; ++i) for (int j = 0; j < i; ++j) y[i] -= A[i * 8 + j] * y[j];
-    for (int i = 0; i < 8; ++i) { const double d = A[i * 8 + i]; y[i] = (d != 0.0 && isfinite(d)) ? y[i] / d : 0.0; }
-    for (int i = 7; i >= 0; --i) for (int j = i + 1; j < 8; ++j) y[i] -= A[j * 8 + i] * y[j];
-    for (int i = 0; i < 8; ++i) x[perm[i]] = y[i];
+    double y = rhs;                                                               // L y = rhs, column oriented
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { const double yj = lm_bcast(y, j); if (lane > j) y -= a[j] * yj; }
+    double x = (dd != 0.0 && isfinite(dd)) ? y / dd : 0.0;
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {                                                // L^T x = z: row i gathers L[j][i] x_j from the lanes j > i
+        const double t = (lane > i && lane < 8) ? a[i] * x : 0.0;
+        double sacc = 0;
+#pragma unroll
+        for (int j = i + 1; j < 8; ++j) sacc += lm_bcast(t, j);
+        if (lane == i) x -= sacc;
+    }
+    return x;
 }
 
-// lane 0: prepare the float parameters of an evaluation at (T, aff) for level lvl (CoarseTracker.cpp:907-916)
-__device__ void lm_prepare_eval(LmState& S, const TrkLmParams& P, const double T[12], const double aff[2]) {
-    const TrkLmLevel& L = P.lv[S.lvl];
+// prepare the float parameters of an evaluation at (T, aff) for level lvl (CoarseTracker.cpp:907-916); the caller's lane 0 passes write = true
+__device__ __forceinline__ void lm_prepare_eval(LmState& S, const TrkLmParams& P, int lvl, float levelCutoffRepeat, const double (&T)[12], double aff0, double aff1, bool write) {
+    const TrkLmLevel& L = P.lv[lvl];
     float expF = P.expRef, expT = P.expNew;
     if (expF == 0 || expT == 0) expT = expF = 1;                                        // AffLight::fromToVecExposure, util/NumType.h:173-185
-    const double a = exp(aff[0] - P.ref_aff[0]) * expT / expF, bq = aff[1] - a * P.ref_aff[1];
-    S.affa = (float)a; S.affb = (float)bq; S.b0 = (float)P.ref_aff[1];
+    const double a = exp(aff0 - P.ref_aff[0]) * expT / expF, bq = aff1 - a * P.ref_aff[1];
     const float Ki[9] = {1.0f / L.fx, 0, -L.cx / L.fx, 0, 1.0f / L.fy, -L.cy / L.fy, 0, 0, 1};
-    float Rf[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rf[i * 3 + j] = (float)T[i * 4 + j];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) S.RKi[i * 3 + j] = Rf[i * 3] * Ki[j] + Rf[i * 3 + 1] * Ki[3 + j] + Rf[i * 3 + 2] * Ki[6 + j];
-    for (int i = 0; i < 9; ++i) S.Ki[i] = Ki[i];
+    float Rf[9], RKi[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Rf[i * 3 + j] = (float)T[i * 4 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) RKi[i * 3 + j] = Rf[i * 3] * Ki[j] + Rf[i * 3 + 1] * Ki[3 + j] + Rf[i * 3 + 2] * Ki[6 + j];
+    if (!write) return;
+    S.affa = (float)a; S.affb = (float)bq; S.b0 = (float)P.ref_aff[1];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { S.RKi[i] = RKi[i]; S.Ki[i] = Ki[i]; }
+#pragma unroll
     for (int i = 0; i < 3; ++i) S.t[i] = (float)T[i * 4 + 3];
-    S.cutoff = kCoarseCutoffTH * S.levelCutoffRepeat;
+    S.cutoff = kCoarseCutoffTH * levelCutoffRepeat;
     S.maxEnergy = 2 * kHuberTH * S.cutoff - kHuberTH * kHuberTH;
 }
 __device__ __forceinline__ double lm_scale(int r) { return r < 3 ? (double)kScaleXiRot : r < 6 ? (double)kScaleXiTrans : r == 6 ? (double)kScaleA : (double)kScaleB; }
 __device__ __forceinline__ int lm_max_iterations(int lvl) { return lvl == 0 ? 10 : lvl == 1 ? 20 : 50; }      // maxIterations[] (:1085)
-// lane 0: sums (52 doubles) -> stats6 + scaled H,b (CoarseTracker.cpp:1040-1046, 869-884)
-__device__ void lm_finish_eval(const double* o, double st[6], double* H, double* b) {
-    const double E = o[45], nE = o[46], nSat = o[47], nW = o[48], sT = o[49], sRT = o[50], sN = o[51];
-    st[0] = E; st[1] = nE; st[2] = sT / (sN + 0.1); st[3] = 0; st[4] = sRT / (sN + 0.1); st[5] = (double)((float)nSat / (float)nE);
-    const double npad = (double)(((long)nW + 3) & ~3L), inv = 1.0 / npad;
-    for (int r = 0; r < 8; ++r) {
-        for (int cc = 0; cc < 8; ++cc) {
-            const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;
-            H[r * 8 + cc] = o[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] * inv * lm_scale(r) * lm_scale(cc);       // upper-triangular index of the 9x9
-        }
-        b[r] = o[r * 9 - r * (r - 1) / 2 + (8 - r)] * inv * lm_scale(r);
-    }
-}
-
-// Grid barrier for the persistent LM kernel: every block adds 1 (agent-scope release) and spins (agent-scope acquire) until the
-// monotonically increasing counter reaches `target`. The grid is small (<= kLmMaxBlocks workgroups of 256 lanes, far below the
-// 256 CUs), so all blocks are co-resident; the spin is bounded anyway so a lost block ends the kernel with an error instead of
-// hanging the device. __threadfence() on both sides makes the block partials (plain stores) visible across the XCD L2s.
-__device__ __forceinline__ bool lm_grid_barrier(unsigned* bar, unsigned target, int* lds_flag, int light) {
-    if (light) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // partial stores (agent-scope atomics, write-through) have completed
-    else __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (light) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 1;
-        unsigned spins = 0;
-        while ((light ? __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22)) { ok = 0; break; }
-        }
-        *lds_flag = ok;
-    }
-    __syncthreads();
-    if (!light) __threadfence();
-    return *lds_flag != 0;
-}
+// Exchange of the block partials between the workgroups of the persistent LM kernel: every value travels as ONE 8-byte word
+// {fp32 partial, 32-bit tag} stored with an agent-scope atomic (write-through past the XCD's L2), the tag = launch sequence and
+// evaluation number. A reader polls the words of the blocks it sums until their tags match: the data IS the arrival flag, so there is no
+// counter, no fence and no second round trip (the scheme of low-latency collective protocols). Slots are double-buffered by evaluation
+// parity: a block can run at most one evaluation ahead of the slowest reader, because the next one needs that reader's own partial.
+// The grid is small (<= NALO_LM_MAX_BLOCKS workgroups, far below the 256 CUs) so all blocks are co-resident; the poll is bounded anyway, a
+// lost block ends the kernel with an error instead of hanging the device.
+__device__ __forceinline__ unsigned long long lm_pack(float v, unsigned tag) { return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v); }
 
 // NALO_LM_TICKS: per-phase shader-clock accounting of block 0 (debug builds only), reported in out[26..30]
 #ifdef NALO_LM_TICKS
@@ -174,12 +189,11 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
     __shared__ double sums[64];
     __shared__ double part[kLmThreads / 64][64];
     __shared__ LmState S;
-    __shared__ LmScratch WK;
     __shared__ int bar_ok;
     const int tid = threadIdx.x, blk = blockIdx.x, NB = gridDim.x;
     const float lambdaExtrapolationLimit = 0.001f;
-    unsigned bar_target = 0;
     int timed_out = 0;
+    if (tid == 0) bar_ok = 1;
 
     // every block keeps its own copy of the LM state and advances it with the same inputs (the summed partials): the control flow is
     // replicated, not broadcast, which saves a second grid barrier per evaluation
@@ -190,7 +204,10 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
         S.flow[0] = S.flow[1] = S.flow[2] = 1000;
         S.lvl = P.coarsest; S.it = 0; S.phase = 0; S.next_lvl = -1; S.haveRepeated = P.have_repeated_in; S.good = 1; S.evals = 0; S.done = 0; S.break_pending = 0;
         S.levelCutoffRepeat = 1; S.lambda = 0.01f;
-        lm_prepare_eval(S, P, S.T, S.aff);
+        double T0[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T0[i] = P.T0[i];
+        lm_prepare_eval(S, P, P.coarsest, 1.f, T0, P.aff0[0], P.aff0[1], true);
     }
     __syncthreads();
 
@@ -307,96 +324,134 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
             if (tid < kLmVals) {
                 double s = 0; for (int g = 0; g < kLmThreads / 64; ++g) s += part[g][tid];
                 if (NB == 1) sums[tid] = s;
-                else __hip_atomic_store(&P.partial[((size_t)(S.evals & 1) * NB + blk) * 64 + tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_store(&P.partial[((size_t)(S.evals & 1) * NB + blk) * 64 + tid], lm_pack((float)s, P.tag0 + (unsigned)S.evals), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         LM_TICK(2);
         if (NB > 1) {                                        // block partials -> every block sums them in the same fixed order
-            bar_target += NB;
-            if (!lm_grid_barrier(P.bar, bar_target, &bar_ok, P.light)) { timed_out = 1; break; }
             const int j = tid & 63, g = tid >> 6;
-            const double* pp = P.partial + (size_t)(S.evals & 1) * NB * 64;
+            const unsigned long long* pp = P.partial + (size_t)(S.evals & 1) * NB * 64;
+            const unsigned want = P.tag0 + (unsigned)S.evals;
             double s = 0;
-            if (j < kLmVals) for (int b2 = g; b2 < nbl; b2 += kLmThreads / 64) s += __hip_atomic_load(&pp[(size_t)b2 * 64 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool pending = j < kLmVals;
+            for (unsigned spins = 0; pending; ++spins) {     // all words of this lane's blocks in flight together; repeat until every tag matches
+                pending = false; s = 0;
+                for (int b2 = g; b2 < nbl; b2 += kLmThreads / 64) {
+                    const unsigned long long wv = __hip_atomic_load(&pp[(size_t)b2 * 64 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    pending |= (unsigned)(wv >> 32) != want;
+                    s += (double)__uint_as_float((unsigned)wv);
+                }
+                if (pending) { if (spins > (1u << 21)) { bar_ok = 0; break; } __builtin_amdgcn_s_sleep(1); }
+            }
             part[g][j] = s;
             __syncthreads();
+            if (!bar_ok) { timed_out = 1; break; }
             if (tid < kLmVals) { double t2 = 0; for (int g2 = 0; g2 < kLmThreads / 64; ++g2) t2 += part[g2][tid]; sums[tid] = t2; }
         }
         __syncthreads();
         LM_TICK(3);
-        // ------------------------------------------------------------- lane 0 = the host of the reference
-        if (tid == 0) {
-            S.evals++;
-            int next_action;                                 // 0 = evaluate again (parameters prepared), 1 = propose, 2 = finish level
-            if (S.phase == 0) {
-                lm_finish_eval(sums, S.resOld, S.H, S.b);
-                if (S.resOld[5] > 0.6 && S.levelCutoffRepeat < 50) {                          // :1106-1113
-                    S.levelCutoffRepeat *= 2;
-                    lm_prepare_eval(S, P, S.T, S.aff);
-                    next_action = 0;
-                } else { S.lambda = 0.01f; S.it = 0; S.break_pending = 0; next_action = 1; }
+        // ------------------------------------------------------------- wave 0 = the host of the reference
+        // Scalars of the control flow are computed by every lane of the wave (uniform); the 8x8 solve puts one row per lane; lane 0 writes
+        // the state back. Nothing here waits on memory other than a handful of LDS broadcasts.
+        if (tid < 64) {
+            const int lane = tid;
+            int phase = S.phase, it = S.it, lvl = S.lvl, brk = S.break_pending, haveRep = S.haveRepeated, good = S.good, done = 0, next_lvl = S.next_lvl;
+            float lambda = S.lambda, lcr = S.levelCutoffRepeat;
+            const int evals = S.evals + 1;
+            // sums (52 doubles) -> stats6 and this lane's entry of the scaled H / b (CoarseTracker.cpp:1040-1046, 869-884)
+            const double E = sums[45], nE = sums[46], nSat = sums[47], nW = sums[48], sT = sums[49], sRT = sums[50], sN = sums[51];
+            const double st[6] = {E, nE, sT / (sN + 0.1), 0, sRT / (sN + 0.1), (double)((float)nSat / (float)nE)};
+            const double inv = 1.0 / (double)(((long)nW + 3) & ~3L);
+            const int hr = lane >> 3, hc = lane & 7, lo = hr < hc ? hr : hc, hi = hr < hc ? hc : hr;
+            const double Hval = sums[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] * inv * lm_scale(hr) * lm_scale(hc);     // upper-triangular index of the 9x9
+            const int bl = lane & 7;
+            const double bval = sums[bl * 9 - bl * (bl - 1) / 2 + (8 - bl)] * inv * lm_scale(bl);
+            double ro[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ro[i] = S.resOld[i];
+            int next_action;                                 // 0 = evaluate again at the accepted estimate, 1 = propose, 2 = finish level
+            bool store_H = false, take_T = false;
+            if (phase == 0) {
+                store_H = true;
+                if (st[5] > 0.6 && lcr < 50) { lcr *= 2; next_action = 0; }                      // :1106-1113
+                else { lambda = 0.01f; it = 0; brk = 0; next_action = 1; }
             } else {
-                double* Hn = WK.Hn; double* bn = WK.bn;
-                lm_finish_eval(sums, S.resNew, Hn, bn);
-                const bool accept = (S.resNew[0] / S.resNew[1]) < (S.resOld[0] / S.resOld[1]);  // :1186
-                if (accept) {                                                                  // :1202-1209
-                    for (int i = 0; i < 64; ++i) S.H[i] = Hn[i];
-                    for (int i = 0; i < 8; ++i) S.b[i] = bn[i];
-                    for (int i = 0; i < 6; ++i) S.resOld[i] = S.resNew[i];
-                    for (int i = 0; i < 12; ++i) S.T[i] = S.Tn[i];
-                    S.aff[0] = S.affn[0]; S.aff[1] = S.affn[1];
-                    S.lambda *= 0.5f;
-                } else { S.lambda *= 4; if (S.lambda < lambdaExtrapolationLimit) S.lambda = lambdaExtrapolationLimit; }
-                S.it++;
-                next_action = S.break_pending ? 2 : 1;                                         // `if(!(inc.norm() > 1e-3)) break;` (:1216-1221)
+                const bool accept = (st[0] / st[1]) < (ro[0] / ro[1]);                           // :1186
+                if (accept) { store_H = true; take_T = true; lambda *= 0.5f; }                   // :1202-1209
+                else { lambda *= 4; if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit; }
+                it++;
+                next_action = brk ? 2 : 1;                                                       // `if(!(inc.norm() > 1e-3)) break;` (:1216-1221)
             }
+            if (store_H) {
+                S.H[lane] = Hval;
+                if (lane < 8) S.b[lane] = bval;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) ro[i] = st[i];
+            }
+            if (take_T) { if (lane < 12) S.T[lane] = S.Tn[lane]; else if (lane < 14) S.aff[lane - 12] = S.affn[lane - 12]; }
+            lm_wave_sync();
+            double T[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = S.T[i];
+            const double aff0 = S.aff[0], aff1 = S.aff[1];
             if (next_action == 1) {
-                if (S.it < lm_max_iterations(S.lvl)) {                                             // :1133-1184
-                    double* Hl = WK.Hl; double* nb = WK.nb; double* inc = WK.inc;
-                    for (int i = 0; i < 64; ++i) Hl[i] = S.H[i];
-                    for (int i = 0; i < 8; ++i) { Hl[i * 8 + i] *= (1 + S.lambda); nb[i] = -S.b[i]; }
-                    lm_ldlt8(WK, Hl, nb, inc);
+                if (it < lm_max_iterations(lvl)) {                                               // :1133-1184
+                    double a[8];
+                    const float opl = 1 + lambda;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { a[j] = lane < 8 ? S.H[lane * 8 + j] : 0.0; if (j == lane) a[j] *= opl; }
+                    const double rhs = lane < 8 ? -S.b[lane] : 0.0;
+                    double inc = lm_ldlt8_wave(a, rhs, lane);
                     float extrapFac = 1;
-                    if (S.lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / S.lambda));
-                    for (int i = 0; i < 8; ++i) inc[i] *= extrapFac;
-                    double* incS = WK.incS;
-                    for (int i = 0; i < 8; ++i) incS[i] = inc[i];
-                    for (int i = 0; i < 3; ++i) incS[i] *= kScaleXiRot;                       // labels swapped vs tangent order (:1172-1173)
-                    for (int i = 3; i < 6; ++i) incS[i] *= kScaleXiTrans;
-                    incS[6] *= kScaleA; incS[7] *= kScaleB;
-                    double ssum = 0; for (int i = 0; i < 8; ++i) ssum += incS[i];
-                    if (!isfinite(ssum)) for (int i = 0; i < 8; ++i) incS[i] = 0;
-                    double* E12 = WK.E;
-                    lm_se3_exp(incS, E12);
-                    lm_se3_mul(E12, S.T, S.Tn);
-                    S.affn[0] = S.aff[0] + incS[6]; S.affn[1] = S.aff[1] + incS[7];
-                    double nrm = 0; for (int i = 0; i < 8; ++i) nrm += inc[i] * inc[i];
-                    S.break_pending = !(sqrt(nrm) > 1e-3);
-                    lm_prepare_eval(S, P, S.Tn, S.affn);
-                    S.phase = 1;
+                    if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / lambda));
+                    inc *= extrapFac;
+                    // labels swapped vs tangent order in the reference (:1172-1173): entries 0-2 scale with SCALE_XI_ROT, 3-5 with SCALE_XI_TRANS
+                    const double incSl = inc * (lane < 3 ? (double)kScaleXiRot : lane < 6 ? (double)kScaleXiTrans : lane == 6 ? (double)kScaleA : (double)kScaleB);
+                    double iv[8], is[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { iv[i] = lm_bcast(inc, i); is[i] = lm_bcast(incSl, i); }
+                    double ssum = 0, nrm = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { ssum += is[i]; nrm += iv[i] * iv[i]; }
+                    if (!isfinite(ssum)) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) is[i] = 0;
+                    }
+                    double E12[12], Tn[12];
+                    lm_se3_exp(is, E12);
+                    lm_se3_mul(E12, T, Tn);
+                    const double affn0 = aff0 + is[6], affn1 = aff1 + is[7];
+                    brk = !(sqrt(nrm) > 1e-3);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) S.Tn[i] = Tn[i];
+                        S.affn[0] = affn0; S.affn[1] = affn1;
+                    }
+                    lm_prepare_eval(S, P, lvl, lcr, Tn, affn0, affn1, lane == 0);
+                    phase = 1;
                 } else next_action = 2;
             }
-            if (next_action == 2) {                                                            // level finished (:1225-1235)
-                S.lastRes[S.lvl] = (double)sqrtf((float)(S.resOld[0] / S.resOld[1]));
-                S.flow[0] = S.resOld[2]; S.flow[1] = S.resOld[3]; S.flow[2] = S.resOld[4];
-                if (P.has_minres && S.lastRes[S.lvl] > 1.5 * P.minRes[S.lvl]) { S.good = 0; S.done = 1; }
+            if (next_action == 0) lm_prepare_eval(S, P, lvl, lcr, T, aff0, aff1, lane == 0);
+            if (next_action == 2) {                                                              // level finished (:1225-1235)
+                const double lr = (double)sqrtf((float)(ro[0] / ro[1]));
+                if (lane == 0) { S.lastRes[lvl] = lr; S.flow[0] = ro[2]; S.flow[1] = ro[3]; S.flow[2] = ro[4]; }
+                if (P.has_minres && lr > 1.5 * P.minRes[lvl]) { good = 0; done = 1; }
                 else {
-                    int next = S.lvl - 1;
-                    if (S.levelCutoffRepeat > 1 && !S.haveRepeated) { next = S.lvl; S.haveRepeated = 1; }   // repeat this level once
-                    if (next < P.stop_lvl) { S.done = 1; S.next_lvl = next; }
-                    else { S.lvl = next; S.levelCutoffRepeat = 1; S.phase = 0; lm_prepare_eval(S, P, S.T, S.aff); }
+                    int next = lvl - 1;
+                    if (lcr > 1 && !haveRep) { next = lvl; haveRep = 1; }                        // repeat this level once
+                    if (next < P.stop_lvl) { done = 1; next_lvl = next; }
+                    else { lvl = next; lcr = 1; phase = 0; lm_prepare_eval(S, P, lvl, lcr, T, aff0, aff1, lane == 0); }
                 }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) S.resOld[i] = ro[i];
+                S.phase = phase; S.it = it; S.lvl = lvl; S.break_pending = brk; S.haveRepeated = haveRep; S.good = good; S.next_lvl = next_lvl;
+                S.lambda = lambda; S.levelCutoffRepeat = lcr; S.evals = evals; S.done = done;
             }
         }
         __syncthreads();
         LM_TICK(4);
-    }
-    if (NB > 1 && tid == 0) {                                // the last block out re-arms the barrier for the next launch
-        const unsigned old = __hip_atomic_fetch_add(P.bar + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == (unsigned)NB - 1u) {
-            __hip_atomic_store(P.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(P.bar + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
     if (blk == 0 && tid == 0) {
         double* o = P.out;
@@ -437,11 +492,12 @@ int trk_lm_launch(nalo_ctx* c, int slot_new, const double T0[12], const double a
     for (int l = stop_lvl; l <= coarsest; ++l) maxn = std::max(maxn, c->pc_n[l]);
     static const int max_blocks = [] { const char* e = std::getenv("NALO_LM_BLOCKS"); const int v = e ? std::atoi(e) : NALO_LM_MAX_BLOCKS; return std::min(std::max(v, 1), 256); }();
     const int NB = std::min(max_blocks, (maxn + kLmThreads - 1) / kLmThreads);
-    if (!c->lm_bar.p) { NALO_HIP(c, c->lm_bar.reserve(4)); NALO_HIP(c, hipMemsetAsync(c->lm_bar.p, 0, 16, c->stream)); }
-    NALO_HIP(c, c->lm_partial.reserve((size_t)2 * 256 * 64));
-    P.partial = c->lm_partial.p; P.bar = c->lm_bar.p;
-    static const int light = [] { const char* e = std::getenv("NALO_LM_LIGHT"); return e ? std::atoi(e) : 1; }();
-    P.light = light;
+    if (!c->lm_partial.p || (c->lm_launches & 0xFFFFFu) == 0) {      // first use / tag wrap-around: no stale word may carry a live tag
+        NALO_HIP(c, c->lm_partial.reserve((size_t)2 * 256 * 64));
+        NALO_HIP(c, hipMemsetAsync(c->lm_partial.p, 0, (size_t)2 * 256 * 64 * 8, c->stream));
+    }
+    P.partial = c->lm_partial.p;
+    P.tag0 = (unsigned)((++c->lm_launches & 0xFFFFFu) << 12);
     {
         ProfScope ps(c, "trk_lm");
         trk_lm_kernel<<<NB, kLmThreads, 0, c->stream>>>(P);
@@ -452,11 +508,7 @@ int trk_lm_launch(nalo_ctx* c, int slot_new, const double T0[12], const double a
 #ifdef NALO_LM_TICKS
     { const double* t = c->trk_out_host + 64 + 26; fprintf(stderr, "[lm ticks] evals=%d eval=%.0f blockred=%.0f gridsum=%.0f lane0=%.0f (shader clocks per eval)\n", (int)out24[23], t[0] / out24[23], t[1] / out24[23], t[2] / out24[23], t[3] / out24[23]); }
 #endif
-    if (out24[22] < 0) {                                 // a block never reached the grid barrier: re-arm and report
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipMemset(c->lm_bar.p, 0, 8);
-        return fail(c, NALO_ERR_HIP, "trk_lm_kernel: grid barrier timed out");
-    }
+    if (out24[22] < 0) return fail(c, NALO_ERR_HIP, "trk_lm_kernel: a workgroup's partial never arrived (timeout)");
     return NALO_OK;
 }
 

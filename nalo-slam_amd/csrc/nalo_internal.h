@@ -73,8 +73,8 @@ struct nalo_ctx {
     nalo::DevBuf<double> trk_out;            // 64 doubles
     double* trk_out_host = nullptr;          // pinned, host-mapped: results + sequence flag
     unsigned long long trk_seq = 0;
-    nalo::DevBuf<double> lm_partial;         // persistent LM kernel: [2][blocks][64] block partials
-    nalo::DevBuf<unsigned> lm_bar;           // [0,1] its grid barrier / exit counters, [2] trk_eval's last-block ticket
+    nalo::DevBuf<unsigned long long> lm_partial;   // persistent LM kernel: [2][blocks][64] block partials {fp32, tag}
+    unsigned long long lm_launches = 0;
     nalo::DevBuf<int> scan_tmp;              // compaction counts
     nalo::DevBuf<float> upload_tmp;
     float* pinned_f = nullptr; size_t pinned_f_cap = 0;
