@@ -127,10 +127,19 @@ int nalo_trk_make_k(nalo_ctx* c, float fx, float fy, float cx, float cy) {
 }
 
 static int upload4(nalo_ctx* c, int n, const float* a, const float* b, const float* d, const float* e, float** dev) {
+    // one pinned staging buffer, one H2D copy (four pageable copies cost four blocking round trips); the previous upload has been consumed:
+    // trk_build_ref ends on a flag published after it in stream order
     NALO_HIP(c, c->upload_tmp.reserve((size_t)4 * n + 256));
+    if (c->pinned_f_cap < (size_t)4 * n) {
+        if (c->pinned_f) (void)hipHostFree(c->pinned_f);
+        c->pinned_f = nullptr; c->pinned_f_cap = 0;
+        NALO_HIP(c, hipHostMalloc((void**)&c->pinned_f, (size_t)4 * n * 4 + 1024));
+        c->pinned_f_cap = (size_t)4 * n + 256;
+    }
     float* base = c->upload_tmp.p + 256;
     const float* src[4] = {a, b, d, e};
-    for (int k = 0; k < 4; ++k) { NALO_HIP(c, hipMemcpyAsync(base + (size_t)k * n, src[k], (size_t)n * 4, hipMemcpyHostToDevice, c->stream)); dev[k] = base + (size_t)k * n; }
+    for (int k = 0; k < 4; ++k) { std::memcpy(c->pinned_f + (size_t)k * n, src[k], (size_t)n * 4); dev[k] = base + (size_t)k * n; }
+    NALO_HIP(c, hipMemcpyAsync(base, c->pinned_f, (size_t)4 * n * 4, hipMemcpyHostToDevice, c->stream));
     return NALO_OK;
 }
 

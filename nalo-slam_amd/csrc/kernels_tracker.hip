@@ -152,43 +152,95 @@ __global__ __launch_bounds__(256) void trk_scatter_kernel(const float* __restric
     atomicAdd(idepth + u + w0 * v, nid[i] * weight);
     atomicAdd(wsum + u + w0 * v, weight);
 }
-// step 2 (:408-433): 2x2 SUM pyramid
-__global__ __launch_bounds__(256) void trk_sum_down_kernel(const float* __restrict__ idm, const float* __restrict__ wsm, float* __restrict__ id, float* __restrict__ ws,
-                                                           int wl, int hl, int wlm1) {
+// All levels of steps 2-5 go through ONE launch per step (the per-level launches were ~30 dependent kernels of a few microseconds each).
+struct TrkLevels {
+    float *id[NALO_MAX_LEVELS], *ws[NALO_MAX_LEVELS], *wb[NALO_MAX_LEVELS];      // idepth, weight sums, dilated weight sums (output of step 3/4)
+    const float4* dI[NALO_MAX_LEVELS];                                            // reference frame texels
+    float *pu[NALO_MAX_LEVELS], *pv[NALO_MAX_LEVELS], *pid[NALO_MAX_LEVELS], *pcol[NALO_MAX_LEVELS];
+    int wl[NALO_MAX_LEVELS], hl[NALO_MAX_LEVELS];
+    int blk0[NALO_MAX_LEVELS + 1];                                                // first block of each level in a level-partitioned grid
+    int scan0[NALO_MAX_LEVELS + 1];                                               // counts/offsets base per level inside scan_tmp ([nb counts | nb+1 offsets])
+    int L;
+};
+__global__ __launch_bounds__(256) void trk_zero2_kernel(float* __restrict__ a, float* __restrict__ b, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= wl * hl) return;
-    const int y = i / wl, x = i - y * wl, b = 2 * x + 2 * y * wlm1;
-    id[i] = idm[b] + idm[b + 1] + idm[b + wlm1] + idm[b + wlm1 + 1];
-    ws[i] = wsm[b] + wsm[b + 1] + wsm[b + wlm1] + wsm[b + wlm1 + 1];
+    if (i < n) { a[i] = 0.f; b[i] = 0.f; }
 }
-// steps 3/4 (:437-489): 1-px dilation, diagonal (levels 0,1) or axis (levels >= 2), flat-index neighbours.
-// Reads idepth only where bak>0 and writes only where bak<=0: race-free in place, as the reference notes.
-__global__ __launch_bounds__(256) void trk_dilate_kernel(float* __restrict__ id, float* __restrict__ ws, const float* __restrict__ bak, int wl, int hl, int diag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x + wl;
-    if (i >= wl * hl - wl) return;
-    if (bak[i] > 0) return;
-    const int o0 = diag ? 1 + wl : 1, o1 = diag ? -1 - wl : -1, o2 = diag ? wl - 1 : wl, o3 = diag ? -wl + 1 : -wl;
-    // the reference reads one element before/after the array at the first/last pixel of this range
-    // (i-1-wl = -1, i+1+wl = w*h): those two taps are outside the image and are skipped here.
-    const int npx = wl * hl;
-    float sum = 0, num = 0, numn = 0;
+// step 2 (:408-433): 2x2 SUM pyramid, every level from one pass over level 0. A block owns a 32x32 level-0 tile = 16x16 level-1 pixels, and
+// walks up through LDS (8x8, 4x4, 2x2, 1); each parent is a + b + c + d of its four children in the reference's order, so the values
+// are those of the level-by-level loop bit for bit.
+__global__ __launch_bounds__(256) void trk_sum_down_all_kernel(TrkLevels P) {
+    __shared__ float sid[2][16 * 16], sws[2][16 * 16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles_x = (P.wl[1] + 15) / 16;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    {
+        const int x = bx * 16 + tx, y = by * 16 + ty, w0 = P.wl[0];
+        float a = 0.f, b = 0.f;
+        if (x < P.wl[1] && y < P.hl[1]) {
+            const int o = 2 * x + 2 * y * w0;
+            a = P.id[0][o] + P.id[0][o + 1] + P.id[0][o + w0] + P.id[0][o + w0 + 1];
+            b = P.ws[0][o] + P.ws[0][o + 1] + P.ws[0][o + w0] + P.ws[0][o + w0 + 1];
+            P.id[1][x + y * P.wl[1]] = a; P.ws[1][x + y * P.wl[1]] = b;
+        }
+        sid[0][ty * 16 + tx] = a; sws[0][ty * 16 + tx] = b;
+    }
+    int side = 16, cur = 0;
+    for (int l = 2; l < P.L; ++l) {
+        __syncthreads();
+        const int ps = side; side >>= 1;
+        if (side == 0) break;                                  // more than 6 levels would need a larger tile (NALO_MAX_LEVELS = 6)
+        if (tx < side && ty < side) {
+            const int x = bx * side + tx, y = by * side + ty, o = 2 * tx + 2 * ty * ps;
+            const float a = sid[cur][o] + sid[cur][o + 1] + sid[cur][o + ps] + sid[cur][o + ps + 1];
+            const float b = sws[cur][o] + sws[cur][o + 1] + sws[cur][o + ps] + sws[cur][o + ps + 1];
+            if (x < P.wl[l] && y < P.hl[l]) { P.id[l][x + y * P.wl[l]] = a; P.ws[l][x + y * P.wl[l]] = b; }
+            sid[cur ^ 1][ty * side + tx] = a; sws[cur ^ 1][ty * side + tx] = b;
+        }
+        cur ^= 1;
+    }
+}
+// steps 3/4 (:437-489): 1-px dilation, diagonal (levels 0,1) or axis (levels >= 2), flat-index neighbours. The reference dilates in place
+// against a backup copy of the weights; here the undilated weights ws stay read-only and the result goes to wb (the buffers swap roles
+// afterwards), so no copy is needed. idepth is written in place: it is read only where ws > 0 and written only where ws <= 0.
+__global__ __launch_bounds__(256) void trk_dilate_all_kernel(TrkLevels P) {
+    int l = 0;
+    while (l + 1 < P.L && (int)blockIdx.x >= P.blk0[l + 1]) ++l;
+    const int wl = P.wl[l], npx = wl * P.hl[l];
+    const int i = (blockIdx.x - P.blk0[l]) * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    float* __restrict__ id = P.id[l]; const float* __restrict__ bak = P.ws[l]; float* __restrict__ out = P.wb[l];
+    const float own = bak[i];
+    float res = own;
+    if (i >= wl && i < npx - wl && !(own > 0)) {
+        const int diag = l < 2;
+        const int o0 = diag ? 1 + wl : 1, o1 = diag ? -1 - wl : -1, o2 = diag ? wl - 1 : wl, o3 = diag ? -wl + 1 : -wl;
+        // the reference reads one element before/after the array at the first/last pixel of this range
+        // (i-1-wl = -1, i+1+wl = w*h): those two taps are outside the image and are skipped here.
+        float sum = 0, num = 0, numn = 0;
 #define NALO_TAP(o) { const int j = i + (o); if (j >= 0 && j < npx) { const float b = bak[j]; if (b > 0) { sum += id[j]; num += b; numn++; } } }
-    NALO_TAP(o0) NALO_TAP(o1) NALO_TAP(o2) NALO_TAP(o3)
+        NALO_TAP(o0) NALO_TAP(o1) NALO_TAP(o2) NALO_TAP(o3)
 #undef NALO_TAP
-    if (numn > 0) { id[i] = sum / numn; ws[i] = num / numn; }
+        if (numn > 0) { id[i] = sum / numn; res = num / numn; }
+    }
+    out[i] = res;
 }
-// step 5 (:493-538): normalise + ordered (raster) compaction into pc_*. Pass 0 counts per block, pass 1 writes.
+// step 5 (:493-538): normalise + ordered (raster) compaction into pc_*. Pass 0 counts per block, pass 1 writes. (ws = the dilated weights.)
 constexpr int kCompactChunk = 2048;          // interior elements per block (8 rounds of 256)
 template <int WRITE>
-__global__ __launch_bounds__(256) void trk_compact_kernel(float* __restrict__ id, float* __restrict__ ws, const float4* __restrict__ dIref, int wl, int hl,
-                                                          int* __restrict__ counts, const int* __restrict__ offsets,
-                                                          float* __restrict__ pu, float* __restrict__ pv, float* __restrict__ pid, float* __restrict__ pcol) {
+__global__ __launch_bounds__(256) void trk_compact_all_kernel(TrkLevels P, int* __restrict__ scan) {
     __shared__ int wave_cnt[4];
     __shared__ int running;
+    int l = 0;
+    while (l + 1 < P.L && (int)blockIdx.x >= P.blk0[l + 1]) ++l;
+    const int chunk = blockIdx.x - P.blk0[l], nb = P.blk0[l + 1] - P.blk0[l];
+    const int wl = P.wl[l], hl = P.hl[l];
+    float* __restrict__ id = P.id[l]; float* __restrict__ ws = P.wb[l]; const float4* __restrict__ dIref = P.dI[l];
+    int* counts = scan + P.scan0[l]; const int* offsets = counts + nb;
     const int iw = wl - 4, ih = hl - 4, total = iw * ih;            // interior y in [2,hl-2), x in [2,wl-2)
-    const int base = blockIdx.x * kCompactChunk;
+    const int base = chunk * kCompactChunk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) running = WRITE ? offsets[blockIdx.x] : 0;
+    if (threadIdx.x == 0) running = WRITE ? offsets[chunk] : 0;
     __syncthreads();
     for (int r = 0; r < kCompactChunk / 256; ++r) {
         const int e = base + r * 256 + threadIdx.x;
@@ -208,63 +260,81 @@ __global__ __launch_bounds__(256) void trk_compact_kernel(float* __restrict__ id
         __syncthreads();
         int off = running;
         for (int k = 0; k < wave; ++k) off += wave_cnt[k];
-        if (WRITE && keep) { const int o = off + rank; pu[o] = (float)x; pv[o] = (float)y; pid[o] = val_id; pcol[o] = col; }
+        if (WRITE && keep) { const int o = off + rank; P.pu[l][o] = (float)x; P.pv[l][o] = (float)y; P.pid[l][o] = val_id; P.pcol[l][o] = col; }
         __syncthreads();
         if (threadIdx.x == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         __syncthreads();
     }
-    if (!WRITE && threadIdx.x == 0) counts[blockIdx.x] = running;
+    if (!WRITE && threadIdx.x == 0) counts[chunk] = running;
 }
-// exclusive scan of block counts (nb <= 65536) by one block; total appended at offsets[nb]
-__global__ __launch_bounds__(1024) void scan_counts_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int nb) {
+// exclusive scan of the block counts of every level by one block (a few hundred counts); the per-level totals go to host-mapped memory
+// followed by the sequence number the host polls on: pc_n reaches the host without a stream synchronisation
+__global__ __launch_bounds__(1024) void trk_scan_all_kernel(TrkLevels P, int* __restrict__ scan, double* __restrict__ out, double seq) {
     __shared__ int part[1024];
-    const int per = (nb + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, nb);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += counts[i];
-    part[threadIdx.x] = s;
+    for (int l = 0; l < P.L; ++l) {
+        const int nb = P.blk0[l + 1] - P.blk0[l];
+        const int* counts = scan + P.scan0[l]; int* offsets = scan + P.scan0[l] + nb;
+        const int per = (nb + 1023) / 1024, lo = min((int)threadIdx.x * per, nb), hi = min(lo + per, nb);
+        int s = 0;
+        for (int i = lo; i < hi; ++i) s += counts[i];
+        // block-wide exclusive scan of `part` (wave shuffles, then the 16 wave totals)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        int v = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int nbv = __shfl_up(v, off); if (lane >= off) v += nbv; }
+        if (lane == 63) part[wave] = v;
+        __syncthreads();
+        int wpre = 0, tot = 0;
+        for (int k = 0; k < 16; ++k) { const int pv = part[k]; if (k < wave) wpre += pv; tot += pv; }
+        int run = wpre + v - s;
+        for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+        if (threadIdx.x == 0) { offsets[nb] = tot; out[l] = (double)tot; }
+        __syncthreads();
+    }
+    __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; } offsets[nb] = run; }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+    if (threadIdx.x == 0) __hip_atomic_store(&out[NALO_MAX_LEVELS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const float* dId, const float* dHdi) {
     const int L = c->levels;
+    TrkLevels P;
+    std::memset(&P, 0, sizeof(P));
+    P.L = L;
+    int dil_blocks = 0, cmp_blocks = 0, scan_total = 0;
+    int dil0[NALO_MAX_LEVELS + 1] = {0}, cmp0[NALO_MAX_LEVELS + 1] = {0};
     for (int l = 0; l < L; ++l) {
         const size_t npx = (size_t)c->wl[l] * c->hl[l];
         NALO_HIP(c, c->trk_idepth[l].reserve(npx)); NALO_HIP(c, c->trk_wsum[l].reserve(npx)); NALO_HIP(c, c->trk_wbak[l].reserve(npx));
         NALO_HIP(c, c->pc_u[l].reserve(npx)); NALO_HIP(c, c->pc_v[l].reserve(npx)); NALO_HIP(c, c->pc_id[l].reserve(npx)); NALO_HIP(c, c->pc_col[l].reserve(npx));
-    }
-    const size_t n0 = (size_t)c->wl[0] * c->hl[0];
-    NALO_HIP(c, hipMemsetAsync(c->trk_idepth[0].p, 0, n0 * 4, c->stream));
-    NALO_HIP(c, hipMemsetAsync(c->trk_wsum[0].p, 0, n0 * 4, c->stream));
-    if (n > 0) trk_scatter_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(dKu, dKv, dId, dHdi, n, c->wl[0], c->hl[0], c->trk_idepth[0].p, c->trk_wsum[0].p);
-    for (int l = 1; l < L; ++l) {
-        const int npx = c->wl[l] * c->hl[l];
-        trk_sum_down_kernel<<<(npx + 255) / 256, 256, 0, c->stream>>>(c->trk_idepth[l - 1].p, c->trk_wsum[l - 1].p, c->trk_idepth[l].p, c->trk_wsum[l].p, c->wl[l], c->hl[l], c->wl[l - 1]);
-    }
-    for (int l = 0; l < L; ++l) {
-        const int npx = c->wl[l] * c->hl[l];
-        NALO_HIP(c, hipMemcpyAsync(c->trk_wbak[l].p, c->trk_wsum[l].p, (size_t)npx * 4, hipMemcpyDeviceToDevice, c->stream));
-        const int cnt = npx - 2 * c->wl[l];
-        if (cnt > 0) trk_dilate_kernel<<<(cnt + 255) / 256, 256, 0, c->stream>>>(c->trk_idepth[l].p, c->trk_wsum[l].p, c->trk_wbak[l].p, c->wl[l], c->hl[l], l < 2 ? 1 : 0);
-    }
-    size_t scan_off[NALO_MAX_LEVELS + 1] = {0};
-    for (int l = 0; l < L; ++l) scan_off[l + 1] = scan_off[l] + 2 * (size_t)(((c->wl[l] - 4) * (c->hl[l] - 4) + kCompactChunk - 1) / kCompactChunk) + 2;
-    NALO_HIP(c, c->scan_tmp.reserve(scan_off[L]));
-    for (int l = 0; l < L; ++l) {
+        P.id[l] = c->trk_idepth[l].p; P.ws[l] = c->trk_wsum[l].p; P.wb[l] = c->trk_wbak[l].p; P.dI[l] = c->slots[c->slot_ref].dI[l];
+        P.pu[l] = c->pc_u[l].p; P.pv[l] = c->pc_v[l].p; P.pid[l] = c->pc_id[l].p; P.pcol[l] = c->pc_col[l].p;
+        P.wl[l] = c->wl[l]; P.hl[l] = c->hl[l];
+        dil0[l] = dil_blocks; dil_blocks += (int)((npx + 255) / 256);
         const int total = (c->wl[l] - 4) * (c->hl[l] - 4);
-        const int nb = (total + kCompactChunk - 1) / kCompactChunk;
-        int* counts = c->scan_tmp.p + scan_off[l]; int* offsets = counts + nb;
-        const float4* dIref = c->slots[c->slot_ref].dI[l];
-        trk_compact_kernel<0><<<nb, 256, 0, c->stream>>>(c->trk_idepth[l].p, c->trk_wsum[l].p, dIref, c->wl[l], c->hl[l], counts, nullptr, nullptr, nullptr, nullptr, nullptr);
-        scan_counts_kernel<<<1, 1024, 0, c->stream>>>(counts, offsets, nb);
-        trk_compact_kernel<1><<<nb, 256, 0, c->stream>>>(c->trk_idepth[l].p, c->trk_wsum[l].p, dIref, c->wl[l], c->hl[l], nullptr, offsets, c->pc_u[l].p, c->pc_v[l].p, c->pc_id[l].p, c->pc_col[l].p);
-        NALO_HIP(c, hipMemcpyAsync(&c->pc_n[l], offsets + nb, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        const int nb = total > 0 ? (total + kCompactChunk - 1) / kCompactChunk : 0;
+        cmp0[l] = cmp_blocks; cmp_blocks += nb;
+        P.scan0[l] = scan_total; scan_total += 2 * nb + 2;
     }
-    NALO_HIP(c, hipStreamSynchronize(c->stream));         // one synchronisation for all levels (pc_n is needed on the host)
+    dil0[L] = dil_blocks; cmp0[L] = cmp_blocks; P.scan0[L] = scan_total;
+    NALO_HIP(c, c->scan_tmp.reserve((size_t)scan_total));
+    const int n0 = c->wl[0] * c->hl[0];
+    trk_zero2_kernel<<<(n0 + 255) / 256, 256, 0, c->stream>>>(P.id[0], P.ws[0], n0);
+    if (n > 0) trk_scatter_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(dKu, dKv, dId, dHdi, n, c->wl[0], c->hl[0], P.id[0], P.ws[0]);
+    if (L > 1) trk_sum_down_all_kernel<<<((c->wl[1] + 15) / 16) * ((c->hl[1] + 15) / 16), 256, 0, c->stream>>>(P);
+    for (int l = 0; l <= L; ++l) P.blk0[l] = dil0[l];
+    trk_dilate_all_kernel<<<dil_blocks, 256, 0, c->stream>>>(P);
+    for (int l = 0; l <= L; ++l) P.blk0[l] = cmp0[l];
+    double* dout = nullptr;
+    NALO_HIP(c, hipHostGetDevicePointer((void**)&dout, c->trk_out_host, 0));
+    const double seq = (double)(++c->trk_seq);
+    if (cmp_blocks > 0) trk_compact_all_kernel<0><<<cmp_blocks, 256, 0, c->stream>>>(P, c->scan_tmp.p);
+    trk_scan_all_kernel<<<1, 1024, 0, c->stream>>>(P, c->scan_tmp.p, dout + 96, seq);
+    if (cmp_blocks > 0) trk_compact_all_kernel<1><<<cmp_blocks, 256, 0, c->stream>>>(P, c->scan_tmp.p);
     NALO_HIP(c, hipGetLastError());
+    for (int l = 0; l < L; ++l) std::swap(c->trk_wsum[l], c->trk_wbak[l]);      // the dilated (then normalised) weights are the level's weightSums now
+    if (!poll_flag(c, &c->trk_out_host[96 + NALO_MAX_LEVELS], seq)) return NALO_ERR_HIP;   // pc_n for the host; the point clouds follow in stream order
+    for (int l = 0; l < L; ++l) c->pc_n[l] = (int)c->trk_out_host[96 + l];
     return NALO_OK;
 }
 
