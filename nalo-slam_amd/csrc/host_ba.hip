@@ -10,7 +10,9 @@ namespace nalo {
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly);
 void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix);
 void ba_launch_reset_oob(hipStream_t s, const BADev& B);
-void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc);
+void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
+                      const float* step_partial, int step_blocks, double* step_out);
+void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial);
 int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
@@ -53,7 +55,8 @@ struct BAWindow {
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
     DevBuf<int> blk_host, host_blk, blk_order;
     DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 16
-    hipEvent_t ev_lin = nullptr, ev_th = nullptr;
+    bool step_fused = false, step_sums_deferred = false;            // optimize(): resubstitute + point step in one kernel, its sums finished by the reduce launch
+    bool th_pending = false;                                        // a linearize pass whose frameEnergyTH quantile has not been launched yet
     DevBuf<double> acc13, G, AD, stitched;                      // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | misc (2 W^2) | step sums (3) | TH sum, ranks]
     DevBuf<unsigned> st_ticket;
     StitchDev sd{};
@@ -81,8 +84,7 @@ void ba_destroy(nalo_ctx* c) {
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
     w->blk_host.release(); w->host_blk.release(); w->blk_order.release(); w->acc13.release(); w->G.release(); w->AD.release(); w->st_ticket.release();
     w->stitched.release(); w->th_hist.release();
-    if (w->ev_lin) (void)hipEventDestroy(w->ev_lin);
-    if (w->ev_th) (void)hipEventDestroy(w->ev_th); w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
+    w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
     if (w->ad_host) (void)hipHostFree(w->ad_host);
@@ -221,32 +223,40 @@ static int set_precalc(nalo_ctx* c) {
     return NALO_OK;
 }
 
+static int flush_th(nalo_ctx* c);
 static int upload_frame_th(nalo_ctx* c) {
     BAWindow& w = *c->ba;
+    if (w.points_set && w.dev.th_hist_hi) { int rc = flush_th(c); if (rc) return rc; }   // a pending quantile pass also clears its histogram
     std::vector<float> th(w.W);
     for (int i = 0; i < w.W; ++i) th[i] = w.frames[i].frameEnergyTH;
     NALO_HIP(c, w.frameTH.reserve(w.W));
-    NALO_HIP(c, hipStreamSynchronize(c->side));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
     NALO_HIP(c, hipMemcpy(w.frameTH.p, th.data(), w.W * 4, hipMemcpyHostToDevice));
+    w.th_pending = false;
     w.dev.frameTH = w.frameTH.p;
     return NALO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline pieces
+// setNewFrameEnergyTH of the last linearize pass (FullSystemOptimize.cpp:95-143): three small kernels on the main stream. They are launched
+// lazily: after the stitch has been published (so they run while the host solves), or at the latest before the next pass that reads the value.
+static int flush_th(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    if (!w.th_pending) return NALO_OK;
+    ba_launch_energy_th(c->stream, w.dev);
+    w.th_pending = false;
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
 static int linearize_async(nalo_ctx* c, int mode, int fix) {
     BAWindow& w = *c->ba;
-    NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0));           // frameEnergyTH of the previous pass must have landed
+    int rc = flush_th(c); if (rc) return rc;                          // frameEnergyTH of the previous pass feeds this one
     if (fix || mode == 2) NALO_HIP(c, hipMemsetAsync(w.pt_relbs.p, 0, (size_t)w.Ppad * 4, c->stream));
     {
         ProfScope ps(c, "ba_linearize");
         ba_launch_linearize(c->stream, w.dev, mode, fix);
     }
-    if (mode == 0) {                                                   // quantile on the side stream, overlapped with SC / reduce / stitch / solve
-        NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
-        NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
-        ba_launch_energy_th(c->side, w.dev);
-        NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
-    }
+    if (mode == 0) w.th_pending = true;
     w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
@@ -260,7 +270,7 @@ static int sc_async(nalo_ctx* c, int shift, float margScale, int margOnly) {
     return NALO_OK;
 }
 // fp64 finish + stitch of whichever system is not stitched yet; then (optionally) the cross-rank sum and the D2H copy
-static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
+static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to_host = false) {
     BAWindow& w = *c->ba;
     const int n1 = w.n1, NPL = w.NPL, W = w.W;
     const size_t blk = (size_t)n1 * n1;
@@ -273,10 +283,16 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
     {
         ProfScope ps(c, "ba_reduce");
         const bool top = want_top && !w.stitched_top, sc = want_sc && !w.stitched_sc;
+        if ((top || sc) && (th_to_host || w.hook)) {                  // the threshold rides in the tail {TH, 1.0}: compute it before the publish
+            int rc = flush_th(c); if (rc) return rc;
+            ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
+        }
         if (top || sc) {
             // misc {count, energy} per bin lands in the tail of the stitched buffer; without a cross-rank hook step B publishes
             // rows + tail + sequence number straight into host-mapped memory
-            ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.stitched.p + 2 * blk, w.G.p, top, sc);
+            ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.stitched.p + 2 * blk, w.G.p, top, sc,
+                             w.step_sums_deferred ? w.step_partial.p : nullptr, (w.Ppad + 255) / 256, w.stitched.p + 2 * blk + 2 * W * W);
+            w.step_sums_deferred = false;
             if (ba_launch_stitch(c->stream, w.sd, top, sc, (w.hook || sep_publish) ? nullptr : dmap, npub - (int)(2 * blk), seq)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
             if (top) w.stitched_top = true;
             if (sc) w.stitched_sc = true;
@@ -290,19 +306,17 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc) {
             // sharded window: tail = {step sums (3), this rank's frameEnergyTH of the newest frame, 1.0}. After the SUM over ranks the
             // host installs the MEAN of the per-shard 70 % quantiles as the common threshold (every rank then classifies with the
             // same value; the exact global order statistic would need the histograms all-reduced: SURVEY 8e, next round).
-            NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0));
-            ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
             NALO_HIP(c, hipStreamSynchronize(c->stream));
             w.hook(w.hook_user, w.stitched.p, npub);
             ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
             NALO_HIP(c, hipGetLastError());
         } else if (sep_publish) ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
+        { int rc = flush_th(c); if (rc) return rc; }                  // behind the publish: overlaps the host's solve
         if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
         if (w.hook) {
             const double* tl = w.stitched_host + 2 * blk + 2 * W * W + 3;
             if (tl[1] > 1.5) {                                  // more than one rank: install the common threshold
                 const float th = (float)(tl[0] / tl[1]);
-                NALO_HIP(c, hipStreamSynchronize(c->side));
                 NALO_HIP(c, hipMemcpyAsync(w.frameTH.p + (W - 1), &th, 4, hipMemcpyHostToDevice, c->stream));
                 NALO_HIP(c, hipStreamSynchronize(c->stream));
             }
@@ -325,6 +339,11 @@ static int stitch_and_fetch_for_break(nalo_ctx* c) {
     BAWindow& w = *c->ba;
     if (!w.have_sc || w.sc_shift != 1) { int rc = sc_async(c, 1, 1.f, 0); if (rc) return rc; }
     return stitch_and_fetch(c, true, true);
+}
+// frameEnergyTH of the newest frame as published in the tail {sum over ranks, rank count} (stitch_and_fetch with th_to_host)
+static float tail_th(const BAWindow& w) {
+    const double* tl = w.stitched_host + 2 * (size_t)w.n1 * w.n1 + 2 * w.W * w.W + 3;
+    return (float)(tl[0] / tl[1]);
 }
 static void unpack_system(const BAWindow& w, const double* Ht, double* H, double* b) {
     const int n = w.n, n1 = w.n1;
@@ -379,7 +398,7 @@ static void prior_system(const BAWindow& w, double* H, double* b) {         // a
     for (int h = 0; h < w.W; ++h) for (int i = 0; i < 8; ++i) { const int d = 4 + h * 8 + i; H[(size_t)d * n + d] += w.frames[h].prior[i]; b[d] += w.frames[h].prior[i] * w.frames[h].delta_prior[i]; }
 }
 
-static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out) {
+static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out, bool fuse_step = false) {
     BAWindow& w = *c->ba;
     HostTimer ht(c, "ba.solve_system");
     const int W = w.W, n = w.n, n1 = w.n1;
@@ -443,7 +462,11 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     NALO_HIP(c, hipMemcpyAsync(w.xad.p, xc, ((size_t)W * W * 8 + 64) * 4, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, "ba_resub");
-        ba_launch_resub(c->stream, w.dev, w.xad.p + 64, w.xad.p);
+        if (fuse_step) {
+            NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
+            ba_launch_resub_step(c->stream, w.dev, w.xad.p + 64, w.xad.p, 1.f, w.step_partial.p);
+            w.step_fused = true;
+        } else ba_launch_resub(c->stream, w.dev, w.xad.p + 64, w.xad.p);
     }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
@@ -471,7 +494,8 @@ static int do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float fD
     }
     NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
     double* out3 = w.stitched.p + 2 * (size_t)w.n1 * w.n1 + 2 * w.W * w.W;      // scratch tail of the stitched buffer
-    ba_launch_step(c->stream, w.dev, fD, w.step_partial.p, out3);
+    if (w.step_fused) { w.step_fused = false; w.step_sums_deferred = true; }     // points already stepped by solve_system (fD = 1); sums follow with the reduce
+    else ba_launch_step(c->stream, w.dev, fD, w.step_partial.p, out3);
     int rc = set_precalc(c);
     if (rc) return rc;
     sumA /= w.W; sumB /= w.W; sumR /= w.W; sumT /= w.W;
@@ -527,7 +551,6 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
         w.dev.img[i] = c->slots[s.slot].dI[0];
     }
     w.dev.W = W; w.dev.w = c->w; w.dev.h = c->h;
-    if (!w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming)); NALO_HIP(c, hipEventRecord(w.ev_th, c->side)); }
     NALO_HIP(c, w.th_hist.reserve(2 * 65536 + 16)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, (2 * 65536 + 16) * 4));
     w.dev.th_hist_hi = w.th_hist.p; w.dev.th_hist_lo = w.th_hist.p + 65536; w.dev.th_state = w.th_hist.p + 2 * 65536;
     if (w.HM.size() != (size_t)w.n * w.n) { w.HM.assign((size_t)w.n * w.n, 0.0); w.bM.assign(w.n, 0.0); }
@@ -676,9 +699,8 @@ int nalo_ba_get_prior(nalo_ctx* c, double* HM, double* bM) {
 int nalo_ba_linearize(nalo_ctx* c, int fix, double* energy) {
     NALO_BA_READY("nalo_ba_linearize")
     int rc = linearize_async(c, 0, fix); if (rc) return rc;
-    rc = stitch_and_fetch(c, true, false); if (rc) return rc;
-    NALO_HIP(c, hipStreamSynchronize(c->side));
-    NALO_HIP(c, hipMemcpy(&w.frames[w.W - 1].frameEnergyTH, w.frameTH.p + (w.W - 1), 4, hipMemcpyDeviceToHost));
+    rc = stitch_and_fetch(c, true, false, true); if (rc) return rc;
+    w.frames[w.W - 1].frameEnergyTH = tail_th(w);
     double e = 0; misc_totals(w, &e, &w.resInA);
     if (energy) *energy = e;
     return NALO_OK;
@@ -726,7 +748,7 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
     double lambda = 1e-1;
     for (int it = 0; it < mnumOptIts; ++it) {
         backup_state(w);                                                    // :482
-        rc = solve_system(c, it, lambda, nullptr); if (rc) return rc;       // :485
+        rc = solve_system(c, it, lambda, nullptr, true); if (rc) return rc; // :485 (+ the point part of doStepFromBackup)
         rc = do_step(c, 1, 1, 1, 1, 1, nullptr); if (rc) return rc;         // :501 (stepsize 1: no SOLVER_STEPMOMENTUM)
         rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :511, accepted unconditionally (:519-532)
         lambda *= 0.25;
@@ -745,9 +767,8 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
     rc = set_adjoints(c); if (rc) return rc;
     rc = set_precalc(c); if (rc) return rc;
     rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
-    rc = stitch_and_fetch(c, true, false); if (rc) return rc;
-    NALO_HIP(c, hipStreamSynchronize(c->side));
-    NALO_HIP(c, hipMemcpy(&nf.frameEnergyTH, w.frameTH.p + (W - 1), 4, hipMemcpyDeviceToHost));
+    rc = stitch_and_fetch(c, true, false, true); if (rc) return rc;
+    nf.frameEnergyTH = tail_th(w);
     double e = 0; int nres = 0; misc_totals(w, &e, &nres);
     // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)
     if (rmse) *rmse = std::sqrt((float)(e / (kPatternNum * (double)w.resInA)));

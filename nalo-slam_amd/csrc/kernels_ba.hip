@@ -183,7 +183,8 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 // Lane groups stride over the host's blocks and are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
                                                          const int* __restrict__ host_blk /* [W+1] */, int W, int NPL2, int sc_tiles, int mask, int KS,
-                                                         double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G) {
+                                                         double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G,
+                                                         const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out) {
     __shared__ double part[16][64];
     __shared__ double sums[128];
     if ((int)blockIdx.x < W * W) {
@@ -209,6 +210,15 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
         if (threadIdx.x == 0) { misc[2 * (h + t * W)] = sums[91]; misc[2 * (h + t * W) + 1] = sums[92]; }
         return;
     }
+    if ((int)blockIdx.x == W * W + W * sc_tiles) {             // the deferred sums of doStepFromBackup's break test ride along (optimize())
+        const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+        double s = 0;
+        if (j < 3) for (int b = g; b < step_blocks; b += 16) s += (double)step_partial[(size_t)b * 4 + j];
+        part[g][j] = s;
+        __syncthreads();
+        if (g == 0 && j < 3) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; step_out[j] = t; }
+        return;
+    }
     if (!(mask & 2)) return;
     const int q = blockIdx.x - W * W, h = q / sc_tiles, tile = q - h * sc_tiles;
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6, e = tile * 64 + j;
@@ -218,9 +228,11 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
     __syncthreads();
     if (g == 0 && e < NPL2) { double tt = 0; for (int k = 0; k < 16; ++k) tt += part[k][j]; G[(size_t)h * NPL2 + e] = tt; }
 }
-void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc) {
+void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
+                      const float* step_partial, int step_blocks, double* step_out) {
     const int tiles = (NPL * NPL + 63) / 64;
-    ba_reduce_kernel<<<B.W * B.W + B.W * tiles, 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0), B.sc_split, acc13, misc, G);
+    ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
+                                                                                       B.sc_split, acc13, misc, G, step_partial, step_blocks, step_out);
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)
@@ -472,24 +484,41 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
 
 // ------------------------------------------------------------------------------------------------ a12 + step
 // xAd: [W*W][8] index h*W + t (EnergyFunctional.cpp:270-280), xc: cstep(4)
-__global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __restrict__ xAd, const float* __restrict__ xc) {
+// STEP: optimize() applies the step right away (stepfacD; FullSystemOptimize.cpp:271-276) and leaves the block sums {step^2, |idepth_backup|, count}
+// for the break test in `partial` - one launch instead of resubstitute, doStep and a sum kernel.
+template <bool STEP>
+__global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __restrict__ xAd, const float* __restrict__ xc, float stepfacD, float* __restrict__ partial) {
+    __shared__ float smem[64 * 4];
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= B.Ppad) return;
-    if (!(B.pt_flags[d] & PT_VALID)) return;
-    const int h = B.blk_host[d / kBlk], W = B.W;
-    if (B.pt_ngood[d] == 0) { B.pt_step[d] = 0.f; return; }
-    const float4 pa = B.pt_acc[d], hc = B.pt_hcd[d];
-    float bsum = pa.w;
-    bsum -= xc[0] * hc.x + xc[1] * hc.y + xc[2] * hc.z + xc[3] * hc.w;
-    for (int t = 0; t < W; ++t) {
-        if (t == h) continue;
-        const size_t si = (size_t)t * B.Ppad + d;
-        if (!(B.rs_state[si] & RS_ACTIVE)) continue;
-        const float4 j0 = B.rs_jp0[si], j1 = B.rs_jp1[si];
-        const float* xa = xAd + (size_t)(h * W + t) * 8;
-        bsum -= xa[0] * j0.x + xa[1] * j0.y + xa[2] * j0.z + xa[3] * j0.w + xa[4] * j1.x + xa[5] * j1.y + xa[6] * j1.z + xa[7] * j1.w;
+    float v[3] = {0.f, 0.f, 0.f};
+    if (d < B.Ppad && (B.pt_flags[d] & PT_VALID)) {
+        const int h = B.blk_host[d / kBlk], W = B.W;
+        float stp = 0.f;
+        if (B.pt_ngood[d] != 0) {
+            const float4 pa = B.pt_acc[d], hc = B.pt_hcd[d];
+            float bsum = pa.w;
+            bsum -= xc[0] * hc.x + xc[1] * hc.y + xc[2] * hc.z + xc[3] * hc.w;
+            for (int t = 0; t < W; ++t) {
+                if (t == h) continue;
+                const size_t si = (size_t)t * B.Ppad + d;
+                if (!(B.rs_state[si] & RS_ACTIVE)) continue;
+                const float4 j0 = B.rs_jp0[si], j1 = B.rs_jp1[si];
+                const float* xa = xAd + (size_t)(h * W + t) * 8;
+                bsum -= xa[0] * j0.x + xa[1] * j0.y + xa[2] * j0.z + xa[3] * j0.w + xa[4] * j1.x + xa[5] * j1.y + xa[6] * j1.z + xa[7] * j1.w;
+            }
+            stp = -bsum * pa.z;
+        }
+        B.pt_step[d] = stp;
+        if (STEP) {
+            float4 geo = B.pt_geo[d];
+            const float idb = geo.z;
+            B.pt_backup[d] = idb;
+            geo.z = idb + stepfacD * stp; geo.w = geo.z;
+            B.pt_geo[d] = geo;
+            v[0] = stp * stp; v[1] = fabsf(idb); v[2] = 1.f;
+        }
     }
-    B.pt_step[d] = -bsum * pa.z;
+    if (STEP) block_reduce_cols<3, 256>(v, smem, partial + (size_t)blockIdx.x * 4);
 }
 // idepth = idepth_backup + stepfacD*step; idepth_zero = idepth (FullSystemOptimize.cpp:271-276). sums: {step^2, |idepth_backup|, count}
 __global__ __launch_bounds__(256) void ba_step_kernel(BADev B, float stepfacD, float* __restrict__ partial /* [blocks][4] */) {
@@ -529,7 +558,10 @@ void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int
     ba_publish_kernel<<<1, 1024, 0, s>>>(src, dst_mapped, n, seq);
 }
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc) {
-    ba_resub_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc);
+    ba_resub_kernel<false><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, 0.f, nullptr);
+}
+void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial) {
+    ba_resub_kernel<true><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, stepfacD, partial);
 }
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3) {
     const int nb = (B.Ppad + 255) / 256;
