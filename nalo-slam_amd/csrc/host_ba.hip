@@ -434,6 +434,9 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     }
     for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * n + i] + 10);
     for (int i = 0; i < n; ++i) { double* hf = HF + (size_t)i * n; const double si = sv[i]; for (int j = 0; j < n; ++j) hf[j] = si * hf[j] * sv[j]; bF[i] *= si; }
+    // Eigen's LDLT (the reference, :880) reads the lower triangle only; H_sc carries fp32-rounding asymmetry (w*a_j*a_k vs w*a_k*a_j), so mirror
+    // the lower triangle before the full-storage factorisation
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) HF[(size_t)i * n + j] = HF[(size_t)j * n + i];
     ldlt_solve_inplace(n, HF, bF, x.data(), yv, w.solve_perm.data());
     for (int i = 0; i < n; ++i) x[i] *= sv[i];
     if (iteration >= 2) {                                                   // SOLVER_ORTHOGONALIZE_X_LATER (:898-902)
