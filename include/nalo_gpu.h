@@ -196,8 +196,36 @@ int nalo_dense_make_map(nalo_ctx* ctx, int slot, const float plane[4], float mas
                         uint8_t* out_bgr, int* n, int* accept);
 
 /* ------------------------------------------------------------------------------------------------
+ * the immature-point depth filter and point activation that run either side of the BA.
+ * Point state is caller-owned (the reference keeps it in ImmaturePoint objects): arrays of n points in, updated arrays out.
+ * color/weights are [n][8] (pattern order), gradH is [n][3] = {xx, xy, yy}.
+ *
+ * nalo_imm_create    ImmaturePoint::ImmaturePoint (FullSystem/ImmaturePoint.cpp:32-60), call site FullSystem::makeNewTraces
+ *                    (FullSystem.cpp:1596-1625): color, weights, gradH, energyTH (NaN = point rejected) from the host frame's slot.
+ * nalo_imm_trace     ImmaturePoint::traceOn (ImmaturePoint.cpp:76-435) for every immature point of every host against the frame in
+ *                    slot_new, replaces the loops of FullSystem::traceNewCoarse (FullSystem.cpp:702-744), which computes per host
+ *                    KRKi = K R K^-1 (row-major 3x3), Kt = K t and the affine pair (AffLight::fromToVecExposure): pass them as [nh][9],
+ *                    [nh][3], [nh][2] with host_idx[n] selecting the host of each point.
+ *                    In/out: idepth_min, idepth_max, status (ImmaturePointStatus: 0 GOOD, 1 OOB, 2 OUTLIER, 3 SKIPPED, 4 BADCONDITION,
+ *                    5 UNINITIALIZED), quality. Out: lastTraceUV [n][2], lastTracePixelInterval [n].
+ * nalo_imm_optimize  FullSystem::optimizeImmaturePoint (FullSystem/FullSystemOptPoint.cpp:51-206) incl. ImmaturePoint::linearizeResidual
+ *                    (ImmaturePoint.cpp:497-564), call site FullSystem::activatePointsMT_Reductor (FullSystem.cpp:748-762). Uses the
+ *                    frames, current states (PRE_RTll / PRE_tTll / PRE_aff_mode) and calibration of the window set by nalo_ba_set_window;
+ *                    host[n] = window index of each point's host frame.
+ *                    result[n]: 0 = not well constrained (the point stays immature), -1 = drop the point, 1 = activated with
+ *                    idepth_out[n]; res_in[n][W] = 1 where a PointFrameResidual is created (state IN).
+ * ------------------------------------------------------------------------------------------------ */
+int nalo_imm_create(nalo_ctx* ctx, int slot_host, int n, const int* u, const int* v, float* color, float* weights, float* gradH, float* energyTH);
+int nalo_imm_trace(nalo_ctx* ctx, int slot_new, int n, const float* u, const float* v, const float* color, const float* weights, const float* gradH,
+                   const float* energyTH, const int* host_idx, int nh, const float* KRKi, const float* Kt, const float* aff,
+                   float* idepth_min, float* idepth_max, int* status, float* quality, float* lastTraceUV, float* lastTracePixelInterval);
+int nalo_imm_optimize(nalo_ctx* ctx, int n, const int* host, const float* u, const float* v, const float* color, const float* weights,
+                      const float* energyTH, const float* idepth_min, const float* idepth_max, int minObs,
+                      int* result, float* idepth_out, uint8_t* res_in);
+
+/* ------------------------------------------------------------------------------------------------
  * Profiling: per-kernel HIP-event timing on the ctx stream. Names: "trk_eval", "ba_linearize",
- * "ba_sc", "ba_reduce", "ba_resub", "pyramid". Enable, run, then query (sync inside).
+ * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize". Enable, run, then query (sync inside).
  * ------------------------------------------------------------------------------------------------ */
 int nalo_profile_enable(nalo_ctx* ctx, int on);
 int nalo_profile_reset(nalo_ctx* ctx);

@@ -32,6 +32,7 @@ EXPORTS = [
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_snapshot", "nalo_ba_restore",
+    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
 ]
 
@@ -89,6 +90,9 @@ def load():
     L.nalo_ba_counts.argtypes = [vp, c_ip, c_ip, c_ip]
     L.nalo_ba_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     L.nalo_ba_snapshot.argtypes = [vp]
+    L.nalo_imm_create.argtypes = [vp, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
+    L.nalo_imm_trace.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
+    L.nalo_imm_optimize.argtypes = [vp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_u8p]
     L.nalo_ba_restore.argtypes = [vp]
     L.nalo_dense_make_map.argtypes = [vp, C.c_int, c_fp, C.c_float, c_dp, C.c_int, c_ip, c_ip, c_ip, c_fp, c_fp, c_u8p, c_ip, c_ip]
     L.nalo_profile_enable.argtypes = [vp, C.c_int]
@@ -322,6 +326,36 @@ class Context:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._ck(self.L.nalo_ba_counts(self.h_, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    # ---- immature points
+    def imm_create(self, slot_host, u, v):
+        n = len(u)
+        ui, vi = np.ascontiguousarray(u, np.int32), np.ascontiguousarray(v, np.int32)
+        color, weights, gradH, eth = np.zeros((n, 8), np.float32), np.zeros((n, 8), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+        self._ck(self.L.nalo_imm_create(self.h_, slot_host, n, _i(ui), _i(vi), _f(color), _f(weights), _f(gradH), _f(eth)))
+        return color, weights, gradH, eth
+
+    def imm_trace(self, slot_new, u, v, color, weights, gradH, energyTH, host_idx, KRKi, Kt, aff, idmin, idmax, status, quality):
+        n = len(u)
+        f = lambda a: np.ascontiguousarray(a, np.float32).copy()
+        idmin, idmax, quality = f(idmin), f(idmax), f(quality)
+        status = np.ascontiguousarray(status, np.int32).copy()
+        uv, li = np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+        hi = np.ascontiguousarray(host_idx, np.int32)
+        a = [f(x) for x in (u, v, color, weights, gradH, energyTH)]
+        k = [f(x) for x in (KRKi, Kt, aff)]
+        self._ck(self.L.nalo_imm_trace(self.h_, slot_new, n, *[_f(x) for x in a], _i(hi), len(k[0].reshape(-1, 9)), *[_f(x) for x in k],
+                                       _f(idmin), _f(idmax), _i(status), _f(quality), _f(uv), _f(li)))
+        return idmin, idmax, status, quality, uv, li
+
+    def imm_optimize(self, host, u, v, color, weights, energyTH, idmin, idmax, min_obs):
+        n = len(u)
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        a = [f(x) for x in (u, v, color, weights, energyTH, idmin, idmax)]
+        hi = np.ascontiguousarray(host, np.int32)
+        res, idp, rin = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, self.W), np.uint8)
+        self._ck(self.L.nalo_imm_optimize(self.h_, n, _i(hi), *[_f(x) for x in a], int(min_obs), _i(res), _f(idp), _u8(rin)))
+        return res, idp, rin
 
     def ba_snapshot(self):
         self._ck(self.L.nalo_ba_snapshot(self.h_))

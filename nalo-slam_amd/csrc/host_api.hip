@@ -69,6 +69,8 @@ void nalo_destroy(nalo_ctx* c) {
     c->trk_partial.release(); c->trk_out.release(); c->lm_partial.release(); c->scan_tmp.release(); c->upload_tmp.release();
     if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
     if (c->pinned_f) (void)hipHostFree(c->pinned_f);
+    if (c->imm_host) (void)hipHostFree(c->imm_host);
+    c->imm_dev.release();
     for (auto& kv : c->prof) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -132,6 +134,8 @@ static int upload4(nalo_ctx* c, int n, const float* a, const float* b, const flo
     NALO_HIP(c, c->upload_tmp.reserve((size_t)4 * n + 256));
     if (c->pinned_f_cap < (size_t)4 * n) {
         if (c->pinned_f) (void)hipHostFree(c->pinned_f);
+    if (c->imm_host) (void)hipHostFree(c->imm_host);
+    c->imm_dev.release();
         c->pinned_f = nullptr; c->pinned_f_cap = 0;
         NALO_HIP(c, hipHostMalloc((void**)&c->pinned_f, (size_t)4 * n * 4 + 1024));
         c->pinned_f_cap = (size_t)4 * n + 256;
@@ -323,6 +327,60 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
     if (!good) { *ok = 0; return NALO_OK; }
     std::memcpy(T_io, cur.m, sizeof(cur.m)); aff_io[0] = aff_cur[0]; aff_io[1] = aff_cur[1];
     *ok = !(std::fabs((float)aff_io[0]) > 1.2f || std::fabs((float)aff_io[1]) > 200.f);   // :1243-1245 (affineOptMode != 0)
+    return NALO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ immature points
+int nalo_imm_create(nalo_ctx* c, int slot_host, int n, const int* u, const int* v, float* color, float* weights, float* gradH, float* energyTH) {
+    if (!c || n < 0 || (n > 0 && (!u || !v || !color || !weights || !gradH || !energyTH))) return fail(c, NALO_ERR_ARG, "nalo_imm_create: bad argument");
+    if (slot_host < 0 || slot_host >= (int)c->slots.size() || !c->slots[slot_host].valid) return fail(c, NALO_ERR_STATE, "nalo_imm_create: host slot has no pyramid");
+    if (n == 0) return NALO_OK;
+    NALO_HIP(c, hipSetDevice(c->device));
+    for (int i = 0; i < n; ++i) if (u[i] < 2 || v[i] < 2 || u[i] >= c->w - 3 || v[i] >= c->h - 3) return fail(c, NALO_ERR_ARG, "nalo_imm_create: pattern leaves the image");
+    // words: u(n) v(n) | color(8n) weights(8n) gradH(3n) energyTH(n)
+    const size_t N = (size_t)n;
+    int rc = imm_stage(c, 22 * N); if (rc) return rc;
+    std::memcpy(c->imm_host, u, N * 4); std::memcpy(c->imm_host + N, v, N * 4);
+    float* d = c->imm_dev.p;
+    NALO_HIP(c, hipMemcpyAsync(d, c->imm_host, 2 * N * 4, hipMemcpyHostToDevice, c->stream));
+    rc = imm_create_launch(c, c->slots[slot_host].dI[0], n, (const int*)d, (const int*)(d + N), d + 2 * N, d + 10 * N, d + 18 * N, d + 21 * N);
+    if (rc) return rc;
+    NALO_HIP(c, hipMemcpyAsync(c->imm_host + 2 * N, d + 2 * N, 20 * N * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(color, c->imm_host + 2 * N, 8 * N * 4); std::memcpy(weights, c->imm_host + 10 * N, 8 * N * 4);
+    std::memcpy(gradH, c->imm_host + 18 * N, 3 * N * 4); std::memcpy(energyTH, c->imm_host + 21 * N, N * 4);
+    return NALO_OK;
+}
+
+int nalo_imm_trace(nalo_ctx* c, int slot_new, int n, const float* u, const float* v, const float* color, const float* weights, const float* gradH,
+                   const float* energyTH, const int* host_idx, int nh, const float* KRKi, const float* Kt, const float* aff,
+                   float* idepth_min, float* idepth_max, int* status, float* quality, float* lastTraceUV, float* lastTracePixelInterval) {
+    if (!c || n < 0 || nh < 0 || (n > 0 && (!u || !v || !color || !weights || !gradH || !energyTH || !host_idx || !KRKi || !Kt || !aff || !idepth_min || !idepth_max ||
+                                             !status || !quality || !lastTraceUV || !lastTracePixelInterval)))
+        return fail(c, NALO_ERR_ARG, "nalo_imm_trace: bad argument");
+    if (slot_new < 0 || slot_new >= (int)c->slots.size() || !c->slots[slot_new].valid) return fail(c, NALO_ERR_STATE, "nalo_imm_trace: frame slot has no pyramid");
+    if (n == 0) return NALO_OK;
+    for (int i = 0; i < n; ++i) if (host_idx[i] < 0 || host_idx[i] >= nh) return fail(c, NALO_ERR_ARG, "nalo_imm_trace: host_idx out of range");
+    NALO_HIP(c, hipSetDevice(c->device));
+    HostTimer ht(c, "imm_trace");
+    // words: [0,22n) u v color weights gradH energyTH | [22n,23n) host_idx | [23n,30n) idmin idmax status quality lastUV(2) lastInterval | [30n, +14nh) KRKi Kt aff
+    const size_t N = (size_t)n, H = (size_t)nh;
+    int rc = imm_stage(c, 30 * N + 14 * H); if (rc) return rc;
+    float* hst = c->imm_host;
+    std::memcpy(hst, u, N * 4); std::memcpy(hst + N, v, N * 4); std::memcpy(hst + 2 * N, color, 8 * N * 4); std::memcpy(hst + 10 * N, weights, 8 * N * 4);
+    std::memcpy(hst + 18 * N, gradH, 3 * N * 4); std::memcpy(hst + 21 * N, energyTH, N * 4); std::memcpy(hst + 22 * N, host_idx, N * 4);
+    std::memcpy(hst + 23 * N, idepth_min, N * 4); std::memcpy(hst + 24 * N, idepth_max, N * 4); std::memcpy(hst + 25 * N, status, N * 4); std::memcpy(hst + 26 * N, quality, N * 4);
+    std::memcpy(hst + 27 * N, lastTraceUV, 2 * N * 4); std::memcpy(hst + 29 * N, lastTracePixelInterval, N * 4);     // untouched entries keep the caller's values
+    std::memcpy(hst + 30 * N, KRKi, 9 * H * 4); std::memcpy(hst + 30 * N + 9 * H, Kt, 3 * H * 4); std::memcpy(hst + 30 * N + 12 * H, aff, 2 * H * 4);
+    float* d = c->imm_dev.p;
+    NALO_HIP(c, hipMemcpyAsync(d, hst, (30 * N + 14 * H) * 4, hipMemcpyHostToDevice, c->stream));
+    rc = imm_trace_launch(c, c->slots[slot_new].dI[0], n, d, (const int*)(d + 22 * N), d + 30 * N, d + 30 * N + 9 * H, d + 30 * N + 12 * H,
+                          d + 23 * N, d + 24 * N, (int*)(d + 25 * N), d + 26 * N, d + 27 * N, d + 29 * N);
+    if (rc) return rc;
+    NALO_HIP(c, hipMemcpyAsync(hst + 23 * N, d + 23 * N, 7 * N * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(idepth_min, hst + 23 * N, N * 4); std::memcpy(idepth_max, hst + 24 * N, N * 4); std::memcpy(status, hst + 25 * N, N * 4); std::memcpy(quality, hst + 26 * N, N * 4);
+    std::memcpy(lastTraceUV, hst + 27 * N, 2 * N * 4); std::memcpy(lastTracePixelInterval, hst + 29 * N, N * 4);
     return NALO_OK;
 }
 

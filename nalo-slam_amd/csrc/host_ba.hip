@@ -883,6 +883,45 @@ int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
     return NALO_OK;
 }
 
+// FullSystem::optimizeImmaturePoint for a batch of immature points against the current window (FullSystemOptPoint.cpp:51-206)
+int nalo_imm_optimize(nalo_ctx* c, int n, const int* host, const float* u, const float* v, const float* color, const float* weights,
+                      const float* energyTH, const float* idepth_min, const float* idepth_max, int minObs, int* result, float* idepth_out, uint8_t* res_in) {
+    if (!c || !c->ba || c->ba->W < 2) return fail(c, NALO_ERR_STATE, "nalo_imm_optimize: set the window first (nalo_ba_set_window)");
+    if (n < 0 || (n > 0 && (!host || !u || !v || !color || !weights || !energyTH || !idepth_min || !idepth_max || !result || !idepth_out || !res_in)))
+        return fail(c, NALO_ERR_ARG, "nalo_imm_optimize: bad argument");
+    if (n == 0) return NALO_OK;
+    BAWindow& w = *c->ba;
+    const int W = w.W;
+    for (int i = 0; i < n; ++i) if (host[i] < 0 || host[i] >= W) return fail(c, NALO_ERR_ARG, "nalo_imm_optimize: host out of range");
+    NALO_HIP(c, hipSetDevice(c->device));
+    HostTimer ht(c, "imm_optimize");
+    // words: [0,21n) u v color weights energyTH idmin idmax | [21n,22n) host | [22n, +14 W^2) Rt aff | outputs: result(n) idepth(n) res_in(n*W bytes)
+    const size_t N = (size_t)n, PW = (size_t)W * W, out0 = 22 * N + 14 * PW, outw = 2 * N + (N * W + 3) / 4;
+    int rc = imm_stage(c, out0 + outw); if (rc) return rc;
+    float* hst = c->imm_host;
+    std::memcpy(hst, u, N * 4); std::memcpy(hst + N, v, N * 4); std::memcpy(hst + 2 * N, color, 8 * N * 4); std::memcpy(hst + 10 * N, weights, 8 * N * 4);
+    std::memcpy(hst + 18 * N, energyTH, N * 4); std::memcpy(hst + 19 * N, idepth_min, N * 4); std::memcpy(hst + 20 * N, idepth_max, N * 4); std::memcpy(hst + 21 * N, host, N * 4);
+    float* Rt = hst + 22 * N; float* af = Rt + 12 * PW;
+    for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {               // FrameFramePrecalc::set (HessianBlocks.cpp:203-221) at the current states
+        const HostFrame &hf = w.frames[h], &tf = w.frames[t];
+        const SE3 ll = tf.PRE_worldToCam * hf.PRE_camToWorld;
+        float* o = Rt + (size_t)(h * W + t) * 12;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[i * 3 + j] = (float)ll.R(i, j); o[9 + i] = (float)ll.t(i); }
+        double a[2];
+        aff_from_to(hf.ab_exposure, tf.ab_exposure, hf.state_scaled[6], hf.state_scaled[7], tf.state_scaled[6], tf.state_scaled[7], a);
+        af[(h * W + t) * 2] = (float)a[0]; af[(h * W + t) * 2 + 1] = (float)a[1];
+    }
+    float* d = c->imm_dev.p;
+    NALO_HIP(c, hipMemcpyAsync(d, hst, out0 * 4, hipMemcpyHostToDevice, c->stream));
+    const float K[4] = {w.c_scaledf[0], w.c_scaledf[1], w.c_scaledf[2], w.c_scaledf[3]};
+    rc = imm_optimize_launch(c, w.dev.img, W, K, d + 22 * N, d + 22 * N + 12 * PW, n, (const int*)(d + 21 * N), d, minObs, (int*)(d + out0), d + out0 + N, (uint8_t*)(d + out0 + 2 * N));
+    if (rc) return rc;
+    NALO_HIP(c, hipMemcpyAsync(hst + out0, d + out0, outw * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(result, hst + out0, N * 4); std::memcpy(idepth_out, hst + out0 + N, N * 4); std::memcpy(res_in, hst + out0 + 2 * N, N * W);
+    return NALO_OK;
+}
+
 int nalo_ba_snapshot(nalo_ctx* c) {
     NALO_BA_READY("nalo_ba_snapshot")
     const size_t N = w.Ppad, NS = (size_t)w.W * N;

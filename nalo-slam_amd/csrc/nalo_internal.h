@@ -78,6 +78,7 @@ struct nalo_ctx {
     nalo::DevBuf<int> scan_tmp;              // compaction counts
     nalo::DevBuf<float> upload_tmp;
     float* pinned_f = nullptr; size_t pinned_f_cap = 0;
+    float* imm_host = nullptr; nalo::DevBuf<float> imm_dev; size_t imm_cap = 0;   // immature-point staging (pinned / device)
 
     // ---- BA (opaque; defined in host_ba.cpp)
     nalo::BAWindow* ba = nullptr;
@@ -130,6 +131,14 @@ struct ProfScope {               // HIP-event bracket on the ctx stream (only wh
     }
 };
 
+// kernels_imm.hip
+int imm_create_launch(nalo_ctx* c, const float4* dI, int n, const int* u, const int* v, float* color, float* weights, float* gradH, float* energyTH);
+int imm_trace_launch(nalo_ctx* c, const float4* dI, int n, const float* base, const int* host_idx, const float* KRKi, const float* Kt, const float* aff,
+                     float* idmin, float* idmax, int* status, float* quality, float* lastUV, float* lastInterval);
+int imm_optimize_launch(nalo_ctx* c, const float4* const* dI, int W, const float K[4], const float* Rt, const float* aff, int n, const int* host, const float* base,
+                        int minObs, int* result, float* idepth_out, uint8_t* res_in);
+// staging for the immature-point entry points: pinned host block + device block of `floats` 4-byte words (grown on demand)
+int imm_stage(nalo_ctx* c, size_t words);
 // kernels_pyramid.hip
 int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
 // kernels_tracker.hip

@@ -110,6 +110,10 @@ def lib(kind="f32"):
     L.orc_ba_counts.argtypes = [C.c_void_p, C.c_int]
     L.orc_ba_counts.restype = C.c_int
     L.orc_ba_set_idepth.argtypes = [C.c_void_p, c_fp]
+    L.orc_ba_get_precalc_rt.argtypes = [C.c_void_p, c_fp, c_fp]
+    L.orc_imm_create.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
+    L.orc_imm_trace.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
+    L.orc_imm_optimize.argtypes = [C.c_int, C.POINTER(c_fp), C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_u8p]
     L.orc_dense_bbox.argtypes = [c_fp, C.c_int, C.c_int, C.c_float, c_ip]
     L.orc_dense_make_map.argtypes = [c_fp, c_fp, c_u8p, C.c_int, C.c_int, c_fp, C.c_float, c_ip, C.c_float, C.c_float,
                                      C.c_float, C.c_float, c_dp, c_ip, c_ip, c_fp, c_fp, c_u8p, c_ip]
@@ -158,6 +162,44 @@ def make_images(img, levels, kind="f32"):
     ab = np.zeros(tot, np.float32)
     L.orc_make_images(fp(np.ascontiguousarray(img, np.float32)), w, h, levels, None, fp(dI), fp(ab))
     return dI, ab
+
+
+# ------------------------------------------------------------------ immature points
+def imm_create(dI_host, w, h, u, v, kind="f32"):
+    """ImmaturePoint ctor for n integer pixel positions. dI_host: [w*h,3] level-0 texels. -> color[n,8], weights[n,8], gradH[n,3], energyTH[n]"""
+    n = len(u)
+    color, weights, gradH, eth = np.zeros((n, 8), np.float32), np.zeros((n, 8), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    ui, vi = np.ascontiguousarray(u, np.int32), np.ascontiguousarray(v, np.int32)
+    lib(kind).orc_imm_create(fp(np.ascontiguousarray(dI_host, np.float32)), w, h, n, ip(ui), ip(vi), fp(color), fp(weights), fp(gradH), fp(eth))
+    return color, weights, gradH, eth
+
+
+def imm_trace(dI_new, w, h, u, v, color, weights, gradH, energyTH, host_idx, KRKi, Kt, aff, idmin, idmax, status, quality, kind="f32"):
+    """traceOn for every point (in/out arrays are copied). -> idmin, idmax, status, quality, lastUV[n,2], lastInterval[n]"""
+    n = len(u)
+    f = lambda a: np.ascontiguousarray(a, np.float32).copy()
+    idmin, idmax, quality = f(idmin), f(idmax), f(quality)
+    status = np.ascontiguousarray(status, np.int32).copy()
+    uv, li = np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+    hi = np.ascontiguousarray(host_idx, np.int32)
+    a = [f(x) for x in (u, v, color, weights, gradH, energyTH)]
+    k = [f(x) for x in (KRKi, Kt, aff)]
+    lib(kind).orc_imm_trace(fp(np.ascontiguousarray(dI_new, np.float32)), w, h, n, *[fp(x) for x in a], ip(hi), *[fp(x) for x in k],
+                            fp(idmin), fp(idmax), ip(status), fp(quality), fp(uv), fp(li))
+    return idmin, idmax, status, quality, uv, li
+
+
+def imm_optimize(dI_list, w, h, K, Rt, aff, host, u, v, color, weights, energyTH, idmin, idmax, min_obs, kind="f32"):
+    """optimizeImmaturePoint for every point. dI_list: level-0 texels of the W window frames. -> result[n], idepth[n], res_in[n,W]"""
+    W, n = len(dI_list), len(u)
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    imgs = [f(d) for d in dI_list]
+    arr = (c_fp * W)(*[fp(d) for d in imgs])
+    res, idp, rin = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, W), np.uint8)
+    a = [f(x) for x in (u, v, color, weights, energyTH, idmin, idmax)]
+    Kf, Rtf, aff_f, hi = f(K), f(Rt), f(aff), np.ascontiguousarray(host, np.int32)
+    lib(kind).orc_imm_optimize(W, arr, w, h, fp(Kf), fp(Rtf), fp(aff_f), n, ip(hi), *[fp(x) for x in a], int(min_obs), ip(res), fp(idp), u8p(rin))
+    return res, idp, rin
 
 
 class Tracker:
@@ -333,6 +375,12 @@ class BA:
         o = np.zeros((self.W * self.W, 32), np.float32)
         self.L.orc_ba_get_precalc(self.h_, fp(o))
         return o
+
+    def precalc_rt(self):
+        """PRE_RTll | PRE_tTll [W*W,12] and PRE_aff_mode [W*W,2] of the current states (index host*W + target)"""
+        rt, af = np.zeros((self.W * self.W, 12), np.float32), np.zeros((self.W * self.W, 2), np.float32)
+        self.L.orc_ba_get_precalc_rt(self.h_, fp(rt), fp(af))
+        return rt, af
 
     def adjoints(self):
         n = self.W * self.W

@@ -751,6 +751,10 @@ void orc_ba_get_precalc(OrcBA* ba, float* out /*[W*W][32]*/) {
         memcpy(o,pc->PRE_KRKiTll,36); memcpy(o+9,pc->PRE_KtTll,12); memcpy(o+12,pc->PRE_RTll_0,36); memcpy(o+21,pc->PRE_tTll_0,12);
         o[24]=pc->PRE_aff_mode[0]; o[25]=pc->PRE_aff_mode[1]; o[26]=pc->PRE_b0_mode; }
 }
+/* PRE_RTll | PRE_tTll of the current states (FrameFramePrecalc::set, HessianBlocks.cpp:203-209): what ImmaturePoint::linearizeResidual projects with */
+void orc_ba_get_precalc_rt(OrcBA* ba, float* out /*[W*W][12]*/, float* aff /*[W*W][2]*/) {
+    for (int i=0;i<ba->W*ba->W;i++) { const OrcPrecalc* pc=&ba->pre[i]; memcpy(out+i*12,pc->PRE_RTll,36); memcpy(out+i*12+9,pc->PRE_tTll,12); aff[i*2]=pc->PRE_aff_mode[0]; aff[i*2+1]=pc->PRE_aff_mode[1]; }
+}
 void orc_ba_get_adjoints(OrcBA* ba, double* adHost, double* adTarget, float* adHTdeltaF) {
     int n=ba->W*ba->W; if (adHost) memcpy(adHost,ba->adHost,8*64*n); if (adTarget) memcpy(adTarget,ba->adTarget,8*64*n); if (adHTdeltaF) memcpy(adHTdeltaF,ba->adHTdeltaF,4*8*n);
 }

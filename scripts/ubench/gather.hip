@@ -1,0 +1,81 @@
+// Micro-benchmark for the texel-gather layout of ba_linearize: how fast can gfx950 serve 32 x 16-byte bilinear taps per residual
+//   A: one residual per lane, the 8 pattern pixels in a loop (the current kernel's layout)
+//   B: one pattern pixel per lane, 8 lanes per residual (neighbouring lanes touch neighbouring texels)
+// Points are Morton-sorted inside each host frame, like the BA window. Prints microseconds per pass and effective TB/s of taps.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+__constant__ int pat[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};
+
+__global__ __launch_bounds__(256) void gatherA(const float4* __restrict__ img, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+        const int ix = (int)x, iy = (int)y;
+        const float4* b = img + ix + iy * w;
+        const float4 a0 = b[0], a1 = b[1], a2 = b[w], a3 = b[w + 1];
+        acc += a0.x + a1.y + a2.z + a3.x;
+    }
+    out[i] = acc;
+}
+__global__ __launch_bounds__(256) void gatherB(const float4* __restrict__ img, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 3, k = t & 7;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+    const int ix = (int)x, iy = (int)y;
+    const float4* b = img + ix + iy * w;
+    const float4 a0 = b[0], a1 = b[1], a2 = b[w], a3 = b[w + 1];
+    float acc = a0.x + a1.y + a2.z + a3.x;
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+    if (k == 0) out[i] = acc;
+}
+static uint32_t part1by1(uint32_t x) { x &= 0xffff; x = (x | (x << 8)) & 0x00FF00FF; x = (x | (x << 4)) & 0x0F0F0F0F; x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; }
+int main(int argc, char** argv) {
+    const int w = 1920, h = 1072, W = 8, P = argc > 1 ? atoi(argv[1]) : 250000;
+    const int per = P / W;
+    std::vector<float4*> imgs(W);
+    for (int f = 0; f < W; ++f) { CK(hipMalloc(&imgs[f], (size_t)w * h * 16)); CK(hipMemset(imgs[f], 0, (size_t)w * h * 16)); }
+    // residual list: for each target t, for each host h != t, the host's points (Morton order) reprojected with a small shift
+    std::vector<float2> uv; std::vector<int> tgt_start(W + 1, 0);
+    srand(1);
+    std::vector<std::vector<float2>> pts(W);
+    for (int f = 0; f < W; ++f) {
+        std::vector<std::pair<uint32_t, float2>> v(per);
+        for (auto& e : v) { const float x = 8 + (rand() / (float)RAND_MAX) * (w - 16), y = 8 + (rand() / (float)RAND_MAX) * (h - 16); e.second = make_float2(x, y); e.first = part1by1((uint32_t)x) | (part1by1((uint32_t)y) << 1); }
+        std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first < b.first; });
+        for (auto& e : v) pts[f].push_back(e.second);
+    }
+    std::vector<std::vector<float2>> per_target(W);
+    for (int t = 0; t < W; ++t) for (int f = 0; f < W; ++f) if (f != t) for (auto p : pts[f]) per_target[t].push_back(make_float2(std::min(std::max(p.x + 3.3f * (t - f), 4.f), w - 5.f), p.y));
+    float2* duv; float* dout;
+    const size_t nmax = per_target[0].size();
+    CK(hipMalloc(&duv, nmax * W * 8)); CK(hipMalloc(&dout, nmax * W * 4));
+    for (int t = 0; t < W; ++t) CK(hipMemcpy(duv + t * nmax, per_target[t].data(), nmax * 8, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int variant = 0; variant < 2; ++variant) {
+        float best = 1e9;
+        for (int rep = 0; rep < 5; ++rep) {
+            CK(hipEventRecord(e0));
+            for (int t = 0; t < W; ++t) {
+                const int n = (int)nmax;
+                if (variant == 0) gatherA<<<(n + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else gatherB<<<(n * 8 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+        }
+        const double taps = (double)nmax * W * 32;
+        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", variant ? 'B' : 'A', nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
+    }
+    return 0;
+}

@@ -297,3 +297,43 @@ def test_dense_make_map_oracle():
     i, j = sel[10]
     depth = 1.6 / ((i - cy) / fy)
     assert abs(1 / oid[10] - depth) < 1e-4 * abs(depth)
+
+
+def test_immature_points_filter_and_activation_recover_true_depth():
+    """SURVEY 8(f) rank 1, oracle-free check of the restatement: tracing an immature point along the epipolar line of later frames brackets
+    the scene's true inverse depth, and the 1-D Gauss-Newton of the activation reduces a 5 % depth error."""
+    from imm_helpers import imm_points, host_to_new, true_idepth
+    win = synth.make_window(w=320, h=240, W=4, P=100, seed=9, n_extra=2, step_z=0.25, yaw_deg=0.4)
+    W = win.W
+    dI = [orc.make_images(win.images[i], 1)[0] for i in range(W + 2)]
+    u, v, host = imm_points(win, per_host=400, seed=2)
+    n = len(u)
+    color, weights, gradH, eth = [np.zeros((n, k), np.float32) for k in (8, 8, 3)] + [np.zeros(n, np.float32)]
+    for h in range(W):
+        m = host == h
+        color[m], weights[m], gradH[m], eth[m] = orc.imm_create(dI[h], win.w, win.h, u[m], v[m])
+    assert np.isfinite(eth).all() and np.all(eth == 8 * 144.0)
+    uf, vf = u.astype(np.float32), v.astype(np.float32)
+    st = [np.zeros(n, np.float32), np.full(n, np.nan, np.float32), np.full(n, 5, np.int32), np.full(n, 10000, np.float32)]
+    for new in (W, W + 1):
+        KRKi, Kt, aff = host_to_new(win, new)
+        st = list(orc.imm_trace(dI[new], win.w, win.h, uf, vf, color, weights, gradH, eth, host, KRKi, Kt, aff, *st)[:4])
+    idmin, idmax, status, quality = st
+    good = (status == 0) & (quality > 3)                  # setting_minTraceQuality = 3: what the activation logic trusts (settings.cpp:166)
+    idt = true_idepth(win, u, v, host)
+    assert good.sum() > 0.25 * n
+    inside = (idt[good] > idmin[good] * 0.9) & (idt[good] < idmax[good] * 1.1)
+    assert inside.mean() > 0.9
+    assert (idmax[good] >= idmin[good]).all()
+    # activation from a 5 % wrong interval midpoint
+    rng = np.random.RandomState(4)
+    mid = idt * (1 + 0.05 * rng.randn(n)).astype(np.float32)
+    st6 = synth.perturbed_poses(win, sigma_t=0.0, sigma_r=0.0)
+    ba = orc.ba_from_window(win, "f32", state6=st6)
+    Rt, af = ba.precalc_rt()
+    res, idp, rin = orc.imm_optimize(dI[:W], win.w, win.h, win.K, Rt, af, host, uf, vf, color, weights, eth, mid * 0.9, mid * 1.1, 1)
+    act = res == 1
+    assert act.sum() > 0.5 * n and (rin[act].sum(1) >= 1).all() and (rin[~act] == 0).all()
+    err0 = np.abs(mid[act] - idt[act]) / idt[act]
+    err1 = np.abs(idp[act] - idt[act]) / idt[act]
+    assert np.median(err1) < 0.6 * np.median(err0)         # small image, short baselines: three damped GN steps halve the error
