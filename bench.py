@@ -281,6 +281,11 @@ def main():
             if world == 1:
                 out["stress250k"] = stress_leg()
                 log("stress250k leg done")
+                try:
+                    out["immature"] = imm_leg(cpu=not args.no_cpu_baseline)
+                except Exception as e:
+                    out["immature"] = {"error": repr(e)}
+                log("immature leg done")
                 # The KITTI-sized launch moves 6 MB (0.8 us at 8 TB/s): it is launch-latency bound by construction. The kernel's
                 # roofline position is therefore reported on the largest single-GPU window of this same run (configs[3]);
                 # the figure of the headline workload stays next to it.
@@ -401,6 +406,58 @@ def stress_leg(steps=5, warmup=2):
             res[k] = dict(avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg), achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
     res["traffic"] = load_traffic("stress250k")
     job.ctx.close()
+    return res
+
+
+def imm_leg(per_host=1500, rounds=5, cpu=True):
+    """traceOn for setting_desiredImmatureDensity = 1500 immature points per host x 8 hosts against a new KITTI-sized
+    frame, then optimizeImmaturePoint for the same points. Kernel time from HIP events, call time includes the PCIe staging of the
+    caller-owned point arrays; the CPU figure is the oracle's fast build on one thread (the reference chunks 50 points per thread)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from imm_helpers import imm_points, host_to_new, true_idepth
+    cfg = WORKLOADS["kitti00_8kf"]
+    win = synth.make_window(w=cfg["w"], h=cfg["h"], W=cfg["W"], P=64, seed=9, n_extra=1, step_z=0.25, yaw_deg=0.4)
+    W = win.W
+    c = binding.Context(win.w, win.h, win.K, n_slots=W + 1)
+    for i in range(W + 1):
+        c.frame_upload(i, win.images[i])
+    u, v, host = imm_points(win, per_host=per_host, seed=2)
+    n = len(u)
+    color, weights, gradH, eth = [np.zeros((n, k), np.float32) for k in (8, 8, 3)] + [np.zeros(n, np.float32)]
+    for h in range(W):
+        m = host == h
+        color[m], weights[m], gradH[m], eth[m] = c.imm_create(h, u[m], v[m])
+    uf, vf = u.astype(np.float32), v.astype(np.float32)
+    KRKi, Kt, aff = host_to_new(win, W)
+    st0 = (np.zeros(n, np.float32), np.full(n, np.nan, np.float32), np.full(n, 5, np.int32), np.full(n, 10000, np.float32))
+    c.imm_trace(W, uf, vf, color, weights, gradH, eth, host, KRKi, Kt, aff, *st0)               # warm-up
+    c.profile_enable(True); c.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        g = c.imm_trace(W, uf, vf, color, weights, gradH, eth, host, KRKi, Kt, aff, *st0)
+    t_call = (time.perf_counter() - t0) / rounds
+    ms, nl = c.profile_get("imm_trace")
+    idt = true_idepth(win, u, v, host)
+    c.ba_set_window(list(range(W)), win.world_to_cam[:W])
+    c.imm_optimize(host, uf, vf, color, weights, eth, idt * 0.9, idt * 1.1, 1)
+    c.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        ro = c.imm_optimize(host, uf, vf, color, weights, eth, idt * 0.9, idt * 1.1, 1)
+    t_opt = (time.perf_counter() - t0) / rounds
+    ms2, nl2 = c.profile_get("imm_optimize")
+    c.close()
+    res = {"points": n, "hosts": W, "image": "%dx%d" % (win.w, win.h),
+           "trace_kernel_us": round(ms / max(nl, 1) * 1e3, 1), "trace_call_us": round(t_call * 1e6, 1), "trace_Mpoints_per_s_kernel": round(n / (ms / max(nl, 1) * 1e-3) / 1e6, 2),
+           "trace_status_counts": np.bincount(g[2], minlength=6).tolist(),
+           "optimize_kernel_us": round(ms2 / max(nl2, 1) * 1e3, 1), "optimize_call_us": round(t_opt * 1e6, 1), "activated": int((ro[0] == 1).sum())}
+    if cpu:
+        import orc
+        dI = [orc.make_images(win.images[i], 1, "fast")[0] for i in range(W + 1)]
+        t0 = time.perf_counter()
+        orc.imm_trace(dI[W], win.w, win.h, uf, vf, color, weights, gradH, eth, host, KRKi, Kt, aff, *st0, kind="fast")
+        res["trace_cpu_port_us"] = round((time.perf_counter() - t0) * 1e6, 1)
+        res["trace_cpu_cores"] = 1
     return res
 
 

@@ -152,15 +152,16 @@ __global__ __launch_bounds__(kImmThreads) void imm_trace_kernel(ImmTraceParams P
     int bestIdx = -1;
     if (numSteps >= 100) numSteps = 99;
     for (int i = 0; i < numSteps; ++i) {                                       // discrete search, :275-304
-        float energy = 0;
+        float energy = 0, hits[8];
 #pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-            const float hit = imm_interp31(P.dI, ptx + rot[idx][0], pty + rot[idx][1], w);
-            if (!isfinite(hit)) { energy += 1e5f; continue; }
+        for (int idx = 0; idx < 8; ++idx) hits[idx] = imm_interp31(P.dI, ptx + rot[idx][0], pty + rot[idx][1], w);   // 32 taps in flight
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {                                    // same terms in the same order; the non-finite case is a select, not a branch
+            const float hit = hits[idx];
             const float residual = hit - (aff0 * color[idx] + aff1);
             const float ar = fabsf(residual);
             const float hw = ar < kHuberTH ? 1 : kHuberTH / ar;
-            energy += hw * residual * residual * (2 - hw);
+            energy += isfinite(hit) ? hw * residual * residual * (2 - hw) : 1e5f;
         }
         errors[i * kImmThreads + tid] = energy;
         if (energy < bestEnergy) { bestU = ptx; bestV = pty; bestEnergy = energy; bestIdx = i; }

@@ -20,6 +20,7 @@ from helpers import tracker_inputs, true_rel_pose  # noqa: E402
 from nalo_slam_amd import synth  # noqa: E402
 
 GOLDEN_WINDOW = dict(w=320, h=240, W=3, P=64, seed=11)
+GOLDEN_IMM_WINDOW = dict(w=320, h=240, W=3, P=64, seed=12, n_extra=2, step_z=0.25, yaw_deg=0.4)
 
 
 def main():
@@ -71,5 +72,44 @@ def main():
     print("wrote golden_r01.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "golden_r01.npz")), "bytes")
 
 
+def imm_inputs(win):
+    from imm_helpers import imm_points, host_to_new
+    u, v, host = imm_points(win, per_host=120, seed=5)
+    return u, v, host, host_to_new
+
+
+def main_imm():
+    """SURVEY 8(f) rank 1 (immature points): constructor outputs, two tracing rounds and the activation of a small seeded point set."""
+    win = synth.make_window(**GOLDEN_IMM_WINDOW)
+    W = win.W
+    u, v, host, host_to_new = imm_inputs(win)
+    n = len(u)
+    dI = [orc.make_images(win.images[i], 1)[0] for i in range(W + 2)]
+    out = {"u": u, "v": v, "host": host}
+    color, weights, gradH, eth = [np.zeros((n, k), np.float32) for k in (8, 8, 3)] + [np.zeros(n, np.float32)]
+    for h in range(W):
+        m = host == h
+        color[m], weights[m], gradH[m], eth[m] = orc.imm_create(dI[h], win.w, win.h, u[m], v[m])
+    out.update(color=color, weights=weights, gradH=gradH, energyTH=eth)
+    st = [np.zeros(n, np.float32), np.full(n, np.nan, np.float32), np.full(n, 5, np.int32), np.full(n, 10000, np.float32)]
+    uf, vf = u.astype(np.float32), v.astype(np.float32)
+    for r, new in enumerate((W, W + 1)):
+        KRKi, Kt, aff = host_to_new(win, new)
+        res = orc.imm_trace(dI[new], win.w, win.h, uf, vf, color, weights, gradH, eth, host, KRKi, Kt, aff, *st)
+        for name, a in zip(("idmin", "idmax", "status", "quality", "lastUV", "lastInterval"), res):
+            out["trace%d_%s" % (r, name)] = a
+        st = list(res[:4])
+    ba = orc.ba_from_window(win, "f32")
+    Rt, af = ba.precalc_rt()
+    idmin = np.where(np.isfinite(st[1]) & (st[2] == 0), st[0], np.float32(0.05)).astype(np.float32)
+    idmax = np.where(np.isfinite(st[1]) & (st[2] == 0), st[1], np.float32(0.15)).astype(np.float32)
+    out["opt_idmin"], out["opt_idmax"] = idmin, idmax
+    out["opt_result"], out["opt_idepth"], out["opt_res_in"] = orc.imm_optimize(dI[:W], win.w, win.h, win.K, Rt, af, host, uf, vf, color, weights, eth, idmin, idmax, 1)
+    np.savez_compressed(os.path.join(HERE, "golden_imm_r01.npz"), **out)
+    print("wrote golden_imm_r01.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "golden_imm_r01.npz")), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--imm-only" not in sys.argv:
+        main()
+    main_imm()
