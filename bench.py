@@ -82,8 +82,9 @@ class GpuJob:
         self.ctx.ba_set_window(list(range(W)), win.world_to_cam[:W], state6=st6)
         self.ctx.ba_set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights)
         self.ctx.ba_set_residuals(win.exists)
-        if hook is not None:
-            self.ctx.ba_set_allreduce(hook)
+        if hook is not None:                                             # hook = factory(ctx) -> all-reduce callable (it needs the context's stream)
+            fn = hook(self.ctx)
+            self.ctx.ba_set_allreduce(fn, stream_ordered=getattr(fn, "stream_ordered", False))
         self.ctx.ba_snapshot()
         self.ctx.trk_set_ref(W - 1, *trk)
         self.T0 = [synth.se3_mul(win.world_to_cam[W + k], synth.se3_inv(win.world_to_cam[W - 1])) for k in range(TRACKED_PER_KF)]
@@ -201,7 +202,7 @@ def main():
     sharded = args.workload == "shard1m"
 
     win, st6, trk = make_inputs(args.workload)
-    hook = make_hook(dist, torch, args.backend) if (sharded and world > 1) else None
+    hook = (lambda ctx: make_hook(dist, torch, args.backend, stream=ctx.stream)) if (sharded and world > 1) else None
     job = GpuJob(shard(win, rank, world) if sharded else win, st6, trk, local_rank, hook)
     do_track = not sharded
 
@@ -307,21 +308,33 @@ def main():
         pass
 
 
-def make_hook(dist, torch, backend="nccl"):
-    """All-reduce hook for nalo_ba_set_allreduce: SUM n doubles in place on the device over RCCL (torch.distributed 'nccl')."""
+def make_hook(dist, torch, backend="nccl", stream=None):
+    """All-reduce hook for nalo_ba_set_allreduce: SUM n doubles in place on the device over RCCL (torch.distributed 'nccl').
+    With `stream` (the library's hipStream_t) the collective is enqueued on that stream and the hook returns at once: the
+    library's publish kernel follows in stream order, no host synchronisation per GN iteration (nalo_ba_set_allreduce_mode = 1)."""
     class _Ptr:                                           # wraps the library's device buffer for torch, zero copy
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
 
+    cache = {}
+    ext = torch.cuda.ExternalStream(stream) if (stream and backend == "nccl") else None
+
     def hook(ptr, n):
-        t = torch.as_tensor(_Ptr(ptr, n), device="cuda")
+        t = cache.get((ptr, n))
+        if t is None:
+            t = cache[(ptr, n)] = torch.as_tensor(_Ptr(ptr, n), device="cuda")
         if backend == "nccl":
-            dist.all_reduce(t)                             # payload ~2*(8W+5)^2*8 B = 163 KB at W=12: latency bound over xGMI
+            if ext is not None:
+                with torch.cuda.stream(ext):
+                    dist.all_reduce(t)                     # payload ~2*(8W+5)^2*8 B = 163 KB at W=12: latency bound over xGMI
+                return
+            dist.all_reduce(t)
         else:                                              # rehearsal path: stage through the host
             h = t.cpu()
             dist.all_reduce(h)
             t.copy_(h)
         torch.cuda.current_stream().synchronize()
+    hook.stream_ordered = ext is not None
     return hook
 
 
@@ -342,7 +355,7 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
     win, st6, trk = make_inputs("shard1m")
     part = shard(win, rank, world)
     log("shard1m: uploading %d points" % len(part.host))
-    job = GpuJob(part, st6, trk, local_rank, make_hook(dist, torch, backend))
+    job = GpuJob(part, st6, trk, local_rank, lambda ctx: make_hook(dist, torch, backend, stream=ctx.stream))
     for _ in range(warmup):
         job.step(False)
     job.ctx.profile_enable(True)
@@ -368,6 +381,10 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
         alg = 424.0 * R + 104.0 * P
         ach = alg / (ms / n * 1e-3) / 1e9
         res["ba_linearize"] = dict(avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg), achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
+    for k in ("ba_sc", "ba_reduce", "ba_resub"):
+        ms, n = job.ctx.profile_get(k)
+        if n:
+            res[k + "_us"] = round(ms / n * 1e3, 2)
     job.ctx.close()
     return res
 

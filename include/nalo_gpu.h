@@ -185,6 +185,10 @@ int nalo_ba_restore(nalo_ctx* ctx);
  * before every solve. buf is a DEVICE pointer to n doubles on nalo_stream(ctx). hook == NULL = single GPU. */
 typedef void (*nalo_allreduce_fn)(void* user, double* device_buf, int n);
 int nalo_ba_set_allreduce(nalo_ctx* ctx, nalo_allreduce_fn hook, void* user);
+/* stream_ordered = 1: the hook ENQUEUES its collective on nalo_stream(ctx) (e.g. ncclAllReduce(..., (hipStream_t)nalo_stream(ctx))) and returns
+ * without waiting; the library then neither synchronises before nor after the hook. Default 0: the library synchronises its stream before the
+ * call and the hook returns when the sum is complete. */
+int nalo_ba_set_allreduce_mode(nalo_ctx* ctx, int stream_ordered);
 
 /* ------------------------------------------------------------------------------------------------
  * a14  DenseMapping::updateMap bbox scan + makeMap (FullSystem/MapPoint.cpp:300-310, 334-407), call site

@@ -31,7 +31,7 @@ EXPORTS = [
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
-    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_snapshot", "nalo_ba_restore",
+    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
 ]
@@ -89,6 +89,7 @@ def load():
     L.nalo_ba_get_acc13.argtypes = [vp, c_dp]
     L.nalo_ba_counts.argtypes = [vp, c_ip, c_ip, c_ip]
     L.nalo_ba_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.nalo_ba_set_allreduce_mode.argtypes = [vp, C.c_int]
     L.nalo_ba_snapshot.argtypes = [vp]
     L.nalo_imm_create.argtypes = [vp, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.nalo_imm_trace.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
@@ -363,8 +364,14 @@ class Context:
     def ba_restore(self):
         self._ck(self.L.nalo_ba_restore(self.h_))
 
-    def ba_set_allreduce(self, fn):
-        """fn(device_ptr:int, n:int) sums n doubles in place across ranks."""
+    @property
+    def stream(self):
+        """hipStream_t (as int) every kernel of this context is launched on"""
+        return int(self.L.nalo_stream(self.h_) or 0)
+
+    def ba_set_allreduce(self, fn, stream_ordered=False):
+        """fn(device_ptr:int, n:int) sums n doubles in place across ranks. stream_ordered: fn enqueues on self.stream and does not wait."""
+        self._ck(self.L.nalo_ba_set_allreduce_mode(self.h_, int(bool(stream_ordered) and fn is not None)))
         if fn is None:
             self._hook = None
             self._ck(self.L.nalo_ba_set_allreduce(self.h_, C.cast(None, ALLREDUCE_FN), None))

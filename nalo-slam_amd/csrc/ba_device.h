@@ -55,6 +55,9 @@ struct BADev {
     double* top_partial;                        // [nblocks][W][kTopStride]  (fp64: one rounding less before the cancelling H_A - H_sc)
     double* sc_partial;                         // [nblocks * sc_split][NPL*NPL]
     int sc_split;                               // 1 or 4 workgroups per point block in ba_sc_kernel (4 for small windows)
+    const int* host_blk;                        // [W+1] point-block range of every host
+    const int* sc_grp;                          // [W+1] ba_sc workgroup-group range of every host (groups of sc_bpw blocks)
+    int sc_bpw, sc_groups;                      // blocks per group (1 when sc_split > 1), total groups
 };
 
 // Stitch operands (kernels_ba.hip ba_stitch_kernel)

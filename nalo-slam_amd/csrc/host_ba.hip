@@ -16,7 +16,8 @@ void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const
 int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
-void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq);
+void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
+void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
 void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
 
@@ -53,7 +54,7 @@ struct BAWindow {
     DevBuf<float2> rs_energy, rs_pp1;
     DevBuf<float4> rs_pp0;
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
-    DevBuf<int> blk_host, host_blk, blk_order;
+    DevBuf<int> blk_host, host_blk, blk_order, sc_grp;
     DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 16
     bool step_fused = false, step_sums_deferred = false;            // optimize(): resubstitute + point step in one kernel, its sums finished by the reduce launch
     bool th_pending = false;                                        // a linearize pass whose frameEnergyTH quantile has not been launched yet
@@ -72,6 +73,8 @@ struct BAWindow {
     std::vector<HostFrame> snap_frames; std::vector<double> snap_HM, snap_bM; std::vector<uint8_t> snap_flags_h; double snap_calib[4] = {}; bool have_snap = false;
     nalo_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
+    bool hook_stream_ordered = false;                               // the hook enqueues its collective on nalo_stream(ctx): no host synchronisation around it
+    hipEvent_t ev_lin = nullptr, ev_th = nullptr; bool th_side_inflight = false;   // sharded windows run the quantile kernels on the side stream, under the SC kernel
     bool never_break = false;
 };
 
@@ -82,8 +85,10 @@ void ba_destroy(nalo_ctx* c) {
     w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
-    w->blk_host.release(); w->host_blk.release(); w->blk_order.release(); w->acc13.release(); w->G.release(); w->AD.release(); w->st_ticket.release();
+    w->blk_host.release(); w->host_blk.release(); w->sc_grp.release(); w->blk_order.release(); w->acc13.release(); w->G.release(); w->AD.release(); w->st_ticket.release();
     w->stitched.release(); w->th_hist.release();
+    if (w->ev_lin) (void)hipEventDestroy(w->ev_lin);
+    if (w->ev_th) (void)hipEventDestroy(w->ev_th);
     w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
@@ -242,6 +247,7 @@ static int upload_frame_th(nalo_ctx* c) {
 // lazily: after the stitch has been published (so they run while the host solves), or at the latest before the next pass that reads the value.
 static int flush_th(nalo_ctx* c) {
     BAWindow& w = *c->ba;
+    if (w.th_side_inflight) { NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0)); w.th_side_inflight = false; }
     if (!w.th_pending) return NALO_OK;
     ba_launch_energy_th(c->stream, w.dev);
     w.th_pending = false;
@@ -256,7 +262,15 @@ static int linearize_async(nalo_ctx* c, int mode, int fix) {
         ProfScope ps(c, "ba_linearize");
         ba_launch_linearize(c->stream, w.dev, mode, fix);
     }
-    if (mode == 0) w.th_pending = true;
+    if (mode == 0 && w.hook) {
+        // sharded window: the threshold is part of the all-reduced tail, i.e. on the critical path: run its kernels on the side stream under SC
+        if (!w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming)); }
+        NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
+        NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
+        ba_launch_energy_th(c->side, w.dev);
+        NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
+        w.th_side_inflight = true;
+    } else if (mode == 0) w.th_pending = true;
     w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
@@ -306,21 +320,14 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
             // sharded window: tail = {step sums (3), this rank's frameEnergyTH of the newest frame, 1.0}. After the SUM over ranks the
             // host installs the MEAN of the per-shard 70 % quantiles as the common threshold (every rank then classifies with the
             // same value; the exact global order statistic would need the histograms all-reduced: SURVEY 8e, next round).
-            NALO_HIP(c, hipStreamSynchronize(c->stream));
+            if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
             w.hook(w.hook_user, w.stitched.p, npub);
-            ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
+            ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // more than one rank: the common threshold
+            ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq, w.st_ticket.p + 1);
             NALO_HIP(c, hipGetLastError());
-        } else if (sep_publish) ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq);
+        } else if (sep_publish) ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq, w.st_ticket.p + 1);
         { int rc = flush_th(c); if (rc) return rc; }                  // behind the publish: overlaps the host's solve
         if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
-        if (w.hook) {
-            const double* tl = w.stitched_host + 2 * blk + 2 * W * W + 3;
-            if (tl[1] > 1.5) {                                  // more than one rank: install the common threshold
-                const float th = (float)(tl[0] / tl[1]);
-                NALO_HIP(c, hipMemcpyAsync(w.frameTH.p + (W - 1), &th, 4, hipMemcpyHostToDevice, c->stream));
-                NALO_HIP(c, hipStreamSynchronize(c->stream));
-            }
-        }
         if (w.step_pending) {                                   // finish doStepFromBackup's break test with the sums of the last step
             const double* s3 = w.stitched_host + 2 * blk + 2 * W * W;
             const float numID = (float)s3[2];
@@ -432,6 +439,7 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
         for (int cc = 0; cc < n; ++cc) hf[cc] -= hs[cc] * fsc;
         bF[r] = bLr + (w.bM[r] + sdot) + ha[n] - hs[n];
     }
+    { HostTimer hl(c, "ba.solve.math.ldlt");
     for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * n + i] + 10);
     for (int i = 0; i < n; ++i) { double* hf = HF + (size_t)i * n; const double si = sv[i]; for (int j = 0; j < n; ++j) hf[j] = si * hf[j] * sv[j]; bF[i] *= si; }
     // Eigen's LDLT (the reference, :880) reads the lower triangle only; H_sc carries fp32-rounding asymmetry (w*a_j*a_k vs w*a_k*a_j), so mirror
@@ -439,6 +447,7 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) HF[(size_t)i * n + j] = HF[(size_t)j * n + i];
     ldlt_solve_inplace(n, HF, bF, x.data(), yv, w.solve_perm.data());
     for (int i = 0; i < n; ++i) x[i] *= sv[i];
+    }
     if (iteration >= 2) {                                                   // SOLVER_ORTHOGONALIZE_X_LATER (:898-902)
         if (!w.proj_valid) build_projector(w);
         double coef[7];
@@ -624,8 +633,22 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     NALO_HIP(c, w.blk_host.reserve(w.nblocks)); NALO_HIP(c, w.host_blk.reserve(W + 1));
     const size_t NS = (size_t)W * N;
     NALO_HIP(c, w.rs_state.reserve(NS)); NALO_HIP(c, w.rs_energy.reserve(NS)); NALO_HIP(c, w.rs_jp0.reserve(NS)); NALO_HIP(c, w.rs_jp1.reserve(NS)); NALO_HIP(c, w.rs_cpt.reserve(NS)); NALO_HIP(c, w.rs_pp0.reserve(NS)); NALO_HIP(c, w.rs_pp1.reserve(NS));
-    NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * W * kTopStride)); w.dev.sc_split = w.nblocks <= 256 ? 4 : 1;
-    NALO_HIP(c, w.sc_partial.reserve((size_t)w.nblocks * w.dev.sc_split * w.NPL * w.NPL));
+    NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * W * kTopStride)); {   // ba_sc work distribution: ~1000+ workgroups whatever the window size. Small windows split a point block over 4 (2) workgroups; large
+        // ones put up to 8 blocks of a host through one workgroup so that the NPL^2 fp64 partial is written once per group.
+        static const int force_split = [] { const char* e = std::getenv("NALO_SC_SPLIT"); return e ? std::atoi(e) : 0; }();
+        static const int force_bpw = [] { const char* e = std::getenv("NALO_SC_BPW"); return e ? std::atoi(e) : 0; }();
+        w.dev.sc_split = w.nblocks <= 256 ? 4 : 1;          // measured (scripts/tune_sc.sh): beyond ~256 blocks more workgroups only add partial traffic
+        if (force_split == 1 || force_split == 2 || force_split == 4) w.dev.sc_split = force_split;
+        w.dev.sc_bpw = w.dev.sc_split > 1 ? 1 : (w.nblocks >= 2048 ? 8 : (w.nblocks >= 1024 ? 4 : 2));
+        if (force_bpw > 0 && w.dev.sc_split == 1) w.dev.sc_bpw = force_bpw;
+        std::vector<int> grp(W + 1, 0);
+        for (int h = 0; h < W; ++h) grp[h + 1] = grp[h] + (w.host_blk_h[h + 1] - w.host_blk_h[h] + w.dev.sc_bpw - 1) / w.dev.sc_bpw;
+        w.dev.sc_groups = std::max(grp[W], 1);
+        NALO_HIP(c, w.sc_grp.reserve(W + 1));
+        NALO_HIP(c, hipMemcpy(w.sc_grp.p, grp.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice));
+        w.dev.sc_grp = w.sc_grp.p;
+    }
+    NALO_HIP(c, w.sc_partial.reserve((size_t)w.dev.sc_groups * w.dev.sc_split * w.NPL * w.NPL));
     NALO_HIP(c, hipMemcpy(w.pt_geo.p, geo.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_col0.p, c0.data(), N * 16, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.pt_col1.p, c1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_w0.p, w0.data(), N * 16, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.pt_w1.p, w1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_prior.p, prior.data(), N * 4, hipMemcpyHostToDevice));
@@ -658,7 +681,7 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     NALO_HIP(c, hipMemset(w.rs_state.p, 0, NS)); NALO_HIP(c, hipMemset(w.rs_energy.p, 0, NS * 8)); NALO_HIP(c, hipMemset(w.rs_jp0.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.rs_jp1.p, 0, NS * 16));
     NALO_HIP(c, hipMemset(w.rs_cpt.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.top_partial.p, 0, (size_t)w.nblocks * W * kTopStride * 8));
     BADev& D = w.dev;
-    D.P = P; D.Ppad = w.Ppad; D.nblocks = w.nblocks; D.blk_host = w.blk_host.p;
+    D.P = P; D.Ppad = w.Ppad; D.nblocks = w.nblocks; D.blk_host = w.blk_host.p; D.host_blk = w.host_blk.p;
     D.pt_geo = w.pt_geo.p; D.pt_col0 = w.pt_col0.p; D.pt_col1 = w.pt_col1.p; D.pt_w0 = w.pt_w0.p; D.pt_w1 = w.pt_w1.p; D.pt_prior = w.pt_prior.p;
     D.pt_flags = w.pt_flags.p; D.pt_acc = w.pt_acc.p; D.pt_hcd = w.pt_hcd.p; D.pt_ngood = w.pt_ngood.p; D.pt_step = w.pt_step.p; D.pt_backup = w.pt_backup.p; D.pt_relbs = w.pt_relbs.p;
     D.rs_state = w.rs_state.p; D.rs_energy = w.rs_energy.p; D.rs_jp0 = w.rs_jp0.p; D.rs_jp1 = w.rs_jp1.p; D.rs_cpt = w.rs_cpt.p; D.rs_pp0 = w.rs_pp0.p; D.rs_pp1 = w.rs_pp1.p; D.en_new = w.en_new.p;
@@ -874,6 +897,11 @@ int nalo_ba_get_acc13(nalo_ctx* c, double* H13) {
 int nalo_ba_counts(nalo_ctx* c, int* a, int* l, int* m) {
     if (!c || !c->ba) return fail(c, NALO_ERR_STATE, "nalo_ba_counts: no window");
     if (a) *a = c->ba->resInA; if (l) *l = c->ba->resInL; if (m) *m = c->ba->resInM;
+    return NALO_OK;
+}
+int nalo_ba_set_allreduce_mode(nalo_ctx* c, int stream_ordered) {
+    if (!c || !c->ba) return fail(c, NALO_ERR_STATE, "nalo_ba_set_allreduce_mode: set the window first");
+    c->ba->hook_stream_ordered = stream_ordered != 0;
     return NALO_OK;
 }
 int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {

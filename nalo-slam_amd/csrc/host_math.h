@@ -113,7 +113,7 @@ inline void aff_from_to(float expF, float expT, double aF, double bF, double aT,
 // Right-looking, row-contiguous updates: after the pivot swap row k holds d*L[.][k] (symmetry), so the trailing update is
 // A[i][j] -= l_i * A[k][j] over whole rows (vectorisable); both triangles are kept current, no mirror pass.
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
-__attribute__((target_clones("arch=haswell", "default")))   // the .so is built on one machine and run on another: dispatch at load time
+__attribute__((target_clones("avx2", "default")))   // the .so is built on one machine and run on another: dispatch at load time
 #endif
 inline void ldlt_solve_inplace(int n, double* A, const double* b, double* x, double* y /* n */, int* perm /* n */) {
     for (int i = 0; i < n; ++i) perm[i] = i;

@@ -46,9 +46,25 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
     __shared__ __attribute__((aligned(16))) float A[SUB * NPLP];
     __shared__ __attribute__((aligned(16))) float4 Hc[ROWS];
     __shared__ float Wt[ROWS], Bd[ROWS];
-    const int b = blockIdx.x / KS, ks = blockIdx.x - b * KS, tid = threadIdx.x, h = B.blk_host[b], W = B.W;
+    // workgroup -> (group of up to sc_bpw consecutive point blocks of ONE host, share ks of each block's points). Large windows put several
+    // blocks through one workgroup: the fp64 partial (NPL^2 x 8 B, as large as a block's operands) is then written once per group.
+    const int grp = blockIdx.x / KS, ks = blockIdx.x - grp * KS, tid = threadIdx.x, W = B.W;
+    int h = 0;
+    while (h + 1 < W && grp >= B.sc_grp[h + 1]) ++h;
+    const int b0 = B.host_blk[h] + (grp - B.sc_grp[h]) * B.sc_bpw, b1 = min(b0 + B.sc_bpw, B.host_blk[h + 1]);
     const int ty = tid >> 4, tx = tid & 15;
+    // fp32 products in short runs (8 points) flushed into fp64: the block partial is good to ~1e-8, so the ~100x cancellation in
+    // H_A - H_sc does not amplify summation noise into the poses
+    constexpr int RUN = 8;
+    float acc[T][T];
+    double acc64[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) { acc[i][j] = 0.f; acc64[i][j] = 0.0; }
+    for (int b = b0; b < b1; ++b) {
     const int dbase = b * kBlk + ks * ROWS;
+    __syncthreads();                                           // the previous block's rows / weights have been consumed
     if (tid < ROWS)
     {   // ---- per point (AccumulatedSCHessian.cpp:36-57): EFPoint::{Hdd,bd,Hcd}_acc = sum over the point's active residuals in
         //      target order (AccumulatedTopHessian.cpp:132-157), then HdiF, bdSumF
@@ -86,15 +102,6 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
         }
         Wt[tid] = wgt; Bd[tid] = bds; Hc[tid] = hc;
     }
-    // fp32 products in short runs (8 points) flushed into fp64: the block partial is good to ~1e-8, so the ~100x cancellation in
-    // H_A - H_sc does not amplify summation noise into the poses
-    constexpr int RUN = 8;
-    float acc[T][T];
-    double acc64[T][T];
-#pragma unroll
-    for (int i = 0; i < T; ++i)
-#pragma unroll
-        for (int j = 0; j < T; ++j) { acc[i][j] = 0.f; acc64[i][j] = 0.0; }
     for (int sub = 0; sub < ROWS / SUB; ++sub) {
         const int d0 = dbase + sub * SUB;
         __syncthreads();
@@ -146,6 +153,7 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
                 for (int j = 0; j < T; ++j) { acc64[i][j] += (double)acc[i][j]; acc[i][j] = 0.f; }
         }
     }
+    }                                                          // blocks of this group
     double* out = B.sc_partial + (size_t)blockIdx.x * NPL * NPL;
 #pragma unroll
     for (int i = 0; i < T; ++i)
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
 
 template <int KS>
 static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
-    const int grid = B.nblocks * KS;
+    const int grid = B.sc_groups * KS;
     switch (T) {
         case 1: ba_sc_kernel<1, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
         case 2: ba_sc_kernel<2, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
@@ -169,6 +177,7 @@ static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int shift, float 
 }
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
     if (B.sc_split == 4) launch_sc_ks<4>(s, B, T, shift, priorScaleMarg, margOnly);
+    else if (B.sc_split == 2) launch_sc_ks<2>(s, B, T, shift, priorScaleMarg, margOnly);
     else launch_sc_ks<1>(s, B, T, shift, priorScaleMarg, margOnly);
 }
 void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
@@ -182,7 +191,7 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 //   G[h][e] = sum over the host's blocks of the weighted SYRK partials
 // Lane groups stride over the host's blocks and are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
-                                                         const int* __restrict__ host_blk /* [W+1] */, int W, int NPL2, int sc_tiles, int mask, int KS,
+                                                         const int* __restrict__ host_blk /* [W+1] */, const int* __restrict__ sc_grp /* [W+1] */, int W, int NPL2, int sc_tiles, int mask, int KS,
                                                          double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G,
                                                          const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out) {
     __shared__ double part[16][64];
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
     const int q = blockIdx.x - W * W, h = q / sc_tiles, tile = q - h * sc_tiles;
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6, e = tile * 64 + j;
     double s = 0;
-    if (e < NPL2) for (int b = host_blk[h] * KS + g; b < host_blk[h + 1] * KS; b += 16) s += sc_partial[(size_t)b * NPL2 + e];
+    if (e < NPL2) for (int b = sc_grp[h] * KS + g; b < sc_grp[h + 1] * KS; b += 16) s += sc_partial[(size_t)b * NPL2 + e];
     part[g][j] = s;
     __syncthreads();
     if (g == 0 && e < NPL2) { double tt = 0; for (int k = 0; k < 16; ++k) tt += part[k][j]; G[(size_t)h * NPL2 + e] = tt; }
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
                       const float* step_partial, int step_blocks, double* step_out) {
     const int tiles = (NPL * NPL + 63) / 64;
-    ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
+    ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.sc_grp, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
                                                                                        B.sc_split, acc13, misc, G, step_partial, step_blocks, step_out);
 }
 
@@ -545,17 +554,28 @@ __global__ __launch_bounds__(1024) void ba_sum_partials_kernel(const float* __re
     __syncthreads();
     if (g == 0 && j < nvals) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; out[j] = t; }
 }
-// copies the stitched systems into host-mapped pinned memory and publishes a sequence number the host polls on
-__global__ __launch_bounds__(1024) void ba_publish_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, double seq) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
-    __threadfence_system();
+// copies the stitched systems into host-mapped pinned memory and publishes a sequence number the host polls on (the path after a cross-rank
+// all-reduce; a single GPU publishes from the stitch kernel). Several workgroups copy slices; the last one to take a ticket sets the flag.
+__global__ __launch_bounds__(256) void ba_publish_kernel(const double* __restrict__ src, double* __restrict__ dst, int n, double seq, unsigned* __restrict__ ticket) {
+    __shared__ int is_last;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) __hip_atomic_store(&dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&dst[n], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (is_last && threadIdx.x == 0) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&dst[n], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
+// sharded window, after the all-reduce: tail2 = {sum of the per-rank thresholds, rank count} -> every rank installs the mean
+__global__ void ba_th_install_kernel(const double* __restrict__ tail2, float* __restrict__ th) { if (tail2[1] > 1.5) th[0] = (float)(tail2[0] / tail2[1]); }
+void ba_launch_th_install(hipStream_t s, const double* tail2, float* th) { ba_th_install_kernel<<<1, 1, 0, s>>>(tail2, th); }
 __global__ void ba_th_tail_kernel(const float* __restrict__ th, double* __restrict__ tail2) { tail2[0] = (double)th[0]; tail2[1] = 1.0; }
 void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2) { ba_th_tail_kernel<<<1, 1, 0, s>>>(th, tail2); }
-void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq) {
-    ba_publish_kernel<<<1, 1024, 0, s>>>(src, dst_mapped, n, seq);
+void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket) {
+    const int nb = n > 32768 ? 32 : (n + 1023) / 1024;
+    ba_publish_kernel<<<nb < 1 ? 1 : nb, 256, 0, s>>>(src, dst_mapped, n, seq, ticket);
 }
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc) {
     ba_resub_kernel<false><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, 0.f, nullptr);
