@@ -228,6 +228,26 @@ int nalo_imm_optimize(nalo_ctx* ctx, int n, const int* host, const float* u, con
                       int* result, float* idepth_out, uint8_t* res_in);
 
 /* ------------------------------------------------------------------------------------------------
+ * the two-frame initialiser's Gauss-Newton pass.
+ * nalo_init_calc_res_and_gs  CoarseInitializer::calcResAndGS (FullSystem/CoarseInitializer.cpp:338-610), call sites :129,163 (trackFrame), for one
+ *     pyramid level lvl between the pyramids in slot_first (firstFrame) and slot_new. Pnt members are caller-owned arrays of n points:
+ *     in  u, v, idepth_new, iR, isGood[n] (0/1), energy[n][2], outlierTH;
+ *     out isGood_new, energy_new[n][2], maxstep; in/out lastHessian_new, JbBuffer_new[n][10] (entries the reference leaves untouched stay).
+ *     refToNew = 3x4 row-major [R|t], aff = {a, b} of refToNew_aff; alphaW, alphaK, couplingWeight as in the constructor (:92-95: 150^2, 2.5^2, 1).
+ *     H_out/H_out_sc are 8x8 row-major, b_out/b_out_sc 8, E3 = {E.A, alphaEnergy, E.num} exactly as returned (:609), including the reference's
+ *     behaviour that the regulariser loop feeds E instead of EAlpha (:560-572).
+ * nalo_init_do_step          CoarseInitializer::doStep (:910-938): idepth_new[i] for the good points from JbBuffer (the applied buffer), inc[8], lambda.
+ * applyStep (:939-956) is a member copy on the caller's arrays.
+ * ------------------------------------------------------------------------------------------------ */
+int nalo_init_calc_res_and_gs(nalo_ctx* ctx, int slot_first, int slot_new, int lvl, int n, const float* u, const float* v, const float* idepth_new, const float* iR,
+                              const uint8_t* isGood, const float* energy, const float* outlierTH, const double refToNew[12], const double aff[2],
+                              float alphaW, float alphaK, float couplingWeight,
+                              uint8_t* isGood_new, float* energy_new, float* maxstep, float* lastHessian_new, float* JbBuffer_new,
+                              double* H_out, double* b_out, double* H_out_sc, double* b_out_sc, double E3[3]);
+int nalo_init_do_step(nalo_ctx* ctx, int n, const uint8_t* isGood, const float* JbBuffer, const float* maxstep, const float* idepth, float lambda,
+                      const float inc[8], float* idepth_new);
+
+/* ------------------------------------------------------------------------------------------------
  * Profiling: per-kernel HIP-event timing on the ctx stream. Names: "trk_eval", "ba_linearize",
  * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize". Enable, run, then query (sync inside).
  * ------------------------------------------------------------------------------------------------ */

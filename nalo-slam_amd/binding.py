@@ -32,7 +32,7 @@ EXPORTS = [
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_snapshot", "nalo_ba_restore",
-    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize",
+    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_init_calc_res_and_gs", "nalo_init_do_step",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
 ]
 
@@ -91,6 +91,9 @@ def load():
     L.nalo_ba_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     L.nalo_ba_set_allreduce_mode.argtypes = [vp, C.c_int]
     L.nalo_ba_snapshot.argtypes = [vp]
+    L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
+                                            c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.nalo_init_do_step.argtypes = [vp, C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
     L.nalo_imm_create.argtypes = [vp, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.nalo_imm_trace.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
     L.nalo_imm_optimize.argtypes = [vp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_u8p]
@@ -327,6 +330,28 @@ class Context:
         a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
         self._ck(self.L.nalo_ba_counts(self.h_, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    # ---- two-frame initialiser
+    def init_calc_res_and_gs(self, slot_first, slot_new, lvl, refToNew, aff, pts, alphaW=150.0 * 150.0, alphaK=2.5 * 2.5, couplingWeight=1.0):
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        n = len(pts["u"])
+        ig = np.ascontiguousarray(pts["isGood"], np.uint8)
+        ign, en, ms = np.zeros(n, np.uint8), np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+        lh, jb = f(pts["lastHessian_new"]).copy(), f(pts["Jb"]).copy()
+        H, b, Hs, bs, E3 = np.zeros(64), np.zeros(8), np.zeros(64), np.zeros(8), np.zeros(3)
+        a = [f(pts[k]) for k in ("u", "v", "idepth_new", "iR")]
+        eng, oth = f(pts["energy"]), f(pts["outlierTH"])
+        T = np.ascontiguousarray(refToNew, np.float64).reshape(-1)
+        af = np.ascontiguousarray(aff, np.float64)
+        self._ck(self.L.nalo_init_calc_res_and_gs(self.h_, slot_first, slot_new, lvl, n, *[_f(x) for x in a], _u8(ig), _f(eng), _f(oth), _d(T), _d(af),
+                                                  alphaW, alphaK, couplingWeight, _u8(ign), _f(en), _f(ms), _f(lh), _f(jb), _d(H), _d(b), _d(Hs), _d(bs), _d(E3)))
+        return dict(H=H.reshape(8, 8), b=b, Hsc=Hs.reshape(8, 8), bsc=bs, E3=E3, isGood_new=ign, energy_new=en, maxstep=ms, lastHessian_new=lh, Jb=jb)
+
+    def init_do_step(self, isGood, Jb, maxstep, idepth, lam, inc, idepth_new):
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        out = f(idepth_new).copy()
+        self._ck(self.L.nalo_init_do_step(self.h_, len(out), _u8(np.ascontiguousarray(isGood, np.uint8)), _f(f(Jb)), _f(f(maxstep)), _f(f(idepth)), float(lam), _f(f(inc)), _f(out)))
+        return out
 
     # ---- immature points
     def imm_create(self, slot_host, u, v):

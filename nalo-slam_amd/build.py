@@ -4,9 +4,9 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["host_api.hip", "host_ba.hip", "kernels_pyramid.hip", "kernels_tracker.hip", "kernels_trk_lm.hip", "kernels_ba.hip", "kernels_ba_lin.hip", "kernels_dense.hip", "kernels_imm.hip"]
+SRC = ["host_api.hip", "host_ba.hip", "kernels_pyramid.hip", "kernels_tracker.hip", "kernels_trk_lm.hip", "kernels_ba.hip", "kernels_ba_lin.hip", "kernels_dense.hip", "kernels_imm.hip", "kernels_init.hip"]
 OUT = os.path.join(HERE, "libnalo_gpu.so")
-NO_CONTRACT = {"kernels_pyramid.hip", "kernels_imm.hip"}   # a1 is bit-exact vs the reference's scalar fp32 code: no FMA contraction
+NO_CONTRACT = {"kernels_pyramid.hip", "kernels_imm.hip", "kernels_init.hip"}   # a1 is bit-exact vs the reference's scalar fp32 code: no FMA contraction
 
 
 def build(force=False, verbose=False):
@@ -19,7 +19,9 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
     for s in srcs:
-        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        # the object name carries the flag set, so moving a file in/out of NO_CONTRACT (or changing NALO_CXXFLAGS) rebuilds it
+        tag = ("nc" if os.path.basename(s) in NO_CONTRACT else "fc") + ("%08x" % (hash(os.environ.get("NALO_CXXFLAGS", "")) & 0xFFFFFFFF) if os.environ.get("NALO_CXXFLAGS") else "")
+        o = os.path.join(HERE, "build", os.path.basename(s) + "." + tag + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):]):
             continue

@@ -384,6 +384,87 @@ int nalo_imm_trace(nalo_ctx* c, int slot_new, int n, const float* u, const float
     return NALO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ two-frame initialiser
+int nalo_init_calc_res_and_gs(nalo_ctx* c, int slot_first, int slot_new, int lvl, int n, const float* u, const float* v, const float* idepth_new, const float* iR,
+                              const uint8_t* isGood, const float* energy, const float* outlierTH, const double refToNew[12], const double aff[2],
+                              float alphaW, float alphaK, float couplingWeight,
+                              uint8_t* isGood_new, float* energy_new, float* maxstep, float* lastHessian_new, float* JbBuffer_new,
+                              double* H_out, double* b_out, double* H_out_sc, double* b_out_sc, double E3[3]) {
+    if (!c || n < 0 || !refToNew || !aff || !H_out || !b_out || !H_out_sc || !b_out_sc || !E3 ||
+        (n > 0 && (!u || !v || !idepth_new || !iR || !isGood || !energy || !outlierTH || !isGood_new || !energy_new || !maxstep || !lastHessian_new || !JbBuffer_new)))
+        return fail(c, NALO_ERR_ARG, "nalo_init_calc_res_and_gs: bad argument");
+    if (lvl < 0 || lvl >= c->levels) return fail(c, NALO_ERR_ARG, "nalo_init_calc_res_and_gs: level out of range");
+    for (int s : {slot_first, slot_new}) if (s < 0 || s >= (int)c->slots.size() || !c->slots[s].valid) return fail(c, NALO_ERR_STATE, "nalo_init_calc_res_and_gs: frame slot has no pyramid");
+    NALO_HIP(c, hipSetDevice(c->device));
+    const SE3 T = SE3::from(refToNew);
+    // RKi = (R * K^-1).cast<float>(), t.cast<float>(), r2new_aff = (exp(a), b) as floats (:347-349)
+    const double fxd = c->fx[lvl], fyd = c->fy[lvl], cxd = c->cx[lvl], cyd = c->cy[lvl];
+    const double Ki[9] = {1.0 / fxd, 0, -cxd / fxd, 0, 1.0 / fyd, -cyd / fyd, 0, 0, 1};
+    float RKi[9], tf[3];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) RKi[i * 3 + j] = (float)(T.R(i, 0) * Ki[j] + T.R(i, 1) * Ki[3 + j] + T.R(i, 2) * Ki[6 + j]); tf[i] = (float)T.t(i); }
+    const float r2new0 = (float)std::exp(aff[0]), r2new1 = (float)aff[1];
+    const float K4[4] = {(float)fxd, (float)fyd, (float)cxd, (float)cyd};
+    const double tsq = T.t(0) * T.t(0) + T.t(1) * T.t(1) + T.t(2) * T.t(2);
+    float alphaEnergy = (float)((double)alphaW * (0.0 + tsq * n));                     // EAlpha.A is always 0 in the reference (:560-575)
+    float alphaOpt;
+    if (alphaEnergy > alphaK * n) { alphaOpt = 0; alphaEnergy = alphaK * n; } else alphaOpt = alphaW;
+    double sums[96] = {};
+    if (n > 0) {
+        // words in: [u | v | idepth_new | iR | energy(2n) | outlierTH | isGood bytes]; out: [energy_new(2n) | maxstep | lastHessian_new | Jb(10n) | isGood_new bytes]; then 96 doubles
+        const size_t N = (size_t)n, NB = (N + 3) / 4, in_w = 7 * N + NB, out_w = 14 * N + NB, tot = in_w + out_w + 2 * 96 + 2;
+        int rc = imm_stage(c, tot); if (rc) return rc;
+        float* hst = c->imm_host;
+        std::memcpy(hst, u, N * 4); std::memcpy(hst + N, v, N * 4); std::memcpy(hst + 2 * N, idepth_new, N * 4); std::memcpy(hst + 3 * N, iR, N * 4);
+        std::memcpy(hst + 4 * N, energy, 2 * N * 4); std::memcpy(hst + 6 * N, outlierTH, N * 4); std::memcpy(hst + 7 * N, isGood, N);
+        float* ho = hst + in_w;
+        std::memcpy(ho + 3 * N, lastHessian_new, N * 4); std::memcpy(ho + 4 * N, JbBuffer_new, 10 * N * 4);          // in/out members
+        float* d = c->imm_dev.p;
+        const size_t sums_off = (in_w + out_w + 1) & ~(size_t)1;                                                      // 8-byte aligned
+        NALO_HIP(c, hipMemcpyAsync(d, hst, (in_w + out_w) * 4, hipMemcpyHostToDevice, c->stream));
+        rc = init_calc_launch(c, c->slots[slot_first].dI[lvl], c->slots[slot_new].dI[lvl], lvl, n, K4, RKi, tf, r2new0, r2new1, alphaOpt, couplingWeight, d, d + in_w, (double*)(d + sums_off));
+        if (rc) return rc;
+        NALO_HIP(c, hipMemcpyAsync(ho, d + in_w, (sums_off - in_w + 2 * 96) * 4, hipMemcpyDeviceToHost, c->stream));
+        NALO_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(energy_new, ho, 2 * N * 4); std::memcpy(maxstep, ho + 2 * N, N * 4); std::memcpy(lastHessian_new, ho + 3 * N, N * 4);
+        std::memcpy(JbBuffer_new, ho + 4 * N, 10 * N * 4); std::memcpy(isGood_new, ho + 14 * N, N);
+        std::memcpy(sums, hst + sums_off, 91 * 8);
+    }
+    // Accumulator9::finish -> float matrix, then topLeftCorner<8,8> / topRightCorner<8,1> (:596-599) and the alpha terms (:601-607)
+    int e = 0;
+    for (int a = 0; a < 9; ++a) for (int b = a; b < 9; ++b, ++e) {
+        const double va = (double)(float)sums[e], vs = (double)(float)sums[45 + e];
+        if (b < 8) { H_out[a * 8 + b] = H_out[b * 8 + a] = va; H_out_sc[a * 8 + b] = H_out_sc[b * 8 + a] = vs; }
+        else if (a < 8) { b_out[a] = va; b_out_sc[a] = vs; }
+    }
+    double xi[6]; se3_log(T, xi);
+    for (int k = 0; k < 3; ++k) {
+        H_out[k * 8 + k] = (double)(float)((float)H_out[k * 8 + k] + alphaOpt * n);
+        b_out[k] = (double)(float)((float)b_out[k] + (float)xi[k] * alphaOpt * n);
+    }
+    E3[0] = (double)(float)sums[90]; E3[1] = alphaEnergy; E3[2] = 2.0 * n;
+    return NALO_OK;
+}
+
+int nalo_init_do_step(nalo_ctx* c, int n, const uint8_t* isGood, const float* JbBuffer, const float* maxstep, const float* idepth, float lambda, const float inc[8], float* idepth_new) {
+    if (!c || n < 0 || !inc || (n > 0 && (!isGood || !JbBuffer || !maxstep || !idepth || !idepth_new))) return fail(c, NALO_ERR_ARG, "nalo_init_do_step: bad argument");
+    if (n == 0) return NALO_OK;
+    NALO_HIP(c, hipSetDevice(c->device));
+    // words: [Jb(10n) | maxstep | idepth | idepth_new (in/out) | inc(8) | isGood bytes]
+    const size_t N = (size_t)n, tot = 13 * N + 8 + (N + 3) / 4;
+    int rc = imm_stage(c, tot); if (rc) return rc;
+    float* hst = c->imm_host;
+    std::memcpy(hst, JbBuffer, 10 * N * 4); std::memcpy(hst + 10 * N, maxstep, N * 4); std::memcpy(hst + 11 * N, idepth, N * 4); std::memcpy(hst + 12 * N, idepth_new, N * 4);
+    std::memcpy(hst + 13 * N, inc, 32); std::memcpy(hst + 13 * N + 8, isGood, N);
+    float* d = c->imm_dev.p;
+    NALO_HIP(c, hipMemcpyAsync(d, hst, tot * 4, hipMemcpyHostToDevice, c->stream));
+    rc = init_do_step_launch(c, n, (const uint8_t*)(d + 13 * N + 8), d, d + 10 * N, d + 11 * N, lambda, d + 13 * N, d + 12 * N);
+    if (rc) return rc;
+    NALO_HIP(c, hipMemcpyAsync(hst + 12 * N, d + 12 * N, N * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(idepth_new, hst + 12 * N, N * 4);
+    return NALO_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ profiling
 static void prof_drain(nalo_ctx* c) {
     for (auto& kv : c->prof) {

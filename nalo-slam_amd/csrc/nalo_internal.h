@@ -139,6 +139,10 @@ int imm_optimize_launch(nalo_ctx* c, const float4* const* dI, int W, const float
                         int minObs, int* result, float* idepth_out, uint8_t* res_in);
 // staging for the immature-point entry points: pinned host block + device block of `floats` 4-byte words (grown on demand)
 int imm_stage(nalo_ctx* c, size_t words);
+// kernels_init.hip
+int init_calc_launch(nalo_ctx* c, const float4* colorRef, const float4* colorNew, int lvl, int n, const float K4[4], const float RKi[9], const float t[3], float r2new0, float r2new1,
+                     float alphaOpt, float couplingWeight, const float* base, float* outw, double* sums91);
+int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float* inc, float* idepth_new);
 // kernels_pyramid.hip
 int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
 // kernels_tracker.hip

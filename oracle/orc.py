@@ -111,6 +111,9 @@ def lib(kind="f32"):
     L.orc_ba_counts.restype = C.c_int
     L.orc_ba_set_idepth.argtypes = [C.c_void_p, c_fp]
     L.orc_ba_get_precalc_rt.argtypes = [C.c_void_p, c_fp, c_fp]
+    L.orc_init_calc_res_and_gs.argtypes = [c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_double, C.c_float, C.c_float, C.c_float, C.c_int,
+                                           c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.orc_init_do_step.argtypes = [C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
     L.orc_imm_create.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.orc_imm_trace.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
     L.orc_imm_optimize.argtypes = [C.c_int, C.POINTER(c_fp), C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_u8p]
@@ -200,6 +203,39 @@ def imm_optimize(dI_list, w, h, K, Rt, aff, host, u, v, color, weights, energyTH
     Kf, Rtf, aff_f, hi = f(K), f(Rt), f(aff), np.ascontiguousarray(host, np.int32)
     lib(kind).orc_imm_optimize(W, arr, w, h, fp(Kf), fp(Rtf), fp(aff_f), n, ip(hi), *[fp(x) for x in a], int(min_obs), ip(res), fp(idp), u8p(rin))
     return res, idp, rin
+
+
+# ------------------------------------------------------------------ two-frame initialiser
+def init_calc_res_and_gs(colorRef, colorNew, wl, hl, K4, refToNew, aff, pts, alphaW=150.0 * 150.0, alphaK=2.5 * 2.5, couplingWeight=1.0, kind="f32"):
+    """CoarseInitializer::calcResAndGS on one level. pts: dict of arrays u, v, idepth_new, iR, isGood, energy[n,2], outlierTH, lastHessian_new, Jb[n,10]
+    (the last two are in/out). -> dict(H, b, Hsc, bsc, E3, isGood_new, energy_new, maxstep, lastHessian_new, Jb)"""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    T = np.asarray(refToNew, np.float64).reshape(3, 4)
+    fx, fy, cx, cy = [float(x) for x in K4]
+    Ki = np.array([[1 / fx, 0, -cx / fx], [0, 1 / fy, -cy / fy], [0, 0, 1.0]])
+    # (R * K^-1) in double, term by term in the order of the C++ host code, then cast (a BLAS matmul may fuse/reorder the three terms)
+    RKi = f([float(T[i, 0]) * float(Ki[0, j]) + float(T[i, 1]) * float(Ki[1, j]) + float(T[i, 2]) * float(Ki[2, j]) for i in range(3) for j in range(3)])
+    t = f(T[:, 3])
+    aff2 = f([np.exp(aff[0]), aff[1]])
+    tlog = f(se3_log(T, kind)[:3])
+    n = len(pts["u"])
+    ig = np.ascontiguousarray(pts["isGood"], np.uint8)
+    ign, en, ms = np.zeros(n, np.uint8), np.zeros((n, 2), np.float32), np.zeros(n, np.float32)
+    lh, jb = f(pts["lastHessian_new"]).copy(), f(pts["Jb"]).copy()
+    H, b, Hs, bs, E3 = np.zeros(64), np.zeros(8), np.zeros(64), np.zeros(8), np.zeros(3)
+    a = [f(pts[k]) for k in ("u", "v", "idepth_new", "iR")]
+    eng, oth = f(pts["energy"]), f(pts["outlierTH"])
+    lib(kind).orc_init_calc_res_and_gs(fp(f(colorRef)), fp(f(colorNew)), wl, hl, fp(f(K4)), fp(RKi), fp(t), fp(aff2), fp(tlog), float((T[:, 3] ** 2).sum()),
+                                       alphaW, alphaK, couplingWeight, n, *[fp(x) for x in a], u8p(ig), fp(eng), fp(oth), u8p(ign), fp(en), fp(ms), fp(lh), fp(jb),
+                                       dp(H), dp(b), dp(Hs), dp(bs), dp(E3))
+    return dict(H=H.reshape(8, 8), b=b, Hsc=Hs.reshape(8, 8), bsc=bs, E3=E3, isGood_new=ign, energy_new=en, maxstep=ms, lastHessian_new=lh, Jb=jb)
+
+
+def init_do_step(isGood, Jb, maxstep, idepth, lam, inc, idepth_new, kind="f32"):
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    out = f(idepth_new).copy()
+    lib(kind).orc_init_do_step(len(out), u8p(np.ascontiguousarray(isGood, np.uint8)), fp(f(Jb)), fp(f(maxstep)), fp(f(idepth)), float(lam), fp(f(inc)), fp(out))
+    return out
 
 
 class Tracker:

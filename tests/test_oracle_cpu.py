@@ -337,3 +337,36 @@ def test_immature_points_filter_and_activation_recover_true_depth():
     err0 = np.abs(mid[act] - idt[act]) / idt[act]
     err1 = np.abs(idp[act] - idt[act]) / idt[act]
     assert np.median(err1) < 0.6 * np.median(err0)         # small image, short baselines: three damped GN steps halve the error
+
+
+def test_initializer_pass_schur_identity_and_descent():
+    """SURVEY 8(f) rank 2, oracle-free checks of the calcResAndGS restatement: (i) the Schur accumulator equals sum_i w_i Jb_i Jb_i^T rebuilt in
+    numpy from the returned per-point buffers, (ii) H is the Gauss-Newton matrix of b: a damped step from a 10 % wrong pose lowers the energy,
+    (iii) the reference's E.num = 2 npts and alphaEnergy = min(alphaW |t|^2 n, alphaK n) behaviour."""
+    win = synth.make_window(w=320, h=240, W=2, P=50, seed=13, n_extra=0, step_z=0.12, yaw_deg=0.3)
+    dI0 = orc.make_images(win.images[0], 1)[0]
+    dI1 = orc.make_images(win.images[1], 1)[0]
+    rng = np.random.RandomState(5)
+    n = 1500
+    u = rng.randint(6, win.w - 7, n).astype(np.float32); v = rng.randint(6, win.h - 7, n).astype(np.float32)
+    d = win.depth[0][v.astype(int), u.astype(int)]
+    idt = np.where(np.isfinite(d), 1.0 / d, 0.1).astype(np.float32)
+    pts = dict(u=u, v=v, idepth_new=idt, iR=idt, isGood=np.ones(n, np.uint8), energy=np.zeros((n, 2), np.float32), outlierTH=np.full(n, 8 * 144.0, np.float32),
+               lastHessian_new=np.zeros(n, np.float32), Jb=np.zeros((n, 10), np.float32))
+    K4 = np.array(win.K, np.float64)
+    T_true = synth.se3_mul(win.world_to_cam[1], synth.se3_inv(win.world_to_cam[0]))
+    T0 = orc.se3_exp(orc.se3_log(T_true) * 0.9)
+    r0 = orc.init_calc_res_and_gs(dI0, dI1, win.w, win.h, K4, T0, (0.0, 0.0), pts, alphaK=1e9, alphaW=0.0)
+    g = r0["isGood_new"] == 1
+    assert g.sum() > 0.8 * n and r0["E3"][2] == 2 * n and r0["E3"][1] == 0.0
+    Jb = r0["Jb"][g].astype(np.float64)
+    Hs = (Jb[:, :9] * Jb[:, 9:10]).T @ Jb[:, :9]
+    assert np.abs(Hs[:8, :8] - r0["Hsc"]).max() < 1e-5 * np.abs(r0["Hsc"]).max() and np.abs(Hs[:8, 8] - r0["bsc"]).max() < 1e-5 * np.abs(r0["bsc"]).max()
+    Hr, br = r0["H"] - r0["Hsc"], r0["b"] - r0["bsc"]
+    inc = -np.linalg.solve(Hr + 0.1 * np.diag(np.diag(Hr)), br)
+    r1 = orc.init_calc_res_and_gs(dI0, dI1, win.w, win.h, K4, synth.se3_mul(orc.se3_exp(inc[:6]), T0), (float(inc[6]), float(inc[7])), pts, alphaK=1e9, alphaW=0.0)
+    rt = orc.init_calc_res_and_gs(dI0, dI1, win.w, win.h, K4, T_true, (0.0, 0.0), pts, alphaK=1e9, alphaW=0.0)
+    assert r1["E3"][0] < r0["E3"][0] and rt["E3"][0] < r0["E3"][0]          # the photometric minimum sits within noise of the true pose
+    ra = orc.init_calc_res_and_gs(dI0, dI1, win.w, win.h, K4, T0, (0.0, 0.0), pts)                 # reference constants: alphaW = 150^2, alphaK = 2.5^2
+    tsq = float((T0[:, 3] ** 2).sum())
+    assert abs(ra["E3"][1] - min(150.0 * 150.0 * tsq * n, 2.5 * 2.5 * n)) < 1e-3 * ra["E3"][1]
