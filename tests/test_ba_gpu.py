@@ -159,9 +159,9 @@ def test_marginalize_points(small_window):
     c.close()
 
 
-@pytest.mark.parametrize("W,P", [(3, 300), (7, 900), (12, 1800)])
+@pytest.mark.parametrize("W,P", [(3, 300), (7, 900), (12, 1800), (16, 2400)])
 def test_window_sizes(W, P):
-    """every SYRK tile width (T = 2, 4, 6) and odd/even window sizes: stitched systems vs the oracle, partial residual graph."""
+    """every SYRK tile width (T = 2, 4, 6, 8 = NALO_MAX_WINDOW) and odd/even window sizes: stitched systems vs the oracle, partial residual graph."""
     win = synth.make_window(w=640, h=480, W=W, P=P, seed=21, full_graph=False)
     st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
     orc.lib().orc_set_sum_mode(0)

@@ -199,3 +199,37 @@ def test_degenerate_windows():
     assert np.isfinite(E) and np.isfinite(HA).all()
     assert np.isfinite(c.ba_optimize(1, never_break=True)) or nA == 0
     c.close()
+
+
+def test_two_contexts_on_two_threads():
+    """the reference drives the tracker and the mapper from different threads (FullSystem::mappingLoop): two contexts used concurrently must not share
+    state. Thread A tracks frames in a loop, thread B optimises a window; both must reproduce their single-threaded results bit for bit."""
+    import threading
+    win = synth.make_window(w=640, h=480, W=5, P=600, seed=31, n_extra=1)
+    st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
+    W = win.W
+    Ku, Kv, idp, hdi = tracker_inputs(win, n=4000, seed=3)
+    T0 = orc.se3_exp(orc.se3_log(true_rel_pose(win, W - 1, W)) * 0.9)
+
+    def track_job(out, reps):
+        c = binding.Context(win.w, win.h, win.K, n_slots=2)
+        c.frame_upload(0, win.images[W - 1]); c.frame_upload(1, win.images[W])
+        for _ in range(reps):
+            c.trk_set_ref(0, Ku, Kv, idp, hdi)
+            out.append(c.trk_track(1, T0, [0, 0], [0, 0], [1, 1], c.levels - 1)[1].copy())
+        c.close()
+
+    def ba_job(out, reps):
+        for _ in range(reps):
+            c = make_ctx(win, st6)
+            c.ba_optimize(4, never_break=True)
+            out.append(c.ba_get_frames()[1].copy())
+            c.close()
+
+    ref_t, ref_b = [], []
+    track_job(ref_t, 1); ba_job(ref_b, 1)
+    got_t, got_b = [], []
+    ta, tb = threading.Thread(target=track_job, args=(got_t, 6)), threading.Thread(target=ba_job, args=(got_b, 3))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert len(got_t) == 6 and len(got_b) == 3
+    assert all(np.array_equal(t, ref_t[0]) for t in got_t) and all(np.array_equal(b, ref_b[0]) for b in got_b)
