@@ -18,6 +18,7 @@ void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const floa
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
 void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
+int ba_launch_gn(hipStream_t s, const GNDev& G, int iteration, int never_break, double lambda);
 void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
 
@@ -56,6 +57,10 @@ struct BAWindow {
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
     DevBuf<int> blk_host, host_blk, blk_order, sc_grp;
     DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 16
+    // device-side Gauss-Newton loop (kernels_ba_gn.hip): constants + states of one optimize() call
+    DevBuf<double> gn_d; DevBuf<float> gn_f; DevBuf<int> gn_i; GNDev gn{};
+    double* gn_host = nullptr; size_t gn_host_cap = 0;              // pinned staging (doubles; the float part follows)
+    bool th_on_side = false;                                        // run the quantile kernels on the side stream (device loop / sharded windows)
     bool step_fused = false, step_sums_deferred = false;            // optimize(): resubstitute + point step in one kernel, its sums finished by the reduce launch
     bool th_pending = false;                                        // a linearize pass whose frameEnergyTH quantile has not been launched yet
     DevBuf<double> acc13, G, AD, stitched;                      // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | misc (2 W^2) | step sums (3) | TH sum, ranks]
@@ -92,6 +97,8 @@ void ba_destroy(nalo_ctx* c) {
     w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
+    if (w->gn_host) (void)hipHostFree(w->gn_host);
+    w->gn_d.release(); w->gn_f.release(); w->gn_i.release();
     if (w->ad_host) (void)hipHostFree(w->ad_host);
     if (w->ev_ad) (void)hipEventDestroy(w->ev_ad);
     delete w;
@@ -176,6 +183,8 @@ static int set_adjoints(nalo_ctx* c) {
     NALO_HIP(c, hipEventRecord(w.ev_ad, c->stream));
     w.sd.AD = w.AD.p;
     if (!w.st_ticket.p) { NALO_HIP(c, w.st_ticket.reserve(4)); NALO_HIP(c, hipMemset(w.st_ticket.p, 0, 16)); }
+    if (!w.gn_i.p) { NALO_HIP(c, w.gn_i.reserve(4)); NALO_HIP(c, hipMemset(w.gn_i.p, 0, 16)); }
+    w.dev.stop = nullptr; w.sd.stop = nullptr;                        // only the device-side GN loop arms the early-exit flag
     w.sd.ticket = w.st_ticket.p; w.sd.W = W; w.sd.n1 = n1; w.sd.NPL = w.NPL;
     w.proj_valid = false;
     return NALO_OK;
@@ -200,7 +209,7 @@ static int set_precalc(nalo_ctx* c) {
     for (int i = 0; i < 4; ++i) w.cDeltaF[i] = (float)(w.c_value[i] - w.c_value_zero[i]);
     for (auto& f : w.frames) frame_take_data(f);
     const size_t nfl = (size_t)W * W * kPreStride;
-    if (w.up_cap < nfl + 64) { if (w.up_host) (void)hipHostFree(w.up_host); NALO_HIP(c, hipHostMalloc((void**)&w.up_host, (nfl + 64 + (size_t)W * W * 8) * 4)); w.up_cap = nfl + 64; }
+    if (w.up_cap < nfl + 80) { if (w.up_host) (void)hipHostFree(w.up_host); NALO_HIP(c, hipHostMalloc((void**)&w.up_host, (nfl + 80 + (size_t)W * W * 8) * 4)); w.up_cap = nfl + 80; }   // [pre | calib 16 | xc 64 | xAd]
     float* rec = w.up_host;
     const float fx = w.c_scaledf[0], fy = w.c_scaledf[1], cx = w.c_scaledf[2], cy = w.c_scaledf[3];
     const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1.0f / fx, 0, -cx / fx, 0, 1.0f / fy, -cy / fy, 0, 0, 1};
@@ -220,11 +229,13 @@ static int set_precalc(nalo_ctx* c) {
         o[24] = (float)a[0]; o[25] = (float)a[1]; o[26] = (float)(host.state_zero[7] * kScaleB);
         for (int k = 0; k < 8; ++k) o[27 + k] = w.adHTdeltaF[(size_t)(h + t * W) * 8 + k];
     }
-    NALO_HIP(c, w.pre.reserve(nfl));
-    NALO_HIP(c, hipMemcpyAsync(w.pre.p, rec, nfl * 4, hipMemcpyHostToDevice, c->stream));
-    w.dev.pre = w.pre.p;
-    w.dev.fxl = fx; w.dev.fyl = fy; w.dev.cxl = cx; w.dev.cyl = cy; w.dev.fxli = w.c_scaledi[0]; w.dev.fyli = w.c_scaledi[1];
-    for (int i = 0; i < 4; ++i) w.dev.cDelta[i] = w.cDeltaF[i];
+    float* cal = rec + nfl;                                               // CalibHessian::value_scaledf / value_scaledi + cDeltaF travel with the records
+    cal[0] = fx; cal[1] = fy; cal[2] = cx; cal[3] = cy; cal[4] = w.c_scaledi[0]; cal[5] = w.c_scaledi[1];
+    for (int i = 0; i < 4; ++i) cal[6 + i] = w.cDeltaF[i];
+    NALO_HIP(c, w.pre.reserve(nfl + 16));
+    NALO_HIP(c, hipMemcpyAsync(w.pre.p, rec, (nfl + 16) * 4, hipMemcpyHostToDevice, c->stream));
+    w.dev.pre = w.pre.p; w.dev.calib = w.pre.p + nfl;
+
     return NALO_OK;
 }
 
@@ -262,7 +273,7 @@ static int linearize_async(nalo_ctx* c, int mode, int fix) {
         ProfScope ps(c, "ba_linearize");
         ba_launch_linearize(c->stream, w.dev, mode, fix);
     }
-    if (mode == 0 && w.hook) {
+    if (mode == 0 && (w.hook || w.th_on_side)) {
         // sharded window: the threshold is part of the all-reduced tail, i.e. on the critical path: run its kernels on the side stream under SC
         if (!w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming)); }
         NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
@@ -457,8 +468,8 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     if (x_out) std::memcpy(x_out, x.data(), n * 8);
     // resubstituteF_MT (:263-289)
     for (int i = 0; i < 4; ++i) w.c_step[i] = -x[i];
-    float* xAd = w.up_host + (size_t)W * W * kPreStride + 64;
-    float* xc = w.up_host + (size_t)W * W * kPreStride;
+    float* xAd = w.up_host + (size_t)W * W * kPreStride + 16 + 64;
+    float* xc = w.up_host + (size_t)W * W * kPreStride + 16;
     std::vector<float> xF(n);
     for (int i = 0; i < n; ++i) xF[i] = (float)x[i];
     for (int i = 0; i < 4; ++i) xc[i] = xF[i];
@@ -763,12 +774,126 @@ int nalo_ba_do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float f
     return do_step(c, fC, fT, fR, fA, fD, canbreak);
 }
 
+// FullSystemOptimize.cpp:550-602: fix the newest frame's linearisation point, linearizeAll(true), rmse
+static int optimize_epilogue(nalo_ctx* c, double* rmse) {
+    BAWindow& w = *c->ba;
+    const int W = w.W;
+    HostTimer hte(c, "ba.opt.epilogue");
+    HostFrame& nf = w.frames[W - 1];                                        // :550-557
+    const double nsz[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
+    nf.evalPT = nf.PRE_worldToCam;
+    frame_set_state(nf, nsz); frame_set_state_zero(nf, nsz);
+    int rc = set_adjoints(c); if (rc) return rc;
+    rc = set_precalc(c); if (rc) return rc;
+    rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
+    rc = stitch_and_fetch(c, true, false, true); if (rc) return rc;
+    nf.frameEnergyTH = tail_th(w);
+    double e = 0; int nres = 0; misc_totals(w, &e, &nres);
+    // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)
+    if (rmse) *rmse = std::sqrt((float)(e / (kPatternNum * (double)w.resInA)));
+    return NALO_OK;
+}
+
+// The GN loop with the frame-side work on the device (kernels_ba_gn.hip): every iteration is queued without waiting; ONE synchronisation at the end
+// brings the states back. Used when nothing forces the host into the loop: no hook, or a stream-ordered hook (nalo_ba_set_allreduce_mode).
+static int optimize_device_loop(nalo_ctx* c, int mnumOptIts, int never_break) {
+    BAWindow& w = *c->ba;
+    const int W = w.W, n = w.n, n1 = w.n1, NPL = w.NPL;
+    const size_t blk = (size_t)n1 * n1, PW = (size_t)W * W;
+    if (!w.proj_valid) build_projector(w);
+    // doubles: [HM n*n | bM n | Sproj 7n | state_zero 10W | evalPT 12W | prior 8W | c_zero 4 || state 10W | c_value 4 | backup 10W | step 10W | c_backup 4 | w2c 12W | c2w 12W | x n]
+    const size_t o_HM = 0, o_bM = o_HM + (size_t)n * n, o_S = o_bM + n, o_sz = o_S + 7 * (size_t)n, o_ev = o_sz + 10 * W, o_pr = o_ev + 12 * W, o_cz = o_pr + 8 * W,
+                 o_st = o_cz + 4, o_cv = o_st + 10 * W, n_up = o_cv + 4, o_bk = n_up, o_sp = o_bk + 10 * W, o_cb = o_sp + 10 * W, o_w2c = o_cb + 4, o_c2w = o_w2c + 12 * W,
+                 o_x = o_c2w + 12 * W, n_d = o_x + n;
+    // floats: [ab_exposure W | adHostF 64 W^2 | adTargetF 64 W^2 | sums 4]
+    const size_t f_ab = 0, f_ah = f_ab + 16, f_at = f_ah + 64 * PW, n_fup = f_at + 64 * PW, f_sum = n_fup, n_f = f_sum + 4;
+    const size_t host_words = n_up + (n_fup + 1) / 2 + 16;
+    if (w.gn_host_cap < host_words) { if (w.gn_host) (void)hipHostFree(w.gn_host); w.gn_host = nullptr; NALO_HIP(c, hipHostMalloc((void**)&w.gn_host, host_words * 8)); w.gn_host_cap = host_words; }
+    NALO_HIP(c, w.gn_d.reserve(n_d)); NALO_HIP(c, w.gn_f.reserve(n_f));
+    double* hd = w.gn_host; float* hf = (float*)(w.gn_host + n_up);
+    std::memcpy(hd + o_HM, w.HM.data(), (size_t)n * n * 8); std::memcpy(hd + o_bM, w.bM.data(), (size_t)n * 8); std::memcpy(hd + o_S, w.Sproj.data(), (size_t)n * 7 * 8);
+    for (int f = 0; f < W; ++f) {
+        const HostFrame& fr = w.frames[f];
+        std::memcpy(hd + o_sz + 10 * f, fr.state_zero, 80); std::memcpy(hd + o_ev + 12 * f, fr.evalPT.m, 96); std::memcpy(hd + o_pr + 8 * f, fr.prior, 64);
+        std::memcpy(hd + o_st + 10 * f, fr.state, 80);
+        hf[f_ab + f] = fr.ab_exposure;
+    }
+    for (int i = 0; i < 4; ++i) { hd[o_cz + i] = w.c_value_zero[i]; hd[o_cv + i] = w.c_value[i]; }
+    std::memcpy(hf + f_ah, w.adHostF.data(), 64 * PW * 4); std::memcpy(hf + f_at, w.adTargetF.data(), 64 * PW * 4);
+    NALO_HIP(c, hipMemcpyAsync(w.gn_d.p, hd, n_up * 8, hipMemcpyHostToDevice, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(w.gn_f.p, hf, n_fup * 4, hipMemcpyHostToDevice, c->stream));
+    NALO_HIP(c, hipMemsetAsync(w.gn_i.p, 0, 16, c->stream));
+    NALO_HIP(c, w.xad.reserve(PW * 8 + 64));
+    GNDev& G = w.gn;
+    G.W = W; G.n = n;
+    G.HM = w.gn_d.p + o_HM; G.bM = w.gn_d.p + o_bM; G.Sproj = w.gn_d.p + o_S; G.state_zero = w.gn_d.p + o_sz; G.evalPT = w.gn_d.p + o_ev; G.prior = w.gn_d.p + o_pr; G.c_zero = w.gn_d.p + o_cz;
+    G.state = w.gn_d.p + o_st; G.c_value = w.gn_d.p + o_cv; G.backup = w.gn_d.p + o_bk; G.step = w.gn_d.p + o_sp; G.c_backup = w.gn_d.p + o_cb; G.w2c = w.gn_d.p + o_w2c; G.c2w = w.gn_d.p + o_c2w;
+    G.x = w.gn_d.p + o_x;
+    G.ab_exposure = w.gn_f.p + f_ab; G.adHostF = w.gn_f.p + f_ah; G.adTargetF = w.gn_f.p + f_at; G.sums = w.gn_f.p + f_sum;
+    G.stitched = w.stitched.p; G.pre = w.pre.p; G.xad = w.xad.p; G.stop = w.gn_i.p; G.iters_done = w.gn_i.p + 1;
+    w.th_on_side = true;
+    w.dev.stop = w.gn_i.p; w.sd.stop = w.gn_i.p;
+    ba_launch_reset_oob(c->stream, w.dev);                                  // :412-429
+    int rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :436 (+ applyRes :459-462)
+    for (int it = 0; it < mnumOptIts; ++it) {
+        rc = sc_async(c, 1, 1.f, 0); if (rc) return rc;
+        {
+            ProfScope ps(c, "ba_reduce");
+            if (w.hook) {                                                   // the threshold rides in the all-reduced tail
+                rc = flush_th(c); if (rc) return rc;
+                ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
+            }
+            ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.stitched.p + 2 * blk, w.G.p, true, true,
+                             w.step_sums_deferred ? w.step_partial.p : nullptr, (w.Ppad + 255) / 256, w.stitched.p + 2 * blk + 2 * W * W);
+            w.step_sums_deferred = false;
+            if (ba_launch_stitch(c->stream, w.sd, true, true, nullptr, 0, 0.0)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
+            w.stitched_top = w.stitched_sc = true;
+        }
+        if (w.hook) {
+            w.hook(w.hook_user, w.stitched.p, (int)(2 * blk + 2 * W * W + 5));  // stream-ordered: enqueued behind the stitch
+            ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));
+        }
+        if (ba_launch_gn(c->stream, G, it, never_break, 1e-5)) return fail(c, NALO_ERR_HIP, "ba_gn_kernel: LDS size rejected");   // SOLVER_FIX_LAMBDA (EnergyFunctional.cpp:779)
+        NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
+        {
+            ProfScope ps(c, "ba_resub");
+            ba_launch_resub_step(c->stream, w.dev, w.xad.p + 64, w.xad.p, 1.f, w.step_partial.p);
+        }
+        w.step_sums_deferred = true;
+        w.dev.pre = w.pre.p; w.dev.calib = w.pre.p + PW * kPreStride;
+        rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :511
+    }
+    // the only synchronisation of the loop: states, calibration, last x, misc of the last solve
+    double* back = w.gn_host;                                               // [state 10W | c_value 4 | x n | misc 2W^2]
+    NALO_HIP(c, hipMemcpyAsync(back, w.gn_d.p + o_st, (10 * (size_t)W + 4) * 8, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(back + 10 * W + 4, w.gn_d.p + o_x, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(back + 10 * W + 4 + n, w.stitched.p + 2 * blk, 2 * PW * 8, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    w.th_on_side = false;
+    w.dev.stop = nullptr; w.sd.stop = nullptr;
+    calib_set_value(w, back + 10 * W);
+    for (int f = 0; f < W; ++f) frame_set_state(w.frames[f], back + 10 * f);
+    w.lastX.assign(back + 10 * W + 4, back + 10 * W + 4 + n);
+    { const double* m = back + 10 * W + 4 + n; double cnt = 0; for (size_t i = 0; i < PW; ++i) cnt += m[2 * i]; w.resInA = (int)(cnt + 0.5); }
+    w.step_pending = false; w.step_fused = false;
+    return NALO_OK;
+}
+
 int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse) {
     NALO_BA_READY("nalo_ba_optimize")
     HostTimer ht(c, "ba_optimize");
     const int W = w.W;
     if (W < 3) mnumOptIts = 20;                                             // FullSystemOptimize.cpp:401-403
     if (W < 4) mnumOptIts = 15;
+    // NALO_BA_DEVICE_GN=1: the frame-side work of every iteration runs on the device and the loop is queued without waiting (kernels_ba_gn.hip).
+    // Correct (same tests) but measured SLOWER on MI355X: the pivoted (8W+4)^2 LDL^T, SE3::exp and the substitutions are latency-bound serial fp64 work
+    // (190 us per iteration in one workgroup against ~60 us for the host round trip incl. PCIe publish, poll, 17 us AVX2 LDL^T and launches). Kept as an
+    // option; the default is the host-driven loop below.
+    static const bool dev_loop = std::getenv("NALO_BA_DEVICE_GN") != nullptr;
+    if (dev_loop && (!w.hook || w.hook_stream_ordered)) {
+        int rc = optimize_device_loop(c, mnumOptIts, never_break); if (rc) return rc;
+        return optimize_epilogue(c, rmse);
+    }
     ba_launch_reset_oob(c->stream, w.dev);                                  // :412-429
     int rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :436 (+ applyRes :459-462)
     double lambda = 1e-1;
@@ -785,20 +910,7 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
             if (w.last_canbreak) break;
         }
     }
-    HostTimer hte(c, "ba.opt.epilogue");
-    HostFrame& nf = w.frames[W - 1];                                        // :550-557
-    const double nsz[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
-    nf.evalPT = nf.PRE_worldToCam;
-    frame_set_state(nf, nsz); frame_set_state_zero(nf, nsz);
-    rc = set_adjoints(c); if (rc) return rc;
-    rc = set_precalc(c); if (rc) return rc;
-    rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
-    rc = stitch_and_fetch(c, true, false, true); if (rc) return rc;
-    nf.frameEnergyTH = tail_th(w);
-    double e = 0; int nres = 0; misc_totals(w, &e, &nres);
-    // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)
-    if (rmse) *rmse = std::sqrt((float)(e / (kPatternNum * (double)w.resInA)));
-    return NALO_OK;
+    return optimize_epilogue(c, rmse);
 }
 
 int nalo_ba_marginalize_points(nalo_ctx* c, const uint8_t* flags, double* M, double* Mb, double* Msc, double* Mbsc) {

@@ -7,15 +7,22 @@
 #include <vector>
 #include <algorithm>
 
+// SE3, se3_exp and aff_from_to are also used by the device-side Gauss-Newton step (kernels_ba_gn.hip): same source, same operation order
+#if defined(__HIPCC__)
+#define NALO_HD __host__ __device__
+#else
+#define NALO_HD
+#endif
+
 namespace nalo {
 
 struct SE3 {                     // row-major 3x4 [R|t]
     double m[12];
-    static SE3 identity() { SE3 s; std::memset(s.m, 0, sizeof(s.m)); s.m[0] = s.m[5] = s.m[10] = 1; return s; }
-    static SE3 from(const double* p) { SE3 s; std::memcpy(s.m, p, sizeof(s.m)); return s; }
-    double R(int i, int j) const { return m[i * 4 + j]; }
-    double t(int i) const { return m[i * 4 + 3]; }
-    SE3 operator*(const SE3& b) const {
+    NALO_HD static SE3 identity() { SE3 s; for (int i = 0; i < 12; ++i) s.m[i] = 0; s.m[0] = s.m[5] = s.m[10] = 1; return s; }
+    NALO_HD static SE3 from(const double* p) { SE3 s; for (int i = 0; i < 12; ++i) s.m[i] = p[i]; return s; }
+    NALO_HD double R(int i, int j) const { return m[i * 4 + j]; }
+    NALO_HD double t(int i) const { return m[i * 4 + 3]; }
+    NALO_HD SE3 operator*(const SE3& b) const {
         SE3 c;
         for (int i = 0; i < 3; ++i) {
             for (int j = 0; j < 3; ++j) c.m[i * 4 + j] = R(i, 0) * b.R(0, j) + R(i, 1) * b.R(1, j) + R(i, 2) * b.R(2, j);
@@ -23,7 +30,7 @@ struct SE3 {                     // row-major 3x4 [R|t]
         }
         return c;
     }
-    SE3 inverse() const {
+    NALO_HD SE3 inverse() const {
         SE3 c;
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) c.m[i * 4 + j] = R(j, i);
         for (int i = 0; i < 3; ++i) c.m[i * 4 + 3] = -(c.R(i, 0) * t(0) + c.R(i, 1) * t(1) + c.R(i, 2) * t(2));
@@ -43,7 +50,7 @@ struct SE3 {                     // row-major 3x4 [R|t]
 };
 
 // exp: tangent (upsilon, omega) -> SE3; rotation through the unit quaternion (cos(th/2), sin(th/2)/th * omega)
-inline SE3 se3_exp(const double xi[6]) {
+NALO_HD inline SE3 se3_exp(const double xi[6]) {
     const double wx = xi[3], wy = xi[4], wz = xi[5];
     const double th2 = wx * wx + wy * wy + wz * wz, th = std::sqrt(th2);
     double qi, qr;
@@ -60,7 +67,7 @@ inline SE3 se3_exp(const double xi[6]) {
     double O2[9];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
     double V[9];
-    if (th < 1e-10) std::memcpy(V, Rm, sizeof(V));
+    if (th < 1e-10) { for (int i = 0; i < 9; ++i) V[i] = Rm[i]; }
     else {
         const double a = (1 - std::cos(th)) / th2, b = (th - std::sin(th)) / (th2 * th);
         for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + b * O2[i];
@@ -103,7 +110,7 @@ inline void se3_log(const SE3& T, double xi[6]) {
 }
 
 // AffLight::fromToVecExposure (util/NumType.h:173-185)
-inline void aff_from_to(float expF, float expT, double aF, double bF, double aT, double bT, double out[2]) {
+NALO_HD inline void aff_from_to(float expF, float expT, double aF, double bF, double aT, double bT, double out[2]) {
     if (expF == 0 || expT == 0) expT = expF = 1;
     const double a = std::exp(aT - aF) * expT / expF;
     out[0] = a; out[1] = bT - a * bF;

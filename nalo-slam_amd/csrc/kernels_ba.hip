@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
     __shared__ float Wt[ROWS], Bd[ROWS];
     // workgroup -> (group of up to sc_bpw consecutive point blocks of ONE host, share ks of each block's points). Large windows put several
     // blocks through one workgroup: the fp64 partial (NPL^2 x 8 B, as large as a block's operands) is then written once per group.
+    if (B.stop && B.stop[0]) return;
     const int grp = blockIdx.x / KS, ks = blockIdx.x - grp * KS, tid = threadIdx.x, W = B.W;
     int h = 0;
     while (h + 1 < W && grp >= B.sc_grp[h + 1]) ++h;
@@ -193,8 +194,9 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
                                                          const int* __restrict__ host_blk /* [W+1] */, const int* __restrict__ sc_grp /* [W+1] */, int W, int NPL2, int sc_tiles, int mask, int KS,
                                                          double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G,
-                                                         const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out) {
+                                                         const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out, const int* __restrict__ stop) {
     __shared__ double part[16][64];
+    if (stop && stop[0]) return;
     __shared__ double sums[128];
     if ((int)blockIdx.x < W * W) {
         if (!(mask & 1)) return;
@@ -241,7 +243,7 @@ void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NP
                       const float* step_partial, int step_blocks, double* step_out) {
     const int tiles = (NPL * NPL + 63) / 64;
     ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.sc_grp, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
-                                                                                       B.sc_split, acc13, misc, G, step_partial, step_blocks, step_out);
+                                                                                       B.sc_split, acc13, misc, G, step_partial, step_blocks, step_out, B.stop);
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)
@@ -371,6 +373,7 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
 __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, int ad_in_lds, double* mapped, int ntail, double seq) {
     extern __shared__ double lds[];
     __shared__ int is_last;
+    if (D.stop && D.stop[0]) return;
     const int W = D.W, n1 = D.n1, n = n1 - 1, NPL = D.NPL, tid = threadIdx.x, NT = blockDim.x;
     const int sys = blockIdx.x / (W + 1), g = blockIdx.x - sys * (W + 1);
     const double* __restrict__ adH = D.AD;
@@ -498,6 +501,7 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
 template <bool STEP>
 __global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __restrict__ xAd, const float* __restrict__ xc, float stepfacD, float* __restrict__ partial) {
     __shared__ float smem[64 * 4];
+    if (B.stop && B.stop[0]) return;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     float v[3] = {0.f, 0.f, 0.f};
     if (d < B.Ppad && (B.pt_flags[d] & PT_VALID)) {
@@ -594,7 +598,8 @@ void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partia
 // that target the newest frame, by a two-level 16+16-bit radix select on the float bit patterns (monotone for x >= 0):
 // the high-half histogram is filled by ba_linearize_kernel itself (integer atomics), then find-hi -> low-half histogram of the
 // matching entries -> find-lo + the threshold formula (:130-133). Runs on the side stream, overlapped with SC/reduce/stitch.
-__global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new) {
+__global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new, const int* __restrict__ stop) {
+    if (stop && stop[0]) return;
     __shared__ unsigned wsum[16], wpre[17];
     __shared__ unsigned s_sel, s_run;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -641,7 +646,8 @@ __global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) z4[i] = make_uint4(0u, 0u, 0u, 0u);                    // ready for the next pass
 }
-__global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo) {
+__global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo, const int* __restrict__ stop) {
+    if (stop && stop[0]) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float f = en[i];
@@ -650,9 +656,9 @@ __global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__
     if ((u >> 16) == state[2]) atomicAdd(&hist_lo[u & 0xFFFFu], 1u);
 }
 void ba_launch_energy_th(hipStream_t s, const BADev& B) {
-    ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr);
-    ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo);
-    ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1));
+    ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr, B.stop);
+    ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo, B.stop);
+    ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1), B.stop);
 }
 
 }  // namespace nalo

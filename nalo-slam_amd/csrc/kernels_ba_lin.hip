@@ -60,7 +60,10 @@ struct QuadStream {
 template <int MODE, int FIX>
 __global__ __launch_bounds__(kBlk, NALO_LIN_WAVES) void ba_linearize_kernel(BADev B) {
     __shared__ __attribute__((aligned(16))) float smem[(kBlk / 4) * kTopStride];
+    if (B.stop && B.stop[0]) return;                                                // the queued GN loop has terminated (kernels_ba_gn.hip)
     const int W = B.W, tid = threadIdx.x;
+    // CalibHessian::value_scaledf / value_scaledi live in device memory (block-uniform scalar loads): the GN step may be taken on the device
+    const float cal_fxl = B.calib[0], cal_fyl = B.calib[1], cal_cxl = B.calib[2], cal_cyl = B.calib[3], cal_fxli = B.calib[4], cal_fyli = B.calib[5];
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so launch index j of a target runs on the XCD group
     // j % 8. Group x walks blk_order[x][*] = the x-th spatial eighth (Morton range) of every host's points, so each XCD's
     // private 4 MiB L2 only ever sees ~1/8 of the target image instead of all of it (speed only, never correctness).
@@ -99,14 +102,14 @@ __global__ __launch_bounds__(kBlk, NALO_LIN_WAVES) void ba_linearize_kernel(BADe
         if (state == 1) { newState = 1; }                                                       // Residuals.cpp:82-83
         else {
             const float wM3G = (float)(B.w - 3), hM3G = (float)(B.h - 3);
-            const float KliP0 = (pu - B.cxl) * B.fxli, KliP1 = (pv - B.cyl) * B.fyli;           // ResidualProjections.h:70-73
+            const float KliP0 = (pu - cal_cxl) * cal_fxli, KliP1 = (pv - cal_cyl) * cal_fyli;           // ResidualProjections.h:70-73
             // ---- centre projection at idepth_zero (projectPoint, ResidualProjections.h:61-87)
             const float p0 = pc[12] * KliP0 + pc[13] * KliP1 + pc[14] + pc[21] * idz;
             const float p1 = pc[15] * KliP0 + pc[16] * KliP1 + pc[17] + pc[22] * idz;
             const float p2 = pc[18] * KliP0 + pc[19] * KliP1 + pc[20] + pc[23] * idz;
             const float drescale = 1.0f / p2, new_idepth = idz * drescale;
             const float u = p0 * drescale, vv = p1 * drescale;
-            const float Ku0 = u * B.fxl + B.cxl, Kv0 = vv * B.fyl + B.cyl;
+            const float Ku0 = u * cal_fxl + cal_cxl, Kv0 = vv * cal_fyl + cal_cyl;
             bool ok = (drescale > 0.f) && Ku0 > 1.1f && Kv0 > 1.1f && Ku0 < wM3G && Kv0 < hM3G;
             // ---- the 8 pattern pixels at the current idepth (projectPoint, ResidualProjections.h:47-57)
             float Kus[8], Kvs[8];
@@ -124,21 +127,21 @@ __global__ __launch_bounds__(kBlk, NALO_LIN_WAVES) void ba_linearize_kernel(BADe
             else {
                 cKu = Ku0; cKv = Kv0; cId = new_idepth;
                 const float t0x = pc[21], t0y = pc[22], t0z = pc[23];
-                Jpdd0 = drescale * (t0x - t0z * u) * kScaleIdepth * B.fxl;                       // Residuals.cpp:116-117
-                Jpdd1 = drescale * (t0y - t0z * vv) * kScaleIdepth * B.fyl;
+                Jpdd0 = drescale * (t0x - t0z * u) * kScaleIdepth * cal_fxl;                       // Residuals.cpp:116-117
+                Jpdd1 = drescale * (t0y - t0z * vv) * kScaleIdepth * cal_fyl;
                 // x = (Jpdc[0], Jpdxi[0]), y = (Jpdc[1], Jpdxi[1])                              :123-156
                 x[2] = drescale * (pc[18] * u - pc[12]);
-                x[3] = B.fxl * drescale * (pc[19] * u - pc[13]) * B.fyli;
+                x[3] = cal_fxl * drescale * (pc[19] * u - pc[13]) * cal_fyli;
                 x[0] = KliP0 * x[2]; x[1] = KliP1 * x[3];
-                y[2] = B.fyl * drescale * (pc[18] * vv - pc[15]) * B.fxli;
+                y[2] = cal_fyl * drescale * (pc[18] * vv - pc[15]) * cal_fxli;
                 y[3] = drescale * (pc[19] * vv - pc[16]);
                 y[0] = KliP0 * y[2]; y[1] = KliP1 * y[3];
                 x[0] = (x[0] + u) * kScaleF; x[1] *= kScaleF; x[2] = (x[2] + 1) * kScaleC; x[3] *= kScaleC;
                 y[0] *= kScaleF; y[1] = (y[1] + vv) * kScaleF; y[2] *= kScaleC; y[3] = (y[3] + 1) * kScaleC;
-                x[4] = new_idepth * B.fxl; x[5] = 0.f; x[6] = -new_idepth * u * B.fxl;
-                x[7] = -u * vv * B.fxl; x[8] = (1 + u * u) * B.fxl; x[9] = -vv * B.fxl;
-                y[4] = 0.f; y[5] = new_idepth * B.fyl; y[6] = -new_idepth * vv * B.fyl;
-                y[7] = -(1 + vv * vv) * B.fyl; y[8] = u * vv * B.fyl; y[9] = u * B.fyl;
+                x[4] = new_idepth * cal_fxl; x[5] = 0.f; x[6] = -new_idepth * u * cal_fxl;
+                x[7] = -u * vv * cal_fxl; x[8] = (1 + u * u) * cal_fxl; x[9] = -vv * cal_fxl;
+                y[4] = 0.f; y[5] = new_idepth * cal_fyl; y[6] = -new_idepth * vv * cal_fyl;
+                y[7] = -(1 + vv * vv) * cal_fyl; y[8] = u * vv * cal_fyl; y[9] = u * cal_fyl;
                 float jx = 0.f, jy = 0.f;
                 if (MODE == 2) {                                                                 // Jp*delta (EnergyFunctionalStructs.cpp:94-99)
                     const float dd = idepth - idz;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(kBlk, NALO_LIN_WAVES) void ba_linearize_kernel(BADe
                     for (int i = 0; i < 6; ++i) { jx += x[4 + i] * pc[27 + i]; jy += y[4 + i] * pc[27 + i]; }
                     float cxs = 0.f, cys = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { cxs += x[i] * B.cDelta[i]; cys += y[i] * B.cDelta[i]; }
+                    for (int i = 0; i < 4; ++i) { cxs += x[i] * B.calib[6 + i]; cys += y[i] * B.calib[6 + i]; }
                     jx = jx + cxs + Jpdd0 * dd; jy = jy + cys + Jpdd1 * dd;
                 }
                 const float affLL0 = pc[24], affLL1 = pc[25], b0 = pc[26];
