@@ -219,6 +219,11 @@ int nalo_dense_make_map(nalo_ctx* ctx, int slot, const float plane[4], float mas
  *                    result[n]: 0 = not well constrained (the point stays immature), -1 = drop the point, 1 = activated with
  *                    idepth_out[n]; res_in[n][W] = 1 where a PointFrameResidual is created (state IN).
  * ------------------------------------------------------------------------------------------------ */
+/* CoarseDistanceMap::makeDistanceMap + growDistBFS (FullSystem/CoarseTracker.cpp:1410-1561), call site FullSystem::activatePointsMT
+ * (FullSystem.cpp:797-798). Uses the ACTIVE POINTS of the window set by nalo_ba_set_points (already on the device); frame = window index of the newest frame
+ * (its own points are skipped); KRKi[W][9] = K[1] R Ki[0] and Kt[W][3] = K[1] t per host (floats, as :1424-1425). out = fwdWarpedIDDistFinal [w1*h1]
+ * (level-1 size), 1000 = farther than 39. addIntoDistFinal (:1556-1561, one seed per newly activated point, sequential) stays on the caller's copy. */
+int nalo_dist_make_map(nalo_ctx* ctx, int frame, const float* KRKi, const float* Kt, float* out);
 int nalo_imm_create(nalo_ctx* ctx, int slot_host, int n, const int* u, const int* v, float* color, float* weights, float* gradH, float* energyTH);
 int nalo_imm_trace(nalo_ctx* ctx, int slot_new, int n, const float* u, const float* v, const float* color, const float* weights, const float* gradH,
                    const float* energyTH, const int* host_idx, int nh, const float* KRKi, const float* Kt, const float* aff,

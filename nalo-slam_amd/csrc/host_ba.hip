@@ -1023,6 +1023,27 @@ int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
     return NALO_OK;
 }
 
+// CoarseDistanceMap::makeDistanceMap for the window's active points (CoarseTracker.cpp:1410-1444)
+int nalo_dist_make_map(nalo_ctx* c, int frame, const float* KRKi, const float* Kt, float* out) {
+    if (!c || !c->ba || !c->ba->points_set) return fail(c, NALO_ERR_STATE, "nalo_dist_make_map: set the window and its points first");
+    BAWindow& w = *c->ba;
+    if (!KRKi || !Kt || !out || frame < 0 || frame >= w.W || c->levels < 2) return fail(c, NALO_ERR_ARG, "nalo_dist_make_map: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    const int W = w.W, w1 = c->wl[1], h1 = c->hl[1];
+    const size_t npx = (size_t)w1 * h1, words = 12 * (size_t)W + npx + (npx + 3) / 4 + 8;
+    int rc = imm_stage(c, words); if (rc) return rc;
+    float* hst = c->imm_host; float* d = c->imm_dev.p;
+    std::memcpy(hst, KRKi, 9 * (size_t)W * 4); std::memcpy(hst + 9 * W, Kt, 3 * (size_t)W * 4);
+    NALO_HIP(c, hipMemcpyAsync(d, hst, 12 * (size_t)W * 4, hipMemcpyHostToDevice, c->stream));
+    float* dout = d + 12 * W; uint8_t* seed = (uint8_t*)(dout + npx);
+    rc = dist_make_launch(c, w.pt_geo.p, w.pt_flags.p, w.blk_host.p, w.Ppad, frame, d, d + 9 * W, seed, dout);
+    if (rc) return rc;
+    NALO_HIP(c, hipMemcpyAsync(hst + 12 * W, dout, npx * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(out, hst + 12 * W, npx * 4);
+    return NALO_OK;
+}
+
 // FullSystem::optimizeImmaturePoint for a batch of immature points against the current window (FullSystemOptPoint.cpp:51-206)
 int nalo_imm_optimize(nalo_ctx* c, int n, const int* host, const float* u, const float* v, const float* color, const float* weights,
                       const float* energyTH, const float* idepth_min, const float* idepth_max, int minObs, int* result, float* idepth_out, uint8_t* res_in) {

@@ -330,6 +330,70 @@ __global__ __launch_bounds__(kImmThreads) void imm_optimize_kernel(ImmOptParams 
     P.result[p] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- CoarseDistanceMap
+// CoarseDistanceMap::makeDistanceMap + growDistBFS (reference src/FullSystem/CoarseTracker.cpp:1410-1561): the window's active points (already in HBM:
+// pt_geo) are projected to level 1 of the newest frame, seeds get 0, then 39 breadth-first rounds (odd rounds over 8 neighbours, even rounds over 4,
+// border pixels never expand). A BFS level is a pure function of the seeds within 39 pixels, so every workgroup grows its own 32x32 output tile plus a
+// 39-pixel halo entirely in LDS (one byte per cell, 39 barriers, no global synchronisation); the result is the integer map of the sequential queue.
+constexpr int kDistTile = 32, kDistHalo = 39, kDistSide = kDistTile + 2 * kDistHalo;     // 110
+__global__ __launch_bounds__(256) void dist_seed_kernel(const float4* __restrict__ pt_geo, const uint8_t* __restrict__ pt_flags, const int* __restrict__ blk_host, int Ppad, int frame,
+                                                        const float* __restrict__ KRKi, const float* __restrict__ Kt, int w1, int h1, uint8_t* __restrict__ seed) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= Ppad || !(pt_flags[d] & 1)) return;
+    const int h = blk_host[d >> 8];
+    if (h == frame) return;
+    const float4 g = pt_geo[d];                                                 // {u, v, idepth_scaled, idepth_zero}
+    const float* M = KRKi + h * 9; const float* T = Kt + h * 3;
+    float ptp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ptp[k] = M[k * 3] * g.x + M[k * 3 + 1] * g.y + M[k * 3 + 2] * 1 + T[k] * g.z;
+    const int u = (int)(ptp[0] / ptp[2] + 0.5f), v = (int)(ptp[1] / ptp[2] + 0.5f);
+    if (!(u > 0 && v > 0 && u < w1 && v < h1)) return;
+    seed[u + w1 * v] = 1;
+}
+__global__ __launch_bounds__(256) void dist_bfs_kernel(const uint8_t* __restrict__ seed, int w1, int h1, float* __restrict__ out) {
+    __shared__ uint8_t cell[kDistSide * kDistSide];
+    const int tiles_x = (w1 + kDistTile - 1) / kDistTile;
+    const int x0 = (blockIdx.x % tiles_x) * kDistTile - kDistHalo, y0 = (blockIdx.x / tiles_x) * kDistTile - kDistHalo;
+    for (int e = threadIdx.x; e < kDistSide * kDistSide; e += blockDim.x) {
+        const int lx = e % kDistSide, ly = e / kDistSide, x = x0 + lx, y = y0 + ly;
+        cell[e] = (x >= 0 && y >= 0 && x < w1 && y < h1 && seed[x + w1 * y]) ? 0 : 255;
+    }
+    __syncthreads();
+    for (int k = 1; k < 40; ++k) {
+        const bool eight = (k & 1) != 0;
+        for (int e = threadIdx.x; e < kDistSide * kDistSide; e += blockDim.x) {
+            if (cell[e] != 255) continue;
+            const int lx = e % kDistSide, ly = e / kDistSide, x = x0 + lx, y = y0 + ly;
+            if (x < 0 || y < 0 || x >= w1 || y >= h1) continue;
+            bool hit = false;
+            // a neighbour q at level k-1 reaches this cell unless q lies on the image border (:1455, :1491)
+#define NALO_DIST_TAP(dx, dy) { const int qx = lx + (dx), qy = ly + (dy); if (qx >= 0 && qy >= 0 && qx < kDistSide && qy < kDistSide && cell[qx + qy * kDistSide] == k - 1) { \
+                const int gx = x + (dx), gy = y + (dy); if (!(gx == 0 || gy == 0 || gx == w1 - 1 || gy == h1 - 1)) hit = true; } }
+            NALO_DIST_TAP(-1, 0) NALO_DIST_TAP(1, 0) NALO_DIST_TAP(0, -1) NALO_DIST_TAP(0, 1)
+            if (eight) { NALO_DIST_TAP(-1, -1) NALO_DIST_TAP(1, -1) NALO_DIST_TAP(-1, 1) NALO_DIST_TAP(1, 1) }
+#undef NALO_DIST_TAP
+            if (hit) cell[e] = (uint8_t)k;                                      // cells written this round hold k, never k-1: in place is race free
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < kDistTile * kDistTile; e += blockDim.x) {
+        const int lx = e % kDistTile, ly = e / kDistTile, x = x0 + kDistHalo + lx, y = y0 + kDistHalo + ly;
+        if (x < w1 && y < h1) { const uint8_t c = cell[(lx + kDistHalo) + (ly + kDistHalo) * kDistSide]; out[x + w1 * y] = c == 255 ? 1000.f : (float)c; }
+    }
+}
+int dist_make_launch(nalo_ctx* c, const float4* pt_geo, const uint8_t* pt_flags, const int* blk_host, int Ppad, int frame, const float* KRKi, const float* Kt, uint8_t* seed, float* out) {
+    const int w1 = c->wl[1], h1 = c->hl[1];
+    NALO_HIP(c, hipMemsetAsync(seed, 0, (size_t)w1 * h1, c->stream));
+    if (Ppad > 0) dist_seed_kernel<<<(Ppad + 255) / 256, 256, 0, c->stream>>>(pt_geo, pt_flags, blk_host, Ppad, frame, KRKi, Kt, w1, h1, seed);
+    {
+        ProfScope ps(c, "dist_bfs");
+        dist_bfs_kernel<<<((w1 + kDistTile - 1) / kDistTile) * ((h1 + kDistTile - 1) / kDistTile), 256, 0, c->stream>>>(seed, w1, h1, out);
+    }
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- launchers
 int imm_stage(nalo_ctx* c, size_t words) {
     if (c->imm_cap >= words) return NALO_OK;

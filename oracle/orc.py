@@ -114,6 +114,7 @@ def lib(kind="f32"):
     L.orc_init_calc_res_and_gs.argtypes = [c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_double, C.c_float, C.c_float, C.c_float, C.c_int,
                                            c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.orc_init_do_step.argtypes = [C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
+    L.orc_dist_make_map.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
     L.orc_imm_create.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.orc_imm_trace.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
     L.orc_imm_optimize.argtypes = [C.c_int, C.POINTER(c_fp), C.c_int, C.c_int, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_u8p]
@@ -168,6 +169,15 @@ def make_images(img, levels, kind="f32"):
 
 
 # ------------------------------------------------------------------ immature points
+def dist_make_map(w1, h1, frame, host, u, v, idepth, KRKi, Kt, kind="f32"):
+    """CoarseDistanceMap::makeDistanceMap -> [h1, w1] float map (1000 = farther than 39)"""
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    out = np.zeros((h1, w1), np.float32)
+    a = [f(x) for x in (u, v, idepth, KRKi, Kt)]
+    lib(kind).orc_dist_make_map(w1, h1, frame, len(a[0]), ip(np.ascontiguousarray(host, np.int32)), *[fp(x) for x in a], fp(out))
+    return out
+
+
 def imm_create(dI_host, w, h, u, v, kind="f32"):
     """ImmaturePoint ctor for n integer pixel positions. dI_host: [w*h,3] level-0 texels. -> color[n,8], weights[n,8], gradH[n,3], energyTH[n]"""
     n = len(u)

@@ -282,3 +282,41 @@ next_point:;
 #undef IMM_LIN
     }
 }
+
+/* CoarseDistanceMap::makeDistanceMap + growDistBFS (FullSystem/CoarseTracker.cpp:1410-1561). Points of every window frame
+ * except `frame` are projected to level 1 of `frame` with the caller's KRKi = K[1] R Ki[0] and Kt = K[1] t (per host, floats), seeds get 0, then 39
+ * BFS rounds: odd rounds grow over 8 neighbours, even rounds over 4; pixels on the image border never expand. out = fwdWarpedIDDistFinal [w1*h1]. */
+void orc_dist_make_map(int w1, int h1, int frame, int n, const int* host, const float* u, const float* v, const float* idepth,
+                       const float* KRKi, const float* Kt, float* out) {
+    const int wh1 = w1 * h1;
+    /* every pixel enters a frontier at most once (plus the seeds) */
+    int* bufA = (int*)malloc(sizeof(int) * 2 * ((size_t)wh1 + n + 16)); int* bufB = (int*)malloc(sizeof(int) * 2 * ((size_t)wh1 + n + 16));
+    for (int i = 0; i < wh1; i++) out[i] = 1000;
+    int num = 0;
+    for (int p = 0; p < n; p++) {
+        if (host[p] == frame) continue;
+        const float* M = KRKi + host[p] * 9; const float* T = Kt + host[p] * 3;
+        real ptp[3]; for (int k = 0; k < 3; k++) ptp[k] = (real)M[k * 3] * u[p] + (real)M[k * 3 + 1] * v[p] + (real)M[k * 3 + 2] * 1 + (real)T[k] * idepth[p];
+        const int uu = (int)(ptp[0] / ptp[2] + 0.5f), vv = (int)(ptp[1] / ptp[2] + 0.5f);
+        if (!(uu > 0 && vv > 0 && uu < w1 && vv < h1)) continue;
+        out[uu + w1 * vv] = 0;
+        bufA[2 * num] = uu; bufA[2 * num + 1] = vv; num++;
+    }
+    int* cur = bufA; int* nxt = bufB;
+    for (int k = 1; k < 40; k++) {
+        int num2 = num; int* t = cur; cur = nxt; nxt = t;          /* swap: nxt holds the frontier, cur receives the new one */
+        num = 0;
+        static const int d4[4][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}};
+        static const int d8[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, 1}, {-1, -1}, {1, -1}};
+        const int nd = (k % 2 == 0) ? 4 : 8;
+        for (int i = 0; i < num2; i++) {
+            const int x = nxt[2 * i], y = nxt[2 * i + 1];
+            if (x == 0 || y == 0 || x == w1 - 1 || y == h1 - 1) continue;
+            for (int d = 0; d < nd; d++) {
+                const int xx = x + (nd == 4 ? d4[d][0] : d8[d][0]), yy = y + (nd == 4 ? d4[d][1] : d8[d][1]);
+                if (out[xx + yy * w1] > k) { out[xx + yy * w1] = (float)k; cur[2 * num] = xx; cur[2 * num + 1] = yy; num++; }
+            }
+        }
+    }
+    free(bufA); free(bufB);
+}

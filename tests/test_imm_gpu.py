@@ -100,3 +100,26 @@ def test_optimize_bit_exact_and_recovers_truth(scene):
     err0 = np.abs(mid[act] - idt[act]) / idt[act]
     err1 = np.abs(idp[act] - idt[act]) / idt[act]
     assert np.median(err1) < 0.25 * np.median(err0)        # three GN steps pull the 5 % error to about 1 %
+
+
+def test_distance_map_exact(scene):
+    """CoarseDistanceMap::makeDistanceMap (SURVEY 8(f) rank 3, part): integer BFS levels from the window's projected points, exact equality."""
+    win, c, _ = scene
+    W = win.W
+    c.ba_set_window(list(range(W)), win.world_to_cam[:W])
+    c.ba_set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights)
+    fx, fy, cx, cy = [np.float32(x) for x in win.K]
+    K1 = np.array([[fx * np.float32(0.5), 0, np.float32((cx + 0.5) / 2 - 0.5)], [0, fy * np.float32(0.5), np.float32((cy + 0.5) / 2 - 0.5)], [0, 0, 1]], np.float32)
+    Ki0 = np.array([[1 / fx, 0, -cx / fx], [0, 1 / fy, -cy / fy], [0, 0, 1]], np.float32)
+    frame = W - 1
+    KRKi, Kt = np.zeros((W, 9), np.float32), np.zeros((W, 3), np.float32)
+    for h in range(W):
+        T = synth.se3_mul(win.world_to_cam[frame], synth.se3_inv(win.world_to_cam[h]))
+        KRKi[h] = ((K1 @ T[:, :3].astype(np.float32)) @ Ki0).reshape(-1)
+        Kt[h] = K1 @ T[:, 3].astype(np.float32)
+    got = c.dist_make_map(frame, KRKi, Kt)
+    ref = orc.dist_make_map(win.w >> 1, win.h >> 1, frame, win.host, win.u, win.v, win.idepth, KRKi, Kt)
+    assert np.array_equal(got, ref)
+    vals = np.unique(got)
+    assert vals.min() == 0 and vals.max() == 1000 and set(range(1, 40)).issubset(set(vals.astype(int).tolist()))
+    assert (got == 0).sum() > 0.5 * (win.host != frame).sum()          # most of the other frames' points land inside the newest frame

@@ -370,3 +370,24 @@ def test_initializer_pass_schur_identity_and_descent():
     ra = orc.init_calc_res_and_gs(dI0, dI1, win.w, win.h, K4, T0, (0.0, 0.0), pts)                 # reference constants: alphaW = 150^2, alphaK = 2.5^2
     tsq = float((T0[:, 3] ** 2).sum())
     assert abs(ra["E3"][1] - min(150.0 * 150.0 * tsq * n, 2.5 * 2.5 * n)) < 1e-3 * ra["E3"][1]
+
+
+def test_distance_map_matches_dilation_formulation():
+    """SURVEY 8(f) rank 3 (part): the queue-based BFS of CoarseDistanceMap::growDistBFS restated as array dilations in numpy (independent formulation):
+    level k = unreached pixels with a level-(k-1) neighbour that is not on the image border, 8-neighbourhood for odd k, 4 for even k."""
+    rng = np.random.RandomState(3)
+    w1, h1, n = 97, 61, 40
+    u = rng.randint(1, w1, n).astype(np.float32); v = rng.randint(1, h1, n).astype(np.float32)
+    I = np.tile(np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], np.float32), (2, 1)); Z = np.zeros((2, 3), np.float32)
+    got = orc.dist_make_map(w1, h1, 1, np.zeros(n, np.int32), u, v, np.ones(n, np.float32), I, Z)      # identity projection: seeds at (u, v)
+    ref = np.full((h1, w1), 1000.0, np.float32)
+    ref[v.astype(int), u.astype(int)] = 0
+    inner = np.zeros((h1, w1), bool); inner[1:-1, 1:-1] = True
+    for k in range(1, 40):
+        src = (ref == k - 1) & inner
+        grow = np.zeros_like(src)
+        shifts = [(0, 1), (0, -1), (1, 0), (-1, 0)] + ([(1, 1), (1, -1), (-1, 1), (-1, -1)] if k % 2 == 1 else [])
+        for dy, dx in shifts:
+            grow |= np.roll(np.roll(src, dy, 0), dx, 1)          # `inner` keeps the wrap-around of roll out of play
+        ref[grow & (ref > k)] = k
+    assert np.array_equal(got, ref)
