@@ -223,6 +223,9 @@ int nalo_dense_make_map(nalo_ctx* ctx, int slot, const float plane[4], float mas
  * (FullSystem.cpp:797-798). Uses the ACTIVE POINTS of the window set by nalo_ba_set_points (already on the device); frame = window index of the newest frame
  * (its own points are skipped); KRKi[W][9] = K[1] R Ki[0] and Kt[W][3] = K[1] t per host (floats, as :1424-1425). out = fwdWarpedIDDistFinal [w1*h1]
  * (level-1 size), 1000 = farther than 39. addIntoDistFinal (:1556-1561, one seed per newly activated point, sequential) stays on the caller's copy. */
+/* PixelSelector::makeHists (FullSystem/PixelSelector2.cpp:78-142): block thresholds of the frame in `slot`; ths and thsSmoothed are [(w/32)*(h/32)].
+ * PixelSelector::select stays on the host: it indexes randomPattern with the running count of selected points (a raster-order dependency). */
+int nalo_pixsel_make_hists(nalo_ctx* ctx, int slot, float* ths, float* thsSmoothed);
 int nalo_dist_make_map(nalo_ctx* ctx, int frame, const float* KRKi, const float* Kt, float* out);
 int nalo_imm_create(nalo_ctx* ctx, int slot_host, int n, const int* u, const int* v, float* color, float* weights, float* gradH, float* energyTH);
 int nalo_imm_trace(nalo_ctx* ctx, int slot_new, int n, const float* u, const float* v, const float* color, const float* weights, const float* gradH,

@@ -32,7 +32,7 @@ EXPORTS = [
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_snapshot", "nalo_ba_restore",
-    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map",
+    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
 ]
 
@@ -94,6 +94,7 @@ def load():
     L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
                                             c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.nalo_init_do_step.argtypes = [vp, C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
+    L.nalo_pixsel_make_hists.argtypes = [vp, C.c_int, c_fp, c_fp]
     L.nalo_dist_make_map.argtypes = [vp, C.c_int, c_fp, c_fp, c_fp]
     L.nalo_imm_create.argtypes = [vp, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.nalo_imm_trace.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
@@ -353,6 +354,12 @@ class Context:
         out = f(idepth_new).copy()
         self._ck(self.L.nalo_init_do_step(self.h_, len(out), _u8(np.ascontiguousarray(isGood, np.uint8)), _f(f(Jb)), _f(f(maxstep)), _f(f(idepth)), float(lam), _f(f(inc)), _f(out)))
         return out
+
+    def pixsel_make_hists(self, slot):
+        nb = (self.w // 32) * (self.h // 32)
+        ths, sm = np.zeros(nb, np.float32), np.zeros(nb, np.float32)
+        self._ck(self.L.nalo_pixsel_make_hists(self.h_, slot, _f(ths), _f(sm)))
+        return ths, sm
 
     def dist_make_map(self, frame, KRKi, Kt):
         out = np.zeros((self.h >> 1, self.w >> 1), np.float32)

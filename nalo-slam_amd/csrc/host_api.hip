@@ -331,6 +331,21 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
 }
 
 // ------------------------------------------------------------------------------------------------ immature points
+int nalo_pixsel_make_hists(nalo_ctx* c, int slot, float* ths, float* thsSmoothed) {
+    if (!c || !ths || !thsSmoothed) return fail(c, NALO_ERR_ARG, "nalo_pixsel_make_hists: bad argument");
+    if (slot < 0 || slot >= (int)c->slots.size() || !c->slots[slot].valid) return fail(c, NALO_ERR_STATE, "nalo_pixsel_make_hists: frame slot has no pyramid");
+    NALO_HIP(c, hipSetDevice(c->device));
+    const size_t nb = (size_t)(c->w / 32) * (c->h / 32);
+    if (nb == 0) return NALO_OK;
+    int rc = imm_stage(c, 2 * nb + 8); if (rc) return rc;
+    float* d = c->imm_dev.p;
+    rc = pixsel_hists_launch(c, c->slots[slot].absg[0], d, d + nb); if (rc) return rc;
+    NALO_HIP(c, hipMemcpyAsync(c->imm_host, d, 2 * nb * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(ths, c->imm_host, nb * 4); std::memcpy(thsSmoothed, c->imm_host + nb, nb * 4);
+    return NALO_OK;
+}
+
 int nalo_imm_create(nalo_ctx* c, int slot_host, int n, const int* u, const int* v, float* color, float* weights, float* gradH, float* energyTH) {
     if (!c || n < 0 || (n > 0 && (!u || !v || !color || !weights || !gradH || !energyTH))) return fail(c, NALO_ERR_ARG, "nalo_imm_create: bad argument");
     if (slot_host < 0 || slot_host >= (int)c->slots.size() || !c->slots[slot_host].valid) return fail(c, NALO_ERR_STATE, "nalo_imm_create: host slot has no pyramid");

@@ -394,6 +394,50 @@ int dist_make_launch(nalo_ctx* c, const float4* pt_geo, const uint8_t* pt_flags,
     return NALO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- PixelSelector::makeHists
+// PixelSelector2.cpp:78-142: one workgroup per 32x32 block builds the 50-bin histogram of (int)sqrtf(absSquaredGrad) in LDS (integer atomics), lane 0
+// takes computeHistQuantil(0.5) + setting_minGradHistAdd; a second tiny launch smooths the block thresholds (3x3 mean, squared). One read of the image.
+__global__ __launch_bounds__(256) void pixsel_hist_kernel(const float* __restrict__ absg0, int w, int h, int w32, float* __restrict__ ths) {
+    __shared__ int hist[50];
+    const int bx = blockIdx.x % w32, by = blockIdx.x / w32;
+    if (threadIdx.x < 50) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+        const int i = e & 31, j = e >> 5, it = i + 32 * bx, jt = j + 32 * by;
+        if (it > w - 2 || jt > h - 2 || it < 1 || jt < 1) continue;
+        int g = (int)sqrtf(absg0[it + jt * w]);
+        if (g > 48) g = 48;
+        atomicAdd(&hist[g + 1], 1); atomicAdd(&hist[0], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int th = (int)(hist[0] * 0.5f + 0.5f), q = 90;                              // computeHistQuantil (:67-76); bins above 49 are empty
+        for (int i = 0; i < 90; ++i) { th -= (i + 1 < 50 ? hist[i + 1] : 0); if (th < 0) { q = i; break; } }
+        ths[blockIdx.x] = q + 7.0f;
+    }
+}
+__global__ __launch_bounds__(256) void pixsel_smooth_kernel(const float* __restrict__ ths, int w32, int h32, float* __restrict__ thsSmoothed) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= w32 * h32) return;
+    const int x = e % w32, y = e / w32;
+    float sum = 0, num = 0;
+    if (x > 0) { if (y > 0) { num++; sum += ths[x - 1 + (y - 1) * w32]; } if (y < h32 - 1) { num++; sum += ths[x - 1 + (y + 1) * w32]; } num++; sum += ths[x - 1 + y * w32]; }
+    if (x < w32 - 1) { if (y > 0) { num++; sum += ths[x + 1 + (y - 1) * w32]; } if (y < h32 - 1) { num++; sum += ths[x + 1 + (y + 1) * w32]; } num++; sum += ths[x + 1 + y * w32]; }
+    if (y > 0) { num++; sum += ths[x + (y - 1) * w32]; }
+    if (y < h32 - 1) { num++; sum += ths[x + (y + 1) * w32]; }
+    num++; sum += ths[x + y * w32];
+    thsSmoothed[e] = (sum / num) * (sum / num);
+}
+int pixsel_hists_launch(nalo_ctx* c, const float* absg0, float* ths, float* thsSmoothed) {
+    const int w32 = c->w / 32, h32 = c->h / 32;
+    if (w32 * h32 > 0) {
+        pixsel_hist_kernel<<<w32 * h32, 256, 0, c->stream>>>(absg0, c->w, c->h, w32, ths);
+        pixsel_smooth_kernel<<<(w32 * h32 + 255) / 256, 256, 0, c->stream>>>(ths, w32, h32, thsSmoothed);
+    }
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- launchers
 int imm_stage(nalo_ctx* c, size_t words) {
     if (c->imm_cap >= words) return NALO_OK;

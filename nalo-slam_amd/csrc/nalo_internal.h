@@ -138,6 +138,7 @@ int imm_trace_launch(nalo_ctx* c, const float4* dI, int n, const float* base, co
 int imm_optimize_launch(nalo_ctx* c, const float4* const* dI, int W, const float K[4], const float* Rt, const float* aff, int n, const int* host, const float* base,
                         int minObs, int* result, float* idepth_out, uint8_t* res_in);
 int dist_make_launch(nalo_ctx* c, const float4* pt_geo, const uint8_t* pt_flags, const int* blk_host, int Ppad, int frame, const float* KRKi, const float* Kt, uint8_t* seed, float* out);
+int pixsel_hists_launch(nalo_ctx* c, const float* absg0, float* ths, float* thsSmoothed);
 // staging for the immature-point entry points: pinned host block + device block of `floats` 4-byte words (grown on demand)
 int imm_stage(nalo_ctx* c, size_t words);
 // kernels_init.hip

@@ -114,6 +114,7 @@ def lib(kind="f32"):
     L.orc_init_calc_res_and_gs.argtypes = [c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_double, C.c_float, C.c_float, C.c_float, C.c_int,
                                            c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.orc_init_do_step.argtypes = [C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
+    L.orc_pixsel_make_hists.argtypes = [c_fp, C.c_int, C.c_int, c_fp, c_fp]
     L.orc_dist_make_map.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
     L.orc_imm_create.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.orc_imm_trace.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
@@ -169,6 +170,13 @@ def make_images(img, levels, kind="f32"):
 
 
 # ------------------------------------------------------------------ immature points
+def pixsel_make_hists(absg0, w, h, kind="f32"):
+    nb = (w // 32) * (h // 32)
+    ths, sm = np.zeros(nb, np.float32), np.zeros(nb, np.float32)
+    lib(kind).orc_pixsel_make_hists(fp(np.ascontiguousarray(absg0, np.float32)), w, h, fp(ths), fp(sm))
+    return ths, sm
+
+
 def dist_make_map(w1, h1, frame, host, u, v, idepth, KRKi, Kt, kind="f32"):
     """CoarseDistanceMap::makeDistanceMap -> [h1, w1] float map (1000 = farther than 39)"""
     f = lambda a: np.ascontiguousarray(a, np.float32)

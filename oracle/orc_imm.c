@@ -320,3 +320,32 @@ void orc_dist_make_map(int w1, int h1, int frame, int n, const int* host, const 
     }
     free(bufA); free(bufB);
 }
+
+/* PixelSelector::makeHists (FullSystem/PixelSelector2.cpp:78-142) with computeHistQuantil (:67-76): per 32x32 block the
+ * histogram of (int)sqrtf(absSquaredGrad) (capped at 48) over the pixels with 1 <= x <= w-2, 1 <= y <= h-2, ths = quantile(0.5) + 7
+ * (setting_minGradHistCut / setting_minGradHistAdd, settings.cpp:154-155), thsSmoothed = (3x3 box mean of ths)^2. */
+void orc_pixsel_make_hists(const float* absg0, int w, int h, float* ths, float* thsSmoothed) {
+    const int w32 = w / 32, h32 = h / 32;
+    for (int y = 0; y < h32; y++) for (int x = 0; x < w32; x++) {
+        int hist[50]; memset(hist, 0, sizeof(hist));
+        for (int j = 0; j < 32; j++) for (int i = 0; i < 32; i++) {
+            const int it = i + 32 * x, jt = j + 32 * y;
+            if (it > w - 2 || jt > h - 2 || it < 1 || jt < 1) continue;
+            int g = (int)sqrtf(absg0[it + jt * w]);
+            if (g > 48) g = 48;
+            hist[g + 1]++; hist[0]++;
+        }
+        int th = (int)(hist[0] * 0.5f + 0.5f), q = 90;
+        for (int i = 0; i < 90; i++) { th -= (i + 1 < 50 ? hist[i + 1] : 0); if (th < 0) { q = i; break; } }
+        ths[x + y * w32] = q + 7.0f;
+    }
+    for (int y = 0; y < h32; y++) for (int x = 0; x < w32; x++) {
+        float sum = 0, num = 0;
+        if (x > 0) { if (y > 0) { num++; sum += ths[x - 1 + (y - 1) * w32]; } if (y < h32 - 1) { num++; sum += ths[x - 1 + (y + 1) * w32]; } num++; sum += ths[x - 1 + y * w32]; }
+        if (x < w32 - 1) { if (y > 0) { num++; sum += ths[x + 1 + (y - 1) * w32]; } if (y < h32 - 1) { num++; sum += ths[x + 1 + (y + 1) * w32]; } num++; sum += ths[x + 1 + y * w32]; }
+        if (y > 0) { num++; sum += ths[x + (y - 1) * w32]; }
+        if (y < h32 - 1) { num++; sum += ths[x + (y + 1) * w32]; }
+        num++; sum += ths[x + y * w32];
+        thsSmoothed[x + y * w32] = (sum / num) * (sum / num);
+    }
+}

@@ -123,3 +123,13 @@ def test_distance_map_exact(scene):
     vals = np.unique(got)
     assert vals.min() == 0 and vals.max() == 1000 and set(range(1, 40)).issubset(set(vals.astype(int).tolist()))
     assert (got == 0).sum() > 0.5 * (win.host != frame).sum()          # most of the other frames' points land inside the newest frame
+
+
+def test_pixel_selector_hists_exact(scene):
+    """PixelSelector::makeHists (SURVEY 8(f) rank 3, part): per-block gradient histogram quantile and the smoothed thresholds, exact."""
+    win, c, _ = scene
+    ab0 = orc.make_images(win.images[1], 1)[1]
+    ths, sm = c.pixsel_make_hists(1)
+    ths_o, sm_o = orc.pixsel_make_hists(ab0, win.w, win.h)
+    assert np.array_equal(ths, ths_o) and np.array_equal(sm, sm_o)
+    assert ths.min() >= 7 and len(np.unique(ths)) > 3
