@@ -103,3 +103,33 @@ def test_track_recovers_pose_and_matches_oracle(ctx, small_window):
     assert np.abs(aff - aff_o).max() < 1e-3
     assert pose_dist(T, Ttrue) < 2e-3
     assert np.allclose(lr[:win.levels], lr_o[:win.levels], rtol=1e-4)
+
+
+def test_track_abort_and_exposure_paths(small_window):
+    """trackNewestCoarse's early exit on minResForAbort (CoarseTracker.cpp:1227-1229: outputs untouched, returns false) and the affine-brightness path with
+    unequal exposures (AffLight::fromToVecExposure). Runs with whichever LM driver the process selected (persistent kernel by default, host loop
+    under NALO_TRK_HOST_LM=1)."""
+    win = small_window
+    c = binding.Context(win.w, win.h, win.K, n_slots=2)
+    c.frame_upload(0, win.images[win.W - 1]); c.frame_upload(1, (win.images[win.W] * 1.25 + 3.0).astype(np.float32))
+    Ku, Kv, nid, hdi = tracker_inputs(win)
+    trk = orc.Tracker(win.w, win.h, win.levels, win.K)
+    dI_ref, _ = orc.make_images(win.images[win.W - 1], win.levels)
+    dI_new, _ = orc.make_images((win.images[win.W] * 1.25 + 3.0).astype(np.float32), win.levels)
+    trk.set_ref(dI_ref, Ku, Kv, nid, hdi)
+    c.trk_set_ref(0, Ku, Kv, nid, hdi)
+    T0 = orc.se3_exp(orc.se3_log(true_rel_pose(win, win.W - 1, win.W)) * 0.85)
+    # (i) brightness change a' = 1.25 I + 3 with exposures (1, 1.25): the affine pair is recovered the same way by both
+    ok_o, T_o, aff_o, lr_o, _ = trk.track(dI_new, T0, [0, 0], [0, 0], [1.0, 1.25], win.levels - 1)
+    ok, T, aff, lr, lf, nev = c.trk_track(1, T0, [0, 0], [0, 0], [1.0, 1.25], win.levels - 1)
+    assert ok == ok_o == 1 and pose_dist(T, T_o) < 1e-5 and np.abs(aff - aff_o).max() < 1e-3
+    assert abs(aff[0]) + abs(aff[1]) > 1e-2 and pose_dist(T, true_rel_pose(win, win.W - 1, win.W)) < 3e-3   # the affine pair moved, the pose is still recovered
+    # (ii) abort: a tiny minResForAbort makes the coarsest level fail
+    mr = np.full(5, 1e-3)
+    ok_o, T_o, aff_o, lr_o, _ = trk.track(dI_new, T0, [0, 0], [0, 0], [1.0, 1.25], win.levels - 1, min_res=mr)
+    ok, T, aff, lr, lf, nev = c.trk_track(1, T0, [0, 0], [0, 0], [1.0, 1.25], win.levels - 1, min_res=mr)
+    assert ok == ok_o == 0
+    assert np.array_equal(T, np.asarray(T0).reshape(3, 4)) and np.array_equal(aff, [0, 0])      # outputs untouched
+    top = win.levels - 1
+    assert abs(lr[top] - lr_o[top]) < 1e-4 * lr_o[top] and np.isnan(lr[:top]).all() and np.isnan(lr_o[:top]).all()
+    c.close()
