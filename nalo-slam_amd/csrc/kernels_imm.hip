@@ -1,6 +1,6 @@
 // Immature-point kernels for gfx950 (reference paths relative to src/):
 //   imm_create_kernel    ImmaturePoint::ImmaturePoint          FullSystem/ImmaturePoint.cpp:32-60
-//   imm_trace_kernel     ImmaturePoint::traceOn                FullSystem/ImmaturePoint.cpp:76-435   (one lane per immature point)
+//   imm_trace8_kernel    ImmaturePoint::traceOn                FullSystem/ImmaturePoint.cpp:76-435   (eight lanes per immature point; imm_trace_kernel = one lane per point)
 //   imm_optimize_kernel  FullSystem::optimizeImmaturePoint     FullSystem/FullSystemOptPoint.cpp:51-206 with
 //                        ImmaturePoint::linearizeResidual      FullSystem/ImmaturePoint.cpp:497-564
 // These are branchy per-point searches (up to 99 line steps x 8 taps, then <= 3 GN steps), thousands of independent points per frame:
@@ -223,6 +223,167 @@ __global__ __launch_bounds__(kImmThreads) void imm_trace_kernel(ImmTraceParams P
     }
     P.lastInterval[p] = 2 * errorInPixel; P.lastUV[p * 2] = bestU; P.lastUV[p * 2 + 1] = bestV;
     P.status[p] = IPS_GOOD;
+}
+
+// ordered sum over the 8 lanes of a point group: init + t_0 + t_1 + ... + t_7, left to right (the rounding sequence of the scalar loop); every lane
+// of the group receives the total. Lane j takes the running sum of lane j-1 through DPP row_shr:1 (groups of 8 never straddle a 16-lane DPP row).
+__device__ __forceinline__ float imm_group_sum(float init, float t, int l) {
+    float s = init + t;                                                        // meaningful on lane 0
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x111, 0xF, 0xF, true));
+        if (l == j) s = prev + t;
+    }
+    return __shfl(s, (threadIdx.x & 56) | 7, 64);
+}
+
+// Same algorithm with EIGHT LANES PER POINT (lane l = pattern pixel l): the taps of neighbouring lanes fall on neighbouring texels (a wave-wide gather
+// touches ~16 cache lines instead of 64), a step's 32 taps are one round of loads, and 8x more waves are in flight. Every scalar of the control flow is
+// computed redundantly by the 8 lanes (identical values); the per-step sums over the pattern are ORDERED scans through the group (lane j adds its
+// term to the running sum of lane j-1: DPP row_shr:1), so the fp32 sums are those of the sequential loop bit for bit.
+__global__ __launch_bounds__(256) void imm_trace8_kernel(ImmTraceParams P) {
+    __shared__ float errors[100 * 32];                                         // errors[step][group]
+    const int l = threadIdx.x & 7, tid = threadIdx.x >> 3;                     // tid = group (point) inside the block
+    const int p = blockIdx.x * 32 + tid;
+    if (p >= P.n) return;
+    const int lastStatus = P.status[p];
+    if (lastStatus == IPS_OOB) return;
+    const int w = P.w, h = P.h;
+    const float u = P.u[p], v = P.v[p];
+    const int hi = P.host_idx[p];
+    float KRKi[9], Kt[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) KRKi[i] = P.KRKi[hi * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Kt[i] = P.Kt[hi * 3 + i];
+    const float aff0 = P.aff[hi * 2], aff1 = P.aff[hi * 2 + 1];
+    const float color_l = P.color[p * 8 + l], weight_l = P.weights[p * 8 + l];
+    float idepth_min = P.idmin[p], idepth_max = P.idmax[p];
+    const float energyTH = P.energyTH[p];
+    const float maxPixSearch = (w + h) * kImmMaxPixSearch;
+    float pr[3], ptpMin[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pr[i] = KRKi[i * 3] * u + KRKi[i * 3 + 1] * v + KRKi[i * 3 + 2] * 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ptpMin[i] = pr[i] + Kt[i] * idepth_min;
+    const float uMin = ptpMin[0] / ptpMin[2], vMin = ptpMin[1] / ptpMin[2];
+    auto ret_oob = [&]() { if (l == 0) { P.lastUV[p * 2] = -1; P.lastUV[p * 2 + 1] = -1; P.lastInterval[p] = 0; P.status[p] = IPS_OOB; } };
+    if (!(uMin > 4 && vMin > 4 && uMin < w - 5 && vMin < h - 5)) { ret_oob(); return; }
+    float dist, uMax, vMax, ptpMax[3];
+    if (isfinite(idepth_max)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ptpMax[i] = pr[i] + Kt[i] * idepth_max;
+        uMax = ptpMax[0] / ptpMax[2]; vMax = ptpMax[1] / ptpMax[2];
+        if (!(uMax > 4 && vMax > 4 && uMax < w - 5 && vMax < h - 5)) { ret_oob(); return; }
+        dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
+        dist = sqrtf(dist);
+        if (dist < kImmSlackInterval) {                                        // :139-146
+            if (l == 0) { P.lastUV[p * 2] = (uMax + uMin) * 0.5f; P.lastUV[p * 2 + 1] = (vMax + vMin) * 0.5f; P.lastInterval[p] = dist; }
+            if (l == 0) { P.status[p] = IPS_SKIPPED; }
+            return;
+        }
+    } else {
+        dist = maxPixSearch;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ptpMax[i] = pr[i] + Kt[i] * 0.01f;         // :152-161
+        uMax = ptpMax[0] / ptpMax[2]; vMax = ptpMax[1] / ptpMax[2];
+        const float ddx = uMax - uMin, ddy = vMax - vMin;
+        const float d = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
+        uMax = uMin + dist * ddx * d; vMax = vMin + dist * ddy * d;
+        if (!(uMax > 4 && vMax > 4 && uMax < w - 5 && vMax < h - 5)) { ret_oob(); return; }
+    }
+    if (!(idepth_min < 0 || (ptpMin[2] > 0.75f && ptpMin[2] < 1.5f))) { ret_oob(); return; }      // :178-184
+    float dx = kImmStepsize * (uMax - uMin), dy = kImmStepsize * (vMax - vMin);
+    const float gxx = P.gradH[p * 3], gxy = P.gradH[p * 3 + 1], gyy = P.gradH[p * 3 + 2];
+    const float a = (dx * gxx + dy * gxy) * dx + (dx * gxy + dy * gyy) * dy;                          // (v^T gradH) v, :187-188
+    const float b = (dy * gxx + (-dx) * gxy) * dy + (dy * gxy + (-dx) * gyy) * (-dx);
+    float errorInPixel = 0.2f + 0.2f * (a + b) / a;
+    if (errorInPixel * kImmMinImprovement > dist && isfinite(idepth_max)) {
+        if (l == 0) { P.lastUV[p * 2] = (uMax + uMin) * 0.5f; P.lastUV[p * 2 + 1] = (vMax + vMin) * 0.5f; P.lastInterval[p] = dist; }
+        if (l == 0) { P.status[p] = IPS_BADCONDITION; }
+        return;
+    }
+    if (errorInPixel > 10) errorInPixel = 10;
+    dx /= dist; dy /= dist;
+    if (dist > maxPixSearch) { uMax = uMin + maxPixSearch * dx; vMax = vMin + maxPixSearch * dy; dist = maxPixSearch; }
+    int numSteps = (int)(1.9999f + dist / kImmStepsize);
+    const float randShift = uMin * 1000 - floorf(uMin * 1000);
+    float ptx = uMin - randShift * dx, pty = vMin - randShift * dy;
+    const float rot0 = KRKi[0] * kImmPattern[l][0] + KRKi[1] * kImmPattern[l][1];
+    const float rot1 = KRKi[3] * kImmPattern[l][0] + KRKi[4] * kImmPattern[l][1];
+    if (!isfinite(dx) || !isfinite(dy)) { if (l == 0) { P.lastInterval[p] = 0; P.lastUV[p * 2] = -1; P.lastUV[p * 2 + 1] = -1; P.status[p] = IPS_OOB; } return; }
+    float bestU = 0, bestV = 0, bestEnergy = 1e10f;
+    int bestIdx = -1;
+    if (numSteps >= 100) numSteps = 99;
+    for (int i = 0; i < numSteps; ++i) {                                       // discrete search, :275-304
+        float energy;
+        {
+            const float hit = imm_interp31(P.dI, ptx + rot0, pty + rot1, w);
+            const float residual = hit - (aff0 * color_l + aff1);
+            const float ar = fabsf(residual);
+            const float hw = ar < kHuberTH ? 1 : kHuberTH / ar;
+            energy = imm_group_sum(0.f, isfinite(hit) ? hw * residual * residual * (2 - hw) : 1e5f, l);
+        }
+        errors[i * 32 + tid] = energy;
+        if (energy < bestEnergy) { bestU = ptx; bestV = pty; bestEnergy = energy; bestIdx = i; }
+        ptx += dx; pty += dy;
+    }
+    float secondBest = 1e10f;                                                  // :308-316
+    for (int i = 0; i < numSteps; ++i) {
+        const float e = errors[i * 32 + tid];
+        if ((i < bestIdx - kImmMinTraceTestRadius || i > bestIdx + kImmMinTraceTestRadius) && e < secondBest) secondBest = e;
+    }
+    const float newQuality = secondBest / bestEnergy;
+    const float q0 = P.quality[p];
+    if ((newQuality < q0 || numSteps > 10) && l == 0) P.quality[p] = newQuality;
+    float uBak = bestU, vBak = bestV, stepBack = 0;                            // GN refinement along the line, :320-380
+    const float gnstepsize = 1;
+    if (kImmGNIts > 0) bestEnergy = 1e5f;
+    for (int it = 0; it < kImmGNIts; ++it) {
+        float H, bb, energy;
+        {
+            const float3 hit = imm_interp33(P.dI, bestU + rot0, bestV + rot1, w);
+            const bool fin = isfinite(hit.x);
+            const float residual = hit.x - (aff0 * color_l + aff1);
+            const float dResdDist = dx * hit.y + dy * hit.z;
+            const float ar = fabsf(residual);
+            const float hw = ar < kHuberTH ? 1 : kHuberTH / ar;
+            // a non-finite pixel adds 1e5 to the energy and nothing to H, b (x + 0 is exact)
+            H = imm_group_sum(1.f, fin ? hw * dResdDist * dResdDist : 0.f, l);
+            bb = imm_group_sum(0.f, fin ? hw * residual * dResdDist : 0.f, l);
+            energy = imm_group_sum(0.f, fin ? weight_l * weight_l * hw * residual * residual * (2 - hw) : 1e5f, l);
+        }
+        if (energy > bestEnergy) { stepBack *= 0.5f; bestU = uBak + stepBack * dx; bestV = vBak + stepBack * dy; }
+        else {
+            float step = -gnstepsize * bb / H;
+            if (step < -0.5f) step = -0.5f; else if (step > 0.5f) step = 0.5f;
+            if (!isfinite(step)) step = 0;
+            uBak = bestU; vBak = bestV; stepBack = step;
+            bestU += step * dx; bestV += step * dy; bestEnergy = energy;
+        }
+        if (fabsf(stepBack) < kImmGNTh) break;
+    }
+    if (!(bestEnergy < energyTH * kImmExtraSlack)) {                           // :384-394
+        if (l == 0) { P.lastInterval[p] = 0; P.lastUV[p * 2] = -1; P.lastUV[p * 2 + 1] = -1; }
+        if (l == 0) { P.status[p] = lastStatus == IPS_OUTLIER ? IPS_OOB : IPS_OUTLIER; }
+        return;
+    }
+    if (dx * dx > dy * dy) {                                                   // new interval, :398-408
+        idepth_min = (pr[2] * (bestU - errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));
+        idepth_max = (pr[2] * (bestU + errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU + errorInPixel * dx));
+    } else {
+        idepth_min = (pr[2] * (bestV - errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV - errorInPixel * dy));
+        idepth_max = (pr[2] * (bestV + errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV + errorInPixel * dy));
+    }
+    if (idepth_min > idepth_max) { const float tmp = idepth_min; idepth_min = idepth_max; idepth_max = tmp; }
+    if (l == 0) { P.idmin[p] = idepth_min; P.idmax[p] = idepth_max; }                        // the members are assigned before the validity test
+    if (!isfinite(idepth_min) || !isfinite(idepth_max) || (idepth_max < 0)) {
+        if (l == 0) { P.lastInterval[p] = 0; P.lastUV[p * 2] = -1; P.lastUV[p * 2 + 1] = -1; }
+        if (l == 0) { P.status[p] = IPS_OUTLIER; }
+        return;
+    }
+    if (l == 0) { P.lastInterval[p] = 2 * errorInPixel; P.lastUV[p * 2] = bestU; P.lastUV[p * 2 + 1] = bestV; }
+    if (l == 0) { P.status[p] = IPS_GOOD; }
 }
 
 struct ImmOptParams {
@@ -464,7 +625,9 @@ int imm_trace_launch(nalo_ctx* c, const float4* dI, int n, const float* base /* 
     P.idmin = idmin; P.idmax = idmax; P.status = status; P.quality = quality; P.lastUV = lastUV; P.lastInterval = lastInterval;
     if (n > 0) {
         ProfScope ps(c, "imm_trace");
-        imm_trace_kernel<<<(n + kImmThreads - 1) / kImmThreads, kImmThreads, 0, c->stream>>>(P);
+        static const bool scalar = std::getenv("NALO_IMM_SCALAR") != nullptr;       // one lane per point (the first version), for comparison
+        if (scalar) imm_trace_kernel<<<(n + kImmThreads - 1) / kImmThreads, kImmThreads, 0, c->stream>>>(P);
+        else imm_trace8_kernel<<<(n + 31) / 32, 256, 0, c->stream>>>(P);
     }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
