@@ -491,6 +491,113 @@ __global__ __launch_bounds__(kImmThreads) void imm_optimize_kernel(ImmOptParams 
     P.result[p] = 1;
 }
 
+// ---- eight lanes per point (lane l = pattern pixel l), like imm_trace8_kernel. ImmaturePoint::linearizeResidual returns at the FIRST pattern pixel that
+// fails (behind the camera / out of bounds / non-finite), keeping the Hdd / bd contributions of the pixels before it: the group finds that pixel with a
+// ballot and the ordered scans add only the terms of the lanes in front of it.
+constexpr int kImmGroups = 32;
+__device__ __forceinline__ float imm_group_sum_n(float init, float t, int l, int nvalid) {
+    float s = nvalid > 0 ? init + t : init;                                    // meaningful on lane 0
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x111, 0xF, 0xF, true));
+        if (l == j) s = j < nvalid ? prev + t : prev;
+    }
+    return __shfl(s, (threadIdx.x & 56) | 7, 64);
+}
+__device__ __forceinline__ double imm_linearize8(const ImmOptParams& P, int hf, int t, float u_pt, float v_pt, float color_l, float weight_l, int l,
+                                                 float energyTH, float outlierTHSlack, unsigned& st, unsigned& nst, double* en, double* nen, int i, float& Hdd, float& bd, float idepth) {
+    const int sh = 2 * i;
+    if (((st >> sh) & 3u) == IRS_OOB) { nst = (nst & ~(3u << sh)) | ((unsigned)IRS_OOB << sh); return en[i * kImmGroups]; }
+    const float fxl = P.fx, fyl = P.fy, cxl = P.cx, cyl = P.cy, fxli = 1.0f / P.fx, fyli = 1.0f / P.fy;
+    const float wM3G = P.w - 3, hM3G = P.h - 3;
+    const float* Rt = P.Rt + (size_t)(hf * P.W + t) * 12;
+    const float affLL0 = P.aff[(hf * P.W + t) * 2], affLL1 = P.aff[(hf * P.W + t) * 2 + 1];
+    float R[9], tt[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Rt[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tt[k] = Rt[9 + k];
+    const int dx = kImmPattern[l][0], dy = kImmPattern[l][1];
+    const float k0 = (u_pt + dx - cxl) * fxli, k1 = (v_pt + dy - cyl) * fyli;                        // projectPoint, ResidualProjections.h:61-87
+    float ptp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ptp[k] = R[k * 3] * k0 + R[k * 3 + 1] * k1 + R[k * 3 + 2] * 1 + tt[k] * idepth;
+    const float drescale = 1.0f / ptp[2];
+    const float uu = ptp[0] * drescale, vv = ptp[1] * drescale, Ku = uu * fxl + cxl, Kv = vv * fyl + cyl;
+    bool ok = (drescale > 0) && (Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G);
+    const float3 hit = imm_interp33(P.dI[t], ok ? Ku : 2.f, ok ? Kv : 2.f, P.w);                     // a failing lane reads a harmless texel
+    ok = ok && isfinite(hit.x);
+    const unsigned long long bad = __ballot(!ok);
+    const unsigned gb = (unsigned)(bad >> (threadIdx.x & 56)) & 0xFFu;
+    const int nvalid = gb ? __ffs((int)gb) - 1 : 8;                                                  // pattern pixels in front of the first failure
+    const float residual = hit.x - (affLL0 * color_l + affLL1);
+    const float ar = fabsf(residual);
+    float hw = ar < kHuberTH ? 1 : kHuberTH / ar;
+    const float e_t = weight_l * weight_l * hw * residual * residual * (2 - hw);
+    const float dxInterp = hit.y * fxl, dyInterp = hit.z * fyl;
+    const float d_idepth = (dxInterp * drescale * (tt[0] - tt[2] * uu) + dyInterp * drescale * (tt[1] - tt[2] * vv)) * kScaleIdepth;   // derive_idepth :36-45
+    hw *= weight_l * weight_l;
+    Hdd = imm_group_sum_n(Hdd, (hw * d_idepth) * d_idepth, l, nvalid);
+    bd = imm_group_sum_n(bd, (hw * residual) * d_idepth, l, nvalid);
+    float energyLeft = imm_group_sum_n(0.f, e_t, l, nvalid);
+    if (nvalid < 8) { nst = (nst & ~(3u << sh)) | ((unsigned)IRS_OOB << sh); return en[i * kImmGroups]; }
+    unsigned ns;
+    if (energyLeft > energyTH * outlierTHSlack) { energyLeft = energyTH * outlierTHSlack; ns = IRS_OUTLIER; } else ns = IRS_IN;
+    nst = (nst & ~(3u << sh)) | (ns << sh);
+    nen[i * kImmGroups] = (double)energyLeft;
+    return (double)energyLeft;
+}
+
+__global__ __launch_bounds__(256) void imm_optimize8_kernel(ImmOptParams P) {
+    __shared__ double en_s[(NALO_MAX_WINDOW - 1) * kImmGroups], nen_s[(NALO_MAX_WINDOW - 1) * kImmGroups];
+    const int l = threadIdx.x & 7, tid = threadIdx.x >> 3;                     // tid = group (point) inside the block
+    const int p = blockIdx.x * kImmGroups + tid;
+    if (p >= P.n) return;
+    double* en = en_s + tid; double* nen = nen_s + tid;
+    const int W = P.W, hf = P.host[p], nres = W - 1;
+    const float color_l = P.color[p * 8 + l], weight_l = P.weights[p * 8 + l];
+    const float u = P.u[p], v = P.v[p], energyTH = P.energyTH[p];
+    unsigned st = 0, nst = 0;                                                  // state = IN (0) for every residual; newState = OUTLIER
+    for (int i = 0; i < nres; ++i) { en[i * kImmGroups] = 0; nen[i * kImmGroups] = 0; nst |= (unsigned)IRS_OUTLIER << (2 * i); }
+    if (l == 0) for (int t = 0; t < W; ++t) P.res_in[(size_t)p * W + t] = 0;
+    if (l == 0) P.idepth_out[p] = NAN;
+    auto tgt = [&](int i) { return i < hf ? i : i + 1; };                      // residual i <-> the i-th frame that is not the host
+    float lastEnergy = 0, lastHdd = 0, lastbd = 0;
+    float currentIdepth = (P.idmax[p] + P.idmin[p]) * 0.5f;
+    for (int i = 0; i < nres; ++i) {
+        // `float += double`: formed in double, rounded once (FullSystemOptPoint.cpp:79)
+        lastEnergy = (float)((double)lastEnergy + imm_linearize8(P, hf, tgt(i), u, v, color_l, weight_l, l, energyTH, 1000.f, st, nst, en, nen, i, lastHdd, lastbd, currentIdepth));
+        st = (st & ~(3u << (2 * i))) | (((nst >> (2 * i)) & 3u) << (2 * i));
+        en[i * kImmGroups] = nen[i * kImmGroups];
+    }
+    if (!isfinite(lastEnergy) || lastHdd < kImmMinIdepthHAct) { if (l == 0) P.result[p] = 0; return; }
+    float lambda = 0.1f;
+    for (int it = 0; it < kImmGNItsActivation; ++it) {
+        float H = lastHdd; H *= 1 + lambda;
+        const float step = (float)((1.0 / (double)H) * (double)lastbd);        // `(1.0/H) * lastbd` is a double expression, :99
+        const float newIdepth = currentIdepth - step;
+        float newHdd = 0, newbd = 0, newEnergy = 0;
+        for (int i = 0; i < nres; ++i)
+            newEnergy = (float)((double)newEnergy + imm_linearize8(P, hf, tgt(i), u, v, color_l, weight_l, l, energyTH, 1.f, st, nst, en, nen, i, newHdd, newbd, newIdepth));
+        if (!isfinite(lastEnergy) || newHdd < kImmMinIdepthHAct) { if (l == 0) P.result[p] = 0; return; }
+        if (newEnergy < lastEnergy) {
+            currentIdepth = newIdepth; lastHdd = newHdd; lastbd = newbd; lastEnergy = newEnergy;
+            st = nst;
+            for (int i = 0; i < nres; ++i) en[i * kImmGroups] = nen[i * kImmGroups];
+            lambda *= 0.5f;
+        } else lambda *= 5;
+        if ((double)fabsf(step) < 0.0001 * (double)currentIdepth) break;
+    }
+    if (!isfinite(currentIdepth)) { if (l == 0) P.result[p] = -1; return; }
+    int numGood = 0;
+    for (int i = 0; i < nres; ++i) if (((st >> (2 * i)) & 3u) == IRS_IN) numGood++;
+    if (numGood < P.minObs) { if (l == 0) P.result[p] = -1; return; }
+    if (!isfinite(energyTH)) { if (l == 0) P.result[p] = -1; return; }                     // PointHessian inherits energyTH, :158
+    if (l == 0) for (int i = 0; i < nres; ++i) if (((st >> (2 * i)) & 3u) == IRS_IN) P.res_in[(size_t)p * W + tgt(i)] = 1;
+    if (l == 0) P.idepth_out[p] = currentIdepth;
+    if (l == 0) P.result[p] = 1;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- CoarseDistanceMap
 // CoarseDistanceMap::makeDistanceMap + growDistBFS (reference src/FullSystem/CoarseTracker.cpp:1410-1561): the window's active points (already in HBM:
 // pt_geo) are projected to level 1 of the newest frame, seeds get 0, then 39 breadth-first rounds (odd rounds over 8 neighbours, even rounds over 4,
@@ -644,7 +751,9 @@ int imm_optimize_launch(nalo_ctx* c, const float4* const* dI, int W, const float
     P.result = result; P.idepth_out = idepth_out; P.res_in = res_in;
     if (n > 0) {
         ProfScope ps(c, "imm_optimize");
-        imm_optimize_kernel<<<(n + kImmThreads - 1) / kImmThreads, kImmThreads, 0, c->stream>>>(P);
+        static const bool scalar = std::getenv("NALO_IMM_SCALAR") != nullptr;
+        if (scalar) imm_optimize_kernel<<<(n + kImmThreads - 1) / kImmThreads, kImmThreads, 0, c->stream>>>(P);
+        else imm_optimize8_kernel<<<(n + kImmGroups - 1) / kImmGroups, 256, 0, c->stream>>>(P);
     }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
