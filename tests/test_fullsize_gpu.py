@@ -233,3 +233,46 @@ def test_two_contexts_on_two_threads():
     ta.start(); tb.start(); ta.join(); tb.join()
     assert len(got_t) == 6 and len(got_b) == 3
     assert all(np.array_equal(t, ref_t[0]) for t in got_t) and all(np.array_equal(b, ref_b[0]) for b in got_b)
+
+
+def test_image_sizes_with_odd_pyramid_levels():
+    """644x484 -> 322x242 -> 161x121 (odd: the pyramid stops there, 3 levels) and 1226x370 -> 613x185 (2 levels): tile edges of the fused pyramid /
+    coarse-depth kernels, level tables shorter than usual, a width that is not a multiple of 32."""
+    for (w, h, lv) in ((644, 484, 3), (1226, 370, 2)):
+        win = synth.make_window(w=w, h=h, W=3, P=300, seed=17, n_extra=1)
+        assert win.levels == lv
+        c = binding.Context(win.w, win.h, win.K, n_slots=win.W + 1)
+        assert c.levels == lv
+        for i in range(win.W + 1):
+            c.frame_upload(i, win.images[i])
+        dI_ref, ab_ref = orc.make_images(win.images[2], lv)
+        L = orc.lib()
+        for l in range(lv):
+            dI, ab = c.frame_download(2, l)
+            o, n = L.orc_pyr_offset(w, h, l), (w >> l) * (h >> l)
+            assert np.array_equal(dI, dI_ref[o:o + n]) and np.array_equal(ab, ab_ref[o:o + n])
+        Ku, Kv, idp, hdi = tracker_inputs(win, n=2500, seed=4)
+        trk = orc.Tracker(w, h, lv, win.K)
+        trk.set_ref(dI_ref, Ku, Kv, idp, hdi)
+        c.trk_set_ref(2, Ku, Kv, idp, hdi)
+        for l in range(lv):
+            a, b = c.trk_get_pc(l), trk.get_pc(l)
+            assert len(a[0]) == len(b[0]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and rel_err(a[2], b[2]) < 1e-6
+        T0 = orc.se3_exp(orc.se3_log(true_rel_pose(win, 2, 3)) * 0.9)
+        dI_new = orc.make_images(win.images[3], lv)[0]
+        ok_o, T_o = trk.track(dI_new, T0, [0, 0], [0, 0], [1, 1], lv - 1)[:2]
+        ok, T = c.trk_track(3, T0, [0, 0], [0, 0], [1, 1], lv - 1)[:2]
+        assert ok == ok_o and pose_dist(T, T_o) < 1e-5
+        st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
+        c.ba_set_window(list(range(win.W)), win.world_to_cam[:win.W], state6=st6)
+        c.ba_set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights)
+        c.ba_set_residuals(win.exists)
+        ba = orc.ba_from_window(win, "f32", state6=st6)
+        E_o = ba.linearize_all(False); ba.apply_res()
+        E = c.ba_linearize(False)
+        HA, _ = c.ba_accumulate(0); HA_o, _ = ba.accumulate(0)
+        assert abs(E - E_o) <= 1e-5 * E_o and rel_err(HA, HA_o) < 2e-5
+        ths, sm = c.pixsel_make_hists(2)
+        ths_o, sm_o = orc.pixsel_make_hists(ab_ref[:w * h], w, h)
+        assert np.array_equal(ths, ths_o) and np.array_equal(sm, sm_o)
+        c.close()
