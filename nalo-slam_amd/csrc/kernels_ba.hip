@@ -38,11 +38,19 @@ __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__
 // Block = the same 256 points as the linearize block. Thread (ty,tx) of a 16x16 grid owns a TxT tile of G (NPL = 16T columns).
 // KS > 1 splits a block's points over KS workgroups (small windows: a KITTI-sized window has ~12 point blocks for 256 CUs, and the
 // k-loop of a whole block is a 20 us serial chain); the partials are [nblocks * KS][NPL * NPL].
-template <int T, int KS>
+// MFMA = true (default): the SYRK runs on the matrix cores. G is symmetric, so only the T(T+1)/2 upper 16x16 tiles are computed, dealt round-robin to the
+// four waves; per step of 4 points a wave feeds v_mfma_f32_16x16x4_f32 with A[i][k] = a_pk[16 ti + i] and B[k][j] = w_pk a_pk[16 tj + j] (one f32 VGPR each,
+// straight from the staged LDS rows), i.e. the same k-ordered fp32 fma chain as the vector version (exact f32 MFMA), flushed into fp64 every 8 points.
+// The vector version (MFMA = false, NALO_SC_VALU=1) computes all T*T tiles of a 16x16 thread grid.
+typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
+template <int T, int KS, bool MFMA>
 __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
     // rows staged per pass: the whole share when it fits (<= 64 KiB of LDS), so all operand loads of a block are in flight at once
-    constexpr int NPL = 16 * T, ROWS = kBlk / KS, SUB0 = T <= 4 ? 256 : (T <= 6 ? 128 : 64), SUB = SUB0 < ROWS ? SUB0 : ROWS;
-    constexpr int NPLP = NPL + 4;            // padded LDS row: lanes = consecutive rows, so the row stride must not be a multiple of 32 banks
+    constexpr int NPL = 16 * T, ROWS = kBlk / KS;
+    constexpr int SUB0 = MFMA ? (T <= 2 ? 256 : (T <= 4 ? 128 : 64)) : (T <= 4 ? 256 : (T <= 6 ? 128 : 64)), SUB = SUB0 < ROWS ? SUB0 : ROWS;
+    // padded LDS row. Vector version: lanes = consecutive rows, so the row stride must not be a multiple of 32 banks. MFMA version: a wave reads 4
+    // consecutive rows x 16 columns per operand, so the stride is an odd multiple of 16 floats (the 4 rows land on disjoint bank quarters).
+    constexpr int NPLP = MFMA ? NPL + ((T % 2 == 0) ? 16 : 32) : NPL + 4;
     __shared__ __attribute__((aligned(16))) float A[SUB * NPLP];
     __shared__ __attribute__((aligned(16))) float4 Hc[ROWS];
     __shared__ float Wt[ROWS], Bd[ROWS];
@@ -57,12 +65,31 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
     // fp32 products in short runs (8 points) flushed into fp64: the block partial is good to ~1e-8, so the ~100x cancellation in
     // H_A - H_sc does not amplify summation noise into the poses
     constexpr int RUN = 8;
-    float acc[T][T];
-    double acc64[T][T];
+    constexpr int TT = MFMA ? 1 : T;
+    float acc[TT][TT];
+    double acc64[TT][TT];
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < TT; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j) { acc[i][j] = 0.f; acc64[i][j] = 0.0; }
+        for (int j = 0; j < TT; ++j) { acc[i][j] = 0.f; acc64[i][j] = 0.0; }
+    // MFMA: this wave's upper-triangular tiles (row-major enumeration of ti <= tj, tiles wave, wave + 4, ...)
+    constexpr int NTILES = T * (T + 1) / 2, MAXM = (NTILES + 3) / 4;
+    const int wave = tid >> 6, lane = tid & 63;
+    int mti[MAXM], mtj[MAXM];
+    sc_f32x4 macc[MAXM];
+    double macc64[MAXM][4];
+    if constexpr (MFMA) {
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+            int idx = wave + 4 * m, ti = 0;
+            if (idx >= NTILES) idx = NTILES - 1;                   // surplus slot: recomputes the last tile, never stored
+            while (idx >= T - ti) { idx -= T - ti; ++ti; }
+            mti[m] = ti; mtj[m] = ti + idx;
+            macc[m] = (sc_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) macc64[m][r] = 0.0;
+        }
+    }
     for (int b = b0; b < b1; ++b) {
     const int dbase = b * kBlk + ks * ROWS;
     __syncthreads();                                           // the previous block's rows / weights have been consumed
@@ -136,6 +163,27 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
             }
         }
         __syncthreads();
+        if constexpr (MFMA) {
+            for (int k0 = 0; k0 < SUB; k0 += RUN) {
+#pragma unroll
+                for (int st4 = 0; st4 < RUN / 4; ++st4) {
+                    const int prow = k0 + 4 * st4 + (lane >> 4);       // the 4 points of this MFMA step: k = lane >> 4
+                    const float wk = Wt[sub * SUB + prow];
+                    const float* rowp = A + prow * NPLP + (lane & 15);
+#pragma unroll
+                    for (int m = 0; m < MAXM; ++m) {
+                        const float a = rowp[16 * mti[m]], bq = wk * rowp[16 * mtj[m]];
+                        macc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, macc[m], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MAXM; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) macc64[m][r] += (double)macc[m][r];
+                    macc[m] = (sc_f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
         for (int k0 = 0; k0 < SUB; k0 += RUN) {
 #pragma unroll
             for (int k = k0; k < k0 + RUN; ++k) {
@@ -153,33 +201,53 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZer
 #pragma unroll
                 for (int j = 0; j < T; ++j) { acc64[i][j] += (double)acc[i][j]; acc[i][j] = 0.f; }
         }
+        }
     }
     }                                                          // blocks of this group
     double* out = B.sc_partial + (size_t)blockIdx.x * NPL * NPL;
+    if constexpr (MFMA) {
+        // C/D layout of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg; the mirror tile is written too (the reduce kernel reads full matrices)
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+        for (int m = 0; m < MAXM; ++m) {
+            if (wave + 4 * m >= NTILES) continue;
 #pragma unroll
-        for (int j = 0; j < T; ++j) out[(ty * T + i) * NPL + tx * T + j] = acc64[i][j];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * mti[m] + (lane >> 4) * 4 + r, col = 16 * mtj[m] + (lane & 15);
+                out[row * NPL + col] = macc64[m][r];
+                if (mti[m] != mtj[m]) out[col * NPL + row] = macc64[m][r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j) out[(ty * T + i) * NPL + tx * T + j] = acc64[i][j];
+    }
 }
 
-template <int KS>
+template <int KS, bool MFMA>
 static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
     const int grid = B.sc_groups * KS;
     switch (T) {
-        case 1: ba_sc_kernel<1, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 2: ba_sc_kernel<2, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 3: ba_sc_kernel<3, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 4: ba_sc_kernel<4, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 5: ba_sc_kernel<5, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 6: ba_sc_kernel<6, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 7: ba_sc_kernel<7, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        default: ba_sc_kernel<8, KS><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 1: ba_sc_kernel<1, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 2: ba_sc_kernel<2, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 3: ba_sc_kernel<3, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 4: ba_sc_kernel<4, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 5: ba_sc_kernel<5, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 6: ba_sc_kernel<6, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 7: ba_sc_kernel<7, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        default: ba_sc_kernel<8, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
     }
 }
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
-    if (B.sc_split == 4) launch_sc_ks<4>(s, B, T, shift, priorScaleMarg, margOnly);
-    else if (B.sc_split == 2) launch_sc_ks<2>(s, B, T, shift, priorScaleMarg, margOnly);
-    else launch_sc_ks<1>(s, B, T, shift, priorScaleMarg, margOnly);
+    static const bool valu = std::getenv("NALO_SC_VALU") != nullptr;       // the vector-ALU SYRK (first version), for comparison
+    if (valu) {
+        if (B.sc_split == 4) launch_sc_ks<4, false>(s, B, T, shift, priorScaleMarg, margOnly);
+        else launch_sc_ks<1, false>(s, B, T, shift, priorScaleMarg, margOnly);
+    } else {
+        if (B.sc_split == 4) launch_sc_ks<4, true>(s, B, T, shift, priorScaleMarg, margOnly);
+        else launch_sc_ks<1, true>(s, B, T, shift, priorScaleMarg, margOnly);
+    }
 }
 void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
     const size_t n = (size_t)B.W * B.Ppad;
