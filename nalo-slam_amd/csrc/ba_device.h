@@ -53,7 +53,7 @@ struct BADev {
     unsigned *th_hist_hi, *th_hist_lo, *th_state;   // radix-select histograms (2 x 65536) + {count, k_rem, prefix_hi}
     // partials
     double* top_partial;                        // [nblocks][W][kTopStride]  (fp64: one rounding less before the cancelling H_A - H_sc)
-    double* sc_partial;                         // [nblocks * sc_split][NPL*NPL]
+    double* sc_partial;                         // [sc_groups * sc_split][T(T+1)/2 upper tiles][256] (MFMA register order)
     int sc_split;                               // 1 or 4 workgroups per point block in ba_sc_kernel (4 for small windows)
     const int* host_blk;                        // [W+1] point-block range of every host
     const int* sc_grp;                          // [W+1] ba_sc workgroup-group range of every host (groups of sc_bpw blocks)

@@ -659,7 +659,7 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
         NALO_HIP(c, hipMemcpy(w.sc_grp.p, grp.data(), (size_t)(W + 1) * 4, hipMemcpyHostToDevice));
         w.dev.sc_grp = w.sc_grp.p;
     }
-    NALO_HIP(c, w.sc_partial.reserve((size_t)w.dev.sc_groups * w.dev.sc_split * w.NPL * w.NPL));
+    NALO_HIP(c, w.sc_partial.reserve((size_t)w.dev.sc_groups * w.dev.sc_split * (w.T * (w.T + 1) / 2) * 256));
     NALO_HIP(c, hipMemcpy(w.pt_geo.p, geo.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_col0.p, c0.data(), N * 16, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.pt_col1.p, c1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_w0.p, w0.data(), N * 16, hipMemcpyHostToDevice));
     NALO_HIP(c, hipMemcpy(w.pt_w1.p, w1.data(), N * 16, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(w.pt_prior.p, prior.data(), N * 4, hipMemcpyHostToDevice));

@@ -6,9 +6,11 @@
 //                                  (OptimizationBackend/AccumulatedTopHessian.cpp:39-162, MatrixAccumulators.h:754-915)
 //                                  and, in marginalisation mode, EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:89-115).
 //                                  The 296-byte RawResidualJacobian never leaves registers.
+//  ba_pt_acc_kernel      a9        the per-point sums of AccumulatedSCHessianSSE::addPoint (Hdd/bd/Hcd over the active residuals, HdiF, bdSumF)
 //  ba_sc_kernel          a9        AccumulatedSCHessianSSE::addPoint (OptimizationBackend/AccumulatedSCHessian.cpp:34-77) as a
 //                                  per-host weighted SYRK  G_h = sum_p HdiF_p a_p a_p^T,  a_p = [JpJdF(t) for t != h | Hcd | bdSum]:
 //                                  accD = the 8x8 blocks, accE = the Hcd columns, accEB = the bdSum column, accHcc/accbc = the corner.
+//                                  The one GEMM-shaped kernel of the path: fp32 MFMA (v_mfma_f32_16x16x4_f32) over the upper-triangular tiles.
 //  ba_reduce_*           fp64 finish of the per-block fp32 partials (replaces the per-thread replicas summed in stitchDoubleInternal)
 //  ba_stitch_*           a8+a10    stitchDouble for both systems as  H~ = sum_b S_b M_b S_b^T  with S_b built from adHost/adTarget
 //                                  (AccumulatedTopHessian.cpp:171-303, AccumulatedSCHessian.cpp:78-219)
@@ -16,7 +18,7 @@
 //  ba_step_kernel                  point part of FullSystem::doStepFromBackup (FullSystem/FullSystemOptimize.cpp:269-277)
 //  ba_energy_th_kernel             FullSystem::setNewFrameEnergyTH (FullSystemOptimize.cpp:95-143): exact order statistic by radix select
 //
-// All kernels are HBM/latency bound (no MFMA): 16-byte texel gathers, coalesced [target][point] slot arrays,
+// Everything but ba_sc_kernel is HBM/latency bound integer/byte/gather work (no MFMA): 16-byte texel gathers, coalesced [target][point] slot arrays,
 // block-uniform precalc through scalar loads, DPP + LDS reductions, no float atomics on any sum.
 #include "nalo_internal.h"
 #include "ba_device.h"
@@ -34,220 +36,206 @@ __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__
     if ((st & RS_EXISTS) && !(st & RS_LINEARIZED)) { rs_state[i] = (uint8_t)(st & ~RS_STATE_MASK); rs_energy[i] = make_float2(0.f, 0.f); }
 }
 
-// ------------------------------------------------------------------------------------------------ a9: per-host weighted SYRK
-// Block = the same 256 points as the linearize block. Thread (ty,tx) of a 16x16 grid owns a TxT tile of G (NPL = 16T columns).
+// ------------------------------------------------------------------------------------------------ a9: per-point sums, per-host weighted SYRK
+// ba_pt_acc_kernel: per point (AccumulatedSCHessian.cpp:36-57): EFPoint::{Hdd,bd,Hcd}_acc = sum over the point's active residuals in target order
+// (AccumulatedTopHessian.cpp:132-157), then HdiF, bdSumF. One thread per point, no LDS: the W strided 25-byte slot reads of a point are hidden by
+// occupancy instead of stalling the SYRK workgroups (they were the first phase of ba_sc_kernel: 87 of its 390 us on the 1M-point window).
+__global__ __launch_bounds__(kBlk) void ba_pt_acc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
+    if (B.stop && B.stop[0]) return;
+    const int b = blockIdx.x, h = B.blk_host[b], W = B.W, d = b * kBlk + threadIdx.x;
+    const uint8_t pf = B.pt_flags[d];
+    if (!((pf & PT_VALID) && (!margOnly || (pf & PT_MARG)))) return;
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), hc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int ngood = 0;
+    for (int t0 = 0; t0 < W; t0 += 8) {                        // 8 targets' slots in flight at once (clamped, selected below), summed in target order
+        uint8_t rs[8]; float4 q0[8]; float2 q1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const size_t si = (size_t)min(t0 + i, W - 1) * B.Ppad + d;
+            rs[i] = B.rs_state[si]; q0[i] = B.rs_pp0[si]; q1[i] = B.rs_pp1[si];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int t = t0 + i;
+            if (t >= W || t == h || !(rs[i] & RS_ACTIVE)) continue;
+            pa.y += q0[i].x; pa.x += q0[i].y; hc.x += q0[i].z; hc.y += q0[i].w; hc.z += q1[i].x; hc.w += q1[i].y;
+            ++ngood;
+        }
+    }
+    B.pt_hcd[d] = hc; B.pt_ngood[d] = (uint8_t)ngood;
+    if (ngood == 0) { pa.z = 0.f; pa.w = 0.f; }
+    else {
+        float prior = B.pt_prior[d];
+        if (margOnly) { prior *= priorScaleMarg; B.pt_prior[d] = prior; }          // EnergyFunctional.cpp:630
+        float Hs = pa.x + prior;                                                    // Hdd_accAF + Hdd_accLF + priorF (only one of AF/LF is live)
+        if (Hs < 1e-10f) Hs = 1e-10f;
+        pa.z = (float)(1.0 / (double)Hs);
+        pa.w = pa.y;
+        if (shiftPriorToZero) { const float4 geo = B.pt_geo[d]; pa.w += prior * (geo.z - geo.w); }
+    }
+    B.pt_acc[d] = pa;
+}
+
+// ba_sc_kernel: G_h = sum over the host's points of HdiF * row row^T, row = [JpJdF(t != h) (8 each) | Hcd (4) | bdSum | 0..] (NPL = 16T columns).
+// A workgroup walks a group of up to sc_bpw consecutive point blocks of ONE host in passes of SUB points: the rows of a pass are staged in LDS, and
+// the global loads of the NEXT pass are issued into registers before the SYRK of the current one, so HBM latency hides under the matrix work. The fp64
+// partial (NPL^2 x 8 B, as large as a block's operands) is written once per group.
 // KS > 1 splits a block's points over KS workgroups (small windows: a KITTI-sized window has ~12 point blocks for 256 CUs, and the
-// k-loop of a whole block is a 20 us serial chain); the partials are [nblocks * KS][NPL * NPL].
-// MFMA = true (default): the SYRK runs on the matrix cores. G is symmetric, so only the T(T+1)/2 upper 16x16 tiles are computed, dealt round-robin to the
-// four waves; per step of 4 points a wave feeds v_mfma_f32_16x16x4_f32 with A[i][k] = a_pk[16 ti + i] and B[k][j] = w_pk a_pk[16 tj + j] (one f32 VGPR each,
-// straight from the staged LDS rows), i.e. the same k-ordered fp32 fma chain as the vector version (exact f32 MFMA), flushed into fp64 every 8 points.
-// The vector version (MFMA = false, NALO_SC_VALU=1) computes all T*T tiles of a 16x16 thread grid.
+// k-loop of a whole block is a 20 us serial chain); the partials are [groups * KS][NPL * NPL].
+// The SYRK runs on the matrix cores. G is symmetric, so only the T(T+1)/2 upper 16x16 tiles are computed, dealt round-robin to the four waves; per
+// step of 4 points a wave feeds v_mfma_f32_16x16x4_f32 with A[i][k] = a_pk[16 ti + i] and B[k][j] = w_pk a_pk[16 tj + j] (one f32 VGPR each, read
+// from the staged LDS rows): an exact k-ordered fp32 fma chain per entry, flushed into fp64 every RUN points. The partial of a workgroup is the
+// compact list of its upper tiles in MFMA register order ([tile][reg][lane]: every store is 512 contiguous bytes); ba_reduce_kernel mirrors.
+// (The first version computed all T*T tiles with a 16x16 thread grid on the vector ALU: 748 us on the 1M-point / 12-frame window, this one 175.)
 typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
-template <int T, int KS, bool MFMA>
-__global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
-    // rows staged per pass: the whole share when it fits (<= 64 KiB of LDS), so all operand loads of a block are in flight at once
+// upper-triangular 16x16 tile enumeration (row-major over ti <= tj) of the MFMA SYRK
+template <int T> __device__ constexpr int sc_tile_i(int idx) { int ti = 0; while (idx >= T - ti) { idx -= T - ti; ++ti; } return ti; }
+template <int T> __device__ constexpr int sc_tile_j(int idx) { int ti = 0; while (idx >= T - ti) { idx -= T - ti; ++ti; } return ti + idx; }
+// the MFMAs of one 4-point step: tile indices are template constants, so x[ti] / xw[tj] are plain registers
+template <int T, int WAVE, int M, int MAXM>
+__device__ __forceinline__ void sc_mfma_tiles(const float (&x)[T], const float (&xw)[T], sc_f32x4 (&macc)[MAXM]) {
+    if constexpr (M < MAXM) {
+        constexpr int idx = WAVE + 4 * M;
+        if constexpr (idx < T * (T + 1) / 2) {
+            constexpr int ti = sc_tile_i<T>(idx), tj = sc_tile_j<T>(idx);
+            macc[M] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[ti], xw[tj], macc[M], 0, 0, 0);
+        }
+        sc_mfma_tiles<T, WAVE, M + 1, MAXM>(x, xw, macc);
+    }
+}
+// One staged pass (SUB points) of wave WAVE's tiles {WAVE, WAVE + 4, ...}. The tile list is a compile-time property of the wave, so per step of
+// 4 points the wave reads each of the T column blocks of the 4 rows ONCE (x[c]) and every a / w*b operand is a register pick.
+template <int T, int WAVE, int SUB, int NPLP, int RUN, int MAXM>
+__device__ __forceinline__ void sc_mfma_pass(const float* __restrict__ A, const float* __restrict__ Wt, int lane, sc_f32x4 (&macc)[MAXM], double (&macc64)[MAXM][4]) {
+    constexpr int NTILES = T * (T + 1) / 2;
+    const float* rowp = A + (lane >> 4) * NPLP + (lane & 15);  // the 4 points of an MFMA step: k = lane >> 4
+    const float* wp = Wt + (lane >> 4);
+    for (int k0 = 0; k0 < SUB; k0 += RUN) {
+#pragma unroll
+        for (int st4 = 0; st4 < RUN / 4; ++st4) {
+            const int k = k0 + 4 * st4;
+            const float wk = wp[k];
+            float x[T], xw[T];
+#pragma unroll
+            for (int c = 0; c < T; ++c) x[c] = rowp[k * NPLP + 16 * c];
+#pragma unroll
+            for (int c = 0; c < T; ++c) xw[c] = wk * x[c];
+            sc_mfma_tiles<T, WAVE, 0, MAXM>(x, xw, macc);
+        }
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) {
+            if (WAVE + 4 * m >= NTILES) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) macc64[m][r] += (double)macc[m][r];
+            macc[m] = (sc_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+template <int T, int KS>
+__global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly) {
     constexpr int NPL = 16 * T, ROWS = kBlk / KS;
-    constexpr int SUB0 = MFMA ? (T <= 2 ? 256 : (T <= 4 ? 128 : 64)) : (T <= 4 ? 256 : (T <= 6 ? 128 : 64)), SUB = SUB0 < ROWS ? SUB0 : ROWS;
-    // padded LDS row. Vector version: lanes = consecutive rows, so the row stride must not be a multiple of 32 banks. MFMA version: a wave reads 4
-    // consecutive rows x 16 columns per operand, so the stride is an odd multiple of 16 floats (the 4 rows land on disjoint bank quarters).
-    constexpr int NPLP = MFMA ? NPL + ((T % 2 == 0) ? 16 : 32) : NPL + 4;
+    constexpr int SUB0 = T <= 2 ? 256 : (T <= 4 ? 128 : 64), SUB = SUB0 < ROWS ? SUB0 : ROWS, NSUB = ROWS / SUB;
+    // padded LDS row: a wave reads 4 consecutive rows x 16 columns per operand, so the stride is an odd multiple of 16 floats (the 4 rows land on
+    // disjoint bank quarters)
+    constexpr int NPLP = NPL + ((T % 2 == 0) ? 16 : 32);
     __shared__ __attribute__((aligned(16))) float A[SUB * NPLP];
-    __shared__ __attribute__((aligned(16))) float4 Hc[ROWS];
-    __shared__ float Wt[ROWS], Bd[ROWS];
-    // workgroup -> (group of up to sc_bpw consecutive point blocks of ONE host, share ks of each block's points). Large windows put several
-    // blocks through one workgroup: the fp64 partial (NPL^2 x 8 B, as large as a block's operands) is then written once per group.
+    __shared__ float Wt[SUB];
     if (B.stop && B.stop[0]) return;
     const int grp = blockIdx.x / KS, ks = blockIdx.x - grp * KS, tid = threadIdx.x, W = B.W;
     int h = 0;
     while (h + 1 < W && grp >= B.sc_grp[h + 1]) ++h;
     const int b0 = B.host_blk[h] + (grp - B.sc_grp[h]) * B.sc_bpw, b1 = min(b0 + B.sc_bpw, B.host_blk[h + 1]);
-    const int ty = tid >> 4, tx = tid & 15;
-    // fp32 products in short runs (8 points) flushed into fp64: the block partial is good to ~1e-8, so the ~100x cancellation in
-    // H_A - H_sc does not amplify summation noise into the poses
-    constexpr int RUN = 8;
-    constexpr int TT = MFMA ? 1 : T;
-    float acc[TT][TT];
-    double acc64[TT][TT];
-#pragma unroll
-    for (int i = 0; i < TT; ++i)
-#pragma unroll
-        for (int j = 0; j < TT; ++j) { acc[i][j] = 0.f; acc64[i][j] = 0.0; }
-    // MFMA: this wave's upper-triangular tiles (row-major enumeration of ti <= tj, tiles wave, wave + 4, ...)
+    // fp32 products in short runs of 16 points flushed into fp64: the block partial is good to ~1e-8 relative (the reference's AccumulatorXX runs its
+    // fp32 levels for 1000 adds, MatrixAccumulators.h), so the ~100x cancellation in H_A - H_sc does not amplify summation noise into the poses
+    constexpr int RUN = 16;
+    // this wave's upper-triangular tiles (row-major enumeration of ti <= tj): wave, wave + 4, ...
     constexpr int NTILES = T * (T + 1) / 2, MAXM = (NTILES + 3) / 4;
     const int wave = tid >> 6, lane = tid & 63;
-    int mti[MAXM], mtj[MAXM];
     sc_f32x4 macc[MAXM];
     double macc64[MAXM][4];
-    if constexpr (MFMA) {
 #pragma unroll
-        for (int m = 0; m < MAXM; ++m) {
-            int idx = wave + 4 * m, ti = 0;
-            if (idx >= NTILES) idx = NTILES - 1;                   // surplus slot: recomputes the last tile, never stored
-            while (idx >= T - ti) { idx -= T - ti; ++ti; }
-            mti[m] = ti; mtj[m] = ti + idx;
-            macc[m] = (sc_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MAXM; ++m) {
+        macc[m] = (sc_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) macc64[m][r] = 0.0;
-        }
+        for (int r = 0; r < 4; ++r) macc64[m][r] = 0.0;
     }
-    for (int b = b0; b < b1; ++b) {
-    const int dbase = b * kBlk + ks * ROWS;
-    __syncthreads();                                           // the previous block's rows / weights have been consumed
-    if (tid < ROWS)
-    {   // ---- per point (AccumulatedSCHessian.cpp:36-57): EFPoint::{Hdd,bd,Hcd}_acc = sum over the point's active residuals in
-        //      target order (AccumulatedTopHessian.cpp:132-157), then HdiF, bdSumF
-        const int d = dbase + tid;
-        const uint8_t pf = B.pt_flags[d];
-        const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
-        float wgt = 0.f, bds = 0.f;
-        float4 hc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pvalid) {
-            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
-            int ngood = 0;
-            for (int t = 0; t < W; ++t) {
-                if (t == h) continue;
-                const size_t si = (size_t)t * B.Ppad + d;
-                const uint8_t rs = B.rs_state[si];
-                const float4 q0 = B.rs_pp0[si]; const float2 q1 = B.rs_pp1[si];     // unconditional loads, selected below
-                if (!(rs & RS_ACTIVE)) continue;
-                pa.y += q0.x; pa.x += q0.y; hc.x += q0.z; hc.y += q0.w; hc.z += q1.x; hc.w += q1.y;
-                ++ngood;
-            }
-            B.pt_hcd[d] = hc; B.pt_ngood[d] = (uint8_t)ngood;
-            if (ngood == 0) { pa.z = 0.f; pa.w = 0.f; }
-            else {
-                float prior = B.pt_prior[d];
-                if (margOnly) { prior *= priorScaleMarg; B.pt_prior[d] = prior; }          // EnergyFunctional.cpp:630
-                float Hs = pa.x + prior;                                                    // Hdd_accAF + Hdd_accLF + priorF (only one of AF/LF is live)
-                if (Hs < 1e-10f) Hs = 1e-10f;
-                pa.z = (float)(1.0 / (double)Hs);
-                pa.w = pa.y;
-                if (shiftPriorToZero) { const float4 geo = B.pt_geo[d]; pa.w += prior * (geo.z - geo.w); }
-                wgt = pa.z;
-            }
-            B.pt_acc[d] = pa;
-            bds = pa.w;
+    // ---- staging: lane <-> point (coalesced 16-byte loads from the [target][point] arrays), the NQ float4 columns of a row are split over the
+    // 256/SUB threads that share a point; fully unrolled, so every load of a pass is in flight at once.
+    constexpr int NQ = NPL / 4, PARTS = kBlk / SUB, NV = (NQ + PARTS - 1) / PARTS;
+    const int r = tid % SUB, part = __builtin_amdgcn_readfirstlane(tid / SUB);      // SUB >= 64: the column set of a thread is wave-uniform (scalar selects)
+    const int qH = 2 * (W - 1);                                // float4 column of Hcd; qH + 1 = {bdSum, 0, 0, 0} (and carries HdiF to Wt)
+    // fetch = loads only (one 16-byte + one state byte per column, source picked by pointer selects: no branches, no waits); the selects that need the
+    // loaded bytes happen at commit time, after the SYRK of the previous pass
+    float4 raw[NV];
+    uint8_t rst[NV], rpf = 0;
+    auto fetch = [&](int p) {
+        const int pb = p / NSUB, d = (b0 + pb) * kBlk + ks * ROWS + (p - pb * NSUB) * SUB + r;
+        rpf = B.pt_flags[d];
+#pragma unroll
+        for (int qi = 0; qi < NV; ++qi) {
+            const int q = part + qi * PARTS, g = q >> 1;          // q-th float4 of the row, compact target slot g
+            const bool isj = q < qH;
+            const size_t si = (size_t)(isj ? (g < h ? g : g + 1) : 0) * B.Ppad + d;
+            const float4* src = isj ? ((q & 1) ? B.rs_jp1 : B.rs_jp0) + si : (q == qH ? B.pt_hcd : B.pt_acc) + d;
+            raw[qi] = *src;
+            rst[qi] = RS_ACTIVE;
+            if (isj) rst[qi] = B.rs_state[si];                     // scalar branch (q is wave-uniform)
         }
-        Wt[tid] = wgt; Bd[tid] = bds; Hc[tid] = hc;
-    }
-    for (int sub = 0; sub < ROWS / SUB; ++sub) {
-        const int d0 = dbase + sub * SUB;
-        __syncthreads();
-        // ---- stage SUB operand rows: [JpJdF(t != h) (8 each) | Hcd (4) | bdSum | 0..]
-        // lane <-> point (coalesced 16-byte loads from the [target][point] arrays), the NQ float4 columns of a row are split over
-        // the 256/SUB threads that share a point; the loop is fully unrolled so every load of the pass is in flight at once.
+    };
+    const int npass = (b1 - b0) * NSUB;
+    if (npass > 0) fetch(0);
+    for (int p = 0; p < npass; ++p) {
+        __syncthreads();                                       // the previous pass' rows / weights have been consumed
         {
-            constexpr int NQ = NPL / 4, PARTS = kBlk / SUB;
-            const int r = tid % SUB, part = tid / SUB, d = d0 + r;
-            const uint8_t pf = B.pt_flags[d];
-            const bool pvalid = (pf & PT_VALID) && (!margOnly || (pf & PT_MARG));
-            float4 vals[(NQ + PARTS - 1) / PARTS];
+            const bool pvalid = (rpf & PT_VALID) && (!margOnly || (rpf & PT_MARG));
 #pragma unroll
-            for (int qi = 0; qi < (NQ + PARTS - 1) / PARTS; ++qi) {
-                const int q = part + qi * PARTS, g = q >> 1;          // q-th float4 of the row, compact target slot g
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (q < NQ && g < W - 1) {
-                    const int t = g < h ? g : g + 1;
-                    const size_t si = (size_t)t * B.Ppad + d;
-                    const uint8_t rs = B.rs_state[si];
-                    const float4 jv = (q & 1) ? B.rs_jp1[si] : B.rs_jp0[si];      // unconditional: no dependent round trip
-                    if (pvalid && (rs & RS_ACTIVE)) val = jv;
-                } else if (q == 2 * (W - 1)) val = Hc[sub * SUB + r];
-                else if (q == 2 * (W - 1) + 1) val = make_float4(Bd[sub * SUB + r], 0.f, 0.f, 0.f);
-                vals[qi] = val;
-            }
-#pragma unroll
-            for (int qi = 0; qi < (NQ + PARTS - 1) / PARTS; ++qi) {
+            for (int qi = 0; qi < NV; ++qi) {
                 const int q = part + qi * PARTS;
-                if (q < NQ) *reinterpret_cast<float4*>(&A[r * NPLP + 4 * q]) = vals[qi];
+                float4 v = raw[qi];
+                if (q == qH + 1) { Wt[r] = pvalid ? v.z : 0.f; v = make_float4(v.w, 0.f, 0.f, 0.f); }      // pt_acc = {Hdd, bd, HdiF, bdSumF}
+                const bool keep = pvalid && (rst[qi] & RS_ACTIVE) != 0 && q <= qH + 1;
+                if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q < NQ) *reinterpret_cast<float4*>(&A[r * NPLP + 4 * q]) = v;
             }
         }
         __syncthreads();
-        if constexpr (MFMA) {
-            for (int k0 = 0; k0 < SUB; k0 += RUN) {
-#pragma unroll
-                for (int st4 = 0; st4 < RUN / 4; ++st4) {
-                    const int prow = k0 + 4 * st4 + (lane >> 4);       // the 4 points of this MFMA step: k = lane >> 4
-                    const float wk = Wt[sub * SUB + prow];
-                    const float* rowp = A + prow * NPLP + (lane & 15);
-#pragma unroll
-                    for (int m = 0; m < MAXM; ++m) {
-                        const float a = rowp[16 * mti[m]], bq = wk * rowp[16 * mtj[m]];
-                        macc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, macc[m], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < MAXM; ++m) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) macc64[m][r] += (double)macc[m][r];
-                    macc[m] = (sc_f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        } else {
-        for (int k0 = 0; k0 < SUB; k0 += RUN) {
-#pragma unroll
-            for (int k = k0; k < k0 + RUN; ++k) {
-                const float wk = Wt[sub * SUB + k];
-                float ai[T], aj[T];
-#pragma unroll
-                for (int i = 0; i < T; ++i) { ai[i] = wk * A[k * NPLP + ty * T + i]; aj[i] = A[k * NPLP + tx * T + i]; }
-#pragma unroll
-                for (int i = 0; i < T; ++i)
-#pragma unroll
-                    for (int j = 0; j < T; ++j) acc[i][j] += ai[i] * aj[j];
-            }
-#pragma unroll
-            for (int i = 0; i < T; ++i)
-#pragma unroll
-                for (int j = 0; j < T; ++j) { acc64[i][j] += (double)acc[i][j]; acc[i][j] = 0.f; }
-        }
+        if (p + 1 < npass) fetch(p + 1);                       // in flight during the SYRK below
+        switch (wave) {
+            case 0: sc_mfma_pass<T, 0, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 1: sc_mfma_pass<T, 1, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 2: sc_mfma_pass<T, 2, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            default: sc_mfma_pass<T, 3, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
         }
     }
-    }                                                          // blocks of this group
-    double* out = B.sc_partial + (size_t)blockIdx.x * NPL * NPL;
-    if constexpr (MFMA) {
-        // C/D layout of the 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg; the mirror tile is written too (the reduce kernel reads full matrices)
+    // C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
+    double* out = B.sc_partial + (size_t)blockIdx.x * (NTILES * 256);
 #pragma unroll
-        for (int m = 0; m < MAXM; ++m) {
-            if (wave + 4 * m >= NTILES) continue;
+    for (int m = 0; m < MAXM; ++m) {
+        const int idx = wave + 4 * m;
+        if (idx >= NTILES) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * mti[m] + (lane >> 4) * 4 + r, col = 16 * mtj[m] + (lane & 15);
-                out[row * NPL + col] = macc64[m][r];
-                if (mti[m] != mtj[m]) out[col * NPL + row] = macc64[m][r];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < T; ++i)
-#pragma unroll
-            for (int j = 0; j < T; ++j) out[(ty * T + i) * NPL + tx * T + j] = acc64[i][j];
+        for (int rr = 0; rr < 4; ++rr) out[idx * 256 + rr * 64 + lane] = macc64[m][rr];
     }
 }
 
-template <int KS, bool MFMA>
-static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
+template <int KS>
+static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int margOnly) {
     const int grid = B.sc_groups * KS;
     switch (T) {
-        case 1: ba_sc_kernel<1, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 2: ba_sc_kernel<2, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 3: ba_sc_kernel<3, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 4: ba_sc_kernel<4, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 5: ba_sc_kernel<5, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 6: ba_sc_kernel<6, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        case 7: ba_sc_kernel<7, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
-        default: ba_sc_kernel<8, KS, MFMA><<<grid, 256, 0, s>>>(B, shift, priorScaleMarg, margOnly); break;
+        case 1: ba_sc_kernel<1, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
+        case 2: ba_sc_kernel<2, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
+        case 3: ba_sc_kernel<3, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
+        case 4: ba_sc_kernel<4, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
+        case 5: ba_sc_kernel<5, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
+        case 6: ba_sc_kernel<6, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
+        case 7: ba_sc_kernel<7, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
+        default: ba_sc_kernel<8, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
     }
 }
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
-    static const bool valu = std::getenv("NALO_SC_VALU") != nullptr;       // the vector-ALU SYRK (first version), for comparison
-    if (valu) {
-        if (B.sc_split == 4) launch_sc_ks<4, false>(s, B, T, shift, priorScaleMarg, margOnly);
-        else launch_sc_ks<1, false>(s, B, T, shift, priorScaleMarg, margOnly);
-    } else {
-        if (B.sc_split == 4) launch_sc_ks<4, true>(s, B, T, shift, priorScaleMarg, margOnly);
-        else launch_sc_ks<1, true>(s, B, T, shift, priorScaleMarg, margOnly);
-    }
+    ba_pt_acc_kernel<<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
+    if (B.sc_split == 4) launch_sc_ks<4>(s, B, T, margOnly);
+    else launch_sc_ks<1>(s, B, T, margOnly);
 }
 void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
     const size_t n = (size_t)B.W * B.Ppad;
@@ -255,12 +243,12 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 }
 
 // ------------------------------------------------------------------------------------------------ fp64 finish of the partials
-// ONE launch for both systems (blocks [0, W*W) = top bins, the rest = SC tiles of 64 entries per host):
+// ONE launch for both systems (blocks [0, W*W) = top bins, the rest = 64 entries of one upper SC tile of one host):
 //   acc13[(h + t*W)][169] (full symmetric 13x13, AccumulatorApprox::finish layout MatrixAccumulators.h:626-647), misc[h+t*W] = {count, energy}
-//   G[h][e] = sum over the host's blocks of the weighted SYRK partials
-// Lane groups stride over the host's blocks and are combined in a fixed order: deterministic.
+//   G[h][row][col] = G[h][col][row] = sum over the host's workgroups of the compact SYRK partials (MFMA register order, see ba_sc_kernel)
+// Lane groups stride over the host's blocks (8 loads in flight per lane) and are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
-                                                         const int* __restrict__ host_blk /* [W+1] */, const int* __restrict__ sc_grp /* [W+1] */, int W, int NPL2, int sc_tiles, int mask, int KS,
+                                                         const int* __restrict__ host_blk /* [W+1] */, const int* __restrict__ sc_grp /* [W+1] */, int W, int NPL, int sc_tiles, int mask, int KS,
                                                          double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G,
                                                          const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out, const int* __restrict__ stop) {
     __shared__ double part[16][64];
@@ -271,7 +259,17 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
         double (*part8)[128] = reinterpret_cast<double (*)[128]>(&part[0][0]);
         const int h = blockIdx.x % W, t = blockIdx.x / W, j = threadIdx.x & 127, g = threadIdx.x >> 7;     // 8 groups stride over the blocks
         double s = 0;
-        if (j < kTopVals && h != t) for (int b = host_blk[h] + g; b < host_blk[h + 1]; b += 8) s += top_partial[((size_t)b * W + t) * kTopStride + j];
+        if (j < kTopVals && h != t) {
+            const int bend = host_blk[h + 1];
+            int b = host_blk[h] + g;
+            double u[8];
+            for (; b + 56 < bend; b += 64) {                    // 8 independent loads per round: the host's blocks are a long latency-bound walk
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u[k] = top_partial[((size_t)(b + 8 * k) * W + t) * kTopStride + j];
+                s += ((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]));
+            }
+            for (; b < bend; b += 8) s += top_partial[((size_t)b * W + t) * kTopStride + j];
+        }
         part8[g][j] = s;
         __syncthreads();
         if (g == 0) { double tt = 0; for (int k = 0; k < 8; ++k) tt += part8[k][j]; sums[j] = tt; }
@@ -290,27 +288,44 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
         return;
     }
     if ((int)blockIdx.x == W * W + W * sc_tiles) {             // the deferred sums of doStepFromBackup's break test ride along (optimize())
+        // all 1024 lanes stride over the blocks (a 1M-point window has 3907: 16 lanes walking them was an 85 us serial chain), fixed-order tree
         const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
-        double s = 0;
-        if (j < 3) for (int b = g; b < step_blocks; b += 16) s += (double)step_partial[(size_t)b * 4 + j];
-        part[g][j] = s;
+        double s0 = 0, s1 = 0, s2 = 0;
+        for (int b = threadIdx.x; b < step_blocks; b += 1024) {
+            const float4 v = reinterpret_cast<const float4*>(step_partial)[b];
+            s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
+        if (j == 0) { part[g][0] = s0; part[g][1] = s1; part[g][2] = s2; }
         __syncthreads();
-        if (g == 0 && j < 3) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; step_out[j] = t; }
+        if (threadIdx.x < 3) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x]; step_out[threadIdx.x] = t; }
         return;
     }
     if (!(mask & 2)) return;
-    const int q = blockIdx.x - W * W, h = q / sc_tiles, tile = q - h * sc_tiles;
-    const int j = threadIdx.x & 63, g = threadIdx.x >> 6, e = tile * 64 + j;
+    const int q = blockIdx.x - W * W, h = q / sc_tiles, tile = q - h * sc_tiles;      // tile = 4 * (upper tile index) + MFMA register
+    const int j = threadIdx.x & 63, g = threadIdx.x >> 6, e = tile * 64 + j, psz = sc_tiles * 64;
     double s = 0;
-    if (e < NPL2) for (int b = sc_grp[h] * KS + g; b < sc_grp[h + 1] * KS; b += 16) s += sc_partial[(size_t)b * NPL2 + e];
+    for (int b = sc_grp[h] * KS + g; b < sc_grp[h + 1] * KS; b += 16) s += sc_partial[(size_t)b * psz + e];
     part[g][j] = s;
     __syncthreads();
-    if (g == 0 && e < NPL2) { double tt = 0; for (int k = 0; k < 16; ++k) tt += part[k][j]; G[(size_t)h * NPL2 + e] = tt; }
+    if (g == 0) {
+        double tt = 0;
+        for (int k = 0; k < 16; ++k) tt += part[k][j];
+        const int T = NPL >> 4, rr = tile & 3;
+        int ti = 0, tj = tile >> 2;
+        while (tj >= T - ti) { tj -= T - ti; ++ti; }
+        tj += ti;
+        const int row = 16 * ti + (j >> 4) * 4 + rr, col = 16 * tj + (j & 15);
+        double* Gh = G + (size_t)h * NPL * NPL;
+        Gh[row * NPL + col] = tt;
+        if (ti != tj) Gh[col * NPL + row] = tt;
+    }
 }
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
                       const float* step_partial, int step_blocks, double* step_out) {
-    const int tiles = (NPL * NPL + 63) / 64;
-    ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.sc_grp, B.W, NPL * NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
+    const int T = NPL / 16, tiles = T * (T + 1) / 2 * 4;
+    ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.sc_grp, B.W, NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
                                                                                        B.sc_split, acc13, misc, G, step_partial, step_blocks, step_out, B.stop);
 }
 
@@ -618,13 +633,14 @@ __global__ __launch_bounds__(256) void ba_step_kernel(BADev B, float stepfacD, f
 }
 // out[j] = sum_b partial[b*stride + j] in fp64: 16 groups of 64 lanes stride over the blocks, then a fixed-order LDS combine
 __global__ __launch_bounds__(1024) void ba_sum_partials_kernel(const float* __restrict__ partial, int nblocks, int stride, int nvals, double* __restrict__ out) {
-    __shared__ double part[16][64];
-    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ double part[1024];
+    const int L = nvals <= 4 ? 4 : 64, NG = 1024 / L;          // few values: 256 lane groups walk the blocks (a 1M-point window has 3907 of them)
+    const int j = threadIdx.x % L, g = threadIdx.x / L;
     double s = 0;
-    if (j < nvals) for (int b = g; b < nblocks; b += 16) s += (double)partial[(size_t)b * stride + j];
-    part[g][j] = s;
+    if (j < nvals) for (int b = g; b < nblocks; b += NG) s += (double)partial[(size_t)b * stride + j];
+    part[g * L + j] = s;
     __syncthreads();
-    if (g == 0 && j < nvals) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; out[j] = t; }
+    if (g == 0 && j < nvals) { double t = 0; for (int k = 0; k < NG; ++k) t += part[k * L + j]; out[j] = t; }
 }
 // copies the stitched systems into host-mapped pinned memory and publishes a sequence number the host polls on (the path after a cross-rank
 // all-reduce; a single GPU publishes from the stitch kernel). Several workgroups copy slices; the last one to take a ticket sets the flag.
