@@ -223,9 +223,28 @@ int nalo_dense_make_map(nalo_ctx* ctx, int slot, const float plane[4], float mas
  * (FullSystem.cpp:797-798). Uses the ACTIVE POINTS of the window set by nalo_ba_set_points (already on the device); frame = window index of the newest frame
  * (its own points are skipped); KRKi[W][9] = K[1] R Ki[0] and Kt[W][3] = K[1] t per host (floats, as :1424-1425). out = fwdWarpedIDDistFinal [w1*h1]
  * (level-1 size), 1000 = farther than 39. addIntoDistFinal (:1556-1561, one seed per newly activated point, sequential) stays on the caller's copy. */
-/* PixelSelector::makeHists (FullSystem/PixelSelector2.cpp:78-142): block thresholds of the frame in `slot`; ths and thsSmoothed are [(w/32)*(h/32)].
- * PixelSelector::select stays on the host: it indexes randomPattern with the running count of selected points (a raster-order dependency). */
+/* ---- PixelSelector (FullSystem/PixelSelector2.cpp), SURVEY 8(f) rank 3. The selector's state (randomPattern, the block thresholds of
+ * gradHistFrame, the last status map) lives in the context, as it lives in the PixelSelector object.
+ *  nalo_pixsel_set_random       the constructor's randomPattern[w*h] (:40-45: srand(3141592); rand() & 0xFF) and, for FusedWithMask, the first w*h
+ *                               rand() values after srand(3141592) (:496-501; NULL if makeMaps_lidar is not used). Both are libc streams, so the
+ *                               caller draws them and the selection stays identical to the reference built on the same libc.
+ *  nalo_pixsel_make_hists       makeHists (:78-142): block thresholds of the frame in `slot`; ths / thsSmoothed [(w/32)*(h/32)] may be NULL.
+ *  nalo_pixsel_select           select (:564-711) with potential `pot` on the frame make_hists ran on: n = {n2, n3, n4} (its return value),
+ *                               map_out[w*h] (may be NULL) = 0 / 1 / 2 / 4 per pixel like PixelSelectorStatus.
+ *  nalo_pixsel_make_maps        makeMaps (:144-291): makeHists if the frame changed, select, up to recursionsLeft re-selections with the adapted
+ *                               potential, the random sub-selection; *currentPotential is PixelSelector::currentPotential (in/out),
+ *                               *numHaveSub the return value. Call sites: CoarseInitializer.cpp:811, FullSystem.cpp:1663.
+ *  nalo_pixsel_make_maps_lidar  makeMaps_lidar (:293-428) = makeHists + select + FusedWithMask (:431-560) with the mask the frame was uploaded
+ *                               with; *numHave the return value. Call site FullSystem.cpp:1668. (The reference reads mhist[256], one past its
+ *                               array, in the last quantile iteration: taken as 0 here.)
+ *  nalo_pixsel_get_selected     the non-zero pixels of the last map in raster order (idx = x + y*w, status), i.e. what makeNewTraces' loop over
+ *                               the map visits (FullSystem.cpp:1672-1690): *n = their number, the first min(cap, *n) are written. */
+int nalo_pixsel_set_random(nalo_ctx* ctx, const uint8_t* randomPattern, const int* mask_draws);
 int nalo_pixsel_make_hists(nalo_ctx* ctx, int slot, float* ths, float* thsSmoothed);
+int nalo_pixsel_select(nalo_ctx* ctx, int slot, int pot, float thFactor, float* map_out, int n[3]);
+int nalo_pixsel_make_maps(nalo_ctx* ctx, int slot, float density, int recursionsLeft, float thFactor, int* currentPotential, float* map_out, int* numHaveSub);
+int nalo_pixsel_make_maps_lidar(nalo_ctx* ctx, int slot, float thFactor, int currentPotential, float* map_out, int* numHave);
+int nalo_pixsel_get_selected(nalo_ctx* ctx, int cap, int* idx, uint8_t* status, int* n);
 int nalo_dist_make_map(nalo_ctx* ctx, int frame, const float* KRKi, const float* Kt, float* out);
 int nalo_imm_create(nalo_ctx* ctx, int slot_host, int n, const int* u, const int* v, float* color, float* weights, float* gradH, float* energyTH);
 int nalo_imm_trace(nalo_ctx* ctx, int slot_new, int n, const float* u, const float* v, const float* color, const float* weights, const float* gradH,
@@ -257,7 +276,7 @@ int nalo_init_do_step(nalo_ctx* ctx, int n, const uint8_t* isGood, const float* 
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling: per-kernel HIP-event timing on the ctx stream. Names: "trk_eval", "ba_linearize",
- * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize". Enable, run, then query (sync inside).
+ * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize", "pixsel". Enable, run, then query (sync inside).
  * ------------------------------------------------------------------------------------------------ */
 int nalo_profile_enable(nalo_ctx* ctx, int on);
 int nalo_profile_reset(nalo_ctx* ctx);

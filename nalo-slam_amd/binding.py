@@ -33,6 +33,7 @@ EXPORTS = [
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
+    "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
 ]
 
@@ -95,6 +96,11 @@ def load():
                                             c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.nalo_init_do_step.argtypes = [vp, C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
     L.nalo_pixsel_make_hists.argtypes = [vp, C.c_int, c_fp, c_fp]
+    L.nalo_pixsel_set_random.argtypes = [vp, c_u8p, c_ip]
+    L.nalo_pixsel_select.argtypes = [vp, C.c_int, C.c_int, C.c_float, c_fp, c_ip]
+    L.nalo_pixsel_make_maps.argtypes = [vp, C.c_int, C.c_float, C.c_int, C.c_float, c_ip, c_fp, c_ip]
+    L.nalo_pixsel_make_maps_lidar.argtypes = [vp, C.c_int, C.c_float, C.c_int, c_fp, c_ip]
+    L.nalo_pixsel_get_selected.argtypes = [vp, C.c_int, c_ip, c_u8p, c_ip]
     L.nalo_dist_make_map.argtypes = [vp, C.c_int, c_fp, c_fp, c_fp]
     L.nalo_imm_create.argtypes = [vp, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.nalo_imm_trace.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
@@ -360,6 +366,35 @@ class Context:
         ths, sm = np.zeros(nb, np.float32), np.zeros(nb, np.float32)
         self._ck(self.L.nalo_pixsel_make_hists(self.h_, slot, _f(ths), _f(sm)))
         return ths, sm
+
+    def pixsel_set_random(self, randomPattern, mask_draws=None):
+        rp = np.ascontiguousarray(randomPattern, np.uint8)
+        assert rp.size == self.w * self.h
+        dr = None if mask_draws is None else np.ascontiguousarray(mask_draws, np.int32)
+        self._ck(self.L.nalo_pixsel_set_random(self.h_, _u8(rp), None if dr is None else _i(dr)))
+
+    def pixsel_select(self, slot, pot, thFactor=1.0):
+        m, n = np.zeros((self.h, self.w), np.float32), np.zeros(3, np.int32)
+        self._ck(self.L.nalo_pixsel_select(self.h_, slot, pot, float(thFactor), _f(m), _i(n)))
+        return m, n
+
+    def pixsel_make_maps(self, slot, density, potential, recursionsLeft=1, thFactor=1.0):
+        """-> (map [h,w], numHaveSub, new currentPotential)"""
+        m, pot, num = np.zeros((self.h, self.w), np.float32), np.array([potential], np.int32), np.zeros(1, np.int32)
+        self._ck(self.L.nalo_pixsel_make_maps(self.h_, slot, float(density), recursionsLeft, float(thFactor), _i(pot), _f(m), _i(num)))
+        return m, int(num[0]), int(pot[0])
+
+    def pixsel_make_maps_lidar(self, slot, potential, thFactor=1.0):
+        m, num = np.zeros((self.h, self.w), np.float32), np.zeros(1, np.int32)
+        self._ck(self.L.nalo_pixsel_make_maps_lidar(self.h_, slot, float(thFactor), potential, _f(m), _i(num)))
+        return m, int(num[0])
+
+    def pixsel_get_selected(self):
+        n = np.zeros(1, np.int32)
+        self._ck(self.L.nalo_pixsel_get_selected(self.h_, 0, None, None, _i(n)))
+        idx, st = np.zeros(max(int(n[0]), 1), np.int32), np.zeros(max(int(n[0]), 1), np.uint8)
+        self._ck(self.L.nalo_pixsel_get_selected(self.h_, int(n[0]), _i(idx), _u8(st), _i(n)))
+        return idx[:n[0]], st[:n[0]]
 
     def dist_make_map(self, frame, KRKi, Kt):
         out = np.zeros((self.h >> 1, self.w >> 1), np.float32)

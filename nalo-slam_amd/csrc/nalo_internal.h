@@ -51,6 +51,7 @@ struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, h
 
 // precalc record per (host,target), 32 floats: KRKi(9) Kt(3) R0(9) t0(3) aff(2) b0 thmax dp(8)... see kernels_ba.hip
 struct BAWindow;
+struct PixSel;
 
 }  // namespace nalo
 
@@ -82,6 +83,7 @@ struct nalo_ctx {
 
     // ---- BA (opaque; defined in host_ba.cpp)
     nalo::BAWindow* ba = nullptr;
+    nalo::PixSel* pixsel = nullptr;          // pixel selector state (kernels_pixsel.hip)
 
     // ---- host wall-clock accounting (NALO_HOST_TIMING=1 prints it at nalo_destroy)
     std::map<std::string, std::pair<double, long>> host_t;
@@ -139,6 +141,9 @@ int imm_optimize_launch(nalo_ctx* c, const float4* const* dI, int W, const float
                         int minObs, int* result, float* idepth_out, uint8_t* res_in);
 int dist_make_launch(nalo_ctx* c, const float4* pt_geo, const uint8_t* pt_flags, const int* blk_host, int Ppad, int frame, const float* KRKi, const float* Kt, uint8_t* seed, float* out);
 int pixsel_hists_launch(nalo_ctx* c, const float* absg0, float* ths, float* thsSmoothed);
+// kernels_pixsel.hip
+void pixsel_destroy(nalo_ctx* c);
+void pixsel_invalidate_hists(nalo_ctx* c, int slot);
 // staging for the immature-point entry points: pinned host block + device block of `floats` 4-byte words (grown on demand)
 int imm_stage(nalo_ctx* c, size_t words);
 // kernels_init.hip

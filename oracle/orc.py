@@ -177,6 +177,57 @@ def pixsel_make_hists(absg0, w, h, kind="f32"):
     return ths, sm
 
 
+def pixsel_libc_tables(n, kind="f32"):
+    """randomPattern[n] (PixelSelector ctor) and the first n rand() draws after srand(3141592) (FusedWithMask), from this machine's libc"""
+    rp, dr = np.zeros(n, np.uint8), np.zeros(n, np.int32)
+    lib(kind).orc_pixsel_libc_tables(n, rp.ctypes.data_as(C.POINTER(C.c_ubyte)), ip(dr))
+    return rp, dr
+
+
+def _pixsel_imgs(dI, ag0, ag1, ag2):
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    return f(dI), f(ag0), f(ag1), f(ag2)
+
+
+def pixsel_select(dI, ag0, ag1, ag2, w, h, thsSmoothed, randomPattern, pot, thFactor=1.0, kind="f32"):
+    dI, ag0, ag1, ag2 = _pixsel_imgs(dI, ag0, ag1, ag2)
+    m, n = np.zeros((h, w), np.float32), np.zeros(3, np.int32)
+    rp = np.ascontiguousarray(randomPattern, np.uint8)
+    sm = np.zeros((w // 32) * (h // 32) + 100, np.float32)      # the reference's allocation; the tail it never fills is defined as 0 (orc_pixsel.c)
+    sm[:len(thsSmoothed)] = thsSmoothed
+    lib(kind).orc_pixsel_select(fp(dI), fp(ag0), fp(ag1), fp(ag2), w, h, fp(sm), rp.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                pot, C.c_float(thFactor), fp(m), ip(n))
+    return m, n
+
+
+def pixsel_make_maps(dI, ag0, ag1, ag2, w, h, randomPattern, density, potential, recursionsLeft=1, thFactor=1.0, kind="f32"):
+    dI, ag0, ag1, ag2 = _pixsel_imgs(dI, ag0, ag1, ag2)
+    m, pot = np.zeros((h, w), np.float32), np.array([potential], np.int32)
+    rp = np.ascontiguousarray(randomPattern, np.uint8)
+    L = lib(kind)
+    L.orc_pixsel_make_maps.restype = C.c_int
+    num = L.orc_pixsel_make_maps(fp(dI), fp(ag0), fp(ag1), fp(ag2), w, h, rp.ctypes.data_as(C.POINTER(C.c_ubyte)), C.c_float(density), recursionsLeft, C.c_float(thFactor), ip(pot), fp(m))
+    return m, int(num), int(pot[0])
+
+
+def pixsel_fuse_mask(mask, draws, m, kind="f32"):
+    m = np.ascontiguousarray(m, np.float32).copy()
+    n, qm = np.zeros(3, np.int32), np.zeros(2, np.int32)
+    lib(kind).orc_pixsel_fuse_mask(fp(np.ascontiguousarray(mask, np.float32)), ip(np.ascontiguousarray(draws, np.int32)), m.size, fp(m), ip(n), ip(qm))
+    return m, n, qm
+
+
+def pixsel_make_maps_lidar(dI, ag0, ag1, ag2, w, h, randomPattern, mask, draws, potential, thFactor=1.0, kind="f32"):
+    dI, ag0, ag1, ag2 = _pixsel_imgs(dI, ag0, ag1, ag2)
+    m = np.zeros((h, w), np.float32)
+    rp = np.ascontiguousarray(randomPattern, np.uint8)
+    L = lib(kind)
+    L.orc_pixsel_make_maps_lidar.restype = C.c_int
+    num = L.orc_pixsel_make_maps_lidar(fp(dI), fp(ag0), fp(ag1), fp(ag2), w, h, rp.ctypes.data_as(C.POINTER(C.c_ubyte)), fp(np.ascontiguousarray(mask, np.float32)),
+                                       ip(np.ascontiguousarray(draws, np.int32)), C.c_float(thFactor), potential, fp(m))
+    return m, int(num)
+
+
 def dist_make_map(w1, h1, frame, host, u, v, idepth, KRKi, Kt, kind="f32"):
     """CoarseDistanceMap::makeDistanceMap -> [h1, w1] float map (1000 = farther than 39)"""
     f = lambda a: np.ascontiguousarray(a, np.float32)

@@ -391,3 +391,80 @@ def test_distance_map_matches_dilation_formulation():
             grow |= np.roll(np.roll(src, dy, 0), dx, 1)          # `inner` keeps the wrap-around of roll out of play
         ref[grow & (ref > k)] = k
     assert np.array_equal(got, ref)
+
+
+def test_pixel_selector_matches_closed_form_and_bookkeeping():
+    """SURVEY 8(f) rank 3: PixelSelector::select restated WITHOUT the reference's -2 flags (independent formulation, the one the HIP kernels use): every
+    pixel is a candidate of all three levels; a 2pot block keeps its level-2 pixel iff none of its cells selected, a 4pot block its level-3 pixel iff nothing
+    below selected; maxima are first-in-scan-order. Plus the bookkeeping of makeMaps (sub-selection) and FusedWithMask (counts = final statuses)."""
+    w, h, pot, thf = 160, 128, 3, np.float32(1.0)
+    win = synth.make_window(w=w, h=h, W=2, P=20, seed=4, n_extra=0)
+    img = win.images[1].copy()
+    xs = np.arange(40, 100)
+    img[30:80, xs] = (100 + 60 * ((xs // 3) % 2)).astype(np.float32)[None, :]           # dy == 0 exactly: cells whose direction is (0,1) select nothing
+    dI, ab = orc.make_images(img, 3)
+    o1, o2 = w * h, w * h + (w // 2) * (h // 2)
+    imgs = (dI[:o1], ab[:o1], ab[o1:o2], ab[o2:])
+    rp, draws = orc.pixsel_libc_tables(w * h)
+    _, sm = orc.pixsel_make_hists(imgs[1], w, h)
+    got, n = orc.pixsel_select(*imgs, w, h, sm, rp, pot, float(thf))
+    smp = np.zeros(len(sm) + 100, np.float32); smp[:len(sm)] = sm
+    dirs = np.array([[0, 1.0], [0.3827, 0.9239], [0.1951, 0.9808], [0.9239, 0.3827], [0.7071, 0.7071], [0.3827, -0.9239], [0.8315, 0.5556], [0.8315, -0.5556],
+                     [0.5556, -0.8315], [0.9808, 0.1951], [0.9239, -0.3827], [0.7071, -0.7071], [0.5556, 0.8315], [0.9808, -0.1951], [1.0, 0.0], [0.1951, -0.9808]], np.float32)
+    f32 = np.float32
+    ref = np.zeros((h, w), np.float32)
+    n2 = n3 = n4 = 0
+    dw1 = f32(0.75); dw2 = dw1 * dw1
+    ag0, ag1, ag2 = imgs[1], imgs[2], imgs[3]
+    for y4 in range(0, h, 4 * pot):
+        for x4 in range(0, w, 4 * pot):
+            d4 = dirs[rp[n2] & 15]; c4 = (f32(0), -1); any_below = False
+            for y3 in range(y4, min(y4 + 4 * pot, h), 2 * pot):
+                for x3 in range(x4, min(x4 + 4 * pot, w), 2 * pot):
+                    d3 = dirs[rp[n2] & 15]; c3 = (f32(0), -1); any2 = False
+                    for y2 in range(y3, min(y3 + 2 * pot, h), pot):
+                        for x2 in range(x3, min(x3 + 2 * pot, w), pot):
+                            d2 = dirs[rp[n2] & 15]; c2 = (f32(0), -1)
+                            for yf in range(y2, min(y2 + pot, h)):
+                                for xf in range(x2, min(x2 + pot, w)):
+                                    if xf < 4 or xf >= w - 5 or yf < 4 or yf > h - 4:
+                                        continue
+                                    idx = xf + w * yf
+                                    th0 = smp[(xf >> 5) + (yf >> 5) * (w // 32)]; th1 = th0 * dw1; th2 = th1 * dw2
+                                    gx, gy = dI[idx, 1], dI[idx, 2]
+                                    if ag0[idx] > th0 * thf:
+                                        dn = abs(f32(gx * d2[0]) + f32(gy * d2[1]))
+                                        if dn > c2[0]: c2 = (dn, idx)
+                                    if ag1[int(f32(xf) * f32(0.5) + f32(0.25)) + int(f32(yf) * f32(0.5) + f32(0.25)) * (w // 2)] > th1 * thf:
+                                        dn = abs(f32(gx * d3[0]) + f32(gy * d3[1]))
+                                        if dn > c3[0]: c3 = (dn, idx)
+                                    if ag2[int(float(f32(xf) * f32(0.25)) + 0.125) + int(float(f32(yf) * f32(0.25)) + 0.125) * (w // 4)] > th2 * thf:
+                                        dn = abs(f32(gx * d4[0]) + f32(gy * d4[1]))
+                                        if dn > c4[0]: c4 = (dn, idx)
+                            if c2[1] > 0:
+                                ref.flat[c2[1]] = 1; n2 += 1; any2 = True
+                    if not any2 and c3[1] > 0:
+                        ref.flat[c3[1]] = 2; n3 += 1; any_below = True
+                    any_below |= any2
+            if not any_below and c4[1] > 0:
+                ref.flat[c4[1]] = 4; n4 += 1
+    assert np.array_equal(got, ref) and list(n) == [n2, n3, n4] and n2 > 300 and n3 > 0
+    # the stripes really make "above threshold but nothing selected" cells (what forces the GPU's count -> scan -> select scheme to iterate)
+    th = np.repeat(np.repeat(sm.reshape(h // 32, w // 32), 32, 0), 32, 1)
+    a0 = ag0.reshape(h, w)
+    assert sum((a0[y:y + 3, x:x + 3] > th[y:y + 3, x:x + 3]).any() and not (got[y:y + 3, x:x + 3] == 1).any() for y in range(36, 75, 3) for x in range(48, 93, 3)) > 0
+    # makeMaps: sub-selection drops the rank-th selected pixel when randomPattern[rank] > 255 * quotia
+    m, num, newpot = orc.pixsel_make_maps(*imgs, w, h, rp, 200.0, 3, 0, 1.0)
+    tot = int(n.sum()); q = np.float32(200.0) / np.float32(tot)
+    nz = np.flatnonzero(got)
+    keep = rp[:len(nz)] <= np.uint8(int(np.float32(255) * q))
+    assert num == keep.sum() and np.array_equal(np.flatnonzero(m), nz[keep]) and newpot == max(int(np.sqrt(np.float32(tot * 16) / np.float32(200.0)) - 1), 1)
+    # FusedWithMask
+    mask = np.zeros((h, w), np.float32); mask[h // 3:, w // 5:] = np.random.RandomState(5).randint(0, 200, size=(h - h // 3, w - w // 5))
+    fm, fn, qm = orc.pixsel_fuse_mask(mask, draws, got)
+    assert fn[0] == (fm == 1).sum() and fn[1] == (fm == 2).sum() and fn[2] == 0
+    vals = np.sort(mask[mask != 0].astype(int))
+    assert abs(qm[0] - vals[len(vals) // 2]) <= 1 and qm[1] == vals.max()
+    rs = (draws % 1000).astype(np.float32).reshape(h, w) / np.float32(1000.0)
+    assert np.array_equal(fm == 1, ((got == 1) & ~((rs > 0.5) & (mask < qm[0] // 3))) | ((got == 2) & (rs.astype(np.float64) < 0.6) & (mask > qm[0] + (qm[1] - qm[0]) // 2))
+                          | ((got != 1) & (got != 2) & (rs.astype(np.float64) < 0.01) & (mask > qm[0])))
