@@ -307,6 +307,11 @@ def main():
                 except Exception as e:
                     out["immature"] = {"error": repr(e)}
                 log("immature leg done")
+                try:
+                    out["pixel_selector"] = pixsel_leg(cpu=not args.no_cpu_baseline)
+                except Exception as e:
+                    out["pixel_selector"] = {"error": repr(e)}
+                log("pixel selector leg done")
                 # The KITTI-sized launch moves 6 MB (0.8 us at 8 TB/s): it is launch-latency bound by construction. The kernel's
                 # roofline position is therefore reported on the largest single-GPU window of this same run (configs[3]);
                 # the figure of the headline workload stays next to it.
@@ -498,6 +503,46 @@ def imm_leg(per_host=1500, rounds=5, cpu=True):
         orc.imm_trace(dI[W], win.w, win.h, uf, vf, color, weights, gradH, eth, host, KRKi, Kt, aff, *st0, kind="fast")
         res["trace_cpu_port_us"] = round((time.perf_counter() - t0) * 1e6, 1)
         res["trace_cpu_cores"] = 1
+    return res
+
+
+def pixsel_leg(rounds=10, cpu=True):
+    """SURVEY 8(f) rank 3: PixelSelector::makeMaps (makeHists + select + sub-selection, the per-keyframe candidate selection of makeNewTraces) on a
+    KITTI-sized frame, setting_desiredImmatureDensity = 1500. Call time = everything between the C-ABI call and the filled w*h float map on the host
+    (what the reference's caller gets); kernel time from HIP events. The CPU figure is the oracle's fast build on one thread."""
+    cfg = WORKLOADS["kitti00_8kf"]
+    win = synth.make_window(w=cfg["w"], h=cfg["h"], W=2, P=64, seed=9, n_extra=0)
+    import orc
+    w, h = win.w, win.h
+    rp, draws = orc.pixsel_libc_tables(w * h)
+    c = binding.Context(w, h, win.K, n_slots=1)
+    c.frame_upload(0, win.images[1])
+    c.pixsel_set_random(rp, draws)
+    m, num, pot = c.pixsel_make_maps(0, 1500.0, 3)               # warm-up; also adapts the potential like the running system
+    c.profile_enable(True); c.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        c.frame_rebuild(0)                                       # a new frame: the block thresholds are recomputed, as per keyframe
+        m, num, pot2 = c.pixsel_make_maps(0, 1500.0, pot)
+    t_call = (time.perf_counter() - t0) / rounds
+    ms, nl = c.profile_get("pixsel")
+    c.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        c.frame_rebuild(0)
+    t_rebuild = (time.perf_counter() - t0) / rounds
+    c.close()
+    res = {"image": "%dx%d" % (w, h), "density": 1500, "potential": pot, "selected": num,
+           "make_maps_call_us": round((t_call - t_rebuild) * 1e6, 1), "make_maps_gpu_us": round(ms / max(nl, 1) * 1e3, 1)}
+    if cpu:
+        dI, ab = orc.make_images(win.images[1], 3, "fast")
+        o1, o2 = w * h, w * h + (w // 2) * (h // 2)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            mo, numo, _ = orc.pixsel_make_maps(dI[:o1], ab[:o1], ab[o1:o2], ab[o2:], w, h, rp, 1500.0, pot, 1, 1.0, kind="fast")
+        res["make_maps_cpu_port_us"] = round((time.perf_counter() - t0) / 3 * 1e6, 1)
+        res["cpu_cores"] = 1
+        res["same_selection_as_cpu_port"] = bool(numo == num and np.array_equal(mo, m))
     return res
 
 

@@ -45,60 +45,88 @@ struct PixSelArgs {
 
 // SELECT = false: has[slot] = the cell holds a pixel above its block threshold (the speculative "this cell selects").
 // SELECT = true : the selection proper, given pre[slot] = number of selecting cells before slot in scan order.
-template <bool SELECT>
+// L lanes share a cell (1 for pot <= 3, 4 up to 7, 16 above: a cell of potential 16 has 256 pixels): each walks a contiguous raster run of the cell's
+// pixels, "first strict maximum" is then combined in lane order, cells of a 2pot block and of a 4pot block likewise (4L and 16L consecutive lanes; with
+// L = 16 a 4pot block is the whole 256-thread workgroup and its four waves meet in LDS).
+template <int G>
+__device__ __forceinline__ void pixsel_first_max(float& v, int& k, int lane, int stride) {       // over the G lanes lane0, lane0 + stride, ... of this lane's group
+    const int lane0 = lane & ~(G * stride - 1);
+    float bv = 0.f; int bk = -1;
+#pragma unroll
+    for (int j = 0; j < G; ++j) { const float ov = __shfl(v, lane0 + j * stride); const int ok = __shfl(k, lane0 + j * stride); if (ov > bv) { bv = ov; bk = ok; } }
+    v = bv; k = bk;
+}
+template <bool SELECT, int L>
 __global__ __launch_bounds__(256) void pixsel_cells_kernel(PixSelArgs P, uint8_t* __restrict__ has, const int* __restrict__ pre, uint8_t* __restrict__ sel,
                                                            uint8_t* __restrict__ map, int* __restrict__ cnt) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, s = t / L, sub = t % L;
     const bool live = s < P.nslots;
     const int b4 = s >> 4, c = s & 15, b3 = c >> 2, c2 = c & 3, pot = P.pot, w = P.w, h = P.h;
     const int x0 = (b4 % P.nb4x) * 4 * pot + (b3 & 1) * 2 * pot + (c2 & 1) * pot, y0 = (b4 / P.nb4x) * 4 * pot + (b3 >> 1) * 2 * pot + (c2 >> 1) * pot;
     const bool cell = live && x0 < w && y0 < h;
-    const int mx = cell ? min(pot, w - x0) : 0, my = cell ? min(pot, h - y0) : 0;
+    const int mx = cell ? min(pot, w - x0) : 0, my = cell ? min(pot, h - y0) : 0, tot = mx * my, per = (tot + L - 1) / L;
+    const int p0 = min(sub * per, tot), p1 = min(p0 + per, tot);                         // this lane's raster run of the cell
     const int w1 = w / 2, w2 = w / 4, thsStep = w / 32;
     const float dw1 = 0.75f, dw2 = dw1 * dw1;                   // setting_gradDownweightPerLevel (settings.cpp:156)
+    constexpr unsigned long long kCellMask = L >= 64 ? ~0ull : ((1ull << L) - 1);
     if constexpr (!SELECT) {
         bool any = false;
-        for (int y1 = 0; y1 < my; ++y1) for (int x1 = 0; x1 < mx; ++x1) {
-            const int xf = x0 + x1, yf = y0 + y1;
+        for (int p = p0; p < p1; ++p) {
+            const int xf = x0 + p % mx, yf = y0 + p / mx;
             if (xf < 4 || xf >= w - 5 || yf < 4 || yf > h - 4) continue;
             any |= P.ag0[xf + w * yf] > P.thsSmoothed[(xf >> 5) + (yf >> 5) * thsStep] * P.thFactor;
         }
-        if (live) has[s] = any ? 1 : 0;
+        const unsigned long long m = __ballot(any);
+        if (live && sub == 0) has[s] = ((m >> (lane & ~(L - 1))) & kCellMask) ? 1 : 0;
         return;
     } else {
-        const int mypre = live ? pre[s] : 0;
-        const int pre3 = __shfl(mypre, lane & ~3), pre4 = __shfl(mypre, lane & ~15);       // n2 when the 2pot / 4pot block was entered
-        const int i2 = P.rp[mypre] & 15, i3 = P.rp[pre3] & 15, i4 = P.rp[pre4] & 15;
+        const int sl = live ? s : 0;
+        const int i2 = P.rp[pre[sl]] & 15, i3 = P.rp[pre[sl & ~3]] & 15, i4 = P.rp[pre[sl & ~15]] & 15;      // n2 when the cell / 2pot block / 4pot block was entered
         const float d2x = c_dirs[i2][0], d2y = c_dirs[i2][1], d3x = c_dirs[i3][0], d3y = c_dirs[i3][1], d4x = c_dirs[i4][0], d4y = c_dirs[i4][1];
         float v2 = 0.f, v3 = 0.f, v4 = 0.f;
         int k2 = -1, k3 = -1, k4 = -1;
-        for (int y1 = 0; y1 < my; ++y1) for (int x1 = 0; x1 < mx; ++x1) {
-            const int xf = x0 + x1, yf = y0 + y1, idx = xf + w * yf;
+        for (int p = p0; p < p1; ++p) {
+            const int xf = x0 + p % mx, yf = y0 + p / mx, idx = xf + w * yf;
             if (xf < 4 || xf >= w - 5 || yf < 4 || yf > h - 4) continue;
             const float th0 = P.thsSmoothed[(xf >> 5) + (yf >> 5) * thsStep], th1 = th0 * dw1, th2 = th1 * dw2;
-            const float4 t = P.dI[idx];
-            if (P.ag0[idx] > th0 * P.thFactor) { const float dn = fabsf(t.y * d2x + t.z * d2y); if (dn > v2) { v2 = dn; k2 = idx; } }
-            if (P.ag1[(int)(xf * 0.5f + 0.25f) + (int)(yf * 0.5f + 0.25f) * w1] > th1 * P.thFactor) { const float dn = fabsf(t.y * d3x + t.z * d3y); if (dn > v3) { v3 = dn; k3 = idx; } }
-            if (P.ag2[(int)(xf * 0.25f + 0.125) + (int)(yf * 0.25f + 0.125) * w2] > th2 * P.thFactor) { const float dn = fabsf(t.y * d4x + t.z * d4y); if (dn > v4) { v4 = dn; k4 = idx; } }
+            const float4 tx = P.dI[idx];
+            if (P.ag0[idx] > th0 * P.thFactor) { const float dn = fabsf(tx.y * d2x + tx.z * d2y); if (dn > v2) { v2 = dn; k2 = idx; } }
+            if (P.ag1[(int)(xf * 0.5f + 0.25f) + (int)(yf * 0.5f + 0.25f) * w1] > th1 * P.thFactor) { const float dn = fabsf(tx.y * d3x + tx.z * d3y); if (dn > v3) { v3 = dn; k3 = idx; } }
+            if (P.ag2[(int)(xf * 0.25f + 0.125) + (int)(yf * 0.25f + 0.125) * w2] > th2 * P.thFactor) { const float dn = fabsf(tx.y * d4x + tx.z * d4y); if (dn > v4) { v4 = dn; k4 = idx; } }
         }
-        const bool s2 = k2 > 0;
+        if constexpr (L > 1) { pixsel_first_max<L>(v2, k2, lane, 1); pixsel_first_max<L>(v3, k3, lane, 1); pixsel_first_max<L>(v4, k4, lane, 1); }     // the cell
+        const bool s2 = k2 > 0;                                 // identical on the L lanes of the cell
         const unsigned long long m2 = __ballot(s2);
-        // level 2 (map value 2): first strict maximum over the 2pot block's cells in lane order; alive iff none of its cells selected
-        float bv3 = 0.f; int bk3 = -1;
+        // level 2 (map value 2): first strict maximum over the 2pot block's cells in scan order; alive iff none of its cells selected
+        pixsel_first_max<4>(v3, k3, lane, L);
+        constexpr int G2 = 4 * L;                               // lanes of a 2pot block (<= 64)
+        constexpr unsigned long long kG2Mask = G2 >= 64 ? ~0ull : ((1ull << G2) - 1);
+        const bool s3 = ((m2 >> (lane & ~(G2 - 1))) & kG2Mask) == 0 && k3 > 0;
+        bool s4;
+        if constexpr (L <= 4) {                                 // the 4pot block sits inside the wave
+            constexpr int G4 = 16 * L;
+            constexpr unsigned long long kG4Mask = G4 >= 64 ? ~0ull : ((1ull << G4) - 1);
+            const unsigned long long m3 = __ballot(s3);
+            pixsel_first_max<16>(v4, k4, lane, L);
+            s4 = ((m2 >> (lane & ~(G4 - 1))) & kG4Mask) == 0 && ((m3 >> (lane & ~(G4 - 1))) & kG4Mask) == 0 && k4 > 0;
+        } else {                                                // L = 16: wave = 2pot block, workgroup = 4pot block
+            __shared__ float sv[4]; __shared__ int sk[4], sany[4];
+            pixsel_first_max<4>(v4, k4, lane, L);
+            if (lane == 0) { sv[threadIdx.x >> 6] = v4; sk[threadIdx.x >> 6] = k4; sany[threadIdx.x >> 6] = (m2 != 0) || s3; }
+            __syncthreads();
+            float bv = 0.f; int bk = -1; bool below = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float ov = __shfl(v3, (lane & ~3) + j); const int ok = __shfl(k3, (lane & ~3) + j); if (ov > bv3) { bv3 = ov; bk3 = ok; } }
-        const bool s3 = ((m2 >> (lane & ~3)) & 0xFull) == 0 && bk3 > 0;
-        const unsigned long long m3 = __ballot(s3);
-        float bv4 = 0.f; int bk4 = -1;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { const float ov = __shfl(v4, (lane & ~15) + j); const int ok = __shfl(k4, (lane & ~15) + j); if (ov > bv4) { bv4 = ov; bk4 = ok; } }
-        const bool s4 = ((m2 >> (lane & ~15)) & 0xFFFFull) == 0 && ((m3 >> (lane & ~15)) & 0xFFFFull) == 0 && bk4 > 0;
-        if (s2) map[k2] = 1;
-        if (s3 && c2 == 0) map[bk3] = 2;
-        if (s4 && c == 0) map[bk4] = 4;
-        if (live) { sel[s] = s2 ? 1 : 0; if ((has[s] != 0) != s2) cnt[0] = 1; }
+            for (int j = 0; j < 4; ++j) { if (sv[j] > bv) { bv = sv[j]; bk = sk[j]; } below |= sany[j] != 0; }
+            k4 = bk;
+            s4 = !below && bk > 0;
+        }
+        const bool lead = sub == 0;
+        if (s2 && lead) map[k2] = 1;
+        if (s3 && lead && c2 == 0) map[k3] = 2;
+        if (s4 && lead && c == 0) map[k4] = 4;
+        if (live && lead) { sel[s] = s2 ? 1 : 0; if ((has[s] != 0) != s2) cnt[0] = 1; }
         // counts: one integer atomic per wave and level
-        const int n2 = __popcll(m2), n3 = __popcll(__ballot(s3 && c2 == 0)), n4 = __popcll(__ballot(s4 && c == 0));
+        const int n2 = __popcll(__ballot(s2 && lead)), n3 = __popcll(__ballot(s3 && lead && c2 == 0)), n4 = __popcll(__ballot(s4 && lead && c == 0));
         if (lane == 0) { if (n2) atomicAdd(&cnt[1], n2); if (n3) atomicAdd(&cnt[2], n3); if (n4) atomicAdd(&cnt[3], n4); }
     }
 }
@@ -261,21 +289,31 @@ static int pixsel_select_dev(nalo_ctx* c, PixSel* p, int slot, int pot, float th
     A.nslots = A.nb4x * ((c->h + 4 * pot - 1) / (4 * pot)) * 16;
     A.thFactor = thFactor;
     NALO_HIP(c, p->has.reserve(A.nslots)); NALO_HIP(c, p->sel.reserve(A.nslots)); NALO_HIP(c, p->pre.reserve(A.nslots));
-    const int grid = (A.nslots + 255) / 256;
-    pixsel_cells_kernel<false><<<grid, 256, 0, c->stream>>>(A, p->has.p, nullptr, nullptr, nullptr, nullptr);
+    const int L = pot <= 3 ? 1 : (pot <= 7 ? 4 : 16), grid = (int)(((size_t)A.nslots * L + 255) / 256);
+    auto cells = [&](bool select, uint8_t* fl, uint8_t* out) {
+        if (!select) {
+            if (L == 1) pixsel_cells_kernel<false, 1><<<grid, 256, 0, c->stream>>>(A, fl, nullptr, nullptr, nullptr, nullptr);
+            else if (L == 4) pixsel_cells_kernel<false, 4><<<grid, 256, 0, c->stream>>>(A, fl, nullptr, nullptr, nullptr, nullptr);
+            else pixsel_cells_kernel<false, 16><<<grid, 256, 0, c->stream>>>(A, fl, nullptr, nullptr, nullptr, nullptr);
+        } else {
+            if (L == 1) pixsel_cells_kernel<true, 1><<<grid, 256, 0, c->stream>>>(A, fl, p->pre.p, out, p->map.p, p->cnt.p);
+            else if (L == 4) pixsel_cells_kernel<true, 4><<<grid, 256, 0, c->stream>>>(A, fl, p->pre.p, out, p->map.p, p->cnt.p);
+            else pixsel_cells_kernel<true, 16><<<grid, 256, 0, c->stream>>>(A, fl, p->pre.p, out, p->map.p, p->cnt.p);
+        }
+    };
+    cells(false, p->has.p, nullptr);
     uint8_t *flags = p->has.p, *other = p->sel.p;
     for (int round = 0;; ++round) {
         if (round > A.nslots) return fail(c, NALO_ERR_STATE, "nalo_pixsel_select: the selection did not reach its fixed point");
         pixsel_scan_bytes_kernel<<<1, 1024, 0, c->stream>>>(flags, A.nslots, p->pre.p);
         NALO_HIP(c, hipMemsetAsync(p->map.p, 0, npx, c->stream));
         NALO_HIP(c, hipMemsetAsync(p->cnt.p, 0, 8 * sizeof(int), c->stream));
-        pixsel_cells_kernel<true><<<grid, 256, 0, c->stream>>>(A, flags, p->pre.p, other, p->map.p, p->cnt.p);
+        cells(true, flags, other);
         NALO_HIP(c, hipMemcpyAsync(p->host, p->cnt.p, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         NALO_HIP(c, hipStreamSynchronize(c->stream));
         if (!p->host[0]) break;
         std::swap(flags, other);                                // a cell's flag was wrong: redo the scan with the flags the selection produced
     }
-    if (flags != p->has.p) std::swap(p->has, p->sel);
     n[0] = p->host[1]; n[1] = p->host[2]; n[2] = p->host[3];
     p->have_map = true;
     return NALO_OK;
