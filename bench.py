@@ -104,7 +104,9 @@ class GpuJob:
         self.ctx.ba_set_residuals(win.exists)
         if hook is not None:                                             # hook = factory(ctx) -> all-reduce callable (it needs the context's stream)
             fn = hook(self.ctx)
-            self.ctx.ba_set_allreduce(fn, stream_ordered=getattr(fn, "stream_ordered", False))
+            so = getattr(fn, "stream_ordered", False)
+            # stream-ordered: a second hook on the context's side stream, so the threshold's histogram sums overlap the SC / stitch kernels
+            self.ctx.ba_set_allreduce(fn, stream_ordered=so, fn_side=hook(self.ctx, True) if so else None)
         self.ctx.ba_snapshot()
         self.ctx.trk_set_ref(W - 1, *trk)
         self.T0 = [synth.se3_mul(win.world_to_cam[W + k], synth.se3_inv(win.world_to_cam[W - 1])) for k in range(TRACKED_PER_KF)]
@@ -222,7 +224,7 @@ def main():
     sharded = args.workload == "shard1m"
 
     win, st6, trk = make_inputs(args.workload)
-    hook = (lambda ctx: make_hook(dist, torch, args.backend, stream=ctx.stream)) if (sharded and world > 1) else None
+    hook = (lambda ctx, side=False: make_hook(dist, torch, args.backend, stream=ctx.side_stream if side else ctx.stream)) if (sharded and world > 1) else None
     job = GpuJob(shard(win, rank, world) if sharded else win, st6, trk, local_rank, hook)
     do_track = not sharded
 
@@ -383,7 +385,7 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
     emu = int(os.environ.get("NALO_BENCH_EMULATE_WORLD", "0"))        # rehearsal on one GPU: run rank 0's share of an N-rank job
     part = shard(win, 0, emu) if emu > 1 else shard(win, rank, world)
     log("shard1m: uploading %d points" % len(part.host))
-    job = GpuJob(part, st6, trk, local_rank, lambda ctx: make_hook(dist, torch, backend, stream=ctx.stream))
+    job = GpuJob(part, st6, trk, local_rank, lambda ctx, side=False: make_hook(dist, torch, backend, stream=ctx.side_stream if side else ctx.stream))
     for _ in range(warmup):
         job.step(False)
     job.ctx.profile_enable(True)

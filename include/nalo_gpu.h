@@ -181,14 +181,21 @@ int nalo_ba_snapshot(nalo_ctx* ctx);
 int nalo_ba_restore(nalo_ctx* ctx);
 
 /* multi-GPU: the active-point set is sharded by the caller (each rank sets only its points); the stitched
- * buffers {H_A, b_A, H_sc, b_sc, energy, counters, energy histogram} are summed across ranks through this hook
- * before every solve. buf is a DEVICE pointer to n doubles on nalo_stream(ctx). hook == NULL = single GPU. */
+ * buffers {H_A, b_A, H_sc, b_sc, energy, counters} are summed across ranks through this hook before every solve, and so are the two
+ * radix histograms of setNewFrameEnergyTH (FullSystemOptimize.cpp:95-143) after every linearisation: the newest frame's energy threshold is the
+ * exact order statistic over ALL ranks' residuals, i.e. what one GPU holding the whole window computes. Per pass the hook is therefore called three
+ * times, in the same order on every rank: histogram (32768 doubles), histogram (65536), stitched systems. buf is a DEVICE pointer to n doubles.
+ * hook == NULL = single GPU. */
 typedef void (*nalo_allreduce_fn)(void* user, double* device_buf, int n);
 int nalo_ba_set_allreduce(nalo_ctx* ctx, nalo_allreduce_fn hook, void* user);
 /* stream_ordered = 1: the hook ENQUEUES its collective on nalo_stream(ctx) (e.g. ncclAllReduce(..., (hipStream_t)nalo_stream(ctx))) and returns
- * without waiting; the library then neither synchronises before nor after the hook. Default 0: the library synchronises its stream before the
- * call and the hook returns when the sum is complete. */
+ * without waiting; the library then neither synchronises before nor after the hook. Default 0: the library synchronises the stream the buffer was
+ * produced on before the call and the hook returns when the sum is complete. */
 int nalo_ba_set_allreduce_mode(nalo_ctx* ctx, int stream_ordered);
+/* optional, stream-ordered mode: a second hook that enqueues the same sum on nalo_side_stream(ctx). The histogram sums then run on the side stream,
+ * under the Schur-complement / reduce / stitch kernels of the main stream, instead of in line before them. */
+int nalo_ba_set_allreduce_side(nalo_ctx* ctx, nalo_allreduce_fn hook, void* user);
+void* nalo_side_stream(nalo_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------
  * a14  DenseMapping::updateMap bbox scan + makeMap (FullSystem/MapPoint.cpp:300-310, 334-407), call site

@@ -31,7 +31,7 @@ EXPORTS = [
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
-    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_snapshot", "nalo_ba_restore",
+    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
@@ -91,6 +91,9 @@ def load():
     L.nalo_ba_counts.argtypes = [vp, c_ip, c_ip, c_ip]
     L.nalo_ba_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     L.nalo_ba_set_allreduce_mode.argtypes = [vp, C.c_int]
+    L.nalo_ba_set_allreduce_side.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.nalo_side_stream.argtypes = [vp]
+    L.nalo_side_stream.restype = vp
     L.nalo_ba_snapshot.argtypes = [vp]
     L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
                                             c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
@@ -442,15 +445,28 @@ class Context:
         """hipStream_t (as int) every kernel of this context is launched on"""
         return int(self.L.nalo_stream(self.h_) or 0)
 
-    def ba_set_allreduce(self, fn, stream_ordered=False):
-        """fn(device_ptr:int, n:int) sums n doubles in place across ranks. stream_ordered: fn enqueues on self.stream and does not wait."""
+    @property
+    def side_stream(self):
+        """hipStream_t (as int) of the context's second stream (the threshold's histogram sums of a sharded window run there)"""
+        return int(self.L.nalo_side_stream(self.h_) or 0)
+
+    def ba_set_allreduce(self, fn, stream_ordered=False, fn_side=None):
+        """fn(device_ptr:int, n:int) sums n doubles in place across ranks. stream_ordered: fn enqueues on self.stream and does not wait;
+        fn_side (optional, stream-ordered only) does the same on self.side_stream."""
         self._ck(self.L.nalo_ba_set_allreduce_mode(self.h_, int(bool(stream_ordered) and fn is not None)))
         if fn is None:
-            self._hook = None
+            self._hook = self._hook_side = None
             self._ck(self.L.nalo_ba_set_allreduce(self.h_, C.cast(None, ALLREDUCE_FN), None))
+            self._ck(self.L.nalo_ba_set_allreduce_side(self.h_, C.cast(None, ALLREDUCE_FN), None))
             return
         self._hook = ALLREDUCE_FN(lambda user, ptr, n: fn(ptr, n))
         self._ck(self.L.nalo_ba_set_allreduce(self.h_, self._hook, None))
+        if fn_side is not None and stream_ordered:
+            self._hook_side = ALLREDUCE_FN(lambda user, ptr, n: fn_side(ptr, n))
+            self._ck(self.L.nalo_ba_set_allreduce_side(self.h_, self._hook_side, None))
+        else:
+            self._hook_side = None
+            self._ck(self.L.nalo_ba_set_allreduce_side(self.h_, C.cast(None, ALLREDUCE_FN), None))
 
     # ---- profiling
     def profile_enable(self, on=True):

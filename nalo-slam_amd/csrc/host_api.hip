@@ -82,6 +82,7 @@ const char* nalo_last_error(nalo_ctx* c) { return c ? c->err.c_str() : "null ctx
 int nalo_levels(nalo_ctx* c) { return c ? c->levels : NALO_ERR_ARG; }
 int nalo_sync(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; NALO_HIP(c, hipStreamSynchronize(c->stream)); NALO_HIP(c, hipStreamSynchronize(c->side)); return NALO_OK; }
 void* nalo_stream(nalo_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* nalo_side_stream(nalo_ctx* c) { return c ? (void*)c->side : nullptr; }
 
 int nalo_frame_upload(nalo_ctx* c, int slot, const float* irradiance, const float* mask, const uint8_t* bgr, const float* gammaB) {
     if (!c || !irradiance || slot < 0 || slot >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_frame_upload: bad argument");

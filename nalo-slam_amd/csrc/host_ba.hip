@@ -21,6 +21,7 @@ void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
 int ba_launch_gn(hipStream_t s, const GNDev& G, int iteration, int never_break, double lambda);
 void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
+void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int step);
 
 struct HostFrame {
     int slot = 0, frameID = 0;
@@ -79,6 +80,8 @@ struct BAWindow {
     nalo_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
     bool hook_stream_ordered = false;                               // the hook enqueues its collective on nalo_stream(ctx): no host synchronisation around it
+    nalo_allreduce_fn hook_side = nullptr; void* hook_side_user = nullptr;   // same sum, enqueued on nalo_side_stream(ctx): the threshold's histograms
+    DevBuf<double> th_buf;                                          // a histogram as doubles (all-reduce payload)
     hipEvent_t ev_lin = nullptr, ev_th = nullptr; bool th_side_inflight = false;   // sharded windows run the quantile kernels on the side stream, under the SC kernel
     bool never_break = false;
 };
@@ -87,7 +90,7 @@ void ba_destroy(nalo_ctx* c) {
     BAWindow* w = c->ba;
     if (!w) return;
     w->pre.release(); w->frameTH.release(); w->pt_prior.release(); w->pt_step.release(); w->pt_backup.release(); w->pt_relbs.release();
-    w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
+    w->th_buf.release(); w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
     w->blk_host.release(); w->host_blk.release(); w->sc_grp.release(); w->blk_order.release(); w->acc13.release(); w->G.release(); w->AD.release(); w->st_ticket.release();
@@ -276,11 +279,38 @@ static int linearize_async(nalo_ctx* c, int mode, int fix) {
     if (mode == 0 && (w.hook || w.th_on_side)) {
         // sharded window: the threshold is part of the all-reduced tail, i.e. on the critical path: run its kernels on the side stream under SC
         if (!w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming)); }
-        NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
-        NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
-        ba_launch_energy_th(c->side, w.dev);
-        NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
-        w.th_side_inflight = true;
+        if (w.hook && !(w.hook_stream_ordered && !w.hook_side)) {
+            // the EXACT order statistic over all ranks' residuals (what one GPU holding the whole window computes): both radix histograms are summed
+            // across ranks before their search. On the side stream, under SC / reduce / stitch; a blocking hook is called with that stream drained.
+            nalo_allreduce_fn fn = w.hook_side ? w.hook_side : w.hook;
+            void* user = w.hook_side ? w.hook_side_user : w.hook_user;
+            NALO_HIP(c, w.th_buf.reserve(65536));
+            NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
+            NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
+            ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 0);
+            if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->side));
+            fn(user, w.th_buf.p, 32768);
+            ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 1);
+            if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->side));
+            fn(user, w.th_buf.p, 65536);
+            ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 2);
+            NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
+            w.th_side_inflight = true;
+        } else if (w.hook) {
+            // stream-ordered main hook without a side hook: the same exact search, in line on the main stream
+            NALO_HIP(c, w.th_buf.reserve(65536));
+            ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 0);
+            w.hook(w.hook_user, w.th_buf.p, 32768);
+            ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 1);
+            w.hook(w.hook_user, w.th_buf.p, 65536);
+            ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 2);
+        } else {
+            NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
+            NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
+            ba_launch_energy_th(c->side, w.dev);
+            NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
+            w.th_side_inflight = true;
+        }
     } else if (mode == 0) w.th_pending = true;
     w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
     NALO_HIP(c, hipGetLastError());
@@ -328,9 +358,8 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
     if (did) {
         ++w.pub_seq;
         if (w.hook) {
-            // sharded window: tail = {step sums (3), this rank's frameEnergyTH of the newest frame, 1.0}. After the SUM over ranks the
-            // host installs the MEAN of the per-shard 70 % quantiles as the common threshold (every rank then classifies with the
-            // same value; the exact global order statistic would need the histograms all-reduced: SURVEY 8e, next round).
+            // sharded window: tail = {step sums (3), frameEnergyTH of the newest frame, 1.0}. Every rank already holds the SAME threshold (the order
+            // statistic over all ranks' residuals, linearize_async), so sum / count below re-installs that value; the tail keeps its layout.
             if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
             w.hook(w.hook_user, w.stitched.p, npub);
             ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // more than one rank: the common threshold
@@ -1020,6 +1049,12 @@ int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
     if (!c) return NALO_ERR_ARG;
     if (!c->ba) c->ba = new BAWindow();
     c->ba->hook = hook; c->ba->hook_user = user;
+    return NALO_OK;
+}
+int nalo_ba_set_allreduce_side(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
+    if (!c) return NALO_ERR_ARG;
+    if (!c->ba) c->ba = new BAWindow();
+    c->ba->hook_side = hook; c->ba->hook_side_user = user;
     return NALO_OK;
 }
 

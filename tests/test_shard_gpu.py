@@ -1,0 +1,91 @@
+"""GPU test of the sharded window on ONE device: two contexts, each holding half of the active points (bench.shard), driven by two threads
+whose all-reduce hook sums the buffers through the host. What the ranks agree on must be what a single context holding the whole window computes:
+the stitched systems (sum of the shards), the energy, and -- exactly -- the newest frame's energy threshold (setNewFrameEnergyTH is an order statistic:
+both radix histograms are summed across ranks before their search)."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+from nalo_slam_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _Ptr:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+
+def make_ctx(win, st6):
+    c = binding.Context(win.w, win.h, win.K, n_slots=win.W)
+    for i in range(win.W):
+        c.frame_upload(i, win.images[i])
+    c.ba_set_window(list(range(win.W)), win.world_to_cam[:win.W], state6=st6)
+    c.ba_set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights)
+    c.ba_set_residuals(win.exists)
+    return c
+
+
+def test_two_shards_agree_with_the_whole_window():
+    win = synth.make_window(w=640, h=480, W=5, P=1500, seed=12)
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    full = make_ctx(win, st6)
+    e_full = full.ba_linearize()
+    th_full = full.ba_get_frames()[0][win.W - 1].frameEnergyTH
+    HA, bA = full.ba_accumulate(0)
+    r_full = full.ba_optimize(3, never_break=True)
+    th_full2 = full.ba_get_frames()[0][win.W - 1].frameEnergyTH
+    w2c_full = full.ba_get_frames()[1].copy()
+    full.close()
+
+    world = 2
+    bar = threading.Barrier(world)
+    bufs, calls, out, err = [None] * world, [[] for _ in range(world)], [None] * world, []
+
+    def rank_job(r):
+        try:
+            part = bench.shard(win, r, world)
+            c = make_ctx(part, st6)
+
+            def hook(ptr, n):                                    # blocking contract: the library drained the producing stream before the call
+                t = torch.as_tensor(_Ptr(ptr, n), device="cuda")
+                bufs[r] = t.cpu()
+                bar.wait()
+                tot = bufs[0] + bufs[1]
+                bar.wait()
+                t.copy_(tot)
+                torch.cuda.synchronize()
+                calls[r].append(n)
+            c.ba_set_allreduce(hook)
+            e = c.ba_linearize()
+            th = c.ba_get_frames()[0][win.W - 1].frameEnergyTH
+            H, b = c.ba_accumulate(0)
+            c.ba_optimize(3, never_break=True)
+            fr = c.ba_get_frames()
+            out[r] = dict(e=e, th=th, H=H, b=b, th2=fr[0][win.W - 1].frameEnergyTH, w2c=fr[1].copy(), n=len(part.host))
+            c.ba_set_allreduce(None)
+            c.close()
+        except Exception as ex:                                  # never leave the other rank waiting in the barrier
+            err.append(ex)
+            bar.abort()
+
+    ts = [threading.Thread(target=rank_job, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not err, err
+    a, b = out
+    assert a["n"] + b["n"] == len(win.host) and min(a["n"], b["n"]) > 0.3 * len(win.host)
+    # per linearisation: the two histogram sums, then the systems
+    assert calls[0][:3] == [32768, 65536, calls[0][2]] and calls[0] == calls[1]
+    # the threshold is the whole window's order statistic, bit for bit, on both ranks; after the optimisation too (7 passes later)
+    assert a["th"] == b["th"] == th_full
+    assert a["th2"] == b["th2"]
+    assert abs(a["th2"] - th_full2) <= 1e-3 * th_full2           # the trajectories differ in the last digits (fp32 sums in another order), the rule is the same
+    assert abs(a["e"] - e_full) < 1e-5 * e_full and a["e"] == b["e"]
+    assert np.abs(a["H"] - HA).max() < 2e-5 * np.abs(HA).max() and np.array_equal(a["H"], b["H"])
+    for f in range(win.W):
+        d = np.abs(a["w2c"][f] - w2c_full[f]).max()
+        assert d < 1e-5 and np.array_equal(a["w2c"][f], b["w2c"][f])
