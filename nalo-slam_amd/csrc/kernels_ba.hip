@@ -739,7 +739,63 @@ __global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__
     const unsigned u = __float_as_uint(f);
     if ((u >> 16) == state[2]) atomicAdd(&hist_lo[u & 0xFFFFu], 1u);
 }
+// Small windows (<= 16384 point slots, a KITTI-sized window has 2048): the same order statistic in ONE launch. The workgroup keeps the energies in
+// registers and runs a most-significant-first radix select with four 256-bin LDS histograms (5 us instead of the 40 us of the two 65536-bin
+// searches above, which sat between the publish and the next back-substitution). It also clears the bins ba_linearize_kernel counted into.
+__global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restrict__ en, int n, unsigned* __restrict__ hist_hi, float* __restrict__ frameTH_new, const int* __restrict__ stop) {
+    if (stop && stop[0]) return;
+    __shared__ unsigned hist[256], wtot[16];
+    __shared__ unsigned s_bin, s_before;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned v[16]; bool ok[16];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = tid + 1024 * j;
+        const float f = i < n ? en[i] : -1.f;
+        ok[j] = f >= 0.f; v[j] = __float_as_uint(f);
+        if (ok[j]) { ++cnt; hist_hi[v[j] >> 16] = 0u; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane == 0) wtot[wave] = cnt;
+    __syncthreads();
+    unsigned total = 0;
+    for (int i = 0; i < 16; ++i) total += wtot[i];
+    if (total == 0) { if (tid == 0) *frameTH_new = 12.f * 12.f * (float)kPatternNum; return; }       // no residual on the newest frame (:110-114)
+    unsigned k = (unsigned)(int)(0.7f * (float)total), prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (ok[j] && (v[j] & mask) == prefix) atomicAdd(&hist[(v[j] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (wave == 0) {                                        // 4 bins per lane, shuffle scan, the lane and then the bin whose running count passes k
+            const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3], sum = h0 + h1 + h2 + h3;
+            unsigned incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            const unsigned excl = incl - sum;
+            if (excl <= k && k < incl) {
+                unsigned run = excl; int b = 3;
+                if (run + h0 > k) b = 0; else { run += h0; if (run + h1 > k) b = 1; else { run += h1; if (run + h2 > k) b = 2; else run += h2; } }
+                s_bin = 4u * lane + b; s_before = run;
+            }
+        }
+        __syncthreads();
+        prefix |= s_bin << shift; mask |= 255u << shift; k -= s_before;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float nthElement = sqrtf(__uint_as_float(prefix));
+        float th = nthElement * 1.5f;                           // setting_frameEnergyTHFacMedian
+        th = 26.0f * 0.5f + th * (1.f - 0.5f);                  // setting_frameEnergyTHConstWeight
+        *frameTH_new = th * th;                                 // setting_overallEnergyTHWeight = 1
+    }
+}
 void ba_launch_energy_th(hipStream_t s, const BADev& B) {
+    static const bool big = std::getenv("NALO_TH_HIST") != nullptr;        // force the two-histogram path
+    if (B.Ppad <= 16384 && !big) { ba_th_small_kernel<<<1, 1024, 0, s>>>(B.en_new, B.Ppad, B.th_hist_hi, B.frameTH + (B.W - 1), B.stop); return; }
     ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr, B.stop);
     ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo, B.stop);
     ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1), B.stop);
