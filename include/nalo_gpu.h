@@ -284,8 +284,11 @@ int nalo_init_do_step(nalo_ctx* ctx, int n, const uint8_t* isGood, const float* 
 /* ------------------------------------------------------------------------------------------------
  * Profiling: per-kernel HIP-event timing on the ctx stream. Names: "trk_eval", "ba_linearize",
  * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize", "pixsel". Enable, run, then query (sync inside).
+ * nalo_profile_select(ctx, name) restricts the brackets to ONE scope (NULL = all): a recorded event pair costs ~10 us of pipeline bubbles on a
+ * latency-bound window, so a timed run brackets only the kernel it reports ("ba_linearize" carries its timestamps in the dispatch itself).
  * ------------------------------------------------------------------------------------------------ */
 int nalo_profile_enable(nalo_ctx* ctx, int on);
+int nalo_profile_select(nalo_ctx* ctx, const char* kernel);
 int nalo_profile_reset(nalo_ctx* ctx);
 int nalo_profile_get(nalo_ctx* ctx, const char* kernel, double* total_ms, int* launches);
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
-    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_reset", "nalo_profile_get",
+    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get",
 ]
 
 
@@ -112,6 +112,7 @@ def load():
     L.nalo_dense_make_map.argtypes = [vp, C.c_int, c_fp, C.c_float, c_dp, C.c_int, c_ip, c_ip, c_ip, c_fp, c_fp, c_u8p, c_ip, c_ip]
     L.nalo_profile_enable.argtypes = [vp, C.c_int]
     L.nalo_profile_reset.argtypes = [vp]
+    L.nalo_profile_select.argtypes = [vp, C.c_char_p]
     L.nalo_profile_get.argtypes = [vp, C.c_char_p, c_dp, c_ip]
     _LIB = L
     return L
@@ -471,6 +472,10 @@ class Context:
     # ---- profiling
     def profile_enable(self, on=True):
         self._ck(self.L.nalo_profile_enable(self.h_, int(on)))
+
+    def profile_select(self, name=None):
+        """bracket only the scope `name` (None = all scopes)"""
+        self._ck(self.L.nalo_profile_select(self.h_, None if name is None else name.encode()))
 
     def profile_reset(self):
         self._ck(self.L.nalo_profile_reset(self.h_))

@@ -480,6 +480,7 @@ static void prof_drain(nalo_ctx* c) {
     }
 }
 int nalo_profile_enable(nalo_ctx* c, int on) { if (!c) return NALO_ERR_ARG; c->prof_on = on != 0; return NALO_OK; }
+int nalo_profile_select(nalo_ctx* c, const char* kernel) { if (!c) return NALO_ERR_ARG; c->prof_only = kernel ? kernel : ""; return NALO_OK; }
 int nalo_profile_reset(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; prof_drain(c); c->prof.clear(); return NALO_OK; }
 int nalo_profile_get(nalo_ctx* c, const char* kernel, double* total_ms, int* launches) {
     if (!c || !kernel) return NALO_ERR_ARG;

@@ -8,7 +8,7 @@
 namespace nalo {
 
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly);
-void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix);
+void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void ba_launch_reset_oob(hipStream_t s, const BADev& B);
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
                       const float* step_partial, int step_blocks, double* step_out);
@@ -273,8 +273,8 @@ static int linearize_async(nalo_ctx* c, int mode, int fix) {
     int rc = flush_th(c); if (rc) return rc;                          // frameEnergyTH of the previous pass feeds this one
     if (fix || mode == 2) NALO_HIP(c, hipMemsetAsync(w.pt_relbs.p, 0, (size_t)w.Ppad * 4, c->stream));
     {
-        ProfScope ps(c, "ba_linearize");
-        ba_launch_linearize(c->stream, w.dev, mode, fix);
+        ProfScope ps(c, "ba_linearize", true);
+        ba_launch_linearize(c->stream, w.dev, mode, fix, ps.a, ps.b);
     }
     if (mode == 0 && (w.hook || w.th_on_side)) {
         // sharded window: the threshold is part of the all-reduced tail, i.e. on the critical path: run its kernels on the side stream under SC

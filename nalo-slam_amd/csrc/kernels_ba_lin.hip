@@ -13,6 +13,7 @@
 // store by one lane per quad) instead of being held, and the 8x4 texel gather is issued in two halves of 16 loads.
 // Per-point sums over the targets (Hdd, bd, Hcd) are written per slot and summed in a fixed order by ba_sc_kernel.
 #include "nalo_internal.h"
+#include <hip/hip_ext.h>
 #include "ba_device.h"
 #include "reduce.h"
 
@@ -268,8 +269,14 @@ __global__ __launch_bounds__(kBlk, NALO_LIN_WAVES) void ba_linearize_kernel(BADe
     }
 }
 
-void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix) {
+void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const unsigned grid = 8u * (unsigned)B.xcd_len * (unsigned)B.W;
+    if (ev_start) {                                             // profiled launch: the dispatch carries its own start / stop timestamps
+        if (mode == 2) hipExtLaunchKernelGGL((ba_linearize_kernel<2, 0>), dim3(grid), dim3(kBlk), 0, s, ev_start, ev_stop, 0, B);
+        else if (fix) hipExtLaunchKernelGGL((ba_linearize_kernel<0, 1>), dim3(grid), dim3(kBlk), 0, s, ev_start, ev_stop, 0, B);
+        else hipExtLaunchKernelGGL((ba_linearize_kernel<0, 0>), dim3(grid), dim3(kBlk), 0, s, ev_start, ev_stop, 0, B);
+        return;
+    }
     if (mode == 2) ba_linearize_kernel<2, 0><<<grid, kBlk, 0, s>>>(B);
     else if (fix) ba_linearize_kernel<0, 1><<<grid, kBlk, 0, s>>>(B);
     else ba_linearize_kernel<0, 0><<<grid, kBlk, 0, s>>>(B);

@@ -90,6 +90,7 @@ struct nalo_ctx {
 
     // ---- profiling
     bool prof_on = false;
+    std::string prof_only;                   // empty = every scope; else only the scope of that name is bracketed
     std::map<std::string, nalo::ProfEntry> prof;
 };
 
@@ -123,13 +124,15 @@ struct HostTimer {                // wall-clock scope, accumulated per name
     ~HostTimer() { auto& e = c->host_t[name]; e.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); e.second++; }
 };
 
-struct ProfScope {               // HIP-event bracket on the ctx stream (only when profiling is enabled)
-    nalo_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(nalo_ctx* ctx, const char* n) : c(ctx), name(n) {
-        if (c->prof_on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, c->stream); }
+struct ProfScope {               // HIP-event bracket on the ctx stream (only when profiling is enabled, and selected: nalo_profile_select)
+    // external = true: the events are not recorded here but handed to hipExtLaunchKernelGGL, which timestamps the dispatch itself: no barrier
+    // packets around the kernel (an event pair recorded on the stream costs ~10 us of bubbles per bracket on a latency-bound pipeline)
+    nalo_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr; bool external;
+    ProfScope(nalo_ctx* ctx, const char* n, bool ext = false) : c(ctx), name(n), external(ext) {
+        if (c->prof_on && (c->prof_only.empty() || c->prof_only == n)) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); if (!external) (void)hipEventRecord(a, c->stream); }
     }
     ~ProfScope() {
-        if (a) { (void)hipEventRecord(b, c->stream); c->prof[name].pending.emplace_back(a, b); }
+        if (a) { if (!external) (void)hipEventRecord(b, c->stream); c->prof[name].pending.emplace_back(a, b); }
     }
 };
 
