@@ -75,6 +75,9 @@ struct GNDev {
     int *stop, *iters_done;
 };
 
+// {xc (4) | xAd [W*W][8]} of resubstituteFPt for windows of up to 8 frames, passed by value as kernel arguments (ba_resub_kernel)
+struct XadArg { float v[4 + 8 * 64]; };
+
 // Stitch operands (kernels_ba.hip ba_stitch_kernel)
 struct StitchDev {
     const double* AD;                           // [adHost (W*W*64) | adTarget (W*W*64)], index (h + t*W)*64 + i*8 + k

@@ -12,9 +12,9 @@ void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix, hipEv
 void ba_launch_reset_oob(hipStream_t s, const BADev& B);
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
                       const float* step_partial, int step_blocks, double* step_out);
-void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial);
+void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial, const XadArg* karg = nullptr);
 int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
-void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc);
+void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg = nullptr);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
 void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
@@ -511,14 +511,19 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
         }
     }
     NALO_HIP(c, w.xad.reserve((size_t)W * W * 8 + 64));
-    NALO_HIP(c, hipMemcpyAsync(w.xad.p, xc, ((size_t)W * W * 8 + 64) * 4, hipMemcpyHostToDevice, c->stream));
+    XadArg karg; const XadArg* kp = nullptr;
+    static const bool no_karg = std::getenv("NALO_RESUB_COPY") != nullptr;
+    if (W <= 8 && !no_karg) {                                              // small window: {xc, xAd} travel as kernel arguments, no copy
+        std::memcpy(karg.v, xc, 16); std::memcpy(karg.v + 4, xAd, (size_t)W * W * 8 * 4);
+        kp = &karg;
+    } else NALO_HIP(c, hipMemcpyAsync(w.xad.p, xc, ((size_t)W * W * 8 + 64) * 4, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, "ba_resub");
         if (fuse_step) {
             NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
-            ba_launch_resub_step(c->stream, w.dev, w.xad.p + 64, w.xad.p, 1.f, w.step_partial.p);
+            ba_launch_resub_step(c->stream, w.dev, w.xad.p + 64, w.xad.p, 1.f, w.step_partial.p, kp);
             w.step_fused = true;
-        } else ba_launch_resub(c->stream, w.dev, w.xad.p + 64, w.xad.p);
+        } else ba_launch_resub(c->stream, w.dev, w.xad.p + 64, w.xad.p, kp);
     }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;

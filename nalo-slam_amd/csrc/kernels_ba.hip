@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__
 // ba_pt_acc_kernel: per point (AccumulatedSCHessian.cpp:36-57): EFPoint::{Hdd,bd,Hcd}_acc = sum over the point's active residuals in target order
 // (AccumulatedTopHessian.cpp:132-157), then HdiF, bdSumF. One thread per point, no LDS: the W strided 25-byte slot reads of a point are hidden by
 // occupancy instead of stalling the SYRK workgroups (they were the first phase of ba_sc_kernel: 87 of its 390 us on the 1M-point window).
+// SMALL (<= 64 point blocks): latency matters, all slots of 8 targets are fetched before any is used. Large windows are bandwidth bound: the plain
+// loop keeps the register count (and so the occupancy) where the memory system wants it.
+template <bool SMALL>
 __global__ __launch_bounds__(kBlk) void ba_pt_acc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
     if (B.stop && B.stop[0]) return;
     const int b = blockIdx.x, h = B.blk_host[b], W = B.W, d = b * kBlk + threadIdx.x;
@@ -47,18 +50,34 @@ __global__ __launch_bounds__(kBlk) void ba_pt_acc_kernel(BADev B, int shiftPrior
     if (!((pf & PT_VALID) && (!margOnly || (pf & PT_MARG)))) return;
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), hc = make_float4(0.f, 0.f, 0.f, 0.f);
     int ngood = 0;
-    for (int t0 = 0; t0 < W; t0 += 8) {                        // 8 targets' slots in flight at once (clamped, selected below), summed in target order
-        uint8_t rs[8]; float4 q0[8]; float2 q1[8];
+    if constexpr (SMALL) {
+        for (int t0 = 0; t0 < W; t0 += 8) {                    // 8 targets' slots in flight at once, summed in target order
+            uint8_t rs[8]; float4 q0[8]; float2 q1[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const size_t si = (size_t)min(t0 + i, W - 1) * B.Ppad + d;
-            rs[i] = B.rs_state[si]; q0[i] = B.rs_pp0[si]; q1[i] = B.rs_pp1[si];
+            for (int i = 0; i < 8; ++i) {
+                rs[i] = 0;
+                if (t0 + i < W) {                               // wave-uniform: a scalar branch around the loads, no wait
+                    const size_t si = (size_t)(t0 + i) * B.Ppad + d;
+                    rs[i] = B.rs_state[si]; q0[i] = B.rs_pp0[si]; q1[i] = B.rs_pp1[si];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = t0 + i;
+                if (t >= W || t == h || !(rs[i] & RS_ACTIVE)) continue;
+                pa.y += q0[i].x; pa.x += q0[i].y; hc.x += q0[i].z; hc.y += q0[i].w; hc.z += q1[i].x; hc.w += q1[i].y;
+                ++ngood;
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int t = t0 + i;
-            if (t >= W || t == h || !(rs[i] & RS_ACTIVE)) continue;
-            pa.y += q0[i].x; pa.x += q0[i].y; hc.x += q0[i].z; hc.y += q0[i].w; hc.z += q1[i].x; hc.w += q1[i].y;
+    } else {
+#pragma unroll 4
+        for (int t = 0; t < W; ++t) {
+            if (t == h) continue;
+            const size_t si = (size_t)t * B.Ppad + d;
+            const uint8_t rs = B.rs_state[si];
+            const float4 q0 = B.rs_pp0[si]; const float2 q1 = B.rs_pp1[si];     // unconditional loads, selected below
+            if (!(rs & RS_ACTIVE)) continue;
+            pa.y += q0.x; pa.x += q0.y; hc.x += q0.z; hc.y += q0.w; hc.z += q1.x; hc.w += q1.y;
             ++ngood;
         }
     }
@@ -233,7 +252,8 @@ static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int margOnly) {
     }
 }
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
-    ba_pt_acc_kernel<<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
+    if (B.nblocks <= 64) ba_pt_acc_kernel<true><<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
+    else ba_pt_acc_kernel<false><<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
     if (B.sc_split == 4) launch_sc_ks<4>(s, B, T, margOnly);
     else launch_sc_ks<1>(s, B, T, margOnly);
 }
@@ -581,26 +601,51 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
 // xAd: [W*W][8] index h*W + t (EnergyFunctional.cpp:270-280), xc: cstep(4)
 // STEP: optimize() applies the step right away (stepfacD; FullSystemOptimize.cpp:271-276) and leaves the block sums {step^2, |idepth_backup|, count}
 // for the break test in `partial` - one launch instead of resubstitute, doStep and a sum kernel.
-template <bool STEP>
-__global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __restrict__ xAd, const float* __restrict__ xc, float stepfacD, float* __restrict__ partial) {
+// KARG: windows of up to 8 frames get {xc, xAd} (2 KB) as kernel ARGUMENTS (block-uniform: scalar loads from the kernarg segment) - no H2D copy, and
+// its few microseconds of blit + bubble, between the host's solve and this launch.
+template <bool STEP, bool KARG>
+__global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __restrict__ xAd_p, const float* __restrict__ xc_p, XadArg X, float stepfacD, float* __restrict__ partial) {
     __shared__ float smem[64 * 4];
     if (B.stop && B.stop[0]) return;
+    const float* xc = KARG ? X.v : xc_p;
+    const float* xAd = KARG ? X.v + 4 : xAd_p;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     float v[3] = {0.f, 0.f, 0.f};
     if (d < B.Ppad && (B.pt_flags[d] & PT_VALID)) {
-        const int h = B.blk_host[d / kBlk], W = B.W;
+        const int h = __builtin_amdgcn_readfirstlane(B.blk_host[blockIdx.x]), W = B.W;          // blockDim = kBlk: one host per block, so xAd rows are scalar loads
         float stp = 0.f;
         if (B.pt_ngood[d] != 0) {
             const float4 pa = B.pt_acc[d], hc = B.pt_hcd[d];
             float bsum = pa.w;
             bsum -= xc[0] * hc.x + xc[1] * hc.y + xc[2] * hc.z + xc[3] * hc.w;
-            for (int t = 0; t < W; ++t) {
-                if (t == h) continue;
-                const size_t si = (size_t)t * B.Ppad + d;
-                if (!(B.rs_state[si] & RS_ACTIVE)) continue;
-                const float4 j0 = B.rs_jp0[si], j1 = B.rs_jp1[si];
-                const float* xa = xAd + (size_t)(h * W + t) * 8;
-                bsum -= xa[0] * j0.x + xa[1] * j0.y + xa[2] * j0.z + xa[3] * j0.w + xa[4] * j1.x + xa[5] * j1.y + xa[6] * j1.z + xa[7] * j1.w;
+            if constexpr (KARG) {                               // small window: 8 targets' slots in flight at once, subtracted in target order
+                for (int t0 = 0; t0 < W; t0 += 8) {
+                    uint8_t rs[8]; float4 j0[8], j1[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        rs[i] = 0; j0[i] = make_float4(0.f, 0.f, 0.f, 0.f); j1[i] = j0[i];
+                        if (t0 + i < W) {                       // wave-uniform: a scalar branch around the loads, no wait
+                            const size_t si = (size_t)(t0 + i) * B.Ppad + d;
+                            rs[i] = B.rs_state[si]; j0[i] = B.rs_jp0[si]; j1[i] = B.rs_jp1[si];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int t = t0 + i;
+                        const float* xa = xAd + (size_t)(h * W + min(t, W - 1)) * 8;           // uniform address, loaded whatever the lane's residual state
+                        const float term = xa[0] * j0[i].x + xa[1] * j0[i].y + xa[2] * j0[i].z + xa[3] * j0[i].w + xa[4] * j1[i].x + xa[5] * j1[i].y + xa[6] * j1[i].z + xa[7] * j1[i].w;
+                        if (t < W && t != h && (rs[i] & RS_ACTIVE)) bsum -= term;
+                    }
+                }
+            } else {                                            // large window: bandwidth bound, inactive slots are not fetched
+                for (int t = 0; t < W; ++t) {
+                    if (t == h) continue;
+                    const size_t si = (size_t)t * B.Ppad + d;
+                    if (!(B.rs_state[si] & RS_ACTIVE)) continue;
+                    const float4 j0 = B.rs_jp0[si], j1 = B.rs_jp1[si];
+                    const float* xa = xAd + (size_t)(h * W + t) * 8;
+                    bsum -= xa[0] * j0.x + xa[1] * j0.y + xa[2] * j0.z + xa[3] * j0.w + xa[4] * j1.x + xa[5] * j1.y + xa[6] * j1.z + xa[7] * j1.w;
+                }
             }
             stp = -bsum * pa.z;
         }
@@ -665,11 +710,15 @@ void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int
     const int nb = n > 32768 ? 32 : (n + 1023) / 1024;
     ba_publish_kernel<<<nb < 1 ? 1 : nb, 256, 0, s>>>(src, dst_mapped, n, seq, ticket);
 }
-void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc) {
-    ba_resub_kernel<false><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, 0.f, nullptr);
+void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg) {
+    static const XadArg none{};
+    if (karg) ba_resub_kernel<false, true><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, nullptr, nullptr, *karg, 0.f, nullptr);
+    else ba_resub_kernel<false, false><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, none, 0.f, nullptr);
 }
-void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial) {
-    ba_resub_kernel<true><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, stepfacD, partial);
+void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial, const XadArg* karg) {
+    static const XadArg none{};
+    if (karg) ba_resub_kernel<true, true><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, nullptr, nullptr, *karg, stepfacD, partial);
+    else ba_resub_kernel<true, false><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, none, stepfacD, partial);
 }
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3) {
     const int nb = (B.Ppad + 255) / 256;
