@@ -150,8 +150,10 @@ __device__ __forceinline__ void sc_mfma_pass(const float* __restrict__ A, const 
         }
     }
 }
+// KS == 4 (small windows, one pass of 64 points per workgroup) also computes the per-point sums of its 64 points itself (wave 0, under the operand
+// loads of the other columns): one launch less on the latency-bound path.
 template <int T, int KS>
-__global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly) {
+__global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly, int shiftPriorToZero, float priorScaleMarg) {
     constexpr int NPL = 16 * T, ROWS = kBlk / KS;
     constexpr int SUB0 = T <= 2 ? 256 : (T <= 4 ? 128 : 64), SUB = SUB0 < ROWS ? SUB0 : ROWS, NSUB = ROWS / SUB;
     // padded LDS row: a wave reads 4 consecutive rows x 16 columns per operand, so the stride is an odd multiple of 16 floats (the 4 rows land on
@@ -159,6 +161,9 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly) {
     constexpr int NPLP = NPL + ((T % 2 == 0) ? 16 : 32);
     __shared__ __attribute__((aligned(16))) float A[SUB * NPLP];
     __shared__ float Wt[SUB];
+    constexpr bool FUSE = KS == 4;
+    __shared__ __attribute__((aligned(16))) float4 Hc4[FUSE ? SUB : 1];
+    __shared__ float Bd[FUSE ? SUB : 1];
     if (B.stop && B.stop[0]) return;
     const int grp = blockIdx.x / KS, ks = blockIdx.x - grp * KS, tid = threadIdx.x, W = B.W;
     int h = 0;
@@ -196,13 +201,57 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly) {
             const bool isj = q < qH;
             const size_t si = (size_t)(isj ? (g < h ? g : g + 1) : 0) * B.Ppad + d;
             const float4* src = isj ? ((q & 1) ? B.rs_jp1 : B.rs_jp0) + si : (q == qH ? B.pt_hcd : B.pt_acc) + d;
-            raw[qi] = *src;
             rst[qi] = RS_ACTIVE;
+            if (FUSE && !isj) { raw[qi] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }      // the point columns come from this workgroup's own sums (LDS)
+            raw[qi] = *src;
             if (isj) rst[qi] = B.rs_state[si];                     // scalar branch (q is wave-uniform)
         }
     };
     const int npass = (b1 - b0) * NSUB;
     if (npass > 0) fetch(0);
+    if constexpr (FUSE) {
+        // per point (AccumulatedSCHessian.cpp:36-57), exactly ba_pt_acc_kernel<true> for the 64 points of this workgroup
+        if (tid < SUB && npass > 0) {
+            const int d = b0 * kBlk + ks * ROWS + tid;
+            const uint8_t pf = B.pt_flags[d];
+            float wgt = 0.f, bds = 0.f;
+            float4 hc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((pf & PT_VALID) && (!margOnly || (pf & PT_MARG))) {
+                float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+                int ngood = 0;
+                for (int t0 = 0; t0 < W; t0 += 8) {
+                    uint8_t rs[8]; float4 q0[8]; float2 q1[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        rs[i] = 0;
+                        if (t0 + i < W) { const size_t si = (size_t)(t0 + i) * B.Ppad + d; rs[i] = B.rs_state[si]; q0[i] = B.rs_pp0[si]; q1[i] = B.rs_pp1[si]; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int t = t0 + i;
+                        if (t >= W || t == h || !(rs[i] & RS_ACTIVE)) continue;
+                        pa.y += q0[i].x; pa.x += q0[i].y; hc.x += q0[i].z; hc.y += q0[i].w; hc.z += q1[i].x; hc.w += q1[i].y;
+                        ++ngood;
+                    }
+                }
+                B.pt_hcd[d] = hc; B.pt_ngood[d] = (uint8_t)ngood;
+                if (ngood == 0) { pa.z = 0.f; pa.w = 0.f; }
+                else {
+                    float prior = B.pt_prior[d];
+                    if (margOnly) { prior *= priorScaleMarg; B.pt_prior[d] = prior; }      // EnergyFunctional.cpp:630
+                    float Hs = pa.x + prior;
+                    if (Hs < 1e-10f) Hs = 1e-10f;
+                    pa.z = (float)(1.0 / (double)Hs);
+                    pa.w = pa.y;
+                    if (shiftPriorToZero) { const float4 geo = B.pt_geo[d]; pa.w += prior * (geo.z - geo.w); }
+                    wgt = pa.z;
+                }
+                B.pt_acc[d] = pa;
+                bds = pa.w;
+            }
+            Wt[tid] = wgt; Bd[tid] = bds; Hc4[tid] = hc;
+        }
+    }
     for (int p = 0; p < npass; ++p) {
         __syncthreads();                                       // the previous pass' rows / weights have been consumed
         {
@@ -211,7 +260,8 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly) {
             for (int qi = 0; qi < NV; ++qi) {
                 const int q = part + qi * PARTS;
                 float4 v = raw[qi];
-                if (q == qH + 1) { Wt[r] = pvalid ? v.z : 0.f; v = make_float4(v.w, 0.f, 0.f, 0.f); }      // pt_acc = {Hdd, bd, HdiF, bdSumF}
+                if constexpr (FUSE) { if (q == qH) v = Hc4[r]; else if (q == qH + 1) v = make_float4(Bd[r], 0.f, 0.f, 0.f); }
+                else if (q == qH + 1) { Wt[r] = pvalid ? v.z : 0.f; v = make_float4(v.w, 0.f, 0.f, 0.f); }  // pt_acc = {Hdd, bd, HdiF, bdSumF}
                 const bool keep = pvalid && (rst[qi] & RS_ACTIVE) != 0 && q <= qH + 1;
                 if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < NQ) *reinterpret_cast<float4*>(&A[r * NPLP + 4 * q]) = v;
@@ -238,24 +288,24 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly) {
 }
 
 template <int KS>
-static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int margOnly) {
+static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int margOnly, int shift, float priorScaleMarg) {
     const int grid = B.sc_groups * KS;
     switch (T) {
-        case 1: ba_sc_kernel<1, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
-        case 2: ba_sc_kernel<2, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
-        case 3: ba_sc_kernel<3, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
-        case 4: ba_sc_kernel<4, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
-        case 5: ba_sc_kernel<5, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
-        case 6: ba_sc_kernel<6, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
-        case 7: ba_sc_kernel<7, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
-        default: ba_sc_kernel<8, KS><<<grid, 256, 0, s>>>(B, margOnly); break;
+        case 1: ba_sc_kernel<1, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 2: ba_sc_kernel<2, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 3: ba_sc_kernel<3, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 4: ba_sc_kernel<4, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 5: ba_sc_kernel<5, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 6: ba_sc_kernel<6, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 7: ba_sc_kernel<7, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        default: ba_sc_kernel<8, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
     }
 }
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
+    if (B.sc_split == 4) { launch_sc_ks<4>(s, B, T, margOnly, shift, priorScaleMarg); return; }    // small window: the point sums are fused into the SYRK launch
     if (B.nblocks <= 64) ba_pt_acc_kernel<true><<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
     else ba_pt_acc_kernel<false><<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
-    if (B.sc_split == 4) launch_sc_ks<4>(s, B, T, margOnly);
-    else launch_sc_ks<1>(s, B, T, margOnly);
+    launch_sc_ks<1>(s, B, T, margOnly, shift, priorScaleMarg);
 }
 void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
     const size_t n = (size_t)B.W * B.Ppad;
