@@ -1,0 +1,52 @@
+/* On-disk formats of huziqi/NALO-SLAM, restated as plain C entry points of libnalo_gpu.so. Host code only (text files,
+ * no device work); each function cites the reference code whose bytes / parsed values it reproduces. All return 0 on success, a negative
+ * NALO_IO_* code otherwise. */
+#ifndef NALO_IO_H
+#define NALO_IO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { NALO_IO_OK = 0, NALO_IO_ERR_ARG = -1, NALO_IO_ERR_FILE = -2, NALO_IO_ERR_FORMAT = -3 };
+
+/* result.txt -- FullSystem::printResult (FullSystem/FullSystem.cpp:445-499): TUM lines `timestamp tx ty tz qx qy qz qw`, stream precision 15, one
+ * line per frame of allFrameHistory sorted by timestamp (FrameSort, :267). A frame with poseValid == 0 repeats the pose of the frame BEFORE it in the
+ * sorted order (its own stored pose, valid or not), the first frame of the file prints seven zeros instead. The translation goes through Eigen's
+ * operator<< of a row vector (default IOFormat: the three coefficients are right-aligned to their common width), reproduced here.
+ * t: [n][3] camToWorld.translation(), q: [n][4] camToWorld.so3().unit_quaternion() as x y z w. */
+int nalo_io_write_result(const char* path, int n, const double* timestamp, const uint8_t* poseValid, const double* t, const double* q);
+
+/* pcl_data_tmp.pcd -- SampleOutputWrapper::publishKeyframes (IOWrapper/OutputWrapper/SampleOutputWrapper.h:110-134, 150-176): bare `x y z` lines
+ * (no PCD header), default stream precision, of the back-projected points: depth = 1/idepth (float), x = (u*fxi + cxi)*depth, y = (v*fyi + cyi)*depth,
+ * z = depth*(1 + 2*fxi) (float arithmetic, the reference's z term included), world = camToWorld(3x4, double) * (x, y, z, 1).
+ * append != 0 opens the file for appending (the wrapper keeps one stream open over the run). calib_inv = {fxi, fyi, cxi, cyi}. */
+int nalo_io_write_pcd_points(const char* path, int append, int n, const float* u, const float* v, const float* idepth, const float calib_inv[4],
+                             const double camToWorld[12]);
+
+/* camera.txt -- Undistort::getUndistorterForFile + Undistort::readFromFile (util/Undistort.cpp:690-933): line 1 `[Pinhole |RadTan |FOV |EquiDistant |
+ * KannalaBrandt ]` + 5 (FOV, and the prefix-less legacy form) or 8 parameters, line 2 `wOrg hOrg`, line 3 `crop` | `full` | `none` | five floats,
+ * line 4 `w h`. Relative calibrations (cx < 1 and cy < 1) are rescaled: fx*wOrg, fy*hOrg, cx*wOrg - 0.5, cy*hOrg - 0.5. */
+enum { NALO_CAM_PINHOLE = 0, NALO_CAM_RADTAN = 1, NALO_CAM_FOV = 2, NALO_CAM_EQUIDISTANT = 3, NALO_CAM_KANNALABRANDT = 4 };
+typedef struct {
+    int model, n_pars;                 /* 5 or 8 */
+    double pars[8];                    /* parsOrg after the relative rescale */
+    int w_org, h_org, w, h;
+    int rect_mode;                     /* -1 crop, -2 full, -3 none, 0 = explicit output calibration in out_calib */
+    float out_calib[5];
+} nalo_camera_file;
+int nalo_io_read_camera(const char* path, nalo_camera_file* out);
+
+/* pcalib.txt -- PhotometricUndistorter (util/Undistort.cpp:68-110): first line, >= 256 strictly increasing floats, rescaled to 0..255 with the
+ * reference's expression 255.0 * (G[i] - min) / (max - min). G: capacity cap floats; *n = GDepth. */
+int nalo_io_read_pcalib(const char* path, int cap, float* G, int* n);
+
+/* times.txt -- ImageFolderReader::loadTimestamps (util/DatasetReader.h:317-380): lines `id stamp [exposure]`; a zero exposure is replaced by the mean of
+ * its positive neighbours; if the line count differs from n_images both lists are dropped (*n_stamps = *n_exposures = 0); exposures are dropped when
+ * any stays zero. cap = capacity of both arrays. */
+int nalo_io_read_times(const char* path, int n_images, int cap, double* stamps, float* exposures, int* n_stamps, int* n_exposures);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

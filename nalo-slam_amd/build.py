@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["host_api.hip", "host_ba.hip", "kernels_pyramid.hip", "kernels_tracker.hip", "kernels_trk_lm.hip", "kernels_ba.hip", "kernels_ba_lin.hip", "kernels_ba_gn.hip", "kernels_dense.hip", "kernels_imm.hip", "kernels_init.hip", "kernels_pixsel.hip"]
+SRC = ["host_api.hip", "host_ba.hip", "kernels_pyramid.hip", "kernels_tracker.hip", "kernels_trk_lm.hip", "kernels_ba.hip", "kernels_ba_lin.hip", "kernels_ba_gn.hip", "kernels_dense.hip", "kernels_imm.hip", "kernels_init.hip", "kernels_pixsel.hip", "host_io.cpp"]
 OUT = os.path.join(HERE, "libnalo_gpu.so")
 NO_CONTRACT = {"kernels_pyramid.hip", "kernels_imm.hip", "kernels_init.hip", "kernels_pixsel.hip"}   # a1 is bit-exact vs the reference's scalar fp32 code: no FMA contraction
 
@@ -12,7 +12,7 @@ NO_CONTRACT = {"kernels_pyramid.hip", "kernels_imm.hip", "kernels_init.hip", "ke
 def build(force=False, verbose=False):
     csrc = os.path.join(HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in SRC if os.path.exists(os.path.join(csrc, s))]
-    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "nalo_gpu.h")]
+    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "nalo_gpu.h"), os.path.join(HERE, "..", "include", "nalo_io.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     objs = []

@@ -10,8 +10,8 @@ from conftest import ROOT
 from nalo_slam_amd import binding
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "nalo_gpu.h")).read()
+def declared_symbols(header="nalo_gpu.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(nalo_[a-z0-9_]+)\s*\(", txt)) - {"nalo_allreduce_fn"})
 
@@ -26,6 +26,8 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(set(binding.EXPORTS)) == [s for s in syms if s in binding.EXPORTS]
     assert set(binding.EXPORTS) == set(syms)
+    io_syms = declared_symbols("nalo_io.h")
+    assert len(io_syms) == 5 and not [s for s in io_syms if not hasattr(lib, s)]
 
 
 def test_no_cpu_fallback():
