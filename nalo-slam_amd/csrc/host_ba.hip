@@ -21,6 +21,7 @@ void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
 int ba_launch_gn(hipStream_t s, const GNDev& G, int iteration, int never_break, double lambda);
 void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
+void ba_launch_set_th(hipStream_t s, float* dst, const float* th, int W);
 void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int step);
 
 struct HostFrame {
@@ -248,9 +249,8 @@ static int upload_frame_th(nalo_ctx* c) {
     if (w.points_set && w.dev.th_hist_hi) { int rc = flush_th(c); if (rc) return rc; }   // a pending quantile pass also clears its histogram
     std::vector<float> th(w.W);
     for (int i = 0; i < w.W; ++i) th[i] = w.frames[i].frameEnergyTH;
-    NALO_HIP(c, w.frameTH.reserve(w.W));
-    NALO_HIP(c, hipStreamSynchronize(c->stream));
-    NALO_HIP(c, hipMemcpy(w.frameTH.p, th.data(), w.W * 4, hipMemcpyHostToDevice));
+    NALO_HIP(c, w.frameTH.reserve(16));
+    ba_launch_set_th(c->stream, w.frameTH.p, th.data(), w.W);              // W <= 16 values as kernel arguments: stream ordered, nothing to wait for
     w.th_pending = false;
     w.dev.frameTH = w.frameTH.p;
     return NALO_OK;
@@ -325,7 +325,8 @@ static int sc_async(nalo_ctx* c, int shift, float margScale, int margOnly) {
     return NALO_OK;
 }
 // fp64 finish + stitch of whichever system is not stitched yet; then (optionally) the cross-rank sum and the D2H copy
-static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to_host = false) {
+// misc_only: the caller wants the per-bin {count, energy} and the threshold, not the systems: finish the partials, skip the stitch, publish the tail
+static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to_host = false, bool misc_only = false) {
     BAWindow& w = *c->ba;
     const int n1 = w.n1, NPL = w.NPL, W = w.W;
     const size_t blk = (size_t)n1 * n1;
@@ -348,9 +349,12 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
             ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.stitched.p + 2 * blk, w.G.p, top, sc,
                              w.step_sums_deferred ? w.step_partial.p : nullptr, (w.Ppad + 255) / 256, w.stitched.p + 2 * blk + 2 * W * W);
             w.step_sums_deferred = false;
-            if (ba_launch_stitch(c->stream, w.sd, top, sc, (w.hook || sep_publish) ? nullptr : dmap, npub - (int)(2 * blk), seq)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
-            if (top) w.stitched_top = true;
-            if (sc) w.stitched_sc = true;
+            if (misc_only) { if (!w.hook) ba_launch_publish(c->stream, w.stitched.p + 2 * blk, dmap + 2 * blk, npub - (int)(2 * blk), seq, w.st_ticket.p + 1); }
+            else {
+                if (ba_launch_stitch(c->stream, w.sd, top, sc, (w.hook || sep_publish) ? nullptr : dmap, npub - (int)(2 * blk), seq)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
+                if (top) w.stitched_top = true;
+                if (sc) w.stitched_sc = true;
+            }
             did = true;
         }
     }
@@ -360,12 +364,13 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
         if (w.hook) {
             // sharded window: tail = {step sums (3), frameEnergyTH of the newest frame, 1.0}. Every rank already holds the SAME threshold (the order
             // statistic over all ranks' residuals, linearize_async), so sum / count below re-installs that value; the tail keeps its layout.
+            const size_t off = misc_only ? 2 * blk : 0;               // misc_only: only the tail is summed and published
             if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
-            w.hook(w.hook_user, w.stitched.p, npub);
+            w.hook(w.hook_user, w.stitched.p + off, npub - (int)off);
             ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // more than one rank: the common threshold
-            ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq, w.st_ticket.p + 1);
+            ba_launch_publish(c->stream, w.stitched.p + off, dmap + off, npub - (int)off, seq, w.st_ticket.p + 1);
             NALO_HIP(c, hipGetLastError());
-        } else if (sep_publish) ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq, w.st_ticket.p + 1);
+        } else if (sep_publish && !misc_only) ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq, w.st_ticket.p + 1);
         { int rc = flush_th(c); if (rc) return rc; }                  // behind the publish: overlaps the host's solve
         if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
         if (w.step_pending) {                                   // finish doStepFromBackup's break test with the sums of the last step
@@ -820,7 +825,7 @@ static int optimize_epilogue(nalo_ctx* c, double* rmse) {
     int rc = set_adjoints(c); if (rc) return rc;
     rc = set_precalc(c); if (rc) return rc;
     rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
-    rc = stitch_and_fetch(c, true, false, true); if (rc) return rc;
+    rc = stitch_and_fetch(c, true, false, true, true); if (rc) return rc;  // energy, residual count and the threshold: no stitch
     nf.frameEnergyTH = tail_th(w);
     double e = 0; int nres = 0; misc_totals(w, &e, &nres);
     // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)

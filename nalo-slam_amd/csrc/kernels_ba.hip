@@ -307,6 +307,14 @@ void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorSc
     else ba_pt_acc_kernel<false><<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
     launch_sc_ks<1>(s, B, T, margOnly, shift, priorScaleMarg);
 }
+// frameEnergyTH of every window frame as kernel arguments: no staging buffer, no synchronisation (window setup / restore)
+struct ThArg { float v[16]; };
+__global__ void ba_set_th_kernel(float* __restrict__ dst, ThArg a, int W) { if ((int)threadIdx.x < W) dst[threadIdx.x] = a.v[threadIdx.x]; }
+void ba_launch_set_th(hipStream_t s, float* dst, const float* th, int W) {
+    ThArg a;
+    for (int i = 0; i < 16; ++i) a.v[i] = i < W ? th[i] : 0.f;
+    ba_set_th_kernel<<<1, 16, 0, s>>>(dst, a, W);
+}
 void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
     const size_t n = (size_t)B.W * B.Ppad;
     ba_reset_oob_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(B.rs_state, B.rs_energy, n);
