@@ -109,7 +109,48 @@ def main_imm():
     print("wrote golden_imm_r01.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "golden_imm_r01.npz")), "bytes")
 
 
+GOLDEN_PIXSEL = dict(w=320, h=224, W=2, P=20, seed=17, n_extra=0)
+
+
+def pixsel_inputs():
+    """frame (with a stripe patch: dy == 0 exactly), lidar-style mask, and the two libc streams the reference draws (stored: the fixture must not depend
+    on the libc of the machine that replays it)"""
+    win = synth.make_window(**GOLDEN_PIXSEL)
+    img = win.images[1].copy()
+    xs = np.arange(100, 220)
+    img[60:130, xs] = (100 + 60 * ((xs // 3) % 2)).astype(np.float32)[None, :]
+    h, w = img.shape
+    mask = np.zeros((h, w), np.float32)
+    mask[h // 3:, w // 5:] = np.random.RandomState(5).randint(0, 200, size=(h - h // 3, w - w // 5)).astype(np.float32)
+    return win, img, mask
+
+
+def main_pixsel():
+    """SURVEY 8(f) rank 3 (pixel selector): block thresholds, select at two potentials, makeMaps with adaptation + sub-selection, makeMaps_lidar."""
+    win, img, mask = pixsel_inputs()
+    h, w = img.shape
+    rp, draws = orc.pixsel_libc_tables(w * h)
+    dI, ab = orc.make_images(img, 3)
+    o1, o2 = w * h, w * h + (w // 2) * (h // 2)
+    imgs = (dI[:o1], ab[:o1], ab[o1:o2], ab[o2:])
+    out = {"randomPattern": rp, "draws_mod1000": (draws % 1000).astype(np.uint16)}     # FusedWithMask only uses rand() % 1000
+    out["ths"], out["thsSmoothed"] = orc.pixsel_make_hists(imgs[1], w, h)
+    for pot in (3, 6):
+        m, n = orc.pixsel_select(*imgs, w, h, out["thsSmoothed"], rp, pot, 1.0)
+        out["select%d_idx" % pot] = np.flatnonzero(m).astype(np.int32); out["select%d_status" % pot] = m.reshape(-1)[np.flatnonzero(m)].astype(np.uint8); out["select%d_n" % pot] = n
+    m, num, pot = orc.pixsel_make_maps(*imgs, w, h, rp, 600.0, 3, 1, 1.0)
+    out["maps_idx"] = np.flatnonzero(m).astype(np.int32); out["maps_status"] = m.reshape(-1)[np.flatnonzero(m)].astype(np.uint8); out["maps_num_pot"] = np.array([num, pot], np.int32)
+    m, num = orc.pixsel_make_maps_lidar(*imgs, w, h, rp, mask, draws, 3, 1.0)
+    out["lidar_idx"] = np.flatnonzero(m).astype(np.int32); out["lidar_status"] = m.reshape(-1)[np.flatnonzero(m)].astype(np.uint8); out["lidar_num"] = np.array([num], np.int32)
+    np.savez_compressed(os.path.join(HERE, "golden_pixsel_r01.npz"), **out)
+    print("wrote golden_pixsel_r01.npz with", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "golden_pixsel_r01.npz")), "bytes")
+
+
 if __name__ == "__main__":
+    if "--pixsel-only" in sys.argv:
+        main_pixsel()
+        sys.exit(0)
     if "--imm-only" not in sys.argv:
         main()
     main_imm()
+    main_pixsel()
