@@ -498,6 +498,17 @@ def imm_leg(per_host=1500, rounds=5, cpu=True):
         g = c.imm_trace(W, uf, vf, color, weights, gradH, eth, host, KRKi, Kt, aff, *st0)
     t_call = (time.perf_counter() - t0) / rounds
     ms, nl = c.profile_get("imm_trace")
+    # device-resident form: the set is uploaded once, every frame only sends its 14 floats per host and nothing is waited for
+    c.imm_resident_set(uf, vf, color, weights, gradH, eth, host, *st0)
+    c.imm_resident_trace(W, KRKi, Kt, aff); c.sync()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        c.imm_resident_trace(W, KRKi, Kt, aff)
+    c.sync()
+    t_res = (time.perf_counter() - t0) / rounds
+    t0 = time.perf_counter()
+    c.imm_resident_get()
+    t_get = time.perf_counter() - t0
     idt = true_idepth(win, u, v, host)
     c.ba_set_window(list(range(W)), win.world_to_cam[:W])
     c.imm_optimize(host, uf, vf, color, weights, eth, idt * 0.9, idt * 1.1, 1)
@@ -510,6 +521,7 @@ def imm_leg(per_host=1500, rounds=5, cpu=True):
     c.close()
     res = {"points": n, "hosts": W, "image": "%dx%d" % (win.w, win.h),
            "trace_kernel_us": round(ms / max(nl, 1) * 1e3, 1), "trace_call_us": round(t_call * 1e6, 1), "trace_Mpoints_per_s_kernel": round(n / (ms / max(nl, 1) * 1e-3) / 1e6, 2),
+           "trace_resident_us_per_frame": round(t_res * 1e6, 1), "resident_get_us": round(t_get * 1e6, 1),
            "trace_status_counts": np.bincount(g[2], minlength=6).tolist(),
            "optimize_kernel_us": round(ms2 / max(nl2, 1) * 1e3, 1), "optimize_call_us": round(t_opt * 1e6, 1), "activated": int((ro[0] == 1).sum())}
     if cpu:

@@ -257,6 +257,15 @@ int nalo_imm_create(nalo_ctx* ctx, int slot_host, int n, const int* u, const int
 int nalo_imm_trace(nalo_ctx* ctx, int slot_new, int n, const float* u, const float* v, const float* color, const float* weights, const float* gradH,
                    const float* energyTH, const int* host_idx, int nh, const float* KRKi, const float* Kt, const float* aff,
                    float* idepth_min, float* idepth_max, int* status, float* quality, float* lastTraceUV, float* lastTracePixelInterval);
+/* Device-resident form of the tracing state (what a running system uses: ImmaturePoints live across frames, traceNewCoarse touches all of them on
+ * every frame, the host only looks at them when it activates points). nalo_imm_resident_set uploads the whole set (after makeNewTraces / activation,
+ * once per keyframe; lastTraceUV = (-1,-1), lastTracePixelInterval = 0 as the constructor leaves them), nalo_imm_resident_trace = traceNewCoarse for one
+ * new frame: only the nh x {KRKi, Kt, aff} cross PCIe, the call returns without waiting; nalo_imm_resident_get brings the state back (sync inside;
+ * lastTraceUV / lastTracePixelInterval may be NULL). Arrays as in nalo_imm_trace. */
+int nalo_imm_resident_set(nalo_ctx* ctx, int n, const float* u, const float* v, const float* color, const float* weights, const float* gradH, const float* energyTH,
+                          const int* host_idx, const float* idepth_min, const float* idepth_max, const int* status, const float* quality);
+int nalo_imm_resident_trace(nalo_ctx* ctx, int slot_new, int nh, const float* KRKi, const float* Kt, const float* aff);
+int nalo_imm_resident_get(nalo_ctx* ctx, float* idepth_min, float* idepth_max, int* status, float* quality, float* lastTraceUV, float* lastTracePixelInterval);
 int nalo_imm_optimize(nalo_ctx* ctx, int n, const int* host, const float* u, const float* v, const float* color, const float* weights,
                       const float* energyTH, const float* idepth_min, const float* idepth_max, int minObs,
                       int* result, float* idepth_out, uint8_t* res_in);

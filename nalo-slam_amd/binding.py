@@ -32,7 +32,7 @@ EXPORTS = [
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_ba_snapshot", "nalo_ba_restore",
-    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
+    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get",
 ]
@@ -107,6 +107,9 @@ def load():
     L.nalo_dist_make_map.argtypes = [vp, C.c_int, c_fp, c_fp, c_fp]
     L.nalo_imm_create.argtypes = [vp, C.c_int, C.c_int, c_ip, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.nalo_imm_trace.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
+    L.nalo_imm_resident_set.argtypes = [vp, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_fp, c_ip, c_fp]
+    L.nalo_imm_resident_trace.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp]
+    L.nalo_imm_resident_get.argtypes = [vp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
     L.nalo_imm_optimize.argtypes = [vp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_u8p]
     L.nalo_ba_restore.argtypes = [vp]
     L.nalo_dense_make_map.argtypes = [vp, C.c_int, c_fp, C.c_float, c_dp, C.c_int, c_ip, c_ip, c_ip, c_fp, c_fp, c_u8p, c_ip, c_ip]
@@ -424,6 +427,24 @@ class Context:
         k = [f(x) for x in (KRKi, Kt, aff)]
         self._ck(self.L.nalo_imm_trace(self.h_, slot_new, n, *[_f(x) for x in a], _i(hi), len(k[0].reshape(-1, 9)), *[_f(x) for x in k],
                                        _f(idmin), _f(idmax), _i(status), _f(quality), _f(uv), _f(li)))
+        return idmin, idmax, status, quality, uv, li
+
+    def imm_resident_set(self, u, v, color, weights, gradH, energyTH, host_idx, idmin, idmax, status, quality):
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        a = [f(x) for x in (u, v, color, weights, gradH, energyTH)]
+        self._imm_n = len(a[0])
+        self._ck(self.L.nalo_imm_resident_set(self.h_, self._imm_n, *[_f(x) for x in a], _i(np.ascontiguousarray(host_idx, np.int32)), _f(f(idmin)), _f(f(idmax)),
+                                              _i(np.ascontiguousarray(status, np.int32)), _f(f(quality))))
+
+    def imm_resident_trace(self, slot_new, KRKi, Kt, aff):
+        k = [np.ascontiguousarray(x, np.float32) for x in (KRKi, Kt, aff)]
+        self._ck(self.L.nalo_imm_resident_trace(self.h_, slot_new, len(k[0].reshape(-1, 9)), *[_f(x) for x in k]))
+
+    def imm_resident_get(self):
+        n = self._imm_n
+        idmin, idmax, quality, li = [np.zeros(n, np.float32) for _ in range(4)]
+        status, uv = np.zeros(n, np.int32), np.zeros((n, 2), np.float32)
+        self._ck(self.L.nalo_imm_resident_get(self.h_, _f(idmin), _f(idmax), _i(status), _f(quality), _f(uv), _f(li)))
         return idmin, idmax, status, quality, uv, li
 
     def imm_optimize(self, host, u, v, color, weights, energyTH, idmin, idmax, min_obs):

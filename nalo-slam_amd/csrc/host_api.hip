@@ -71,7 +71,7 @@ void nalo_destroy(nalo_ctx* c) {
     if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
     if (c->pinned_f) (void)hipHostFree(c->pinned_f);
     if (c->imm_host) (void)hipHostFree(c->imm_host);
-    c->imm_dev.release();
+    c->imm_dev.release(); c->imm_res.release();
     for (auto& kv : c->prof) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
@@ -384,6 +384,60 @@ int nalo_imm_trace(nalo_ctx* c, int slot_new, int n, const float* u, const float
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(idepth_min, hst + 23 * N, N * 4); std::memcpy(idepth_max, hst + 24 * N, N * 4); std::memcpy(status, hst + 25 * N, N * 4); std::memcpy(quality, hst + 26 * N, N * 4);
     std::memcpy(lastTraceUV, hst + 27 * N, 2 * N * 4); std::memcpy(lastTracePixelInterval, hst + 29 * N, N * 4);
+    return NALO_OK;
+}
+
+// Device-resident immature points: the set is uploaded when it changes (makeNewTraces / activation, once per keyframe), every new frame then only sends
+// its 14 floats per host frame and the trace updates the state in place; the state comes back when the host wants it (activatePointsMT).
+int nalo_imm_resident_set(nalo_ctx* c, int n, const float* u, const float* v, const float* color, const float* weights, const float* gradH, const float* energyTH,
+                          const int* host_idx, const float* idepth_min, const float* idepth_max, const int* status, const float* quality) {
+    if (!c || n < 0 || (n > 0 && (!u || !v || !color || !weights || !gradH || !energyTH || !host_idx || !idepth_min || !idepth_max || !status || !quality)))
+        return fail(c, NALO_ERR_ARG, "nalo_imm_resident_set: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    c->imm_res_n = n; c->imm_res_maxhost = -1;
+    if (n == 0) return NALO_OK;
+    const size_t N = (size_t)n;
+    int rc = imm_stage(c, 30 * N); if (rc) return rc;
+    NALO_HIP(c, c->imm_res.reserve(30 * N + 256));
+    float* hst = c->imm_host;
+    for (int i = 0; i < n; ++i) { if (host_idx[i] < 0) return fail(c, NALO_ERR_ARG, "nalo_imm_resident_set: negative host_idx"); c->imm_res_maxhost = std::max(c->imm_res_maxhost, host_idx[i]); }
+    std::memcpy(hst, u, N * 4); std::memcpy(hst + N, v, N * 4); std::memcpy(hst + 2 * N, color, 8 * N * 4); std::memcpy(hst + 10 * N, weights, 8 * N * 4);
+    std::memcpy(hst + 18 * N, gradH, 3 * N * 4); std::memcpy(hst + 21 * N, energyTH, N * 4); std::memcpy(hst + 22 * N, host_idx, N * 4);
+    std::memcpy(hst + 23 * N, idepth_min, N * 4); std::memcpy(hst + 24 * N, idepth_max, N * 4); std::memcpy(hst + 25 * N, status, N * 4); std::memcpy(hst + 26 * N, quality, N * 4);
+    for (size_t i = 0; i < 2 * N; ++i) hst[27 * N + i] = -1.f;                // ImmaturePoint ctor: lastTraceUV = (-1,-1), lastTracePixelInterval = 0
+    std::memset(hst + 29 * N, 0, N * 4);
+    NALO_HIP(c, hipMemcpyAsync(c->imm_res.p, hst, 30 * N * 4, hipMemcpyHostToDevice, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));                             // the staging buffer is shared with the other immature-point calls
+    return NALO_OK;
+}
+int nalo_imm_resident_trace(nalo_ctx* c, int slot_new, int nh, const float* KRKi, const float* Kt, const float* aff) {
+    if (!c || nh < 1 || nh > 16 || !KRKi || !Kt || !aff) return fail(c, NALO_ERR_ARG, "nalo_imm_resident_trace: bad argument");
+    if (slot_new < 0 || slot_new >= (int)c->slots.size() || !c->slots[slot_new].valid) return fail(c, NALO_ERR_STATE, "nalo_imm_resident_trace: frame slot has no pyramid");
+    if (c->imm_res_n == 0) return NALO_OK;
+    if (c->imm_res_maxhost >= nh) return fail(c, NALO_ERR_ARG, "nalo_imm_resident_trace: a resident point's host_idx is out of range");
+    NALO_HIP(c, hipSetDevice(c->device));
+    HostTimer ht(c, "imm_resident_trace");
+    const size_t N = (size_t)c->imm_res_n, H = (size_t)nh;
+    float hk[224];
+    std::memcpy(hk, KRKi, 9 * H * 4); std::memcpy(hk + 9 * H, Kt, 3 * H * 4); std::memcpy(hk + 12 * H, aff, 2 * H * 4);
+    float* d = c->imm_res.p;
+    int rc = imm_put_launch(c, d + 30 * N, hk, (int)(14 * H)); if (rc) return rc;
+    return imm_trace_launch(c, c->slots[slot_new].dI[0], c->imm_res_n, d, (const int*)(d + 22 * N), d + 30 * N, d + 30 * N + 9 * H, d + 30 * N + 12 * H,
+                            d + 23 * N, d + 24 * N, (int*)(d + 25 * N), d + 26 * N, d + 27 * N, d + 29 * N);
+}
+int nalo_imm_resident_get(nalo_ctx* c, float* idepth_min, float* idepth_max, int* status, float* quality, float* lastTraceUV, float* lastTracePixelInterval) {
+    if (!c) return NALO_ERR_ARG;
+    if (c->imm_res_n == 0) return NALO_OK;
+    if (!idepth_min || !idepth_max || !status || !quality) return fail(c, NALO_ERR_ARG, "nalo_imm_resident_get: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    const size_t N = (size_t)c->imm_res_n;
+    int rc = imm_stage(c, 7 * N); if (rc) return rc;
+    float* hst = c->imm_host;
+    NALO_HIP(c, hipMemcpyAsync(hst, c->imm_res.p + 23 * N, 7 * N * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(idepth_min, hst, N * 4); std::memcpy(idepth_max, hst + N, N * 4); std::memcpy(status, hst + 2 * N, N * 4); std::memcpy(quality, hst + 3 * N, N * 4);
+    if (lastTraceUV) std::memcpy(lastTraceUV, hst + 4 * N, 2 * N * 4);
+    if (lastTracePixelInterval) std::memcpy(lastTracePixelInterval, hst + 6 * N, N * 4);
     return NALO_OK;
 }
 

@@ -706,6 +706,18 @@ int pixsel_hists_launch(nalo_ctx* c, const float* absg0, float* ths, float* thsS
     return NALO_OK;
 }
 
+// a few hundred floats as kernel arguments -> device memory: stream ordered, no staging buffer to protect (per-frame KRKi / Kt / aff of the resident trace)
+struct ImmPutArg { float v[224]; };
+__global__ void imm_put_kernel(float* __restrict__ dst, ImmPutArg a, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = a.v[threadIdx.x]; }
+int imm_put_launch(nalo_ctx* c, float* dst, const float* src, int n) {
+    if (n > 224) return fail(c, NALO_ERR_ARG, "imm_put_launch: more than 224 floats");
+    ImmPutArg a;
+    std::memcpy(a.v, src, (size_t)n * 4);
+    imm_put_kernel<<<1, 256, 0, c->stream>>>(dst, a, n);
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- launchers
 int imm_stage(nalo_ctx* c, size_t words) {
     if (c->imm_cap >= words) return NALO_OK;

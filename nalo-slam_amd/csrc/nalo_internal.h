@@ -80,6 +80,7 @@ struct nalo_ctx {
     nalo::DevBuf<float> upload_tmp;
     float* pinned_f = nullptr; size_t pinned_f_cap = 0;
     float* imm_host = nullptr; nalo::DevBuf<float> imm_dev; size_t imm_cap = 0;   // immature-point staging (pinned / device)
+    nalo::DevBuf<float> imm_res; int imm_res_n = 0, imm_res_maxhost = -1;         // device-resident immature points (nalo_imm_resident_*)
 
     // ---- BA (opaque; defined in host_ba.cpp)
     nalo::BAWindow* ba = nullptr;
@@ -149,6 +150,7 @@ void pixsel_destroy(nalo_ctx* c);
 void pixsel_invalidate_hists(nalo_ctx* c, int slot);
 // staging for the immature-point entry points: pinned host block + device block of `floats` 4-byte words (grown on demand)
 int imm_stage(nalo_ctx* c, size_t words);
+int imm_put_launch(nalo_ctx* c, float* dst, const float* src, int n);
 // kernels_init.hip
 int init_calc_launch(nalo_ctx* c, const float4* colorRef, const float4* colorNew, int lvl, int n, const float K4[4], const float RKi[9], const float t[3], float r2new0, float r2new1,
                      float alphaOpt, float couplingWeight, const float* base, float* outw, double* sums91);

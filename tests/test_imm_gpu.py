@@ -72,6 +72,33 @@ def test_trace_bit_exact_and_brackets_truth(scene):
     assert {0, 1, 2, 3}.issubset(seen)                       # GOOD, OOB, OUTLIER and SKIPPED all occur (BADCONDITION is rare)
 
 
+def test_resident_trace_equals_staged_trace(scene):
+    """the device-resident form (set once, trace per frame without moving the points, get when needed) = three staged calls, bit for bit"""
+    win, c, dI = scene
+    W = win.W
+    u, v, host = imm_points(win, per_host=700, seed=6)
+    n = len(u)
+    color, weights, gradH, eth = [np.zeros((n, k), np.float32) for k in (8, 8, 3)] + [np.zeros(n, np.float32)]
+    for h in range(W):
+        m = host == h
+        color[m], weights[m], gradH[m], eth[m] = c.imm_create(h, u[m], v[m])
+    uf, vf = u.astype(np.float32), v.astype(np.float32)
+    st = [np.zeros(n, np.float32), np.full(n, np.nan, np.float32), np.full(n, 5, np.int32), np.full(n, 10000, np.float32)]
+    c.imm_resident_set(uf, vf, color, weights, gradH, eth, host, *st)
+    uv, li = np.full((n, 2), -1, np.float32), np.zeros(n, np.float32)
+    for new in (W, W + 1, W):
+        KRKi, Kt, aff = host_to_new(win, new)
+        c.imm_resident_trace(new, KRKi, Kt, aff)                                  # returns without waiting
+        g = c.imm_trace(new, uf, vf, color, weights, gradH, eth, host, KRKi, Kt, aff, *st)
+        touched = st[2] != 1                                                        # points that ENTER as OOB return before writing: they keep their values
+        uv[touched], li[touched] = g[4][touched], g[5][touched]
+        st = list(g[:4])
+    r = c.imm_resident_get()
+    for a, b in zip(r[:4], st):
+        assert eq(a, b)
+    assert eq(r[4], uv) and eq(r[5], li)
+
+
 def test_optimize_bit_exact_and_recovers_truth(scene):
     win, c, dI = scene
     W = win.W
