@@ -791,36 +791,54 @@ void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partia
 // matching entries -> find-lo + the threshold formula (:130-133). Runs on the side stream, overlapped with SC/reduce/stitch.
 __global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new, const int* __restrict__ stop) {
     if (stop && stop[0]) return;
-    __shared__ unsigned wsum[16], wpre[17];
-    __shared__ unsigned s_sel, s_run;
+    // wave w owns bins [4096 w, 4096 (w+1)): 16 rounds of coalesced 16-byte loads (round i, lane l = bins 4096 w + 256 i + 4 l ..+3), everything stays in
+    // registers. The bin whose running count passes k is then located wave -> round -> lane -> bin with shuffles only.
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned s_bin, s_run;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned loc[64], sum = 0;
-    const uint4* h4 = reinterpret_cast<const uint4*>(hist + tid * 64);
+    uint4* h4 = reinterpret_cast<uint4*>(hist + wave * 4096) + lane;
+    uint4 q[16];
+    unsigned ls[16], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const uint4 q = h4[i]; loc[4 * i] = q.x; loc[4 * i + 1] = q.y; loc[4 * i + 2] = q.z; loc[4 * i + 3] = q.w; sum += q.x + q.y + q.z + q.w; }
-    // block-wide inclusive scan of the 1024 per-thread counts: shuffles inside a wave, then the 16 wave totals
-    unsigned v = sum;
+    for (int i = 0; i < 16; ++i) { q[i] = h4[i * 64]; ls[i] = q[i].x + q[i].y + q[i].z + q[i].w; sum += ls[i]; }
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const unsigned nb = __shfl_up(v, off); if (lane >= off) v += nb; }
-    if (lane == 63) wsum[wave] = v;
-    if (tid == 0) s_sel = 0xFFFFFFFFu;
+    for (int i = 0; i < 16; ++i) h4[i * 64] = make_uint4(0u, 0u, 0u, 0u);                // ready for the next pass
+    unsigned wtot = sum;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wtot += __shfl_xor(wtot, o);
+    if (lane == 0) wsum[wave] = wtot;
+    if (tid == 0) { s_bin = 65535u; s_run = 0xFFFFFFFFu; }
     __syncthreads();
-    if (tid == 0) { unsigned r = 0; for (int i = 0; i < 16; ++i) { wpre[i] = r; r += wsum[i]; } wpre[16] = r; }
-    __syncthreads();
-    const unsigned incl = v + wpre[wave], excl = incl - sum, total = wpre[16];
+    unsigned total = 0, wpre = 0;
+    for (int i = 0; i < 16; ++i) { if (i == wave) wpre = total; total += wsum[i]; }
     const unsigned k = (level == 0) ? (unsigned)(int)(0.7f * (float)total) : state[1];
-    if (excl <= k && k < incl) { s_sel = (unsigned)tid; s_run = excl; }          // the first thread whose running count passes k (unique)
-    __syncthreads();
-    if (tid == 0) {
-        if (level == 0) { state[0] = total; state[3] = total == 0 ? 1u : 0u; }
-        if (s_sel == 0xFFFFFFFFu) { s_sel = 1023u; s_run = total; }               // k beyond the last entry (empty histogram): last bin
+    if (wpre <= k && k < wpre + wtot) {                         // exactly one wave (none if k >= total: empty histogram)
+        unsigned run = wpre;
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            unsigned isum = ls[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) isum += __shfl_xor(isum, o);
+            if (!done && k < run + isum) {                      // wave-uniform: this round holds the bin
+                unsigned incl = ls[i];
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+                const unsigned lexcl = run + incl - ls[i];
+                if (lexcl <= k && k < lexcl + ls[i]) {
+                    unsigned r2 = lexcl; int bsel = 3;
+                    if (r2 + q[i].x > k) bsel = 0; else { r2 += q[i].x; if (r2 + q[i].y > k) bsel = 1; else { r2 += q[i].y; if (r2 + q[i].z > k) bsel = 2; else r2 += q[i].z; } }
+                    s_bin = (unsigned)(wave * 4096 + i * 256 + 4 * lane + bsel); s_run = r2;
+                }
+                done = true;
+            }
+            if (!done) run += isum;
+        }
     }
     __syncthreads();
-    if (tid == (int)s_sel) {
-        unsigned run = s_run; int bsel = 63;
-        for (int i = 0; i < 64; ++i) { if (run + loc[i] > k) { bsel = i; break; } run += loc[i]; }
-        const unsigned bin = (unsigned)(tid * 64 + bsel);
-        if (level == 0) { state[1] = k - run; state[2] = bin; }
+    if (tid == 0) {
+        const unsigned bin = s_bin, run = s_run == 0xFFFFFFFFu ? total : s_run;       // k beyond the last entry (empty histogram): last bin
+        if (level == 0) { state[0] = total; state[3] = total == 0 ? 1u : 0u; state[1] = k - run; state[2] = bin; }
         else {
             float th;
             if (state[3]) th = 12.f * 12.f * (float)kPatternNum;                        // no residual on the newest frame (:110-114)
@@ -833,9 +851,6 @@ __global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__
             *frameTH_new = th;
         }
     }
-    uint4* z4 = reinterpret_cast<uint4*>(hist + tid * 64);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) z4[i] = make_uint4(0u, 0u, 0u, 0u);                    // ready for the next pass
 }
 __global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo, const int* __restrict__ stop) {
     if (stop && stop[0]) return;
