@@ -463,8 +463,8 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     HostTimer h3(c, "ba.solve.host_math");
     // H = (HL + HM + HA) with the diagonal * (1+lambda), minus Hsc/(1+lambda); b = bL + (bM + HM delta) + bA - bsc   (:795-868), one pass
     // over the published systems; then the Jacobi-scaled LDL^T (:872-885). Scratch lives in the window: no allocation per iteration.
-    w.solve_scratch.resize((size_t)n * n + 4 * (size_t)n); w.solve_perm.resize(n);
-    double* HF = w.solve_scratch.data(); double* bF = HF + (size_t)n * n; double* sv = bF + n; double* yv = sv + n; double* delta = yv + n;
+    w.solve_scratch.resize((size_t)n * n + 5 * (size_t)n); w.solve_perm.resize(n);
+    double* HF = w.solve_scratch.data(); double* bF = HF + (size_t)n * n; double* sv = bF + n; double* yv = sv + n; double* delta = yv + 2 * n;
     std::vector<double>& x = w.lastX; x.resize(n);
     const double* HAp = w.stitched_host; const double* HSp = w.stitched_host + (size_t)n1 * n1;
     misc_totals(w, nullptr, &w.resInA);
@@ -487,8 +487,8 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     { HostTimer hl(c, "ba.solve.math.ldlt");
     for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * n + i] + 10);
     for (int i = 0; i < n; ++i) { double* hf = HF + (size_t)i * n; const double si = sv[i]; for (int j = 0; j < n; ++j) hf[j] = si * hf[j] * sv[j]; bF[i] *= si; }
-    // Eigen's LDLT (the reference, :880) reads the lower triangle only; H_sc carries fp32-rounding asymmetry (w*a_j*a_k vs w*a_k*a_j), so mirror
-    // the lower triangle before the full-storage factorisation
+    // Eigen's LDLT (the reference, :880) reads the lower triangle only; H_sc carries fp32-rounding asymmetry (w*a_j*a_k vs w*a_k*a_j), so the lower
+    // triangle is mirrored into the upper one the factorisation works on
     for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) HF[(size_t)i * n + j] = HF[(size_t)j * n + i];
     ldlt_solve_inplace(n, HF, bF, x.data(), yv, w.solve_perm.data());
     for (int i = 0; i < n; ++i) x[i] *= sv[i];
@@ -512,7 +512,11 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
         w.frames[h].step[8] = w.frames[h].step[9] = 0;
         for (int t = 0; t < W; ++t) {
             const float *AH = &w.adHostF[(size_t)(h + W * t) * 64], *AT = &w.adTargetF[(size_t)(h + W * t) * 64];
-            for (int j = 0; j < 8; ++j) { float s1 = 0, s2 = 0; for (int i = 0; i < 8; ++i) { s1 += xF[4 + 8 * h + i] * AH[i * 8 + j]; s2 += xF[4 + 8 * t + i] * AT[i * 8 + j]; } xAd[(size_t)(W * h + t) * 8 + j] = s1 + s2; }
+            // xAd = x_h^T adHost + x_t^T adTarget: rows of the adjoints are contiguous in j, so j is the inner (vector) loop; per entry the same
+            // i-ordered sums as the scalar form
+            float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 8; ++i) { const float xh = xF[4 + 8 * h + i], xt = xF[4 + 8 * t + i]; for (int j = 0; j < 8; ++j) { s1[j] += xh * AH[i * 8 + j]; s2[j] += xt * AT[i * 8 + j]; } }
+            for (int j = 0; j < 8; ++j) xAd[(size_t)(W * h + t) * 8 + j] = s1[j] + s2[j];
         }
     }
     NALO_HIP(c, w.xad.reserve((size_t)W * W * 8 + 64));
