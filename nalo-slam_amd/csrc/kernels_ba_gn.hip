@@ -92,7 +92,8 @@ __global__ __launch_bounds__(kGnThreads) void ba_gn_kernel(GNDev G, int iteratio
     __syncthreads();
     for (int e = tid; e < n * n; e += NT) { const int i = e / n, j = e - i * n; if (j > i) HF[e] = HF[(size_t)j * n + i]; }
     __syncthreads();
-    // ---- LDL^T with diagonal pivoting, the algorithm of host_math.h ldlt_solve_inplace (same update order: identical result)
+    // ---- LDL^T with diagonal pivoting (right-looking; the host's ldlt_solve_inplace is the left-looking form of the same factorisation: same pivots,
+    //      results equal to rounding)
     for (int k = 0; k < n; ++k) {
         if (tid < 64) {
             // pivot: largest |diagonal| of the trailing block, first one on ties
