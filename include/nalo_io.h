@@ -24,8 +24,8 @@ int nalo_io_write_result(const char* path, int n, const double* timestamp, const
 int nalo_io_write_pcd_points(const char* path, int append, int n, const float* u, const float* v, const float* idepth, const float calib_inv[4],
                              const double camToWorld[12]);
 
-/* camera.txt -- Undistort::getUndistorterForFile + Undistort::readFromFile (util/Undistort.cpp:690-933): line 1 `[Pinhole |RadTan |FOV |EquiDistant |
- * KannalaBrandt ]` + 5 (FOV, and the prefix-less legacy form) or 8 parameters, line 2 `wOrg hOrg`, line 3 `crop` | `full` | `none` | five floats,
+/* camera.txt -- Undistort::getUndistorterForFile (util/Undistort.cpp:266-370) + Undistort::readFromFile (:765-933): line 1 `[Pinhole |RadTan |FOV |EquiDistant |
+ * KannalaBrandt ]` + 5 (FOV, Pinhole) or 8 parameters; the prefix-less legacy forms are 8 values = RadTan, 5 values = FOV, or Pinhole when the 5th is 0; line 2 `wOrg hOrg`, line 3 `crop` | `full` | `none` | five floats,
  * line 4 `w h`. Relative calibrations (cx < 1 and cy < 1) are rescaled: fx*wOrg, fy*hOrg, cx*wOrg - 0.5, cy*hOrg - 0.5. */
 enum { NALO_CAM_PINHOLE = 0, NALO_CAM_RADTAN = 1, NALO_CAM_FOV = 2, NALO_CAM_EQUIDISTANT = 3, NALO_CAM_KANNALABRANDT = 4 };
 typedef struct {

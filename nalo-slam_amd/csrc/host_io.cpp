@@ -79,7 +79,7 @@ int nalo_io_read_camera(const char* path, nalo_camera_file* out) {
     std::string l1, l2, l3, l4;
     std::getline(in, l1); std::getline(in, l2); std::getline(in, l3); std::getline(in, l4);
     std::memset(out, 0, sizeof(*out));
-    // getUndistorterForFile (Undistort.cpp:690-763): the prefix picks the model; the prefix-less legacy forms are FOV (5 values) or RadTan (8)
+    // getUndistorterForFile (Undistort.cpp:266-370): the prefix picks the model; the prefix-less legacy forms are RadTan (8 values) or FOV / pinhole (5)
     static const struct { const char* prefix; int model, npars; } kForms[] = {
         {"RadTan ", NALO_CAM_RADTAN, 8}, {"EquiDistant ", NALO_CAM_EQUIDISTANT, 8}, {"KannalaBrandt ", NALO_CAM_KANNALABRANDT, 8},
         {"FOV ", NALO_CAM_FOV, 5},       {"Pinhole ", NALO_CAM_PINHOLE, 5},         {"", NALO_CAM_RADTAN, 8},                     {"", NALO_CAM_FOV, 5}};
@@ -89,8 +89,9 @@ int nalo_io_read_camera(const char* path, nalo_camera_file* out) {
         if (l1.compare(0, pl, fm.prefix) != 0) continue;
         double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int got = std::sscanf(l1.c_str() + pl, "%lf %lf %lf %lf %lf %lf %lf %lf", &p[0], &p[1], &p[2], &p[3], &p[4], &p[5], &p[6], &p[7]);
-        if (got < fm.npars || (pl == 0 && got != fm.npars && !(fm.npars == 8 && got > 8))) continue;
+        if (got < fm.npars) continue;                           // (prefix-less line with 5 values: sscanf stops at 5, the 8-value form is skipped)
         out->model = fm.model; out->n_pars = fm.npars;
+        if (pl == 0 && fm.npars == 5 && p[4] == 0) out->model = NALO_CAM_PINHOLE;      // legacy 5-value form: omega == 0 is a pinhole (Undistort.cpp:299-313)
         for (int i = 0; i < fm.npars; ++i) out->pars[i] = p[i];
         ok = true;
         break;

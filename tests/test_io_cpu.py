@@ -66,6 +66,8 @@ def test_camera_txt_forms(lib, tmp_path):
         "kitti": ("Pinhole 0.5812 1.9225 0.4964 0.4689 0\n1241 376\ncrop\n1224 368\n", (0, 5, -1, 1241, 376, 1224, 368)),
         "radtan": ("RadTan 458.654 457.296 367.215 248.375 -0.28340811 0.07395907 0.00019359 1.76187114e-05\n752 480\ncrop\n640 480\n", (1, 8, -1, 752, 480, 640, 480)),
         "fov_legacy": ("0.535719308086809 0.669566858850269 0.493248545285398 0.500408664348414 0.897966326944875\n1280 1024\n0.4 0.53 0.5 0.5 0\n640 480\n", (2, 5, 0, 1280, 1024, 640, 480)),
+        "pinhole_legacy": ("700.5 701.5 320.25 240.75 0\n640 480\ncrop\n640 480\n", (0, 5, -1, 640, 480, 640, 480)),
+        "radtan_legacy": ("458.654 457.296 367.215 248.375 -0.28 0.07 0.0002 1.7e-05\n752 480\ncrop\n640 480\n", (1, 8, -1, 752, 480, 640, 480)),
         "kb": ("KannalaBrandt 380.8 380.9 320.1 239.9 -0.01 0.02 -0.03 0.004\n640 480\nnone\n640 480\n", (4, 8, -3, 640, 480, 640, 480)),
         "equi": ("EquiDistant 190.9 190.9 254.9 256.8 0.003 0.0007 -0.002 0.0002\n512 512\nfull\n512 512\n", (3, 8, -2, 512, 512, 512, 512)),
     }
