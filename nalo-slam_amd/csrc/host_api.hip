@@ -73,6 +73,7 @@ void nalo_destroy(nalo_ctx* c) {
     if (c->imm_host) (void)hipHostFree(c->imm_host);
     c->imm_dev.release(); c->imm_res.release();
     for (auto& kv : c->prof) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
@@ -528,12 +529,17 @@ static void prof_drain(nalo_ctx* c) {
         for (auto& ev : kv.second.pending) {
             float ms = 0;
             if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { kv.second.ms += ms; kv.second.n++; }
-            (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second);
+            c->prof_pool.push_back(ev.first); c->prof_pool.push_back(ev.second);
         }
         kv.second.pending.clear();
     }
 }
-int nalo_profile_enable(nalo_ctx* c, int on) { if (!c) return NALO_ERR_ARG; c->prof_on = on != 0; return NALO_OK; }
+int nalo_profile_enable(nalo_ctx* c, int on) {
+    if (!c) return NALO_ERR_ARG;
+    c->prof_on = on != 0;
+    if (on) while (c->prof_pool.size() < 4096) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; c->prof_pool.push_back(e); }
+    return NALO_OK;
+}
 int nalo_profile_select(nalo_ctx* c, const char* kernel) { if (!c) return NALO_ERR_ARG; c->prof_only = kernel ? kernel : ""; return NALO_OK; }
 int nalo_profile_reset(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; prof_drain(c); c->prof.clear(); return NALO_OK; }
 int nalo_profile_get(nalo_ctx* c, const char* kernel, double* total_ms, int* launches) {

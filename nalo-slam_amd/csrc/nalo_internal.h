@@ -92,6 +92,7 @@ struct nalo_ctx {
     // ---- profiling
     bool prof_on = false;
     std::string prof_only;                   // empty = every scope; else only the scope of that name is bracketed
+    std::vector<hipEvent_t> prof_pool;       // idle events
     std::map<std::string, nalo::ProfEntry> prof;
 };
 
@@ -130,7 +131,11 @@ struct ProfScope {               // HIP-event bracket on the ctx stream (only wh
     // packets around the kernel (an event pair recorded on the stream costs ~10 us of bubbles per bracket on a latency-bound pipeline)
     nalo_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr; bool external;
     ProfScope(nalo_ctx* ctx, const char* n, bool ext = false) : c(ctx), name(n), external(ext) {
-        if (c->prof_on && (c->prof_only.empty() || c->prof_only == n)) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); if (!external) (void)hipEventRecord(a, c->stream); }
+        if (c->prof_on && (c->prof_only.empty() || c->prof_only == n)) {
+            // events come from a pool (filled by nalo_profile_enable, refilled as brackets are drained): no hipEventCreate on the measured path
+            for (hipEvent_t* e : {&a, &b}) { if (c->prof_pool.empty()) (void)hipEventCreate(e); else { *e = c->prof_pool.back(); c->prof_pool.pop_back(); } }
+            if (!external) (void)hipEventRecord(a, c->stream);
+        }
     }
     ~ProfScope() {
         if (a) { if (!external) (void)hipEventRecord(b, c->stream); c->prof[name].pending.emplace_back(a, b); }
