@@ -308,6 +308,19 @@ def main():
     if args.workload == "kitti00_8kf" and not args.no_extra:
         log("main leg done: %.1f keyframes/s; starting the shard1m leg" % value)
         job.ctx.close()
+        # The extra legs must never cost the main line: they run under a deadline (a collective that never completes on some fabric would otherwise
+        # hang every rank). On expiry rank 0 prints the line it has, marked, and every rank leaves.
+        import threading
+        deadline_s = float(os.environ.get("NALO_BENCH_EXTRA_DEADLINE", "420"))
+
+        def _expired():
+            if rank == 0:
+                out.setdefault("shard1m", {"error": "extra legs exceeded %.0f s" % deadline_s})
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(deadline_s, _expired)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             res = shard_leg(rank, world, local_rank, dist, torch, backend=args.backend)
         except Exception as e:                      # never lose the main line to the extra leg
@@ -339,6 +352,7 @@ def main():
                                            bound="hbm", achieved=sl["achieved_GBs"], peak=HBM_PEAK_GBS,
                                            unit="GB/s", frac=sl["frac"], traffic=load_traffic("stress250k"), avg_us=sl["avg_us"],
                                            launches=sl["launches"], alg_bytes=sl["alg_bytes"])
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
