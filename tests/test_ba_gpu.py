@@ -181,3 +181,17 @@ def test_window_sizes(W, P):
     st, ac, _, _, _ = c.ba_get_residuals()
     assert np.array_equal(st, st_o) and np.array_equal(ac, ac_o)
     c.close()
+
+
+def test_profile_select_brackets_one_scope(small_window):
+    """nalo_profile_select: only the named scope is timed (what bench.py's timed region relies on); NULL = every scope again"""
+    c = make_ctx(small_window)
+    c.profile_select("ba_linearize"); c.profile_enable(True); c.profile_reset()
+    c.ba_linearize(False); c.ba_accumulate_sc(True)
+    ms_l, n_l = c.profile_get("ba_linearize"); ms_s, n_s = c.profile_get("ba_sc")
+    assert n_l == 1 and 0 < ms_l < 5 and n_s == 0 and ms_s == 0
+    c.profile_select(None); c.profile_reset()
+    c.ba_linearize(False); c.ba_accumulate_sc(True)
+    assert c.profile_get("ba_linearize")[1] == 1 and c.profile_get("ba_sc")[1] == 1
+    c.profile_enable(False)
+    c.close()
