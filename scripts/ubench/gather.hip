@@ -1,6 +1,8 @@
 // Micro-benchmark for the texel-gather layout of ba_linearize: how fast can gfx950 serve 32 x 16-byte bilinear taps per residual
 //   A: one residual per lane, the 8 pattern pixels in a loop (the current kernel's layout)
 //   B: one pattern pixel per lane, 8 lanes per residual (neighbouring lanes touch neighbouring texels)
+//   C: one bilinear TAP per lane, 4 lanes per residual (lanes 0,1 = the two texels of row iy: 32 contiguous bytes; 2,3 = row iy+1), 8 pixels in a loop
+//   D: one (pattern pixel, tap) per lane, 32 lanes per residual: a residual is ONE load instruction of half a wave
 // Points are Morton-sorted inside each host frame, like the BA window. Prints microseconds per pass and effective TB/s of taps.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -39,6 +41,34 @@ __global__ __launch_bounds__(256) void gatherB(const float4* __restrict__ img, c
     acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
     if (k == 0) out[i] = acc;
 }
+__global__ __launch_bounds__(256) void gatherC(const float4* __restrict__ img, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 2, q = t & 3;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+        const int ix = (int)x, iy = (int)y;
+        const float4 a = img[ix + (q & 1) + (iy + (q >> 1)) * w];
+        acc += a.x + a.y;
+    }
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+    if (q == 0) out[i] = acc;
+}
+__global__ __launch_bounds__(256) void gatherD(const float4* __restrict__ img, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 5, k = (t >> 2) & 7, q = t & 3;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+    const int ix = (int)x, iy = (int)y;
+    const float4 a = img[ix + (q & 1) + (iy + (q >> 1)) * w];
+    float acc = a.x + a.y;
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 16);
+    if ((t & 31) == 0) out[i] = acc;
+}
 static uint32_t part1by1(uint32_t x) { x &= 0xffff; x = (x | (x << 8)) & 0x00FF00FF; x = (x | (x << 4)) & 0x0F0F0F0F; x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; }
 int main(int argc, char** argv) {
     const int w = 1920, h = 1072, W = 8, P = argc > 1 ? atoi(argv[1]) : 250000;
@@ -62,20 +92,22 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&duv, nmax * W * 8)); CK(hipMalloc(&dout, nmax * W * 4));
     for (int t = 0; t < W; ++t) CK(hipMemcpy(duv + t * nmax, per_target[t].data(), nmax * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 4; ++variant) {
         float best = 1e9;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
             for (int t = 0; t < W; ++t) {
                 const int n = (int)nmax;
                 if (variant == 0) gatherA<<<(n + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
-                else gatherB<<<(n * 8 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else if (variant == 1) gatherB<<<(n * 8 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else if (variant == 2) gatherC<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else gatherD<<<(unsigned)(((size_t)n * 32 + 255) / 256), 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
         }
         const double taps = (double)nmax * W * 32;
-        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", variant ? 'B' : 'A', nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
+        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", "ABCD"[variant], nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
     }
     return 0;
 }
