@@ -60,3 +60,30 @@ def test_sharded_systems_sum_to_the_window_system():
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert ret["err_HA"] < 1e-12 and ret["err_all"] < 1e-12      # fp64 sums of disjoint point sets: only rounding order differs
     assert ret["count"][0] == ret["count"][1] and ret["shard_sizes"] == 48
+
+
+def test_sharded_threshold_rule_is_the_global_order_statistic():
+    """setNewFrameEnergyTH on a sharded window: the two radix histograms of the float bit patterns are SUMMED across ranks before their
+    searches. Pure arithmetic check of that rule in numpy: summed 16+16-bit histograms select exactly the n-th element (nthIdx = (int)(0.7f * n),
+    FullSystemOptimize.cpp:117-122) of the concatenated energies, whatever the split - which the mean of per-shard quantiles does not."""
+    rng = np.random.RandomState(0)
+    e = np.abs(rng.standard_cauchy(50000)).astype(np.float32) * 40.0            # heavy-tailed, like residual energies
+    e[rng.rand(len(e)) < 0.01] = 0.0
+    es = np.sort(e)
+    rest = rng.permutation(es[len(es) // 5:])
+    shards = [es[: len(es) // 5]] + np.array_split(rest, 2)                     # very unequal shards: one rank holds only the small energies
+    allv = np.concatenate(shards)
+    k = int(np.float32(0.7) * np.float32(len(allv)))
+    want = np.sort(allv)[k]
+
+    bits = [s.view(np.uint32) for s in shards]
+    hi = sum(np.bincount(b >> 16, minlength=65536) for b in bits)               # the first all-reduce
+    cum = np.cumsum(hi)
+    bin_hi = int(np.searchsorted(cum, k, side="right"))
+    k_lo = k - (cum[bin_hi - 1] if bin_hi else 0)
+    lo = sum(np.bincount(b[(b >> 16) == bin_hi] & 0xFFFF, minlength=65536) for b in bits)     # the second all-reduce
+    bin_lo = int(np.searchsorted(np.cumsum(lo), k_lo, side="right"))
+    got = np.array([(bin_hi << 16) | bin_lo], np.uint32).view(np.float32)[0]
+    assert got == want
+    mean_of_quantiles = np.mean([np.sort(s)[int(np.float32(0.7) * np.float32(len(s)))] for s in shards])
+    assert abs(mean_of_quantiles - want) > 0.05 * want                            # the shortcut this replaces is visibly off on unequal shards
