@@ -7,15 +7,15 @@ def mean_counter(tag, ctr, kernel):
     vals = []
     for f in glob.glob(f"gpurun_out/{tag}/{ctr}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+            if kernel in r["Kernel_Name"] and "<0, 0>" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
                 vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 out_path = "profiles/traffic_r01.json"
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for tag, wl in [a.split(":") for a in sys.argv[1:]]:
-    f, nf = mean_counter(tag, "FETCH_SIZE", "ba_linearize_kernel<0, 0>")
-    w, nw = mean_counter(tag, "WRITE_SIZE", "ba_linearize_kernel<0, 0>")
+    f, nf = mean_counter(tag, "FETCH_SIZE", "ba_linearize")
+    w, nw = mean_counter(tag, "WRITE_SIZE", "ba_linearize")
     if f is None or w is None:
         print("no counters for", tag); continue
     out[wl] = int((2 * f + w) * 1024)
