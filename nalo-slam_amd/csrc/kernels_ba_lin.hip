@@ -272,7 +272,7 @@ __global__ __launch_bounds__(kBlk, NALO_LIN_WAVES) void ba_linearize_kernel(BADe
 }
 
 #ifndef NALO_LIN_COOP_NPB
-#define NALO_LIN_COOP_NPB 2
+#define NALO_LIN_COOP_NPB 3      // pattern pixels per batch: 3+3+2 (12 loads in flight per lane, 158 VGPRs) measured best: 198 us on stress250k; 2: 202, 4: 226 (spills)
 #endif
 #ifndef NALO_LIN_COOP_WAVES
 #define NALO_LIN_COOP_WAVES 3      // 4 fits (126 VGPRs, 24.5 KB of LDS) but measures slower: 215 vs 203 us on stress250k
@@ -470,7 +470,22 @@ __global__ __launch_bounds__(kBlk, NALO_LIN_COOP_WAVES) void ba_linearize_coop_k
             exchange(d0_, d1_, d2_, d3_, Kus[k3], Kvs[k3], h3I, h3X, h3Y);
             if (need) { pixel(h0I, h0X, h0Y, color[k0], wgt[k0]); pixel(h1I, h1X, h1Y, color[k1], wgt[k1]); pixel(h2I, h2X, h2Y, color[k2], wgt[k2]); pixel(h3I, h3X, h3Y, color[k3], wgt[k3]); }
         };
-#if NALO_LIN_COOP_NPB == 4
+#if NALO_LIN_COOP_NPB == 3
+        // 3 + 3 + 2 pattern pixels: 12 loads in flight per lane
+        auto batch3 = [&](auto FIRST) __attribute__((always_inline)) {
+            constexpr int k0 = decltype(FIRST)::value, k1 = k0 + 1, k2 = k0 + 2;
+            const int o0 = need ? ((int)Kus[k0] + (int)Kvs[k0] * B.w) : 0, o1 = need ? ((int)Kus[k1] + (int)Kvs[k1] * B.w) : 0, o2 = need ? ((int)Kus[k2] + (int)Kvs[k2] * B.w) : 0;
+            const float4 a0 = img[lin_quad_bcast<0>(o0) + tapoff], a1 = img[lin_quad_bcast<1>(o0) + tapoff], a2 = img[lin_quad_bcast<2>(o0) + tapoff], a3 = img[lin_quad_bcast<3>(o0) + tapoff];
+            const float4 b0_ = img[lin_quad_bcast<0>(o1) + tapoff], b1_ = img[lin_quad_bcast<1>(o1) + tapoff], b2_ = img[lin_quad_bcast<2>(o1) + tapoff], b3_ = img[lin_quad_bcast<3>(o1) + tapoff];
+            const float4 c0_ = img[lin_quad_bcast<0>(o2) + tapoff], c1_ = img[lin_quad_bcast<1>(o2) + tapoff], c2_ = img[lin_quad_bcast<2>(o2) + tapoff], c3_ = img[lin_quad_bcast<3>(o2) + tapoff];
+            float h0I, h0X, h0Y, h1I, h1X, h1Y, h2I, h2X, h2Y;
+            exchange(a0, a1, a2, a3, Kus[k0], Kvs[k0], h0I, h0X, h0Y);
+            exchange(b0_, b1_, b2_, b3_, Kus[k1], Kvs[k1], h1I, h1X, h1Y);
+            exchange(c0_, c1_, c2_, c3_, Kus[k2], Kvs[k2], h2I, h2X, h2Y);
+            if (need) { pixel(h0I, h0X, h0Y, color[k0], wgt[k0]); pixel(h1I, h1X, h1Y, color[k1], wgt[k1]); pixel(h2I, h2X, h2Y, color[k2], wgt[k2]); }
+        };
+        batch3(std::integral_constant<int, 0>{}); batch3(std::integral_constant<int, 3>{}); batch(std::integral_constant<int, 3>{});
+#elif NALO_LIN_COOP_NPB == 4
         batch4(std::integral_constant<int, 0>{}); batch4(std::integral_constant<int, 1>{});
 #else
         batch(std::integral_constant<int, 0>{}); batch(std::integral_constant<int, 1>{}); batch(std::integral_constant<int, 2>{}); batch(std::integral_constant<int, 3>{});
