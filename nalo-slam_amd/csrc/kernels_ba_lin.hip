@@ -1,4 +1,5 @@
-// ba_linearize_kernel — a5+a6+a7 (+a13 in MODE 2) for gfx950, second layout.
+// ba_linearize_kernel / ba_linearize_coop_kernel — a5+a6+a7 (+a13 in MODE 2) for gfx950. The two kernels share every formula; the second (default)
+// fetches the 32 texels of a residual with its quad so that neighbouring lanes read neighbouring texels (see its phase B).
 //
 //   PointFrameResidual::linearize + applyRes + EFResidual::takeDataF   (reference src/FullSystem/Residuals.cpp:78-274,306-328;
 //                                                                       src/OptimizationBackend/EnergyFunctionalStructs.cpp:39-50)
