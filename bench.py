@@ -113,6 +113,18 @@ class GpuJob:
         # constant-velocity style initial guess: 95% of the true motion (prepared once: host-side numpy is not part of the measured path)
         self.T_init = [synth_exp(orc_free_log(T) * 0.95) for T in self.T0]
         self.evals = 0
+        self.last_T = [None] * TRACKED_PER_KF                           # tracked poses of the last step (pose_delta_vs_oracle)
+        self._pinned = None
+
+    def enable_uploads(self):
+        """page-locked copies of the tracked frames: step(upload=True) then pays the per-frame PCIe copy through nalo_frame_upload_async (what a running
+        system does per frame, FullSystem.cpp:1053-1065) instead of rebuilding the pyramid from HBM-resident irradiance"""
+        W = self.win.W
+        self._pinned = []
+        for k in range(TRACKED_PER_KF):
+            a = self.ctx.pinned_array((self.win.h, self.win.w))
+            a[:] = self.win.images[W + k]
+            self._pinned.append(a)
 
     def _prepare_calls(self):
         """ctypes arguments of the per-keyframe calls, built once: the timed loop then goes straight to the C ABI (same entry points, same
@@ -128,17 +140,23 @@ class GpuJob:
         self._ref = [np.ascontiguousarray(x, np.float32) for x in self.trk]
         self._ref_args = tuple(x.ctypes.data_as(fp) for x in self._ref)
 
-    def step(self, track=True):
+    def step(self, track=True, upload=False, keep=False):
         c, W, L = self.ctx, self.win.W, self.ctx.L
         if not hasattr(self, "_trk_args"):
             self._prepare_calls()
         c.ba_restore()
         if track:
+            if upload:                                                       # all three copies go to the copy stream at once: the first one is exposed,
+                for k in range(TRACKED_PER_KF):                              # the others run under the tracking of the frame before
+                    c.frame_upload_async(W + k, self._pinned[k])
             for k in range(TRACKED_PER_KF):
-                c.frame_rebuild(W + k)                                       # a1 on the HBM-resident frame
+                if not upload:
+                    c.frame_rebuild(W + k)                                   # a1 on the HBM-resident frame
                 self._T[:] = self._T0[k]; self._aff[:] = 0
                 c._ck(L.nalo_trk_track(c.h_, W + k, *self._trk_args, c.levels - 1, *self._trk_tail))
                 self.evals += self._ne.value
+                if keep:
+                    self.last_T[k] = self._T.reshape(3, 4).copy()
             c._ck(L.nalo_trk_set_ref(c.h_, W - 1, len(self._ref[0]), *self._ref_args))   # a2 for the new keyframe
         return c.ba_optimize(6, never_break=True)
 
@@ -166,7 +184,61 @@ def orc_free_log(T):
     return np.concatenate([Vi @ t, w])
 
 
-def cpu_baseline(win, st6, trk, budget_s=20.0, track=True):
+def cpu_info():
+    """model name, physical cores (unique physical id / core id pairs), logical CPUs and the CPUs this process may run on"""
+    model, cores = None, set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count()
+    return dict(model=model, physical_cores=len(cores) or None, logical_cpus=os.cpu_count(), usable_cpus=aff)
+
+
+def pose_delta_vs_oracle(job, win, st6, trk):
+    """The second half of BASELINE.json's metric: the SAME keyframe (3 tracked frames + optimize(6)) on the strict fp32 oracle (pointwise fp32 in the
+    reference's order, no FMA contraction, fp64 sums), compared with what the GPU step produced: max |log(T_gpu T_oracle^-1)| over the window's frames
+    and over the tracked frames. Oracle = checker only."""
+    import orc
+    W = win.W
+    job.step(True, keep=True)
+    _, w2c_g, _ = job.ctx.ba_get_frames()
+    st_g = job.ctx.ba_get_residuals()[0]
+    orc.lib("f32").orc_set_sum_mode(0)
+    ba = orc.ba_from_window(win, "f32", state6=st6)
+    ba.set_options(nthreads=6, never_break=True)
+    trkr = orc.Tracker(win.w, win.h, win.levels, win.K, "f32")
+    dref = orc.make_images(win.images[W - 1], win.levels, "f32")[0]
+    trkr.set_ref(dref, *trk)
+    d_trk = []
+    for k in range(TRACKED_PER_KF):
+        dnew = orc.make_images(win.images[W + k], win.levels, "f32")[0]
+        ok, T_o = trkr.track(dnew, job.T_init[k], [0, 0], [0, 0], [1, 1], win.levels - 1)[:2]
+        d_trk.append(float(np.linalg.norm(orc.se3_log(synth.se3_mul(job.last_T[k], synth.se3_inv(T_o))))))
+    ba.optimize(6)
+    d_win = [float(np.linalg.norm(orc.se3_log(synth.se3_mul(w2c_g[f], synth.se3_inv(ba.frame(f)["worldToCam"]))))) for f in range(W)]
+    st_o = ba.slots()[0]
+    return dict(window_max=max(d_win), tracked_max=max(d_trk), residual_decisions_differ=int((st_g != st_o).sum()), residual_slots=int((st_o >= 0).sum()),
+                oracle="strict fp32 restatement (liboracle_f32.so), same inputs, same keyframe", target="< 1e-5 (BASELINE.json)")
+
+
+def cpu_baseline(win, st6, trk, budget_s=20.0, track=True, nthreads=6, linearize_mt=False):
     """The oracle's fast build (fp32 tiers, -O3 -march=native, 6 accumulate threads, single-thread linearise: the reference's
     own threading, util/NumType.h:42, FullSystemOptimize.cpp:154-164) timed on a bounded sample of the same keyframes."""
     import orc
@@ -193,7 +265,8 @@ def cpu_baseline(win, st6, trk, budget_s=20.0, track=True):
         ba.set_points(sub.host, sub.u, sub.v, sub.idepth, sub.color, sub.weights)
         ba.set_residuals(sub.exists)
         ba.prepare()
-        ba.set_options(nthreads=6, never_break=True)
+        ba.set_options(nthreads=nthreads, never_break=True)
+        ba.L.orc_ba_set_linearize_mt(ba.h_, int(linearize_mt))
         t0 = time.perf_counter()
         if track:
             for k in range(TRACKED_PER_KF):
@@ -208,7 +281,11 @@ def cpu_baseline(win, st6, trk, budget_s=20.0, track=True):
     kfs = n_kf / t_total * scale
     sample = "%d keyframes of %s, %d of %d points%s" % (n_kf, "the same window", len(sub.host), len(win.host),
                                                        "" if scale == 1.0 else " (KF/s scaled by the point ratio)")
-    return dict(value=kfs, unit="keyframes/s", cores=6, kind="port", sample=sample)
+    note = ("reference threading: %d accumulate/resubstitute workers (NUM_THREADS, util/NumType.h:42), linearizeAll and the tracker single-threaded "
+            "(FullSystemOptimize.cpp:154-164)" % nthreads) if not linearize_mt else \
+           ("all usable cores: %d workers for accumulate, resubstitute AND linearizeAll (chunks of 50 points, as upstream DSO); the tracker stays "
+            "single-threaded as in the reference" % nthreads)
+    return dict(value=kfs, unit="keyframes/s", cores=nthreads, kind="port", sample=sample, threading=note)
 
 
 def main():
@@ -314,9 +391,31 @@ def main():
             "tracker_evals_per_step": job.evals / max(args.steps, 1),
             "fine_track_rmse": round(float(rm), 4),
         }
+        if world == 1 and do_track:
+            # the per-frame PCIe copy a running system pays (never part of `value`: the contract times HBM-resident inputs)
+            job.enable_uploads()
+            nup = max(2, min(50, args.steps))
+            for _ in range(2):
+                job.step(True, upload=True)
+            job.ctx.sync()
+            t1 = time.perf_counter()
+            for _ in range(nup):
+                job.step(True, upload=True)
+            job.ctx.sync()
+            dtu = (time.perf_counter() - t1) / nup
+            out["with_frame_uploads"] = dict(value=round(1.0 / dtu, 3), unit="keyframes/s", ms_per_step=round(dtu * 1e3, 4), steps=nup,
+                                            note="same step, but the %d tracked frames arrive through nalo_frame_upload_async from pinned host memory "
+                                                 "(%.2f MB each over PCIe, copy stream overlapped with tracking) instead of HBM-resident irradiance" % (TRACKED_PER_KF, win.w * win.h * 4 / 1e6))
         if not args.no_cpu_baseline and world == 1:
+            info = cpu_info()
             out["cpu_baseline"] = cpu_baseline(win, st6, trk, track=do_track)
+            out["cpu_baseline"].update(cpu_model=info["model"], physical_cores=info["physical_cores"], usable_cpus=info["usable_cpus"])
             out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 2)
+            nall = max(1, min(info["usable_cpus"] or 1, info["physical_cores"] or info["usable_cpus"] or 1, 64))
+            out["cpu_baseline_all_cores"] = cpu_baseline(win, st6, trk, budget_s=10.0, track=do_track, nthreads=nall, linearize_mt=True)
+            out["cpu_baseline_all_cores"].update(cpu_model=info["model"], physical_cores=info["physical_cores"], usable_cpus=info["usable_cpus"])
+            if do_track:
+                out["pose_delta_vs_oracle"] = pose_delta_vs_oracle(job, win, st6, trk)
         elif world == 1:
             out["cpu_baseline"] = None
     # extra legs of the default run (same JSON line):
@@ -330,11 +429,17 @@ def main():
         import threading
         deadline_s = float(os.environ.get("NALO_BENCH_EXTRA_DEADLINE", "420"))
 
+        leg_state = {"leg": "shard1m"}                # which extra leg (hence which kernel / collective) was in flight when the deadline hit
+
         def _expired():
+            # a leg that overruns its deadline means a hung kernel or a collective that never completed: the main line is still printed (marked),
+            # but the process must not look clean to the driver: exit non-zero on every rank
+            log("extra leg '%s' exceeded %.0f s: abandoning the GPU work, exit 3" % (leg_state["leg"], deadline_s))
             if rank == 0:
-                out.setdefault("shard1m", {"error": "extra legs exceeded %.0f s" % deadline_s})
-                print(json.dumps(out), flush=True)
-            os._exit(0)
+                snap = dict(out)                      # the main thread may be adding keys: serialise a copy
+                snap["extra_legs_error"] = "leg '%s' exceeded %.0f s (hang or blocked collective); process exited with code 3" % (leg_state["leg"], deadline_s)
+                print(json.dumps(snap, default=str), flush=True)
+            os._exit(3)
         watchdog = threading.Timer(deadline_s, _expired)
         watchdog.daemon = True
         watchdog.start()
@@ -346,13 +451,22 @@ def main():
         if rank == 0:
             out["shard1m"] = res
             if world == 1:
+                leg_state["leg"] = "stress250k"
                 out["stress250k"] = stress_leg()
                 log("stress250k leg done")
+                leg_state["leg"] = "frontend"
+                try:
+                    out["frontend_rooflines"] = frontend_legs()
+                except Exception as e:
+                    out["frontend_rooflines"] = {"error": repr(e)}
+                log("front-end roofline legs done")
+                leg_state["leg"] = "immature"
                 try:
                     out["immature"] = imm_leg(cpu=not args.no_cpu_baseline)
                 except Exception as e:
                     out["immature"] = {"error": repr(e)}
                 log("immature leg done")
+                leg_state["leg"] = "pixel_selector"
                 try:
                     out["pixel_selector"] = pixsel_leg(cpu=not args.no_cpu_baseline)
                 except Exception as e:
@@ -509,6 +623,88 @@ def stress_leg(steps=5, warmup=2):
             res[k] = dict(avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg), achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
     res["traffic"] = load_traffic("stress250k")
     job.ctx.close()
+    return res
+
+
+def frontend_legs(rounds=30):
+    """Roofline legs of the front-end / map kernels on the 1920x1072, 5-level stress frame, each with its ALGORITHMIC bytes:
+      trk_eval   fused calcRes + calcGSSSE (CoarseTracker.cpp:891-1049, 828-885) at level 0: 64 B per point (16 B point + four 12-B taps), at the
+                 n0 = 250 000 points of the spec and at full density (every level-0 pixel a point: the kernel's asymptote)
+      pyramid    makeImages (HessianBlocks.cpp:127-190): 4wh in + 16 wh sum_l 4^-l out  (~25.3 B/px)
+      dense_map  DenseMapping::makeMap (MapPoint.cpp:334-407): 11 B per bbox pixel + 24 B per output point; dense_bbox: 4 B per scanned pixel
+    Times are HIP events on the library's stream around the kernels of each scope."""
+    cfg = WORKLOADS["stress250k"]
+    w, h = cfg["w"], cfg["h"]
+    win = synth.make_window(w=w, h=h, W=2, P=64, seed=7, n_extra=0)
+    scene = synth.Scene(20240601)
+    xi = np.array([0.2, 0.0, 0.5, 0.0, 0.004, 0.0])                       # new frame = reference pose o exp(xi) (SURVEY 8d, config 4)
+    T_rel = synth_exp(xi)
+    img_new, _ = scene.render(w, h, win.K, synth.se3_mul(T_rel, win.world_to_cam[0]))
+    mask = np.zeros((h, w), np.float32)
+    mask[600:1060, 100:1800] = 7.0                                        # a ground cluster of the mp-mask
+    bgr = np.repeat(np.clip(win.images[0], 0, 255).astype(np.uint8)[:, :, None], 3, axis=2)
+    c = binding.Context(w, h, win.K, n_slots=2)
+    c.frame_upload(0, win.images[0], mask=mask, bgr=bgr)
+    c.frame_upload(1, img_new)
+    res = {"image": "%dx%d" % (w, h), "levels": c.levels}
+
+    def timed(scope, fn, alg_bytes, n_rounds=rounds):
+        fn()
+        c.profile_select(scope); c.profile_enable(True); c.profile_reset()
+        for _ in range(n_rounds):
+            fn()
+        ms, n = c.profile_get(scope)
+        c.profile_enable(False)
+        us = ms / max(n, 1) * 1e3
+        ach = alg_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        return dict(avg_us=round(us, 2), launches=n, alg_bytes=int(alg_bytes), achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4), bound="hbm", peak=HBM_PEAK_GBS)
+
+    # ---- tracker evaluation at level 0
+    rng = np.random.RandomState(7)
+    d0 = win.depth[0]
+    for name, n_pts in (("trk_eval_250k", 250000), ("trk_eval_full_density", None)):
+        if n_pts is None:
+            vv, uu = np.mgrid[4:h - 4, 4:w - 4]
+            u, v = uu.reshape(-1), vv.reshape(-1)
+        else:
+            idx = np.unique(rng.randint(4, h - 4, 2 * n_pts) * w + rng.randint(4, w - 4, 2 * n_pts))
+            idx = np.sort(rng.permutation(idx)[:n_pts])                  # raster order, like the compaction of makeCoarseDepthL0 (CoarseTracker.cpp:493-538)
+            u, v = idx % w, idx // w
+        ok = np.isfinite(d0[v, u])
+        u, v = u[ok], v[ok]
+        c.trk_set_pc(0, 0, u.astype(np.float32), v.astype(np.float32), (1.0 / d0[v, u]).astype(np.float32), win.images[0][v, u].astype(np.float32))
+        st = [None]
+
+        def ev():
+            st[0] = c.trk_eval(1, 0, T_rel, [1.0, 0.0], 0.0, 20.0)[0]
+        r = timed("trk_eval", ev, 64.0 * len(u))
+        r.update(points=int(len(u)), residuals_in=int(st[0][1]), note="64 B/point = 16 B point record + four 12-B bilinear taps counted uncached; the launch also "
+                 "needs a finish kernel and a host poll (not in avg_us): %s" % ("spec size, 16 MB: 2 us at 8 TB/s, launch-latency bound by construction" if n_pts else "asymptote of the kernel"))
+        res[name] = r
+    # ---- pyramid
+    L = c.levels
+    alg_pyr = 4.0 * w * h + 16.0 * w * h * sum(0.25 ** l for l in range(L))
+    res["pyramid"] = timed("pyramid", lambda: c.frame_rebuild(1), alg_pyr)
+    res["pyramid"]["note"] = "two launches (box pyramid of all levels, gradients of all levels); 4wh in + 16 B per pixel of every level out"
+    # ---- dense map
+    import ctypes as C
+    cap = w * h
+    plane = np.array([0.0, 1.0, 0.0, -1.6], np.float32)
+    c2w = np.ascontiguousarray(np.concatenate([np.eye(3), np.zeros((3, 1))], 1)).reshape(-1)
+    rect = np.zeros(4, np.int32)
+    ou, ov = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    oid, oc, ob = np.zeros(cap, np.float32), np.zeros(cap, np.float32), np.zeros((cap, 3), np.uint8)
+    n, acc = C.c_int(0), C.c_int(0)
+
+    def dm():
+        c._ck(c.L.nalo_dense_make_map(c.h_, 0, binding._f(plane), 7.0, binding._d(c2w), cap, binding._i(rect), binding._i(ou), binding._i(ov),
+                                      binding._f(oid), binding._f(oc), binding._u8(ob), C.byref(n), C.byref(acc)))
+    dm()
+    bbox_px = int((rect[1] - rect[0]) * (rect[3] - rect[2]))
+    res["dense_map"] = timed("dense_map", dm, 11.0 * bbox_px + 24.0 * n.value, n_rounds=10)
+    res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="count + scan + write launches of makeMap; the D2H copy of the point list is not in avg_us")
+    res["dense_bbox"] = timed("dense_bbox", dm, 4.0 * (w - 4) * (h - 4), n_rounds=10)
+    c.close()
     return res
 
 

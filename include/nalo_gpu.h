@@ -20,6 +20,7 @@
 #ifndef NALO_GPU_H
 #define NALO_GPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -61,6 +62,15 @@ void* nalo_stream(nalo_ctx* ctx);                 /* hipStream_t every kernel of
  * ------------------------------------------------------------------------------------------------ */
 int nalo_frame_upload(nalo_ctx* ctx, int slot, const float* irradiance, const float* mask, const uint8_t* bgr,
                       const float* gammaB);
+/* The per-frame entry of a running pipeline (FullSystem::addActiveFrame -> makeImages, FullSystem.cpp:1053-1065): same as nalo_frame_upload, but the H2D
+ * copies run on the context's copy stream — under the kernels the main stream is executing for the previous frame — and the pyramid kernels are queued
+ * behind them. Returns immediately; irradiance / mask / bgr / gammaB must stay untouched until nalo_frame_wait(ctx, slot) or nalo_sync returns.
+ * Asynchronous only from pinned host memory: nalo_host_alloc / nalo_host_free (= hipHostMalloc / hipHostFree) hand out such buffers. */
+int nalo_frame_upload_async(nalo_ctx* ctx, int slot, const float* irradiance, const float* mask, const uint8_t* bgr,
+                            const float* gammaB);
+int nalo_frame_wait(nalo_ctx* ctx, int slot);
+void* nalo_host_alloc(size_t bytes);
+void nalo_host_free(void* p);
 /* makeImages again from the level-0 irradiance already resident in the slot (asynchronous on the ctx stream): the
  * HBM-resident form of a1, used when the caller's frames already live on the device */
 int nalo_frame_rebuild(nalo_ctx* ctx, int slot);
@@ -161,9 +171,23 @@ int nalo_ba_optimize(nalo_ctx* ctx, int mnumOptIts, int never_break, double* rms
  * M, Mb, Msc, Mbsc (optional outputs) are the stitched systems. */
 int nalo_ba_marginalize_points(nalo_ctx* ctx, const uint8_t* flags, double* M, double* Mb, double* Msc, double* Mbsc);
 
+/* EnergyFunctional::marginalizeFrame (OptimizationBackend/EnergyFunctional.cpp:498-610), call site FullSystem::marginalizeFrame
+ * (FullSystem/FullSystemMarginalize.cpp:155). Host fp64 on HM/bM: the frame `idx` (window index) is permuted to the end, its prior is added,
+ * the scaled 8x8 block is inverted and eliminated by a Schur complement; HM/bM shrink to 8(W-1)+4. The frame must not host active points any more
+ * (the reference asserts it: marginalise or drop them with nalo_ba_marginalize_points / by not re-submitting them). The frame leaves the window:
+ * W decreases by one, nalo_ba_get_frames / nalo_ba_get_prior return the remaining frames, and the device window must be re-issued with
+ * nalo_ba_set_window (+ set_points, set_residuals) before the next linearisation — FullSystem::marginalizeFrame likewise drops every residual
+ * that targets the frame and recomputes the precalc values and adjoints (:161-212). When that next nalo_ba_set_window has exactly ONE frame more
+ * than the prior covers, HM/bM are extended by a zero block for it, as EnergyFunctional::insertFrame does (:437-442); any other size mismatch
+ * resets the prior to zero. */
+int nalo_ba_marginalize_frame(nalo_ctx* ctx, int idx);
+
 /* read-back of window state (host pointers, any may be NULL) */
 int nalo_ba_get_frames(nalo_ctx* ctx, nalo_frame_state* frames /* W */, double* worldToCam /* W x 12 PRE_worldToCam */,
                        double calib[4]);
+/* Hdd_accAF / bd_accAF / Hcd_accAF / HdiF / bdSumF are values of the last ACCUMULATION, as in the reference (addPoint<0>, AccumulatedSCHessianSSE::addPoint):
+ * after nalo_ba_optimize those of its last solveSystemF — what CoarseTracker::makeCoarseDepthL0 reads as HdiF (CoarseTracker.cpp:396), so read them
+ * BEFORE nalo_ba_marginalize_points (which re-accumulates); after an explicit nalo_ba_linearize the accumulation of that linearisation is run on demand. */
 int nalo_ba_get_points(nalo_ctx* ctx, float* idepth, float* step, float* HdiF, float* bdSumF, float* Hdd_accAF,
                        float* bd_accAF, float* Hcd_accAF /* P x 4 */, float* maxRelBaseline);
 /* per residual slot [p*W + t]: state (-1 none, 0 IN, 1 OOB, 2 OUTLIER), active flag, JpJdF (8), state_NewEnergyWithOutlier,
@@ -292,7 +316,7 @@ int nalo_init_do_step(nalo_ctx* ctx, int n, const uint8_t* isGood, const float* 
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling: per-kernel HIP-event timing on the ctx stream. Names: "trk_eval", "ba_linearize",
- * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize", "pixsel". Enable, run, then query (sync inside).
+ * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize", "pixsel", "dist_bfs", "dense_bbox", "dense_map". Enable, run, then query (sync inside).
  * nalo_profile_select(ctx, name) restricts the brackets to ONE scope (NULL = all): a recorded event pair costs ~10 us of pipeline bubbles on a
  * latency-bound window, so a timed run brackets only the kernel it reports ("ba_linearize" carries its timestamps in the dispatch itself).
  * ------------------------------------------------------------------------------------------------ */

@@ -26,11 +26,11 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 
 EXPORTS = [
     "nalo_create", "nalo_destroy", "nalo_last_error", "nalo_levels", "nalo_sync", "nalo_stream",
-    "nalo_frame_upload", "nalo_frame_rebuild", "nalo_frame_download",
+    "nalo_frame_upload", "nalo_frame_upload_async", "nalo_frame_wait", "nalo_host_alloc", "nalo_host_free", "nalo_frame_rebuild", "nalo_frame_download",
     "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
-    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_get_frames", "nalo_ba_get_points",
+    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
@@ -62,6 +62,12 @@ def load():
     L.nalo_stream.argtypes = [vp]
     L.nalo_stream.restype = vp
     L.nalo_frame_upload.argtypes = [vp, C.c_int, c_fp, c_fp, c_u8p, c_fp]
+    L.nalo_frame_upload_async.argtypes = [vp, C.c_int, c_fp, c_fp, c_u8p, c_fp]
+    L.nalo_frame_wait.argtypes = [vp, C.c_int]
+    L.nalo_host_alloc.argtypes = [C.c_size_t]
+    L.nalo_host_alloc.restype = vp
+    L.nalo_host_free.argtypes = [vp]
+    L.nalo_host_free.restype = None
     L.nalo_frame_rebuild.argtypes = [vp, C.c_int]
     L.nalo_frame_download.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp]
     L.nalo_trk_make_k.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
@@ -84,6 +90,7 @@ def load():
     L.nalo_ba_do_step.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_ip]
     L.nalo_ba_optimize.argtypes = [vp, C.c_int, C.c_int, c_dp]
     L.nalo_ba_marginalize_points.argtypes = [vp, c_u8p, c_dp, c_dp, c_dp, c_dp]
+    L.nalo_ba_marginalize_frame.argtypes = [vp, C.c_int]
     L.nalo_ba_get_frames.argtypes = [vp, C.POINTER(FrameState), c_dp, c_dp]
     L.nalo_ba_get_points.argtypes = [vp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]
     L.nalo_ba_get_residuals.argtypes = [vp, c_i8p, c_u8p, c_fp, c_fp, c_fp]
@@ -156,11 +163,15 @@ class Context:
         self.W = 0
         self.P = 0
         self._hook = None
+        self._pinned = []
 
     def close(self):
         if self.h_:
             self.L.nalo_destroy(self.h_)
             self.h_ = C.c_void_p()
+            for p in self._pinned:
+                self.L.nalo_host_free(p)
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -176,11 +187,35 @@ class Context:
         self._ck(self.L.nalo_sync(self.h_))
 
     # ---- frames
-    def frame_upload(self, slot, img, mask=None, bgr=None):
+    def frame_upload(self, slot, img, mask=None, bgr=None, gammaB=None):
         img = np.ascontiguousarray(img, np.float32)
         m = None if mask is None else np.ascontiguousarray(mask, np.float32)
         b = None if bgr is None else np.ascontiguousarray(bgr, np.uint8)
-        self._ck(self.L.nalo_frame_upload(self.h_, slot, _f(img), _f(m), _u8(b), None))
+        g = None if gammaB is None else np.ascontiguousarray(gammaB, np.float32)
+        assert g is None or g.size == 256
+        self._ck(self.L.nalo_frame_upload(self.h_, slot, _f(img), _f(m), _u8(b), _f(g)))
+
+    def frame_upload_async(self, slot, img, mask=None, bgr=None, gammaB=None):
+        """img (and mask / bgr) must be contiguous arrays of the right dtype that stay alive and untouched until frame_wait(slot): no conversion, no copy
+        here (pinned_array() gives page-locked arrays, the only kind the copy engine reads asynchronously)"""
+        assert img.dtype == np.float32 and img.flags.c_contiguous and img.size == self.w * self.h
+        assert mask is None or (mask.dtype == np.float32 and mask.flags.c_contiguous)
+        assert bgr is None or (bgr.dtype == np.uint8 and bgr.flags.c_contiguous)
+        assert gammaB is None or (gammaB.dtype == np.float32 and gammaB.size == 256)
+        self._ck(self.L.nalo_frame_upload_async(self.h_, slot, _f(img), _f(mask), _u8(bgr), _f(gammaB)))
+
+    def frame_wait(self, slot):
+        self._ck(self.L.nalo_frame_wait(self.h_, slot))
+
+    def pinned_array(self, shape, dtype=np.float32):
+        """numpy array over page-locked host memory from nalo_host_alloc (freed when the context closes)"""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.L.nalo_host_alloc(n)
+        if not p:
+            raise NaloError("nalo_host_alloc(%d) failed" % n)
+        self._pinned.append(p)
+        buf = (C.c_char * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def frame_rebuild(self, slot):
         self._ck(self.L.nalo_frame_rebuild(self.h_, slot))
@@ -233,7 +268,10 @@ class Context:
         return ok.value, T.reshape(3, 4), aff, lr, lf, ne.value
 
     # ---- BA
-    def ba_set_window(self, slots, evalPT, aff=None, exposure=None, th=None, frame_ids=None, state6=None, calib=None):
+    def ba_set_window(self, slots, evalPT, aff=None, exposure=None, th=None, frame_ids=None, state6=None, calib=None, calib_zero=None,
+                      states=None, states_zero=None):
+        """states / states_zero ([W][10], unscaled FrameHessian::state / state_zero) give the general form a running window needs; without them the
+        frames are set like FrameHessian::setEvalPT_scaled (state_zero = [0.., a/SCALE_A, b/SCALE_B, 0, 0]) plus an optional state6."""
         W = len(slots)
         arr = (FrameState * W)()
         for i in range(W):
@@ -243,28 +281,52 @@ class Context:
             e = np.ascontiguousarray(evalPT[i], np.float64).reshape(-1)
             for k in range(12):
                 fs.worldToCam_evalPT[k] = e[k]
-            a, b = (0.0, 0.0) if aff is None else aff[i]
-            # FrameHessian::setEvalPT_scaled (HessianBlocks.h:247-255): state = [0.., a/SCALE_A, b/SCALE_B, 0, 0], state_zero = state
-            st = np.zeros(10)
-            st[6] = np.float32(1.0 / 10.0) * a
-            st[7] = np.float32(1.0 / 1000.0) * b
-            for k in range(10):
-                fs.state_zero[k] = st[k]
-            if state6 is not None:
-                st[:6] = state6[i]
-            for k in range(10):
-                fs.state[k] = st[k]
+            if states is not None:
+                for k in range(10):
+                    fs.state[k] = float(states[i][k])
+                    fs.state_zero[k] = float(states_zero[i][k])
+            else:
+                a, b = (0.0, 0.0) if aff is None else aff[i]
+                # FrameHessian::setEvalPT_scaled (HessianBlocks.h:247-255): state = [0.., a/SCALE_A, b/SCALE_B, 0, 0], state_zero = state
+                st = np.zeros(10)
+                st[6] = np.float32(1.0 / 10.0) * a
+                st[7] = np.float32(1.0 / 1000.0) * b
+                for k in range(10):
+                    fs.state_zero[k] = st[k]
+                if state6 is not None:
+                    st[:6] = state6[i]
+                for k in range(10):
+                    fs.state[k] = st[k]
             fs.ab_exposure = 1.0 if exposure is None else float(exposure[i])
             fs.frameEnergyTH = 8 * 8 * 8.0 if th is None else float(th[i])
         cal = np.asarray(self.K if calib is None else calib, np.float64)
-        self._ck(self.L.nalo_ba_set_window(self.h_, W, arr, _d(cal), _d(cal)))
+        calz = cal if calib_zero is None else np.asarray(calib_zero, np.float64)
+        self._ck(self.L.nalo_ba_set_window(self.h_, W, arr, _d(cal), _d(calz)))
         self.W = W
 
-    def ba_set_points(self, host, u, v, idepth, color, weights, has_prior=None):
+    def ba_set_points(self, host, u, v, idepth, color, weights, has_prior=None, idepth_zero=None):
         a = [np.ascontiguousarray(host, np.int32)] + [np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color, weights)]
         hp = None if has_prior is None else np.ascontiguousarray(has_prior, np.int32)
+        iz = None if idepth_zero is None else np.ascontiguousarray(idepth_zero, np.float32)
         self.P = len(a[0])
-        self._ck(self.L.nalo_ba_set_points(self.h_, self.P, _i(a[0]), _f(a[1]), _f(a[2]), _f(a[3]), None, _f(a[4]), _f(a[5]), _i(hp)))
+        self._ck(self.L.nalo_ba_set_points(self.h_, self.P, _i(a[0]), _f(a[1]), _f(a[2]), _f(a[3]), _f(iz), _f(a[4]), _f(a[5]), _i(hp)))
+
+    def ba_set_prior(self, HM=None, bM=None):
+        H = None if HM is None else np.ascontiguousarray(HM, np.float64)
+        b = None if bM is None else np.ascontiguousarray(bM, np.float64)
+        assert H is None or H.size == self.n * self.n
+        self._ck(self.L.nalo_ba_set_prior(self.h_, _d(H), _d(b)))
+
+    def ba_get_prior(self):
+        n = self.n
+        H, b = np.zeros(n * n), np.zeros(n)
+        self._ck(self.L.nalo_ba_get_prior(self.h_, _d(H), _d(b)))
+        return H.reshape(n, n), b
+
+    def ba_marginalize_frame(self, idx):
+        """EnergyFunctional::marginalizeFrame on HM/bM; the window shrinks by one frame (re-issue set_window / set_points / set_residuals next)"""
+        self._ck(self.L.nalo_ba_marginalize_frame(self.h_, int(idx)))
+        self.W -= 1
 
     def ba_set_residuals(self, exists):
         self._ck(self.L.nalo_ba_set_residuals(self.h_, _u8(np.ascontiguousarray(exists, np.uint8))))

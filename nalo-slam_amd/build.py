@@ -2,6 +2,7 @@
 import os
 import subprocess
 import sys
+import zlib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = ["host_api.hip", "host_ba.hip", "kernels_pyramid.hip", "kernels_tracker.hip", "kernels_trk_lm.hip", "kernels_ba.hip", "kernels_ba_lin.hip", "kernels_ba_gn.hip", "kernels_dense.hip", "kernels_imm.hip", "kernels_init.hip", "kernels_pixsel.hip", "host_io.cpp"]
@@ -20,7 +21,7 @@ def build(force=False, verbose=False):
     procs = []
     for s in srcs:
         # the object name carries the flag set, so moving a file in/out of NO_CONTRACT (or changing NALO_CXXFLAGS) rebuilds it
-        tag = ("nc" if os.path.basename(s) in NO_CONTRACT else "fc") + ("%08x" % (hash(os.environ.get("NALO_CXXFLAGS", "")) & 0xFFFFFFFF) if os.environ.get("NALO_CXXFLAGS") else "")
+        tag = ("nc" if os.path.basename(s) in NO_CONTRACT else "fc") + ("%08x" % (zlib.crc32(os.environ.get("NALO_CXXFLAGS", "").encode()) & 0xFFFFFFFF) if os.environ.get("NALO_CXXFLAGS") else "")
         o = os.path.join(HERE, "build", os.path.basename(s) + "." + tag + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):]):

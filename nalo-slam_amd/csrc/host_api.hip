@@ -58,7 +58,9 @@ void nalo_destroy(nalo_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     ba_destroy(c);
     pixsel_destroy(c);
+    if (c->copy) (void)hipStreamSynchronize(c->copy);
     for (auto& s : c->slots) {
+        if (s.ev_up) (void)hipEventDestroy(s.ev_up);
         for (int l = 0; l < NALO_MAX_LEVELS; ++l) { if (s.I[l]) (void)hipFree(s.I[l]); if (s.dI[l]) (void)hipFree(s.dI[l]); if (s.absg[l]) (void)hipFree(s.absg[l]); }
         if (s.mask) (void)hipFree(s.mask);
         if (s.bgr) (void)hipFree(s.bgr);
@@ -74,14 +76,17 @@ void nalo_destroy(nalo_ctx* c) {
     c->imm_dev.release(); c->imm_res.release();
     for (auto& kv : c->prof) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+    if (c->gamma_dev) (void)hipFree(c->gamma_dev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->copy) (void)hipStreamDestroy(c->copy);
     delete c;
 }
 
 const char* nalo_last_error(nalo_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 int nalo_levels(nalo_ctx* c) { return c ? c->levels : NALO_ERR_ARG; }
-int nalo_sync(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; NALO_HIP(c, hipStreamSynchronize(c->stream)); NALO_HIP(c, hipStreamSynchronize(c->side)); return NALO_OK; }
+int nalo_sync(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; if (c->copy) NALO_HIP(c, hipStreamSynchronize(c->copy)); NALO_HIP(c, hipStreamSynchronize(c->stream)); NALO_HIP(c, hipStreamSynchronize(c->side)); return NALO_OK; }
 void* nalo_stream(nalo_ctx* c) { return c ? (void*)c->stream : nullptr; }
 void* nalo_side_stream(nalo_ctx* c) { return c ? (void*)c->side : nullptr; }
 
@@ -102,6 +107,44 @@ int nalo_frame_upload(nalo_ctx* c, int slot, const float* irradiance, const floa
     s.valid = true;
     return NALO_OK;
 }
+
+// Asynchronous form of nalo_frame_upload for a per-frame pipeline (FullSystem::addActiveFrame -> makeImages, FullSystem.cpp:1053-1065): the H2D copies run
+// on the context's copy stream, under whatever the main stream is executing (the previous frame's tracking), the pyramid kernels are queued on the main
+// stream behind an event. Returns at once: the host buffers must stay untouched until nalo_frame_wait(ctx, slot) (or nalo_sync) returns. Truly
+// asynchronous only from pinned host memory (nalo_host_alloc / hipHostMalloc); pageable buffers work but are staged by the HIP runtime.
+int nalo_frame_upload_async(nalo_ctx* c, int slot, const float* irradiance, const float* mask, const uint8_t* bgr, const float* gammaB) {
+    if (!c || !irradiance || slot < 0 || slot >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_frame_upload_async: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    FrameSlot& s = c->slots[slot];
+    if (!c->copy) { NALO_HIP(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking)); NALO_HIP(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming)); }
+    if (!s.ev_up) NALO_HIP(c, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+    const size_t n0 = (size_t)c->w * c->h;
+    if (mask && !s.mask) NALO_HIP(c, hipMalloc((void**)&s.mask, n0 * 4));
+    if (bgr && !s.bgr) NALO_HIP(c, hipMalloc((void**)&s.bgr, n0 * 3));
+    if (gammaB && !c->gamma_dev) NALO_HIP(c, hipMalloc((void**)&c->gamma_dev, 256 * 4));
+    if (s.valid) {                                                   // kernels already queued on the main stream may still read this slot
+        NALO_HIP(c, hipEventRecord(c->ev_main, c->stream));
+        NALO_HIP(c, hipStreamWaitEvent(c->copy, c->ev_main, 0));
+    }
+    NALO_HIP(c, hipMemcpyAsync(s.I[0], irradiance, n0 * 4, hipMemcpyHostToDevice, c->copy));
+    if (mask) NALO_HIP(c, hipMemcpyAsync(s.mask, mask, n0 * 4, hipMemcpyHostToDevice, c->copy));
+    if (bgr) NALO_HIP(c, hipMemcpyAsync(s.bgr, bgr, n0 * 3, hipMemcpyHostToDevice, c->copy));
+    if (gammaB) NALO_HIP(c, hipMemcpyAsync(c->gamma_dev, gammaB, 256 * 4, hipMemcpyHostToDevice, c->copy));
+    NALO_HIP(c, hipEventRecord(s.ev_up, c->copy));
+    NALO_HIP(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
+    int rc = pyramid_build(c, s, gammaB ? c->gamma_dev : nullptr);
+    if (rc) return rc;
+    pixsel_invalidate_hists(c, slot);
+    s.valid = true;
+    return NALO_OK;
+}
+int nalo_frame_wait(nalo_ctx* c, int slot) {
+    if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_frame_wait: bad slot");
+    if (c->slots[slot].ev_up) NALO_HIP(c, hipEventSynchronize(c->slots[slot].ev_up));
+    return NALO_OK;
+}
+void* nalo_host_alloc(size_t bytes) { void* p = nullptr; return hipHostMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
+void nalo_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int nalo_frame_rebuild(nalo_ctx* c, int slot) {
     if (!c || slot < 0 || slot >= (int)c->slots.size() || !c->slots[slot].valid) return fail(c, NALO_ERR_ARG, "nalo_frame_rebuild: bad slot");
@@ -138,8 +181,6 @@ static int upload4(nalo_ctx* c, int n, const float* a, const float* b, const flo
     NALO_HIP(c, c->upload_tmp.reserve((size_t)4 * n + 256));
     if (c->pinned_f_cap < (size_t)4 * n) {
         if (c->pinned_f) (void)hipHostFree(c->pinned_f);
-    if (c->imm_host) (void)hipHostFree(c->imm_host);
-    c->imm_dev.release();
         c->pinned_f = nullptr; c->pinned_f_cap = 0;
         NALO_HIP(c, hipHostMalloc((void**)&c->pinned_f, (size_t)4 * n * 4 + 1024));
         c->pinned_f_cap = (size_t)4 * n + 256;

@@ -71,9 +71,12 @@ struct BAWindow {
     double* ad_host = nullptr; size_t ad_cap = 0;                   // pinned staging of AD
     hipEvent_t ev_ad = nullptr;
     double* stitched_host = nullptr;                                // pinned mirror
-    float* up_host = nullptr;                                       // pinned upload staging (precalc, xAd)
+    float* up_host = nullptr;                                       // pinned upload staging: [precalc records | calib 16 | xc 64 | xAd]
+    float* up_host2 = nullptr;                                      // second precalc staging block: set_precalc alternates between the two, each guarded by
+    hipEvent_t ev_up[2] = {nullptr, nullptr}; int up_idx = 0;       // the event of its last H2D copy (a copy queued behind a long kernel may still be pending)
     size_t up_cap = 0;
     bool have_lin = false, have_sc = false, stitched_top = false, stitched_sc = false, points_set = false, res_set = false;
+    bool pt_acc_on_read = false;                                    // nalo_ba_get_points may run the per-point accumulation of an explicit nalo_ba_linearize
     int sc_shift = -1;
     // snapshot of the mutable window state (bench/test utility: replay the same synthetic keyframe)
     DevBuf<float4> snap_geo; DevBuf<uint8_t> snap_state, snap_flags; DevBuf<float> snap_prior;
@@ -101,6 +104,8 @@ void ba_destroy(nalo_ctx* c) {
     w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
+    if (w->up_host2) (void)hipHostFree(w->up_host2);
+    for (hipEvent_t e : w->ev_up) if (e) (void)hipEventDestroy(e);
     if (w->gn_host) (void)hipHostFree(w->gn_host);
     w->gn_d.release(); w->gn_f.release(); w->gn_i.release();
     if (w->ad_host) (void)hipHostFree(w->ad_host);
@@ -213,8 +218,20 @@ static int set_precalc(nalo_ctx* c) {
     for (int i = 0; i < 4; ++i) w.cDeltaF[i] = (float)(w.c_value[i] - w.c_value_zero[i]);
     for (auto& f : w.frames) frame_take_data(f);
     const size_t nfl = (size_t)W * W * kPreStride;
-    if (w.up_cap < nfl + 80) { if (w.up_host) (void)hipHostFree(w.up_host); NALO_HIP(c, hipHostMalloc((void**)&w.up_host, (nfl + 80 + (size_t)W * W * 8) * 4)); w.up_cap = nfl + 80; }   // [pre | calib 16 | xc 64 | xAd]
-    float* rec = w.up_host;
+    if (w.up_cap < nfl + 80) {                                             // [pre | calib 16 | xc 64 | xAd]; hipHostFree waits for copies in flight
+        if (w.up_host) (void)hipHostFree(w.up_host);
+        if (w.up_host2) (void)hipHostFree(w.up_host2);
+        w.up_host = w.up_host2 = nullptr; w.up_cap = 0;
+        NALO_HIP(c, hipHostMalloc((void**)&w.up_host, (nfl + 80 + (size_t)W * W * 8) * 4));
+        NALO_HIP(c, hipHostMalloc((void**)&w.up_host2, (nfl + 16) * 4));
+        w.up_cap = nfl + 80;
+    }
+    // the records are rewritten while the previous copy may still be queued behind a kernel (optimize: do_step -> set_precalc, then the epilogue's
+    // set_precalc with no wait in between; nalo_ba_restore likewise): alternate two staging blocks, each guarded by the event of its last copy
+    w.up_idx ^= 1;
+    if (!w.ev_up[w.up_idx]) NALO_HIP(c, hipEventCreateWithFlags(&w.ev_up[w.up_idx], hipEventDisableTiming));
+    else NALO_HIP(c, hipEventSynchronize(w.ev_up[w.up_idx]));
+    float* rec = w.up_idx ? w.up_host2 : w.up_host;
     const float fx = w.c_scaledf[0], fy = w.c_scaledf[1], cx = w.c_scaledf[2], cy = w.c_scaledf[3];
     const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1.0f / fx, 0, -cx / fx, 0, 1.0f / fy, -cy / fy, 0, 0, 1};
     for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
@@ -238,6 +255,7 @@ static int set_precalc(nalo_ctx* c) {
     for (int i = 0; i < 4; ++i) cal[6 + i] = w.cDeltaF[i];
     NALO_HIP(c, w.pre.reserve(nfl + 16));
     NALO_HIP(c, hipMemcpyAsync(w.pre.p, rec, (nfl + 16) * 4, hipMemcpyHostToDevice, c->stream));
+    NALO_HIP(c, hipEventRecord(w.ev_up[w.up_idx], c->stream));
     w.dev.pre = w.pre.p; w.dev.calib = w.pre.p + nfl;
 
     return NALO_OK;
@@ -619,7 +637,14 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     w.dev.W = W; w.dev.w = c->w; w.dev.h = c->h;
     NALO_HIP(c, w.th_hist.reserve(2 * 65536 + 16)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, (2 * 65536 + 16) * 4));
     w.dev.th_hist_hi = w.th_hist.p; w.dev.th_hist_lo = w.th_hist.p + 65536; w.dev.th_state = w.th_hist.p + 2 * 65536;
-    if (w.HM.size() != (size_t)w.n * w.n) { w.HM.assign((size_t)w.n * w.n, 0.0); w.bM.assign(w.n, 0.0); }
+    if (w.HM.size() == (size_t)(w.n - 8) * (w.n - 8) && w.n > 12) {
+        // one frame appended to a window that carries a prior = EnergyFunctional::insertFrame (EnergyFunctional.cpp:437-442): conservativeResize, the new
+        // frame's rows / columns zero
+        const int no = w.n - 8;
+        std::vector<double> H2((size_t)w.n * w.n, 0.0), b2(w.n, 0.0);
+        for (int r = 0; r < no; ++r) { std::memcpy(&H2[(size_t)r * w.n], &w.HM[(size_t)r * no], (size_t)no * 8); b2[r] = w.bM[r]; }
+        w.HM.swap(H2); w.bM.swap(b2);
+    } else if (w.HM.size() != (size_t)w.n * w.n) { w.HM.assign((size_t)w.n * w.n, 0.0); w.bM.assign(w.n, 0.0); }
     w.lastX.assign(w.n, 0.0);
     const size_t blk = (size_t)w.n1 * w.n1;
     NALO_HIP(c, w.acc13.reserve((size_t)W * W * 169));
@@ -779,6 +804,7 @@ int nalo_ba_get_prior(nalo_ctx* c, double* HM, double* bM) {
 int nalo_ba_linearize(nalo_ctx* c, int fix, double* energy) {
     NALO_BA_READY("nalo_ba_linearize")
     int rc = linearize_async(c, 0, fix); if (rc) return rc;
+    w.pt_acc_on_read = true;
     rc = stitch_and_fetch(c, true, false, true); if (rc) return rc;
     w.frames[w.W - 1].frameEnergyTH = tail_th(w);
     double e = 0; misc_totals(w, &e, &w.resInA);
@@ -829,6 +855,7 @@ static int optimize_epilogue(nalo_ctx* c, double* rmse) {
     int rc = set_adjoints(c); if (rc) return rc;
     rc = set_precalc(c); if (rc) return rc;
     rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
+    w.pt_acc_on_read = false;                                               // the per-point sums stay those of the last solve
     rc = stitch_and_fetch(c, true, false, true, true); if (rc) return rc;  // energy, residual count and the threshold: no stitch
     nf.frameEnergyTH = tail_th(w);
     double e = 0; int nres = 0; misc_totals(w, &e, &nres);
@@ -983,6 +1010,49 @@ int nalo_ba_marginalize_points(nalo_ctx* c, const uint8_t* flags, double* M, dou
     return NALO_OK;
 }
 
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cpp:498-610): host fp64, (8W+4)^2. The frame is permuted to the end of HM/bM, its prior is
+// added, the system is scaled by 1/sqrt(|diag|+10), the frame's 8x8 block is inverted and Schur-complemented away, unscaled, symmetrised.
+int nalo_ba_marginalize_frame(nalo_ctx* c, int idx) {
+    if (!c || !c->ba || c->ba->W < 2) return fail(c, NALO_ERR_STATE, "nalo_ba_marginalize_frame: set the window first");
+    BAWindow& w = *c->ba;
+    if (idx < 0 || idx >= w.W) return fail(c, NALO_ERR_ARG, "nalo_ba_marginalize_frame: frame index out of range");
+    if (w.W < 3) return fail(c, NALO_ERR_STATE, "nalo_ba_marginalize_frame: a window needs two frames");
+    if (w.points_set) for (int d = 0; d < w.Ppad; ++d)              // assert((int)fh->points.size()==0) at :505
+        if ((w.flags_h[d] & PT_VALID) && w.blk_host_h[d / kBlk] == idx) return fail(c, NALO_ERR_STATE, "nalo_ba_marginalize_frame: the frame still hosts active points (marginalise or drop them first)");
+    const int odim = w.n, ndim = odim - 8;
+    std::vector<int> perm; perm.reserve(odim);
+    for (int i = 0; i < odim; ++i) if (i < 4 || (i - 4) / 8 != idx) perm.push_back(i);
+    for (int i = 0; i < 8; ++i) perm.push_back(4 + 8 * idx + i);
+    std::vector<double> H((size_t)odim * odim), b(odim), S(odim), Si(odim);
+    for (int i = 0; i < odim; ++i) { b[i] = w.bM[perm[i]]; for (int j = 0; j < odim; ++j) H[(size_t)i * odim + j] = w.HM[(size_t)perm[i] * odim + perm[j]]; }
+    const HostFrame& fh = w.frames[idx];
+    for (int i = 0; i < 8; ++i) { H[(size_t)(ndim + i) * odim + ndim + i] += fh.prior[i]; b[ndim + i] += fh.prior[i] * fh.delta_prior[i]; }   // :544-545
+    for (int i = 0; i < odim; ++i) { S[i] = std::sqrt(std::fabs(H[(size_t)i * odim + i]) + 10); Si[i] = 1.0 / S[i]; }                     // :552-553
+    for (int i = 0; i < odim; ++i) { for (int j = 0; j < odim; ++j) H[(size_t)i * odim + j] = Si[i] * H[(size_t)i * odim + j] * Si[j]; b[i] *= Si[i]; }
+    double hp[64], hpi[64];
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) hp[i * 8 + j] = H[(size_t)(ndim + i) * odim + ndim + j];
+    if (!inv_lu(8, hp, hpi)) return fail(c, NALO_ERR_STATE, "nalo_ba_marginalize_frame: singular frame block");                            // :564-567 (0.5f*(hpi+hpi) is the identity)
+    std::vector<double> bli((size_t)ndim * 8);
+    for (int r = 0; r < ndim; ++r) for (int cc = 0; cc < 8; ++cc) { double s = 0; for (int k = 0; k < 8; ++k) s += H[(size_t)(ndim + k) * odim + r] * hpi[k * 8 + cc]; bli[(size_t)r * 8 + cc] = s; }
+    for (int r = 0; r < ndim; ++r) {                                                                                                            // :570-572
+        for (int cc = 0; cc < ndim; ++cc) { double s = 0; for (int k = 0; k < 8; ++k) s += bli[(size_t)r * 8 + k] * H[(size_t)(ndim + k) * odim + cc]; H[(size_t)r * odim + cc] -= s; }
+        double s = 0; for (int k = 0; k < 8; ++k) s += bli[(size_t)r * 8 + k] * b[ndim + k];
+        b[r] -= s;
+    }
+    for (int i = 0; i < odim; ++i) { for (int j = 0; j < odim; ++j) H[(size_t)i * odim + j] = S[i] * H[(size_t)i * odim + j] * S[j]; b[i] *= S[i]; }   // :575-576
+    std::vector<double> HMn((size_t)ndim * ndim), bMn(ndim);
+    for (int i = 0; i < ndim; ++i) { for (int j = 0; j < ndim; ++j) HMn[(size_t)i * ndim + j] = 0.5 * (H[(size_t)i * odim + j] + H[(size_t)j * odim + i]); bMn[i] = b[i]; }   // :579-580
+    w.HM.swap(HMn); w.bM.swap(bMn);
+    // the frame leaves the window (:583-590; FullSystem::marginalizeFrame drops every residual that targets it and re-runs setPrecalcValues / setAdjointsF,
+    // FullSystemMarginalize.cpp:155-212): the device arrays are laid out per window size, so the caller re-issues nalo_ba_set_window (+ points, residuals)
+    // for the frames that remain — with the next keyframe appended, set_window extends HM/bM like insertFrame does.
+    w.frames.erase(w.frames.begin() + idx);
+    w.W -= 1; w.n = 8 * w.W + 4; w.n1 = w.n + 1;
+    w.points_set = false; w.res_set = false; w.have_lin = w.have_sc = false; w.proj_valid = false; w.have_snap = false;
+    w.lastX.assign(w.n, 0.0);
+    return NALO_OK;
+}
+
 int nalo_ba_get_frames(nalo_ctx* c, nalo_frame_state* frames, double* worldToCam, double calib[4]) {
     if (!c || !c->ba || c->ba->W < 2) return fail(c, NALO_ERR_STATE, "nalo_ba_get_frames: set the window first");
     BAWindow& w = *c->ba;
@@ -1003,7 +1073,10 @@ int nalo_ba_get_points(nalo_ctx* c, float* idepth, float* step, float* HdiF, flo
     if (!c || !c->ba || !c->ba->points_set) return fail(c, NALO_ERR_STATE, "nalo_ba_get_points: no points");
     BAWindow& w = *c->ba;
     const size_t N = w.Ppad;
-    if (w.have_lin && !w.have_sc) { int rc = sc_async(c, 1, 1.f, 0); if (rc) return rc; }    // Hdd/bd/Hcd/HdiF are produced by the SC pass
+    // Hdd/bd/Hcd/HdiF/bdSumF are values of the last ACCUMULATION (addPoint<0> / AccumulatedSCHessianSSE::addPoint), as in the reference: after
+    // nalo_ba_optimize they are those of the last solveSystemF, which is what CoarseTracker::makeCoarseDepthL0 reads (HdiF, CoarseTracker.cpp:396).
+    // After an explicit nalo_ba_linearize the accumulation of that linearisation is run here if the caller has not asked for it yet.
+    if (w.have_lin && !w.have_sc && w.pt_acc_on_read) { int rc = sc_async(c, 1, 1.f, 0); if (rc) return rc; }
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     std::vector<float4> geo(N), acc(N), hcd(N);
     std::vector<float> stp(N), rel(N);

@@ -166,6 +166,34 @@ inline void ldlt_solve(int n, const double* Ain, const double* b, double* x) {
     ldlt_solve_inplace(n, A.data(), b, x, y.data(), perm.data());
 }
 
+// inverse of a small dense matrix (n <= 16) by LU with partial pivoting (what Eigen's fixed-size inverse() does for n > 4), fp64; false if singular
+inline bool inv_lu(int n, const double* A, double* Ai) {
+    double LU[256]; int piv[16];
+    if (n > 16) return false;
+    std::memcpy(LU, A, sizeof(double) * n * n);
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        for (int r = k + 1; r < n; ++r) if (std::fabs(LU[r * n + k]) > std::fabs(LU[p * n + k])) p = r;
+        piv[k] = p;
+        if (p != k) for (int j = 0; j < n; ++j) std::swap(LU[k * n + j], LU[p * n + j]);
+        if (LU[k * n + k] == 0.0) return false;
+        for (int r = k + 1; r < n; ++r) {
+            const double l = LU[r * n + k] / LU[k * n + k];
+            LU[r * n + k] = l;
+            for (int j = k + 1; j < n; ++j) LU[r * n + j] -= l * LU[k * n + j];
+        }
+    }
+    for (int c = 0; c < n; ++c) {                                   // solve L U x = P e_c
+        double y[16];
+        for (int i = 0; i < n; ++i) y[i] = (i == c);
+        for (int k = 0; k < n; ++k) if (piv[k] != k) std::swap(y[k], y[piv[k]]);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) y[i] -= LU[i * n + j] * y[j];
+        for (int i = n - 1; i >= 0; --i) { for (int j = i + 1; j < n; ++j) y[i] -= LU[i * n + j] * y[j]; y[i] /= LU[i * n + i]; }
+        for (int i = 0; i < n; ++i) Ai[i * n + c] = y[i];
+    }
+    return true;
+}
+
 // cyclic Jacobi for small symmetric matrices; A destroyed, V columns = eigenvectors
 inline void sym_eig(int n, double* A, double* V, double* w) {
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j);

@@ -143,7 +143,7 @@ extern "C" int nalo_dense_make_map(nalo_ctx* c, int slot, const float plane[4], 
     const int init[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
     NALO_HIP(c, hipMemcpyAsync(c->scan_tmp.p, init, 16, hipMemcpyHostToDevice, c->stream));
     const int total0 = (c->w - 4) * (c->h - 4);
-    dense_bbox_kernel<<<std::min((total0 + 255) / 256, 2048), 256, 0, c->stream>>>(s.mask, c->w, c->h, mask_value, c->scan_tmp.p);
+    { ProfScope ps(c, "dense_bbox"); dense_bbox_kernel<<<std::min((total0 + 255) / 256, 2048), 256, 0, c->stream>>>(s.mask, c->w, c->h, mask_value, c->scan_tmp.p); }
     int rect[4];
     NALO_HIP(c, hipMemcpyAsync(rect, c->scan_tmp.p, 16, hipMemcpyDeviceToHost, c->stream));
     NALO_HIP(c, hipStreamSynchronize(c->stream));
@@ -168,9 +168,12 @@ extern "C" int nalo_dense_make_map(nalo_ctx* c, int slot, const float plane[4], 
         int* du = (int*)c->upload_tmp.p; int* dv = du + capz; float* did = (float*)(dv + capz); float* dcol = did + capz;
         uint8_t* dbgr = (uint8_t*)(dcol + capz);
         double* dworld = (double*)(c->upload_tmp.p + capz * 5 + (capz * 5 % 2));
-        dense_map_kernel<0><<<nb, 256, 0, c->stream>>>(P, counts, nullptr, cap, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        dense_scan_kernel<<<1, 1024, 0, c->stream>>>(counts, offsets, nb);
-        dense_map_kernel<1><<<nb, 256, 0, c->stream>>>(P, nullptr, offsets, cap, du, dv, did, dcol, dbgr, dworld);
+        {
+            ProfScope ps(c, "dense_map");
+            dense_map_kernel<0><<<nb, 256, 0, c->stream>>>(P, counts, nullptr, cap, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+            dense_scan_kernel<<<1, 1024, 0, c->stream>>>(counts, offsets, nb);
+            dense_map_kernel<1><<<nb, 256, 0, c->stream>>>(P, nullptr, offsets, cap, du, dv, did, dcol, dbgr, dworld);
+        }
         NALO_HIP(c, hipMemcpyAsync(&n, offsets + nb, 4, hipMemcpyDeviceToHost, c->stream));
         NALO_HIP(c, hipStreamSynchronize(c->stream));
         if (n > cap) return fail(c, NALO_ERR_ARG, "nalo_dense_make_map: cap too small");

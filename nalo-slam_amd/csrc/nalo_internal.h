@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -45,6 +46,7 @@ struct FrameSlot {
     float* mask = nullptr;                   // level 0 (densemap only)
     uint8_t* bgr = nullptr;
     bool valid = false;
+    hipEvent_t ev_up = nullptr;              // nalo_frame_upload_async: the slot's H2D copies (copy stream) have completed
 };
 
 struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
@@ -61,7 +63,9 @@ struct nalo_ctx {
     int wl[NALO_MAX_LEVELS], hl[NALO_MAX_LEVELS];
     float fx[NALO_MAX_LEVELS], fy[NALO_MAX_LEVELS], cx[NALO_MAX_LEVELS], cy[NALO_MAX_LEVELS];   // tracker pyramid intrinsics
     float K0[4];
-    hipStream_t stream = nullptr, side = nullptr;
+    hipStream_t stream = nullptr, side = nullptr, copy = nullptr;   // copy: H2D frame uploads of nalo_frame_upload_async (overlap the kernels of `stream`)
+    hipEvent_t ev_main = nullptr;            // main-stream marker the copy stream waits on before it overwrites a slot that has been used
+    float* gamma_dev = nullptr;              // 256-entry gamma table of the asynchronous upload path
     std::string err;
     std::vector<nalo::FrameSlot> slots;
 
@@ -107,14 +111,21 @@ inline int fail(nalo_ctx* c, int code, const std::string& msg) { if (c) c->err =
     } while (0)
 
 // Wait for a kernel to publish `seq` into host-mapped memory (system-scope release on the device side). Spinning on the
-// flag costs a few microseconds; hipStreamSynchronize costs tens. Falls back to a stream sync after 5 s (kernel fault).
+// flag costs a few microseconds; hipStreamSynchronize costs tens. Every 2^20 spins the stream is queried for a fault and the wall clock is
+// checked: after NALO_POLL_TIMEOUT_S (default 10 s) without the flag the call fails with NALO_ERR_HIP (a faulted kernel or a collective
+// that never completes must not stall the caller for minutes).
 inline bool poll_flag(nalo_ctx* c, volatile double* flag, double seq) {
+    static const double timeout_s = [] { const char* e = std::getenv("NALO_POLL_TIMEOUT_S"); const double v = e ? std::atof(e) : 10.0; return v > 0 ? v : 10.0; }();
+    std::chrono::steady_clock::time_point t0;
+    bool timing = false;
     for (unsigned long long spins = 0;; ++spins) {
         if (*flag == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return true; }
         if ((spins & 0xFFFFF) == 0xFFFFF) {
             const hipError_t e = hipStreamQuery(c->stream);
             if (e != hipSuccess && e != hipErrorNotReady) { c->err = std::string("kernel failed: ") + hipGetErrorString(e); return false; }
-            if (spins > (1ull << 34)) { c->err = "timeout waiting for the device"; return false; }
+            const auto now = std::chrono::steady_clock::now();
+            if (!timing) { t0 = now; timing = true; }
+            else if (std::chrono::duration<double>(now - t0).count() > timeout_s) { c->err = "timeout waiting for the device"; return false; }
         }
         __builtin_ia32_pause();
     }

@@ -110,6 +110,12 @@ def lib(kind="f32"):
     L.orc_ba_counts.argtypes = [C.c_void_p, C.c_int]
     L.orc_ba_counts.restype = C.c_int
     L.orc_ba_set_idepth.argtypes = [C.c_void_p, c_fp]
+    L.orc_ba_get_center_projected.argtypes = [C.c_void_p, c_fp]
+    L.orc_ba_get_frame_state_zero.argtypes = [C.c_void_p, C.c_int, c_dp]
+    L.orc_ba_set_frame_full.argtypes = [C.c_void_p, C.c_int, c_fp, c_dp, c_dp, c_dp, C.c_float, C.c_float, C.c_int]
+    L.orc_ba_set_idepth_zero.argtypes = [C.c_void_p, c_fp]
+    L.orc_ba_set_calib_zero.argtypes = [C.c_void_p, c_dp]
+    L.orc_ba_marginalize_frame.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp]
     L.orc_ba_get_precalc_rt.argtypes = [C.c_void_p, c_fp, c_fp]
     L.orc_init_calc_res_and_gs.argtypes = [c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_double, C.c_float, C.c_float, C.c_float, C.c_int,
                                            c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
@@ -387,10 +393,37 @@ class BA:
         self.L.orc_ba_set_frame(self.h_, i, fp(self._keep[i]), dp(np.ascontiguousarray(evalPT, np.float64).reshape(-1)),
                                 aff[0], aff[1], exposure, th, i if frame_id is None else frame_id, dp(s6))
 
-    def set_points(self, host, u, v, idepth, color, weights, has_prior=None):
+    def set_frame_full(self, i, dI0, evalPT, state, state_zero, exposure=1.0, th=8 * 8 * 8.0, frame_id=None):
+        self._keep[i] = np.ascontiguousarray(dI0, np.float32)
+        self.L.orc_ba_set_frame_full(self.h_, i, fp(self._keep[i]), dp(np.ascontiguousarray(evalPT, np.float64).reshape(-1)),
+                                     dp(np.ascontiguousarray(state, np.float64)), dp(np.ascontiguousarray(state_zero, np.float64)),
+                                     exposure, th, i if frame_id is None else frame_id)
+
+    def set_points(self, host, u, v, idepth, color, weights, has_prior=None, idepth_zero=None):
         a = [np.ascontiguousarray(host, np.int32)] + [np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color, weights)]
         hp = None if has_prior is None else np.ascontiguousarray(has_prior, np.int32)
         self.L.orc_ba_set_points(self.h_, ip(a[0]), fp(a[1]), fp(a[2]), fp(a[3]), fp(a[4]), fp(a[5]), ip(hp))
+        if idepth_zero is not None:
+            self.L.orc_ba_set_idepth_zero(self.h_, fp(np.ascontiguousarray(idepth_zero, np.float32)))
+
+    def set_calib_zero(self, calib_zero_scaled):
+        self.L.orc_ba_set_calib_zero(self.h_, dp(np.ascontiguousarray(calib_zero_scaled, np.float64)))
+
+    def set_prior(self, HM, bM):
+        self.L.orc_ba_set_prior(self.h_, dp(np.ascontiguousarray(HM, np.float64)), dp(np.ascontiguousarray(bM, np.float64)))
+
+    def get_prior(self):
+        n = self.n
+        H, b = np.zeros(n * n), np.zeros(n)
+        self.L.orc_ba_get_prior(self.h_, dp(H), dp(b))
+        return H.reshape(n, n), b
+
+    def marginalize_frame(self, idx):
+        """EnergyFunctional::marginalizeFrame -> (HM, bM) of the window without frame idx"""
+        n = self.n - 8
+        H, b = np.zeros(n * n), np.zeros(n)
+        self.L.orc_ba_marginalize_frame(self.h_, int(idx), dp(H), dp(b))
+        return H.reshape(n, n), b
 
     def set_residuals(self, exists):
         self.L.orc_ba_set_residuals(self.h_, u8p(np.ascontiguousarray(exists, np.uint8)))
@@ -455,6 +488,11 @@ class BA:
         self.L.orc_ba_get_slots(self.h_, st.ctypes.data_as(C.POINTER(C.c_int8)), u8p(ac), fp(jp), fp(en))
         return st.reshape(self.P, self.W), ac.reshape(self.P, self.W), jp.reshape(self.P, self.W, 8), en.reshape(self.P, self.W)
 
+    def center_projected(self):
+        o = np.zeros((self.P, self.W, 3), np.float32)
+        self.L.orc_ba_get_center_projected(self.h_, fp(o))
+        return o
+
     def points(self):
         P = self.P
         o = {k: np.zeros(P, np.float32) for k in ("idepth", "step", "HdiF", "bdSumF", "Hdd", "bd")}
@@ -469,7 +507,9 @@ class BA:
         st, w2c, ev = np.zeros(10), np.zeros(12), np.zeros(12)
         th = C.c_float(0)
         self.L.orc_ba_get_frame(self.h_, f, dp(st), dp(w2c), dp(ev), C.byref(th))
-        return dict(state=st, worldToCam=w2c.reshape(3, 4), evalPT=ev.reshape(3, 4), frameEnergyTH=th.value)
+        sz = np.zeros(10)
+        self.L.orc_ba_get_frame_state_zero(self.h_, f, dp(sz))
+        return dict(state=st, state_zero=sz, worldToCam=w2c.reshape(3, 4), evalPT=ev.reshape(3, 4), frameEnergyTH=th.value)
 
     def calib(self):
         v = np.zeros(4)

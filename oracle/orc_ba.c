@@ -70,6 +70,17 @@ static void frame_take_data(OrcFrame* f) {
 }
 
 /* ---------------------------------------------------------------- create / setters */
+static void alloc_replicas(OrcBA* ba, int upto) {          /* per-worker accumulator replicas (AccumulatedTopHessian.h:144-149, AccumulatedSCHessian.h) */
+    int W=ba->W;
+    for (int t=ba->nt_alloc;t<upto;t++) {
+        for (int i=0;i<W*W;i++) { orc_tier_init(&ba->accTopA[t][i],91); orc_tier_init(&ba->accTopL[t][i],91); }
+        ba->accD[t]=(OrcTier*)calloc(W*W*W,sizeof(OrcTier)); ba->accE[t]=(OrcTier*)calloc(W*W,sizeof(OrcTier)); ba->accEB[t]=(OrcTier*)calloc(W*W,sizeof(OrcTier));
+        for (int i=0;i<W*W*W;i++) orc_tier_init(&ba->accD[t][i],64);
+        for (int i=0;i<W*W;i++) { orc_tier_init(&ba->accE[t][i],32); orc_tier_init(&ba->accEB[t][i],8); }
+        orc_tier_init(&ba->accHcc[t],16); orc_tier_init(&ba->accbc[t],4);
+    }
+    if (upto>ba->nt_alloc) ba->nt_alloc=upto;
+}
 OrcBA* orc_ba_create(int W, int P, int w, int h, double fx, double fy, double cx, double cy) {
     OrcBA* ba=(OrcBA*)calloc(1,sizeof(OrcBA));
     ba->W=W; ba->P=P; ba->w=w; ba->h=h;
@@ -85,21 +96,15 @@ OrcBA* orc_ba_create(int W, int P, int w, int h, double fx, double fy, double cx
     ba->adHost=(double*)calloc(W*W*64,8); ba->adTarget=(double*)calloc(W*W*64,8);
     ba->adHostF=(float*)calloc(W*W*64,4); ba->adTargetF=(float*)calloc(W*W*64,4); ba->adHTdeltaF=(float*)calloc(W*W*8,4);
     int n=W*8+ORC_CPARS; ba->HM=(double*)calloc(n*n,8); ba->bM=(double*)calloc(n,8); ba->lastX=(double*)calloc(n,8);
-    ba->accTopA=calloc(ORC_NTHREADS,sizeof(*ba->accTopA)); ba->accTopL=calloc(ORC_NTHREADS,sizeof(*ba->accTopL));
-    for (int t=0;t<ORC_NTHREADS;t++) {
-        for (int i=0;i<W*W;i++) { orc_tier_init(&ba->accTopA[t][i],91); orc_tier_init(&ba->accTopL[t][i],91); }
-        ba->accD[t]=(OrcTier*)calloc(W*W*W,sizeof(OrcTier)); ba->accE[t]=(OrcTier*)calloc(W*W,sizeof(OrcTier)); ba->accEB[t]=(OrcTier*)calloc(W*W,sizeof(OrcTier));
-        for (int i=0;i<W*W*W;i++) orc_tier_init(&ba->accD[t][i],64);
-        for (int i=0;i<W*W;i++) { orc_tier_init(&ba->accE[t][i],32); orc_tier_init(&ba->accEB[t][i],8); }
-        orc_tier_init(&ba->accHcc[t],16); orc_tier_init(&ba->accbc[t],4);
-    }
+    ba->accTopA=calloc(ORC_MAXTHREADS,sizeof(*ba->accTopA)); ba->accTopL=calloc(ORC_MAXTHREADS,sizeof(*ba->accTopL));
+    ba->nt_alloc=0; alloc_replicas(ba, ORC_NTHREADS);
     for (int i=0;i<4;i++) ba->cPrior[i]=SETTING_INITIAL_CALIB_HESSIAN;
     ba->nthreads_used=ORC_NTHREADS;
     return ba;
 }
 void orc_ba_destroy(OrcBA* ba) {
     int W=ba->W;
-    for (int t=0;t<ORC_NTHREADS;t++) {
+    for (int t=0;t<ba->nt_alloc;t++) {
         for (int i=0;i<W*W;i++) { orc_tier_free(&ba->accTopA[t][i]); orc_tier_free(&ba->accTopL[t][i]); orc_tier_free(&ba->accE[t][i]); orc_tier_free(&ba->accEB[t][i]); }
         for (int i=0;i<W*W*W;i++) orc_tier_free(&ba->accD[t][i]);
         free(ba->accD[t]); free(ba->accE[t]); free(ba->accEB[t]); orc_tier_free(&ba->accHcc[t]); orc_tier_free(&ba->accbc[t]);
@@ -119,6 +124,25 @@ void orc_ba_set_frame(OrcBA* ba, int i, const float* dI, const double evalPT[12]
     frame_set_state_zero(f, f->state);
     if (state6) { for (int k=0;k<6;k++) st[k]=state6[k]; frame_set_state(f, st); }
     frame_take_data(f);
+}
+/* General form for a window that carries state between keyframes: evalPT (FEJ point), state and state_zero as the running system holds them
+ * (FrameHessian::setStateZero / setState, HessianBlocks.h:208-255, HessianBlocks.cpp:73-106). Both are the UNSCALED 10-vectors. */
+void orc_ba_set_frame_full(OrcBA* ba, int i, const float* dI, const double evalPT[12], const double state[10], const double state_zero[10],
+                           float exposure, float frameEnergyTH, int frameID) {
+    OrcFrame* f=&ba->frames[i];
+    f->dI=dI; memcpy(f->evalPT,evalPT,sizeof(double)*12); f->ab_exposure=exposure; f->frameEnergyTH=frameEnergyTH; f->frameID=frameID;
+    frame_set_state(f, state_zero);
+    frame_set_state_zero(f, state_zero);
+    frame_set_state(f, state);
+    frame_take_data(f);
+}
+/* PointHessian::idepth_zero differing from idepth (setIdepthZero / setIdepth are separate setters, HessianBlocks.h:449-460) */
+void orc_ba_set_idepth_zero(OrcBA* ba, const float* idepth_zero) {
+    for (int p=0;p<ba->P;p++) { OrcPoint* pt=&ba->pts[p]; pt->idepth_zero=idepth_zero[p]; pt->idepth_zero_scaled=SCALE_IDEPTH*idepth_zero[p]; pt->deltaF=pt->idepth-pt->idepth_zero; }
+}
+/* CalibHessian::value_zero differing from value (HessianBlocks.h:364-395): vs = {fx,fy,cx,cy} of the linearisation point, scaled units */
+void orc_ba_set_calib_zero(OrcBA* ba, const double vs[4]) {
+    ba->c_value_zero[0]=(1.0f/SCALE_F)*vs[0]; ba->c_value_zero[1]=(1.0f/SCALE_F)*vs[1]; ba->c_value_zero[2]=(1.0f/SCALE_C)*vs[2]; ba->c_value_zero[3]=(1.0f/SCALE_C)*vs[3];
 }
 void orc_ba_set_points(OrcBA* ba, const int* host, const float* u, const float* v, const float* idepth,
                        const float* color, const float* weights, const int* hasDepthPrior) {
@@ -331,9 +355,9 @@ static void set_new_frame_energy_th(OrcBA* ba) {
 }
 /* FullSystem::linearizeAll(fixLinearization), FullSystemOptimize.cpp:52-87, 144-211.
  * activeResiduals = existing, non-linearized residuals (FullSystemOptimize.cpp:412-429). */
-double orc_ba_linearize_all(OrcBA* ba, int fix) {
-    double t0=now_s(), E=0; int W=ba->W;
-    for (int p=0;p<ba->P;p++) { if (ba->pts[p].removed) continue;
+static double linearize_points(OrcBA* ba, int fix, int lo, int hi) {
+    double E=0; int W=ba->W;
+    for (int p=lo;p<hi;p++) { if (ba->pts[p].removed) continue;
         for (int t=0;t<W;t++) { OrcRes* r=RES(ba,p,t); if (!r->exists || r->isLinearized) continue;
             E += linearize(ba,p,t);
             if (fix) {
@@ -351,6 +375,27 @@ double orc_ba_linearize_all(OrcBA* ba, int fix) {
                 } else r->exists=2;                     /* toRemove -> dropResidual after the TH update (:184-205) */
             }
         } }
+    return E;
+}
+typedef struct { OrcBA* ba; int fix, tid, nt; double E; } LinJob;
+static void* lin_job_run(void* arg) {
+    LinJob* j=(LinJob*)arg; OrcBA* ba=j->ba; j->E=0;
+    for (int c=j->tid; c*50<ba->P; c+=j->nt) { int lo=c*50, hi=lo+50; if (hi>ba->P) hi=ba->P; j->E+=linearize_points(ba,j->fix,lo,hi); }
+    return 0;
+}
+double orc_ba_linearize_all(OrcBA* ba, int fix) {
+    double t0=now_s(), E=0; int W=ba->W;
+#ifdef ORC_FAST
+    if (ba->linearize_mt && ba->nthreads_used>1) {     /* upstream DSO's linearizeAll_Reductor over chunks of points; residuals are independent */
+        LinJob jobs[ORC_MAXTHREADS]; pthread_t th[ORC_MAXTHREADS]; int nt=ba->nthreads_used;
+        for (int t=0;t<nt;t++) { jobs[t].ba=ba; jobs[t].fix=fix; jobs[t].tid=t; jobs[t].nt=nt; }
+        for (int t=1;t<nt;t++) pthread_create(&th[t],0,lin_job_run,&jobs[t]);
+        lin_job_run(&jobs[0]);
+        for (int t=1;t<nt;t++) pthread_join(th[t],0);
+        for (int t=0;t<nt;t++) E+=jobs[t].E;
+    } else
+#endif
+    E=linearize_points(ba,fix,0,ba->P);
     set_new_frame_energy_th(ba);
     if (fix) for (size_t i=0;i<(size_t)ba->P*W;i++) if (ba->res[i].exists==2) { ba->res[i].exists=0; ba->res[i].isActive=0; }
     ba->t_linearize += now_s()-t0;
@@ -437,7 +482,7 @@ static void top_stitch(OrcBA* ba, OrcTier (*acc)[ORC_MAXW*ORC_MAXW], int usePrio
     for (int k=0;k<W*W;k++) {
         int h=k%W, t=k/W, hIdx=ORC_CPARS+h*8, tIdx=ORC_CPARS+t*8;
         double accH[169]; memset(accH,0,sizeof(accH));
-        for (int tid=0;tid<ORC_NTHREADS;tid++) { double H13[169]; OrcTier* A=&acc[tid][k]; top_finish13(A,H13); if (A->num==0) continue; for (int i=0;i<169;i++) accH[i]+=H13[i]; }
+        for (int tid=0;tid<ba->nt_alloc;tid++) { double H13[169]; OrcTier* A=&acc[tid][k]; top_finish13(A,H13); if (A->num==0) continue; for (int i=0;i<169;i++) accH[i]+=H13[i]; }
         if (H13_all) memcpy(H13_all+k*169,accH,sizeof(accH));
         const double *AH=ba->adHost+k*64, *AT=ba->adTarget+k*64, *M=accH+4*13+4;
         amb8(AH,M,13,AH,H+hIdx*n+hIdx,n); amb8(AT,M,13,AT,H+tIdx*n+tIdx,n); amb8(AH,M,13,AT,H+hIdx*n+tIdx,n);
@@ -488,9 +533,9 @@ static void sc_add_point(OrcBA* ba, int tid, int p, int shiftPriorToZero) {
         tierx_update(&ba->accEB[tid][r1ht],8,r1->JpJdF,(real)(pt->HdiF*pt->bdSumF));
     }
 }
-static void tier_sum_threads(OrcTier** arr, int idx, int n, double* out) {
+static void tier_sum_threads(int nt, OrcTier** arr, int idx, int n, double* out) {
     for (int i=0;i<n;i++) out[i]=0;
-    for (int tid=0;tid<ORC_NTHREADS;tid++) { OrcTier* T=&arr[tid][idx]; orc_tier_shift(T,1); if (T->numIn1m==0) continue; for (int i=0;i<n;i++) out[i]+=orc_tier_get(T,i); }
+    for (int tid=0;tid<nt;tid++) { OrcTier* T=&arr[tid][idx]; orc_tier_shift(T,1); if (T->numIn1m==0) continue; for (int i=0;i<n;i++) out[i]+=orc_tier_get(T,i); }
 }
 /* AccumulatedSCHessianSSE::stitchDoubleInternal + MT tail, AccumulatedSCHessian.cpp:78-157, .h:93-133 */
 static void sc_stitch(OrcBA* ba, double* H, double* b) {
@@ -498,20 +543,20 @@ static void sc_stitch(OrcBA* ba, double* H, double* b) {
     memset(H,0,sizeof(double)*n*n); memset(b,0,sizeof(double)*n);
     for (int k0=0;k0<W*W;k0++) {
         int i=k0%W, j=k0/W, iIdx=ORC_CPARS+i*8, jIdx=ORC_CPARS+j*8, ijIdx=i+W*j;
-        double Hpc[32], bp[8]; tier_sum_threads(ba->accE,ijIdx,32,Hpc); tier_sum_threads(ba->accEB,ijIdx,8,bp);
+        double Hpc[32], bp[8]; tier_sum_threads(ba->nt_alloc,ba->accE,ijIdx,32,Hpc); tier_sum_threads(ba->nt_alloc,ba->accEB,ijIdx,8,bp);
         const double *AHij=ba->adHost+ijIdx*64, *ATij=ba->adTarget+ijIdx*64;
         for (int r=0;r<8;r++) { for (int c=0;c<4;c++) { double s1=0,s2=0; for (int kk=0;kk<8;kk++) { s1+=AHij[r*8+kk]*Hpc[kk*4+c]; s2+=ATij[r*8+kk]*Hpc[kk*4+c]; } H[(iIdx+r)*n+c]+=s1; H[(jIdx+r)*n+c]+=s2; }
             double s1=0,s2=0; for (int kk=0;kk<8;kk++) { s1+=AHij[r*8+kk]*bp[kk]; s2+=ATij[r*8+kk]*bp[kk]; } b[iIdx+r]+=s1; b[jIdx+r]+=s2; }
         for (int k=0;k<W;k++) {
-            int kIdx=ORC_CPARS+k*8, ijk=ijIdx+k*nf2, ik=i+W*k; double D[64]; tier_sum_threads(ba->accD,ijk,64,D);
+            int kIdx=ORC_CPARS+k*8, ijk=ijIdx+k*nf2, ik=i+W*k; double D[64]; tier_sum_threads(ba->nt_alloc,ba->accD,ijk,64,D);
             const double *AHik=ba->adHost+ik*64, *ATik=ba->adTarget+ik*64;
             amb8(AHij,D,8,AHik,H+iIdx*n+iIdx,n); amb8(ATij,D,8,ATik,H+jIdx*n+kIdx,n);
             amb8(ATij,D,8,AHik,H+jIdx*n+iIdx,n); amb8(AHij,D,8,ATik,H+iIdx*n+kIdx,n);
         }
     }
     double Hcc[16], bc[4];
-    { OrcTier* a[ORC_NTHREADS]; for (int t=0;t<ORC_NTHREADS;t++) a[t]=&ba->accHcc[t]; tier_sum_threads(a,0,16,Hcc);
-      for (int t=0;t<ORC_NTHREADS;t++) a[t]=&ba->accbc[t]; tier_sum_threads(a,0,4,bc); }
+    { OrcTier* a[ORC_MAXTHREADS]; for (int t=0;t<ba->nt_alloc;t++) a[t]=&ba->accHcc[t]; tier_sum_threads(ba->nt_alloc,a,0,16,Hcc);
+      for (int t=0;t<ba->nt_alloc;t++) a[t]=&ba->accbc[t]; tier_sum_threads(ba->nt_alloc,a,0,4,bc); }
     for (int r=0;r<4;r++) { for (int c=0;c<4;c++) H[r*n+c]+=Hcc[r*4+c]; b[r]+=bc[r]; }
     for (int h=0;h<W;h++) { int hIdx=ORC_CPARS+h*8; for (int r=0;r<8;r++) for (int c=0;c<4;c++) H[c*n+hIdx+r]=H[(hIdx+r)*n+c]; }
 }
@@ -531,10 +576,10 @@ static void* job_run(void* arg) {
     return 0;
 }
 static void run_jobs(OrcBA* ba, int kind, int mode, int shift, const float* xc, const float* xAd) {
-    Job jobs[ORC_NTHREADS]; int nt=ba->nthreads_used;
+    Job jobs[ORC_MAXTHREADS]; int nt=ba->nthreads_used;
     for (int t=0;t<nt;t++) { jobs[t].ba=ba; jobs[t].tid=t; jobs[t].kind=kind; jobs[t].mode=mode; jobs[t].shift=shift; jobs[t].xc=xc; jobs[t].xAd=xAd; }
 #ifdef ORC_FAST
-    pthread_t th[ORC_NTHREADS];
+    pthread_t th[ORC_MAXTHREADS];
     for (int t=1;t<nt;t++) pthread_create(&th[t],0,job_run,&jobs[t]);
     job_run(&jobs[0]);
     for (int t=1;t<nt;t++) pthread_join(th[t],0);
@@ -546,16 +591,16 @@ static void run_jobs(OrcBA* ba, int kind, int mode, int shift, const float* xc, 
 void orc_ba_accumulate(OrcBA* ba, int mode, double* H, double* b, double* H13_all) {
     double t0=now_s(); int W=ba->W;
     OrcTier (*acc)[ORC_MAXW*ORC_MAXW] = mode==1 ? ba->accTopL : ba->accTopA;
-    for (int t=0;t<ORC_NTHREADS;t++) { for (int i=0;i<W*W;i++) orc_tier_zero(&acc[t][i]); ba->nres[t]=0; }
+    for (int t=0;t<ba->nt_alloc;t++) { for (int i=0;i<W*W;i++) orc_tier_zero(&acc[t][i]); ba->nres[t]=0; }
     run_jobs(ba,0,mode,0,0,0);
     top_stitch(ba,acc,mode==1,H,b,H13_all);
-    int nr=0; for (int t=0;t<ORC_NTHREADS;t++) nr+=ba->nres[t];
+    int nr=0; for (int t=0;t<ba->nt_alloc;t++) nr+=ba->nres[t];
     if (mode==0) ba->resInA=nr; else if (mode==1) ba->resInL=nr;
     ba->t_accumulate += now_s()-t0;
 }
 static void sc_zero(OrcBA* ba) {
     int W=ba->W;
-    for (int t=0;t<ORC_NTHREADS;t++) { for (int i=0;i<W*W*W;i++) orc_tier_zero(&ba->accD[t][i]);
+    for (int t=0;t<ba->nt_alloc;t++) { for (int i=0;i<W*W*W;i++) orc_tier_zero(&ba->accD[t][i]);
         for (int i=0;i<W*W;i++) { orc_tier_zero(&ba->accE[t][i]); orc_tier_zero(&ba->accEB[t][i]); } orc_tier_zero(&ba->accHcc[t]); orc_tier_zero(&ba->accbc[t]); }
 }
 /* accumulateSCF_MT, EnergyFunctional.cpp:244-261 */
@@ -702,7 +747,7 @@ void orc_ba_marginalize_points(OrcBA* ba, const uint8_t* flags, double* M, doubl
         for (int t=0;t<W;t++) { OrcRes* r=RES(ba,p,t); if (!r->exists) continue;
             r->state_NewEnergy=r->state_energy=0; r->state_NewState=ORC_OUTLIER; r->state_state=ORC_IN;
             linearize(ba,p,t); r->isLinearized=0; apply_res(r); if (r->isActive) fix_linearization(ba,p,t); } }
-    for (int t=0;t<ORC_NTHREADS;t++) { for (int i=0;i<W*W;i++) orc_tier_zero(&ba->accTopA[t][i]); ba->nres[t]=0; }
+    for (int t=0;t<ba->nt_alloc;t++) { for (int i=0;i<W*W;i++) orc_tier_zero(&ba->accTopA[t][i]); ba->nres[t]=0; }
     sc_zero(ba);
     for (int p=0;p<ba->P;p++) { if (!flags[p] || ba->pts[p].removed) continue;
         ba->pts[p].priorF *= SETTING_IDEPTH_FIX_PRIOR_MARGFAC;
@@ -712,6 +757,49 @@ void orc_ba_marginalize_points(OrcBA* ba, const uint8_t* flags, double* M, doubl
     ba->resInM += ba->nres[0];
     for (int i=0;i<n*n;i++) ba->HM[i]+=SETTING_MARG_WEIGHT_FAC*(M[i]-Msc[i]);
     for (int i=0;i<n;i++) ba->bM[i]+=SETTING_MARG_WEIGHT_FAC*(Mb[i]-Mbsc[i]);
+}
+
+/* ---------------------------------------------------------------- EnergyFunctional::marginalizeFrame, EnergyFunctional.cpp:498-610
+ * Works on HM/bM only (the frame has no points left: assert at :505). Writes the (n-8)^2 prior and (n-8) vector to HM_out/bM_out; the caller
+ * rebuilds the window without frame `idx` (FullSystem::marginalizeFrame, FullSystemMarginalize.cpp:148-213, drops the residuals targeting it). */
+static void inv8_lu(const double* A, double* Ai) {           /* Eigen's fixed-size inverse() for 8x8 = partial-pivot LU */
+    double M[8][16];
+    for (int i=0;i<8;i++) for (int j=0;j<8;j++) { M[i][j]=A[i*8+j]; M[i][8+j]=(i==j); }
+    for (int c=0;c<8;c++) {
+        int piv=c; for (int r=c+1;r<8;r++) if (fabs(M[r][c])>fabs(M[piv][c])) piv=r;
+        if (piv!=c) for (int j=0;j<16;j++) { double t=M[c][j]; M[c][j]=M[piv][j]; M[piv][j]=t; }
+        double d=1.0/M[c][c];
+        for (int j=0;j<16;j++) M[c][j]*=d;
+        for (int r=0;r<8;r++) if (r!=c) { double f=M[r][c]; if (f!=0) for (int j=0;j<16;j++) M[r][j]-=f*M[c][j]; }
+    }
+    for (int i=0;i<8;i++) for (int j=0;j<8;j++) Ai[i*8+j]=M[i][8+j];
+}
+void orc_ba_marginalize_frame(OrcBA* ba, int idx, double* HM_out, double* bM_out) {
+    int W=ba->W, odim=NDIM(ba), ndim=odim-8;
+    double* H=(double*)malloc(8*(size_t)odim*odim); double* b=(double*)malloc(8*odim);
+    /* permutation: frame idx moves to the end, the frames behind it move up (:519-540) */
+    int* perm=(int*)malloc(sizeof(int)*odim); int k=0;
+    for (int i=0;i<odim;i++) { int f=(i<ORC_CPARS)?-1:(i-ORC_CPARS)/8; if (f!=idx) perm[k++]=i; }
+    for (int i=0;i<8;i++) perm[k++]=ORC_CPARS+8*idx+i;
+    for (int i=0;i<odim;i++) { b[i]=ba->bM[perm[i]]; for (int j=0;j<odim;j++) H[(size_t)i*odim+j]=ba->HM[(size_t)perm[i]*odim+perm[j]]; }
+    OrcFrame* fh=&ba->frames[idx];
+    for (int i=0;i<8;i++) { H[(size_t)(ndim+i)*odim+ndim+i]+=fh->prior[i]; b[ndim+i]+=fh->prior[i]*fh->delta_prior[i]; }   /* :544-545 */
+    double* S=(double*)malloc(8*odim);
+    for (int i=0;i<odim;i++) S[i]=sqrt(fabs(H[(size_t)i*odim+i])+10);                                                         /* :552-553 */
+    for (int i=0;i<odim;i++) { for (int j=0;j<odim;j++) H[(size_t)i*odim+j]=(1.0/S[i])*H[(size_t)i*odim+j]*(1.0/S[j]); b[i]=(1.0/S[i])*b[i]; }
+    double hp[64], hpi[64];
+    for (int i=0;i<8;i++) for (int j=0;j<8;j++) hp[i*8+j]=H[(size_t)(ndim+i)*odim+ndim+j];
+    for (int i=0;i<64;i++) hp[i]=0.5f*(hp[i]+hp[i]);                                                                            /* :564-567 (sic: hpi+hpi, not the transpose) */
+    inv8_lu(hp,hpi);
+    for (int i=0;i<64;i++) hpi[i]=0.5f*(hpi[i]+hpi[i]);
+    /* bli = BL^T * hpi (ndim x 8); TL -= bli * BL; bTop -= bli * bTail (:570-572) */
+    double* bli=(double*)malloc(8*(size_t)ndim*8);
+    for (int r=0;r<ndim;r++) for (int c=0;c<8;c++) { double s=0; for (int kk=0;kk<8;kk++) s+=H[(size_t)(ndim+kk)*odim+r]*hpi[kk*8+c]; bli[r*8+c]=s; }
+    for (int r=0;r<ndim;r++) { for (int c=0;c<ndim;c++) { double s=0; for (int kk=0;kk<8;kk++) s+=bli[r*8+kk]*H[(size_t)(ndim+kk)*odim+c]; H[(size_t)r*odim+c]-=s; }
+        double s=0; for (int kk=0;kk<8;kk++) s+=bli[r*8+kk]*b[ndim+kk]; b[r]-=s; }
+    for (int i=0;i<odim;i++) { for (int j=0;j<odim;j++) H[(size_t)i*odim+j]=S[i]*H[(size_t)i*odim+j]*S[j]; b[i]=S[i]*b[i]; }   /* :575-576 */
+    for (int i=0;i<ndim;i++) { for (int j=0;j<ndim;j++) HM_out[(size_t)i*ndim+j]=0.5*(H[(size_t)i*odim+j]+H[(size_t)j*odim+i]); bM_out[i]=b[i]; }   /* :579-580 */
+    free(H); free(b); free(perm); free(S); free(bli); (void)W;
 }
 
 /* ---------------------------------------------------------------- getters for the tests */
@@ -734,6 +822,10 @@ void orc_ba_get_slots(OrcBA* ba, int8_t* state, uint8_t* active, float* JpJdF /*
         if (JpJdF) for (int k=0;k<8;k++) JpJdF[i*8+k]=(float)r->JpJdF[k];
         if (energyNew) energyNew[i]=(float)r->state_NewEnergyWithOutlier; }
 }
+/* centerProjectedTo of every residual slot [P*W][3] (what CoarseTracker::makeCoarseDepthL0 reads, CoarseTracker.cpp:388-405) */
+void orc_ba_get_center_projected(OrcBA* ba, float* out) {
+    for (size_t i=0;i<(size_t)ba->P*ba->W;i++) for (int k=0;k<3;k++) out[3*i+k]=ba->res[i].centerProjectedTo[k];
+}
 void orc_ba_get_points(OrcBA* ba, float* idepth, float* step, float* HdiF, float* bdSumF, float* Hdd, float* bd, float* Hcd4, float* maxRelBaseline) {
     for (int p=0;p<ba->P;p++) { OrcPoint* pt=&ba->pts[p];
         if (idepth) idepth[p]=pt->idepth; if (step) step[p]=pt->step; if (HdiF) HdiF[p]=pt->HdiF; if (bdSumF) bdSumF[p]=pt->bdSumF;
@@ -745,6 +837,7 @@ void orc_ba_get_frame(OrcBA* ba, int f, double* state10, double* worldToCam12, d
     if (state10) memcpy(state10,fr->state,80); if (worldToCam12) memcpy(worldToCam12,fr->PRE_worldToCam,96);
     if (evalPT12) memcpy(evalPT12,fr->evalPT,96); if (frameEnergyTH) *frameEnergyTH=fr->frameEnergyTH;
 }
+void orc_ba_get_frame_state_zero(OrcBA* ba, int f, double* sz10) { memcpy(sz10,ba->frames[f].state_zero,80); }
 void orc_ba_get_calib(OrcBA* ba, double* value_scaled4) { memcpy(value_scaled4,ba->c_value_scaled,32); }
 void orc_ba_get_precalc(OrcBA* ba, float* out /*[W*W][32]*/) {
     for (int i=0;i<ba->W*ba->W;i++) { const OrcPrecalc* pc=&ba->pre[i]; float* o=out+i*32; memset(o,0,128);
@@ -760,7 +853,14 @@ void orc_ba_get_adjoints(OrcBA* ba, double* adHost, double* adTarget, float* adH
 }
 void orc_ba_get_prior(OrcBA* ba, double* HM, double* bM) { int n=NDIM(ba); memcpy(HM,ba->HM,8*n*n); memcpy(bM,ba->bM,8*n); }
 void orc_ba_set_prior(OrcBA* ba, const double* HM, const double* bM) { int n=NDIM(ba); memcpy(ba->HM,HM,8*n*n); memcpy(ba->bM,bM,8*n); }
-void orc_ba_set_options(OrcBA* ba, int nthreads, int never_break) { ba->nthreads_used = nthreads<1?1:(nthreads>ORC_NTHREADS?ORC_NTHREADS:nthreads); ba->never_break=never_break; }
+void orc_ba_set_options(OrcBA* ba, int nthreads, int never_break) {
+    if (nthreads<1) nthreads=1; if (nthreads>ORC_MAXTHREADS) nthreads=ORC_MAXTHREADS;
+    if (nthreads>ba->nt_alloc) alloc_replicas(ba,nthreads);
+    ba->nthreads_used=nthreads; ba->never_break=never_break;
+}
+/* 1 = linearizeAll chunked over the workers (upstream DSO; this fork runs it single-threaded, FullSystemOptimize.cpp:154-164): only for the
+ * all-cores baseline line of bench.py */
+void orc_ba_set_linearize_mt(OrcBA* ba, int on) { ba->linearize_mt=on; }
 void orc_ba_get_timers(OrcBA* ba, double* t4) { t4[0]=ba->t_linearize; t4[1]=ba->t_accumulate; t4[2]=ba->t_solve; t4[3]=ba->t_other; }
 int orc_ba_counts(OrcBA* ba, int which) { return which==0?ba->resInA: which==1?ba->resInL: ba->resInM; }
 void orc_ba_set_idepth(OrcBA* ba, const float* idepth) { for (int p=0;p<ba->P;p++) { OrcPoint* pt=&ba->pts[p]; pt->idepth=idepth[p]; pt->idepth_scaled=idepth[p]; pt->idepth_zero=idepth[p]; pt->idepth_zero_scaled=idepth[p]; pt->deltaF=0; } }

@@ -60,7 +60,8 @@ typedef struct {
     int removed;
 } OrcPoint;
 
-#define ORC_NTHREADS 6                 /* util/NumType.h:42 */
+#define ORC_NTHREADS 6                 /* util/NumType.h:42: the reference's NUM_THREADS (default replica / worker count) */
+#define ORC_MAXTHREADS 64              /* upper bound for the all-cores baseline line (orc_ba_set_options) */
 
 typedef struct OrcBA {
     int W, P, w, h;
@@ -76,9 +77,11 @@ typedef struct OrcBA {
     double *lastX; int resInA, resInL, resInM;
     /* accumulators: [tid][...] */
     OrcTier (*accTopA)[ORC_MAXW*ORC_MAXW], (*accTopL)[ORC_MAXW*ORC_MAXW];
-    OrcTier *accD[ORC_NTHREADS], *accE[ORC_NTHREADS], *accEB[ORC_NTHREADS], accHcc[ORC_NTHREADS], accbc[ORC_NTHREADS];
-    int nres[ORC_NTHREADS];
-    int nthreads_used;                 /* 1 or 6 */
+    OrcTier *accD[ORC_MAXTHREADS], *accE[ORC_MAXTHREADS], *accEB[ORC_MAXTHREADS], accHcc[ORC_MAXTHREADS], accbc[ORC_MAXTHREADS];
+    int nres[ORC_MAXTHREADS];
+    int nt_alloc;                      /* accumulator replicas allocated (>= nthreads_used) */
+    int nthreads_used;                 /* 1 .. nt_alloc; 6 = the reference */
+    int linearize_mt;                  /* 0 = single-threaded linearizeAll as in this fork (FullSystemOptimize.cpp:154-164); 1 = chunked over the workers (upstream DSO) */
     int never_break;
     double t_linearize, t_accumulate, t_solve, t_other;   /* wall seconds, for the baseline report */
 } OrcBA;

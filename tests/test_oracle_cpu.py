@@ -468,3 +468,50 @@ def test_pixel_selector_matches_closed_form_and_bookkeeping():
     rs = (draws % 1000).astype(np.float32).reshape(h, w) / np.float32(1000.0)
     assert np.array_equal(fm == 1, ((got == 1) & ~((rs > 0.5) & (mask < qm[0] // 3))) | ((got == 2) & (rs.astype(np.float64) < 0.6) & (mask > qm[0] + (qm[1] - qm[0]) // 2))
                           | ((got != 1) & (got != 2) & (rs.astype(np.float64) < 0.01) & (mask > qm[0])))
+
+
+def test_marginalize_frame_matches_dense_schur_and_solution_identity(small_window):
+    """EnergyFunctional::marginalizeFrame restatement vs an independent numpy formulation: (i) the permuted, prior-augmented, scaled Schur complement
+    written with numpy's inverse; (ii) the defining property — solving the marginalised system gives the same remaining variables as solving the full
+    one (frame prior included) and dropping the frame's 8 entries."""
+    win = small_window
+    st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
+    aff = [(0.0, 0.0), (0.01, 1.0), (-0.02, -2.0), (0.015, 0.5)]
+    ba = orc.ba_from_window(win, "f32", state6=st6, aff=aff)
+    ba.linearize_all(False); ba.apply_res()
+    ba.marginalize_points((np.arange(len(win.host)) % 3 == 0).astype(np.uint8))
+    HM, bM = ba.get_prior()
+    n = ba.n
+    rng = np.random.RandomState(0)
+    A = rng.randn(n, n)
+    HM = HM + 1e-3 * np.abs(HM).max() * (A @ A.T) / n                # strictly positive definite, still dominated by the real prior
+    ba.set_prior(HM, bM)
+    for idx in range(win.W):
+        H_o, b_o = ba.marginalize_frame(idx)
+        fr = ba.frame(idx)
+        prior = np.zeros(8)
+        if idx == 0:
+            prior[:3], prior[3:6], prior[6:] = 1e10, 1e11, 1e14       # frameID 0: setting_initial{Trans,Rot,Aff}Prior (settings.cpp:58-61)
+        else:
+            prior[6], prior[7] = 1e12, 1e8                            # setting_affineOptModeA / B (settings.cpp:128-129)
+        keep = [i for i in range(n) if i < 4 or (i - 4) // 8 != idx]
+        fr_i = [4 + 8 * idx + k for k in range(8)]
+        Hf = HM.copy(); bf = bM.copy()
+        Hf[np.ix_(fr_i, fr_i)] += np.diag(prior)
+        bf[fr_i] += prior * fr["state"][:8]                           # delta_prior = state (getPriorZero() = 0)
+        p = keep + fr_i
+        Hp, bp = Hf[np.ix_(p, p)], bf[p]
+        S = np.sqrt(np.abs(np.diag(Hp)) + 10)
+        Hs, bs = Hp / S[:, None] / S[None, :], bp / S
+        nd = n - 8
+        D_inv = np.linalg.inv(Hs[nd:, nd:])
+        Hm = Hs[:nd, :nd] - Hs[nd:, :nd].T @ D_inv @ Hs[nd:, :nd]
+        bm = bs[:nd] - Hs[nd:, :nd].T @ D_inv @ bs[nd:]
+        Hm = Hm * S[:nd, None] * S[None, :nd]
+        bm = bm * S[:nd]
+        Hm = 0.5 * (Hm + Hm.T)
+        assert rel_err(H_o, Hm) < 1e-9 and rel_err(b_o, bm) < 1e-9
+        assert np.abs(H_o - H_o.T).max() == 0
+        x_full = np.linalg.solve(Hp, bp)
+        x_marg = np.linalg.solve(H_o, b_o)
+        assert np.abs(x_marg - x_full[:nd]).max() < 1e-6 * np.abs(x_full[:nd]).max()
