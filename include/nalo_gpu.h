@@ -220,6 +220,23 @@ int nalo_ba_set_allreduce_mode(nalo_ctx* ctx, int stream_ordered);
  * under the Schur-complement / reduce / stitch kernels of the main stream, instead of in line before them. */
 int nalo_ba_set_allreduce_side(nalo_ctx* ctx, nalo_allreduce_fn hook, void* user);
 void* nalo_side_stream(nalo_ctx* ctx);
+/* The native form of the exchange: the library calls ncclAllReduce (RCCL over xGMI) itself, stream-ordered on nalo_stream / nalo_side_stream — no
+ * callback into the caller per Gauss-Newton iteration. librccl is opened with dlopen when the first of these is called (NALO_ERR_UNSUPPORTED if absent).
+ *   nalo_rccl_unique_id    ncclGetUniqueId: rank 0 draws one id per communicator and ships it to the other ranks (MPI, a file, torch.distributed ...)
+ *   nalo_ba_rccl_init      ncclCommInitRank for the main and (id_side != NULL) the side communicator on this context's device; collective over the ranks;
+ *                          the context owns and destroys the communicators
+ *   nalo_ba_set_rccl_comm  the same with ncclComm_t handles the caller owns (comm_side may be NULL: the histogram sums then run in line on the main
+ *                          stream); comm_main == NULL returns to single-GPU operation
+ * Two communicators because the stitched systems (main stream) and the two radix histograms of setNewFrameEnergyTH (side stream, under the
+ * Schur-complement kernels) are in flight at the same time, and RCCL serialises the operations of one communicator. Call after nalo_ba_set_window. */
+int nalo_rccl_unique_id(char id[128]);
+int nalo_ba_rccl_init(nalo_ctx* ctx, int nranks, int rank, const char id_main[128], const char id_side[128]);
+int nalo_ba_set_rccl_comm(nalo_ctx* ctx, void* comm_main, void* comm_side);
+/* The partition a sharded window uses: which of the P active points rank `rank` of `world` keeps. Every rank gets the same share of every
+ * host frame (all (host, target) bins stay evenly populated) as a contiguous range of the host's points in Hilbert order of their 8x8-pixel cells — a
+ * spatially compact part of the image, so a rank's texel gathers keep the locality of the unsharded window. keep[] (capacity P) receives the ascending
+ * point indices; the return value is their number (< 0: NALO_ERR_ARG). Host code, needs no device. */
+int nalo_shard_points(int P, int W, const int* host, const float* u, const float* v, int img_w, int img_h, int rank, int world, int* keep);
 
 /* ------------------------------------------------------------------------------------------------
  * a14  DenseMapping::updateMap bbox scan + makeMap (FullSystem/MapPoint.cpp:300-310, 334-407), call site

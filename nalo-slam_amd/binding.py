@@ -31,7 +31,7 @@ EXPORTS = [
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_get_frames", "nalo_ba_get_points",
-    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_ba_snapshot", "nalo_ba_restore",
+    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get",
@@ -101,6 +101,10 @@ def load():
     L.nalo_ba_set_allreduce_side.argtypes = [vp, ALLREDUCE_FN, vp]
     L.nalo_side_stream.argtypes = [vp]
     L.nalo_side_stream.restype = vp
+    L.nalo_rccl_unique_id.argtypes = [C.c_char_p]
+    L.nalo_ba_rccl_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    L.nalo_ba_set_rccl_comm.argtypes = [vp, vp, vp]
+    L.nalo_shard_points.argtypes = [C.c_int, C.c_int, c_ip, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_ip]
     L.nalo_ba_snapshot.argtypes = [vp]
     L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
                                             c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
@@ -146,6 +150,27 @@ def _u8(a):
 
 class NaloError(RuntimeError):
     pass
+
+
+def shard_points(host, u, v, W, img_w, img_h, rank, world):
+    """indices (ascending) of the active points rank `rank` of `world` keeps: nalo_shard_points, host code (no device needed)"""
+    L = load()
+    h = np.ascontiguousarray(host, np.int32)
+    uu, vv = np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32)
+    keep = np.zeros(len(h), np.int32)
+    n = L.nalo_shard_points(len(h), int(W), _i(h), _f(uu), _f(vv), int(img_w), int(img_h), int(rank), int(world), _i(keep))
+    if n < 0:
+        raise NaloError("nalo_shard_points: bad argument (%d)" % n)
+    return keep[:n].copy()
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId (rank 0 draws it, the caller ships it to the other ranks)"""
+    buf = C.create_string_buffer(128)
+    rc = load().nalo_rccl_unique_id(buf)
+    if rc != 0:
+        raise NaloError("nalo_rccl_unique_id failed (%d): librccl missing?" % rc)
+    return buf.raw
 
 
 class Context:
@@ -551,6 +576,10 @@ class Context:
         else:
             self._hook_side = None
             self._ck(self.L.nalo_ba_set_allreduce_side(self.h_, C.cast(None, ALLREDUCE_FN), None))
+
+    def ba_rccl_init(self, nranks, rank, id_main, id_side=None):
+        """native RCCL exchange (ncclCommInitRank on this context's device, collective over the ranks); ids from rccl_unique_id()"""
+        self._ck(self.L.nalo_ba_rccl_init(self.h_, int(nranks), int(rank), id_main, id_side))
 
     # ---- profiling
     def profile_enable(self, on=True):

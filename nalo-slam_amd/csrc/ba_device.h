@@ -27,6 +27,7 @@ struct BADev {
     const float* calib;                         // [10] {fxl, fyl, cxl, cyl, fxli, fyli (CalibHessian::value_scaledf / value_scaledi), cDeltaF[4] (EnergyFunctional)}
     const int* stop;                            // device-side GN loop: 1 = the loop has terminated, every kernel returns at once
     const float4* img[16];                      // level-0 {I,dx,dy,0} of every window frame
+    int lin_sub;                                // ba_linearize workgroups (= fp64 partials) per point block: 1 = 256 threads, 4 = one wave each (small windows)
     const float* pre;                           // [W*W][kPreStride], index h*W + t
     float* frameTH;                             // [W] frameEnergyTH (device resident, updated by the quantile kernel)
     const int* blk_host;                        // [nblocks]
@@ -52,7 +53,7 @@ struct BADev {
     float* en_new;                              // [Ppad] state_NewEnergyWithOutlier of residuals targeting frame W-1 (-1 = none)
     unsigned *th_hist_hi, *th_hist_lo, *th_state;   // radix-select histograms (2 x 65536) + {count, k_rem, prefix_hi}
     // partials
-    double* top_partial;                        // [nblocks][W][kTopStride]  (fp64: one rounding less before the cancelling H_A - H_sc)
+    double* top_partial;                        // [nblocks*lin_sub][W][kTopStride]: one partial per ba_linearize workgroup and target (fp64: one rounding less before the cancelling H_A - H_sc)
     double* sc_partial;                         // [sc_groups * sc_split][T(T+1)/2 upper tiles][256] (MFMA register order)
     int sc_split;                               // 1 or 4 workgroups per point block in ba_sc_kernel (4 for small windows)
     const int* host_blk;                        // [W+1] point-block range of every host

@@ -56,6 +56,7 @@ void nalo_destroy(nalo_ctx* c) {
     if (std::getenv("NALO_HOST_TIMING")) for (auto& kv : c->host_t) fprintf(stderr, "[nalo host] %-28s calls=%6ld total=%10.1f us  avg=%8.2f us\n", kv.first.c_str(), kv.second.second, kv.second.first, kv.second.first / std::max(1L, kv.second.second));
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    rccl_release(c);
     ba_destroy(c);
     pixsel_destroy(c);
     if (c->copy) (void)hipStreamSynchronize(c->copy);

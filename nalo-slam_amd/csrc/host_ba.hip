@@ -681,13 +681,23 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     w.blk_host_h.assign(w.nblocks, 0);
     for (int h = 0; h < W; ++h) for (int b = w.host_blk_h[h]; b < w.host_blk_h[h + 1]; ++b) w.blk_host_h[b] = h;
     w.d2p.assign(w.Ppad, -1); w.p2d.assign(P, -1);
-    // inside a host: Morton order of the 8x8-pixel tile, so the 64 lanes of a wave gather neighbouring texels (cache-line reuse
-    // in L1/L2 instead of 64 scattered lines per load instruction). Sums are order independent up to rounding.
-    auto morton = [](unsigned x, unsigned y) { unsigned long long r = 0; for (int i = 0; i < 16; ++i) r |= ((unsigned long long)((x >> i) & 1) << (2 * i)) | ((unsigned long long)((y >> i) & 1) << (2 * i + 1)); return r; };
+    // inside a host: HILBERT order of the 8x8-pixel cell. Any run of consecutive points then covers a compact, connected patch of the host image (a
+    // Morton range can jump across a quadrant boundary), so the 64 residuals of a wave project into a small window of the target image: that window is
+    // what ba_linearize_tile_kernel stages in LDS, and what keeps the gather kernel's texels in L1/L2. Sums are order independent up to rounding.
+    unsigned hn = 1; while ((int)hn * 8 < std::max(c->w, c->h)) hn <<= 1;
+    auto hilbert = [hn](unsigned x, unsigned y) {
+        unsigned long long d = 0;
+        for (unsigned s = hn / 2; s > 0; s /= 2) {
+            const unsigned rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+            d += (unsigned long long)s * s * ((3u * rx) ^ ry);
+            if (ry == 0) { if (rx == 1) { x = hn - 1 - x; y = hn - 1 - y; } const unsigned tmp = x; x = y; y = tmp; }
+        }
+        return d;
+    };
     std::vector<int> order(P);
     for (int p = 0; p < P; ++p) order[p] = p;
     std::vector<unsigned long long> key(P);
-    for (int p = 0; p < P; ++p) key[p] = ((unsigned long long)host[p] << 40) | morton((unsigned)std::max(0.f, u[p]) >> 3, (unsigned)std::max(0.f, v[p]) >> 3);
+    for (int p = 0; p < P; ++p) key[p] = ((unsigned long long)host[p] << 40) | hilbert(std::min(hn - 1, (unsigned)std::max(0.f, u[p]) >> 3), std::min(hn - 1, (unsigned)std::max(0.f, v[p]) >> 3));
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
     std::vector<int> fill(W);
     for (int h = 0; h < W; ++h) fill[h] = w.host_blk_h[h] * kBlk;
@@ -712,7 +722,8 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     NALO_HIP(c, w.blk_host.reserve(w.nblocks)); NALO_HIP(c, w.host_blk.reserve(W + 1));
     const size_t NS = (size_t)W * N;
     NALO_HIP(c, w.rs_state.reserve(NS)); NALO_HIP(c, w.rs_energy.reserve(NS)); NALO_HIP(c, w.rs_jp0.reserve(NS)); NALO_HIP(c, w.rs_jp1.reserve(NS)); NALO_HIP(c, w.rs_cpt.reserve(NS)); NALO_HIP(c, w.rs_pp0.reserve(NS)); NALO_HIP(c, w.rs_pp1.reserve(NS));
-    NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * W * kTopStride)); {   // ba_sc work distribution: ~1000+ workgroups whatever the window size. Small windows split a point block over 4 (2) workgroups; large
+    w.dev.lin_sub = w.nblocks >= 128 ? 1 : 4;             // small windows: one workgroup per wave fills more CUs (kernels_ba_lin.hip)
+    NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * w.dev.lin_sub * W * kTopStride)); {   // ba_sc work distribution: ~1000+ workgroups whatever the window size. Small windows split a point block over 4 (2) workgroups; large
         // ones put up to 8 blocks of a host through one workgroup so that the NPL^2 fp64 partial is written once per group.
         static const int force_split = [] { const char* e = std::getenv("NALO_SC_SPLIT"); return e ? std::atoi(e) : 0; }();
         static const int force_bpw = [] { const char* e = std::getenv("NALO_SC_BPW"); return e ? std::atoi(e) : 0; }();
@@ -758,7 +769,7 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     NALO_HIP(c, hipMemset(w.pt_acc.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_hcd.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_step.p, 0, N * 4));
     NALO_HIP(c, hipMemset(w.pt_backup.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_relbs.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_ngood.p, 0, N));
     NALO_HIP(c, hipMemset(w.rs_state.p, 0, NS)); NALO_HIP(c, hipMemset(w.rs_energy.p, 0, NS * 8)); NALO_HIP(c, hipMemset(w.rs_jp0.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.rs_jp1.p, 0, NS * 16));
-    NALO_HIP(c, hipMemset(w.rs_cpt.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.top_partial.p, 0, (size_t)w.nblocks * W * kTopStride * 8));
+    NALO_HIP(c, hipMemset(w.rs_cpt.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.top_partial.p, 0, (size_t)w.nblocks * w.dev.lin_sub * W * kTopStride * 8));
     BADev& D = w.dev;
     D.P = P; D.Ppad = w.Ppad; D.nblocks = w.nblocks; D.blk_host = w.blk_host.p; D.host_blk = w.host_blk.p;
     D.pt_geo = w.pt_geo.p; D.pt_col0 = w.pt_col0.p; D.pt_col1 = w.pt_col1.p; D.pt_w0 = w.pt_w0.p; D.pt_w1 = w.pt_w1.p; D.pt_prior = w.pt_prior.p;

@@ -326,7 +326,7 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 //   G[h][row][col] = G[h][col][row] = sum over the host's workgroups of the compact SYRK partials (MFMA register order, see ba_sc_kernel)
 // Lane groups stride over the host's blocks (8 loads in flight per lane) and are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
-                                                         const int* __restrict__ host_blk /* [W+1] */, const int* __restrict__ sc_grp /* [W+1] */, int W, int NPL, int sc_tiles, int mask, int KS,
+                                                         const int* __restrict__ host_blk /* [W+1] */, const int* __restrict__ sc_grp /* [W+1] */, int W, int NPL, int sc_tiles, int mask, int KS, int lin_sub,
                                                          double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G,
                                                          const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out, const int* __restrict__ stop) {
     __shared__ double part[16][64];
@@ -338,8 +338,8 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
         const int h = blockIdx.x % W, t = blockIdx.x / W, j = threadIdx.x & 127, g = threadIdx.x >> 7;     // 8 groups stride over the blocks
         double s = 0;
         if (j < kTopVals && h != t) {
-            const int bend = host_blk[h + 1];
-            int b = host_blk[h] + g;
+            const int bend = host_blk[h + 1] * lin_sub;         // lin_sub partials per point block (kernels_ba_lin.hip)
+            int b = host_blk[h] * lin_sub + g;
             double u[8];
             for (; b + 56 < bend; b += 64) {                    // 8 independent loads per round: the host's blocks are a long latency-bound walk
 #pragma unroll
@@ -404,7 +404,7 @@ void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NP
                       const float* step_partial, int step_blocks, double* step_out) {
     const int T = NPL / 16, tiles = T * (T + 1) / 2 * 4;
     ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.sc_grp, B.W, NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
-                                                                                       B.sc_split, acc13, misc, G, step_partial, step_blocks, step_out, B.stop);
+                                                                                       B.sc_split, B.lin_sub, acc13, misc, G, step_partial, step_blocks, step_out, B.stop);
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)

@@ -89,6 +89,7 @@ struct nalo_ctx {
     // ---- BA (opaque; defined in host_ba.cpp)
     nalo::BAWindow* ba = nullptr;
     nalo::PixSel* pixsel = nullptr;          // pixel selector state (kernels_pixsel.hip)
+    void* rccl = nullptr;                    // RCCL communicators of the sharded BA (host_rccl.hip)
 
     // ---- host wall-clock accounting (NALO_HOST_TIMING=1 prints it at nalo_destroy)
     std::map<std::string, std::pair<double, long>> host_t;
@@ -161,6 +162,8 @@ int imm_optimize_launch(nalo_ctx* c, const float4* const* dI, int W, const float
                         int minObs, int* result, float* idepth_out, uint8_t* res_in);
 int dist_make_launch(nalo_ctx* c, const float4* pt_geo, const uint8_t* pt_flags, const int* blk_host, int Ppad, int frame, const float* KRKi, const float* Kt, uint8_t* seed, float* out);
 int pixsel_hists_launch(nalo_ctx* c, const float* absg0, float* ths, float* thsSmoothed);
+// host_rccl.hip
+void rccl_release(nalo_ctx* c);
 // kernels_pixsel.hip
 void pixsel_destroy(nalo_ctx* c);
 void pixsel_invalidate_hists(nalo_ctx* c, int slot);

@@ -162,3 +162,14 @@ def perturbed_poses(win: Window, seed=3, sigma_t=0.01, sigma_r=0.001):
     st[1:, :3] = sigma_t * rng.randn(win.W - 1, 3) / 0.5     # state_scaled = 0.5 * state for translation
     st[1:, 3:] = sigma_r * rng.randn(win.W - 1, 3)
     return st
+
+
+def shard_window(win: Window, rank: int, world: int) -> Window:
+    """The part of a window's active points rank `rank` of `world` holds (points keep their residuals, frames are replicated): the partition
+    is the library's (nalo_shard_points: the same share of every host frame, a contiguous Hilbert range of the host's points)."""
+    if world == 1:
+        return win
+    from . import binding
+    idx = binding.shard_points(win.host, win.u, win.v, win.W, win.w, win.h, rank, world)
+    return dataclasses.replace(win, host=win.host[idx], u=win.u[idx], v=win.v[idx], idepth=win.idepth[idx], idepth_true=win.idepth_true[idx],
+                               color=win.color[idx], weights=win.weights[idx], exists=win.exists[idx])

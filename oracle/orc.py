@@ -111,6 +111,7 @@ def lib(kind="f32"):
     L.orc_ba_counts.restype = C.c_int
     L.orc_ba_set_idepth.argtypes = [C.c_void_p, c_fp]
     L.orc_ba_get_center_projected.argtypes = [C.c_void_p, c_fp]
+    L.orc_ba_set_linearize_mt.argtypes = [C.c_void_p, C.c_int]
     L.orc_ba_get_frame_state_zero.argtypes = [C.c_void_p, C.c_int, c_dp]
     L.orc_ba_set_frame_full.argtypes = [C.c_void_p, C.c_int, c_fp, c_dp, c_dp, c_dp, C.c_float, C.c_float, C.c_int]
     L.orc_ba_set_idepth_zero.argtypes = [C.c_void_p, c_fp]
