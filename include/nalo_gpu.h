@@ -321,7 +321,7 @@ int nalo_imm_optimize(nalo_ctx* ctx, int n, const int* host, const float* u, con
  *     H_out/H_out_sc are 8x8 row-major, b_out/b_out_sc 8, E3 = {E.A, alphaEnergy, E.num} exactly as returned (:609), including the reference's
  *     behaviour that the regulariser loop feeds E instead of EAlpha (:560-572).
  * nalo_init_do_step          CoarseInitializer::doStep (:910-938): idepth_new[i] for the good points from JbBuffer (the applied buffer), inc[8], lambda.
- * applyStep (:939-956) is a member copy on the caller's arrays.
+ * applyStep (:939-956) is a member copy on the caller's arrays (or use nalo_init_track_frame below, which runs the whole loop).
  * ------------------------------------------------------------------------------------------------ */
 int nalo_init_calc_res_and_gs(nalo_ctx* ctx, int slot_first, int slot_new, int lvl, int n, const float* u, const float* v, const float* idepth_new, const float* iR,
                               const uint8_t* isGood, const float* energy, const float* outlierTH, const double refToNew[12], const double aff[2],
@@ -330,6 +330,25 @@ int nalo_init_calc_res_and_gs(nalo_ctx* ctx, int slot_first, int slot_new, int l
                               double* H_out, double* b_out, double* H_out_sc, double* b_out_sc, double E3[3]);
 int nalo_init_do_step(nalo_ctx* ctx, int n, const uint8_t* isGood, const float* JbBuffer, const float* maxstep, const float* idepth, float lambda,
                       const float inc[8], float* idepth_new);
+/* The whole initialiser behind the boundary (the CoarseInitializer object lives in the context; Pnt arrays on the host side of the library, the two
+ * per-point image passes and both point selections on the device):
+ * nalo_init_set_first    CoarseInitializer::setFirst (FullSystem/CoarseInitializer.cpp:785-880), call site FullSystem::addActiveFrame (FullSystem.cpp:1101):
+ *     makeK from the context's calibration, level 0 selected by a fresh PixelSelector (makeMaps(., 0.03 w h, 1, false, 2), currentPotential 3: needs
+ *     nalo_pixsel_set_random), levels >= 1 by makePixelStatus / gridMaxSelection (FullSystem/PixelSelector.h:38-253) with densities {0.05, 0.15, 0.5, 1} w h,
+ *     Pnt construction, makeNN (:992-1069; the reference's nanoflann k-d tree, tie order included). *sparsityFactor is the reference's GLOBAL of that name
+ *     (util/settings.cpp:223, initially 5; makePixelStatus keeps adapting it from call to call): in/out. numPoints[lvl] (optional) = points per level.
+ * nalo_init_track_frame  CoarseInitializer::trackFrame (:81-285), call site FullSystem.cpp:1106: the coarse-to-fine LM over pose, (fixed) affine and the
+ *     inverse depths with propagateDown / resetPoints / calcResAndGS / doStep / calcEC / applyStep / optReg / propagateUp; exposures are
+ *     firstFrame->ab_exposure and newFrame->ab_exposure. *ok = its return value (snapped && frameID > snappedAt + 5).
+ * nalo_init_get_state    thisToNext (3x4), thisToNext_aff {a, b}, snapped, frameID, snappedAt (+ the number of calcResAndGS evaluations so far); any may be NULL.
+ * nalo_init_get_points   the Pnt members FullSystem::initializeFromInitializer reads (FullSystem.cpp:1601-1660: u, v, iR, my_type of level 0) and the rest
+ *     of the state, for one level: *n = numPoints[lvl], the first min(cap, *n) entries are written; energy2 is [n][2], neighbours / neighboursDist [n][10];
+ *     any output may be NULL. */
+int nalo_init_set_first(nalo_ctx* ctx, int slot_first, int* sparsityFactor, int numPoints[NALO_MAX_LEVELS]);
+int nalo_init_track_frame(nalo_ctx* ctx, int slot_new, float exposure_first, float exposure_new, int* ok);
+int nalo_init_get_state(nalo_ctx* ctx, double thisToNext[12], double aff[2], int* snapped, int* frameID, int* snappedAt, int* n_evals);
+int nalo_init_get_points(nalo_ctx* ctx, int lvl, int cap, int* n, float* u, float* v, float* idepth, float* iR, uint8_t* isGood, float* lastHessian, float* energy2,
+                         float* my_type, float* outlierTH, int* parent, float* parentDist, int* neighbours, float* neighboursDist);
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling: per-kernel HIP-event timing on the ctx stream. Names: "trk_eval", "ba_linearize",

@@ -32,7 +32,7 @@ EXPORTS = [
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
-    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_dist_make_map", "nalo_pixsel_make_hists",
+    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get",
 ]
@@ -109,6 +109,10 @@ def load():
     L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
                                             c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.nalo_init_do_step.argtypes = [vp, C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
+    L.nalo_init_set_first.argtypes = [vp, C.c_int, c_ip, c_ip]
+    L.nalo_init_track_frame.argtypes = [vp, C.c_int, C.c_float, C.c_float, c_ip]
+    L.nalo_init_get_state.argtypes = [vp, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip]
+    L.nalo_init_get_points.argtypes = [vp, C.c_int, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_fp, c_fp, c_ip, c_fp, c_ip, c_fp]
     L.nalo_pixsel_make_hists.argtypes = [vp, C.c_int, c_fp, c_fp]
     L.nalo_pixsel_set_random.argtypes = [vp, c_u8p, c_ip]
     L.nalo_pixsel_select.argtypes = [vp, C.c_int, C.c_int, C.c_float, c_fp, c_ip]
@@ -454,6 +458,35 @@ class Context:
         out = f(idepth_new).copy()
         self._ck(self.L.nalo_init_do_step(self.h_, len(out), _u8(np.ascontiguousarray(isGood, np.uint8)), _f(f(Jb)), _f(f(maxstep)), _f(f(idepth)), float(lam), _f(f(inc)), _f(out)))
         return out
+
+    def init_set_first(self, slot_first, sparsityFactor=5):
+        """CoarseInitializer::setFirst -> (points per level, the updated global sparsityFactor)"""
+        sf, num = np.array([sparsityFactor], np.int32), np.zeros(6, np.int32)
+        self._ck(self.L.nalo_init_set_first(self.h_, slot_first, _i(sf), _i(num)))
+        return num[:self.levels].copy(), int(sf[0])
+
+    def init_track_frame(self, slot_new, exposure_first=1.0, exposure_new=1.0):
+        ok = np.zeros(1, np.int32)
+        self._ck(self.L.nalo_init_track_frame(self.h_, slot_new, C.c_float(exposure_first), C.c_float(exposure_new), _i(ok)))
+        return bool(ok[0])
+
+    def init_state(self):
+        T, aff, st = np.zeros(12), np.zeros(2), np.zeros(4, np.int32)
+        p = lambda k: st[k:k + 1].ctypes.data_as(C.POINTER(C.c_int))
+        self._ck(self.L.nalo_init_get_state(self.h_, _d(T), _d(aff), p(0), p(1), p(2), p(3)))
+        return dict(thisToNext=T.reshape(3, 4), aff=aff, snapped=bool(st[0]), frameID=int(st[1]), snappedAt=int(st[2]), n_evals=int(st[3]))
+
+    def init_points(self, lvl):
+        n = np.zeros(1, np.int32)
+        self._ck(self.L.nalo_init_get_points(self.h_, lvl, 0, _i(n), *([None] * 13)))
+        n = int(n[0]); m = max(n, 1)
+        f = lambda k=1: np.zeros((m, k) if k > 1 else m, np.float32)
+        o = dict(u=f(), v=f(), idepth=f(), iR=f(), isGood=np.zeros(m, np.uint8), lastHessian=f(), energy=f(2), my_type=f(), outlierTH=f(), parent=np.zeros(m, np.int32),
+                 parentDist=f(), neighbours=np.zeros((m, 10), np.int32), neighboursDist=f(10))
+        nn = np.zeros(1, np.int32)
+        self._ck(self.L.nalo_init_get_points(self.h_, lvl, n, _i(nn), _f(o["u"]), _f(o["v"]), _f(o["idepth"]), _f(o["iR"]), _u8(o["isGood"]), _f(o["lastHessian"]), _f(o["energy"]),
+                                             _f(o["my_type"]), _f(o["outlierTH"]), _i(o["parent"]), _f(o["parentDist"]), _i(o["neighbours"]), _f(o["neighboursDist"])))
+        return {k: a[:n] for k, a in o.items()}
 
     def pixsel_make_hists(self, slot):
         nb = (self.w // 32) * (self.h // 32)

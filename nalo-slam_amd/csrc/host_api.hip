@@ -59,6 +59,7 @@ void nalo_destroy(nalo_ctx* c) {
     rccl_release(c);
     ba_destroy(c);
     pixsel_destroy(c);
+    init_destroy(c);
     if (c->copy) (void)hipStreamSynchronize(c->copy);
     for (auto& s : c->slots) {
         if (s.ev_up) (void)hipEventDestroy(s.ev_up);

@@ -54,6 +54,7 @@ struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, h
 // precalc record per (host,target), 32 floats: KRKi(9) Kt(3) R0(9) t0(3) aff(2) b0 thmax dp(8)... see kernels_ba.hip
 struct BAWindow;
 struct PixSel;
+struct Initializer;
 
 }  // namespace nalo
 
@@ -90,6 +91,7 @@ struct nalo_ctx {
     nalo::BAWindow* ba = nullptr;
     nalo::PixSel* pixsel = nullptr;          // pixel selector state (kernels_pixsel.hip)
     void* rccl = nullptr;                    // RCCL communicators of the sharded BA (host_rccl.hip)
+    nalo::Initializer* init = nullptr;       // two-frame initialiser state (host_init.hip)
 
     // ---- host wall-clock accounting (NALO_HOST_TIMING=1 prints it at nalo_destroy)
     std::map<std::string, std::pair<double, long>> host_t;
@@ -164,6 +166,8 @@ int dist_make_launch(nalo_ctx* c, const float4* pt_geo, const uint8_t* pt_flags,
 int pixsel_hists_launch(nalo_ctx* c, const float* absg0, float* ths, float* thsSmoothed);
 // host_rccl.hip
 void rccl_release(nalo_ctx* c);
+// host_init.hip
+void init_destroy(nalo_ctx* c);
 // kernels_pixsel.hip
 void pixsel_destroy(nalo_ctx* c);
 void pixsel_invalidate_hists(nalo_ctx* c, int slot);

@@ -557,3 +557,127 @@ def ba_from_window(win, kind="f32", state6=None, aff=None, th=None):
     ba.set_residuals(win.exists)
     ba.prepare()
     return ba
+
+
+# ------------------------------------------------------------------ the rest of the two-frame initialiser (orc_initfull.c)
+def _knn(fn, u, v, qu, qv, k):
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    u, v, qu, qv = f(u), f(v), f(qu), f(qv)
+    idx, dist = np.zeros((len(qu), k), np.int32), np.zeros((len(qu), k), np.float32)
+    fn.argtypes = [C.c_int, c_fp, c_fp, C.c_int, c_fp, c_fp, C.c_int, c_ip, c_fp]
+    fn.restype = C.c_int
+    rc = fn(len(u), fp(u), fp(v), len(qu), fp(qu), fp(qv), k, ip(idx), fp(dist))
+    assert rc == 0
+    return idx, dist
+
+
+def kdtree_knn(u, v, qu, qv, k, kind="f32"):
+    """the oracle's restatement of nanoflann's tree build + KNN search (tie order included)"""
+    return _knn(lib(kind).orc_kdtree_knn, u, v, qu, qv, k)
+
+
+_REF_NANOFLANN = None
+
+
+def ref_nanoflann():
+    """oracle/_ref/libref_nanoflann.so = the REFERENCE's own util/nanoflann.h behind our driver (oracle/ref_nanoflann.cpp); built here by `make -C oracle`
+    while /root/reference exists, shipped prebuilt to the GPU box. None if it was never built."""
+    global _REF_NANOFLANN
+    if _REF_NANOFLANN is None:
+        path = os.path.join(_DIR, "_ref", "libref_nanoflann.so")
+        if not os.path.exists(path):
+            build()
+        _REF_NANOFLANN = C.CDLL(path) if os.path.exists(path) else False
+    return _REF_NANOFLANN or None
+
+
+def ref_nanoflann_knn(u, v, qu, qv, k):
+    return _knn(ref_nanoflann().ref_nanoflann_knn, u, v, qu, qv, k)
+
+
+def grid_max_selection(dI3, w, h, pot, THFac=1.0, kind="f32"):
+    m = np.zeros((h, w), np.uint8)
+    L = lib(kind)
+    L.orc_grid_max_selection.argtypes = [c_fp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.orc_grid_max_selection.restype = C.c_int
+    n = L.orc_grid_max_selection(fp(np.ascontiguousarray(dI3, np.float32)), u8p(m), w, h, pot, THFac)
+    return m, n
+
+
+def make_pixel_status(dI3, w, h, desiredDensity, sparsityFactor, recsLeft=5, THFac=1.0, kind="f32"):
+    """-> (map [h,w] uint8, numGoodPoints, the updated global sparsityFactor)"""
+    m, sf = np.zeros((h, w), np.uint8), np.array([sparsityFactor], np.int32)
+    L = lib(kind)
+    L.orc_make_pixel_status.argtypes = [c_fp, c_u8p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, c_ip]
+    L.orc_make_pixel_status.restype = C.c_int
+    n = L.orc_make_pixel_status(fp(np.ascontiguousarray(dI3, np.float32)), u8p(m), w, h, desiredDensity, recsLeft, THFac, ip(sf))
+    return m, n, int(sf[0])
+
+
+class Initializer:
+    """CoarseInitializer (setFirst + trackFrame and everything they call) on the CPU."""
+    FIELDS = {"u": (np.float32, 1), "v": (np.float32, 1), "idepth": (np.float32, 1), "idepth_new": (np.float32, 1), "iR": (np.float32, 1), "lastHessian": (np.float32, 1),
+              "energy": (np.float32, 2), "outlierTH": (np.float32, 1), "my_type": (np.float32, 1), "neighboursDist": (np.float32, 10), "parentDist": (np.float32, 1),
+              "isGood": (np.uint8, 1), "parent": (np.int32, 1), "neighbours": (np.int32, 10), "maxstep": (np.float32, 1)}
+
+    def __init__(self, w, h, levels, K, kind="f32"):
+        self.L = lib(kind)
+        self.kind, self.w, self.h, self.levels = kind, w, h, levels
+        self.L.orc_initf_create.restype = C.c_void_p
+        self.L.orc_initf_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        self.L.orc_initf_destroy.argtypes = [C.c_void_p]
+        self.L.orc_initf_set_first.argtypes = [C.c_void_p, C.POINTER(c_fp), c_fp, c_ip]
+        self.L.orc_initf_track_frame.argtypes = [C.c_void_p, C.POINTER(c_fp), C.c_float, C.c_float]
+        self.L.orc_initf_track_frame.restype = C.c_int
+        self.L.orc_initf_num.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_initf_num.restype = C.c_int
+        self.L.orc_initf_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
+        self.L.orc_initf_get.restype = C.c_int
+        self.L.orc_initf_get_state.argtypes = [C.c_void_p, c_dp, c_dp, c_ip]
+        self.h_ = self.L.orc_initf_create(w, h, levels, *[float(x) for x in K])
+
+    def close(self):
+        if self.h_:
+            self.L.orc_initf_destroy(self.h_)
+            self.h_ = None
+
+    def __del__(self):
+        self.close()
+
+    def _pyr(self, img):
+        dI, ab = make_images(img, self.levels, self.kind)
+        offs = [self.L.orc_pyr_offset(self.w, self.h, l) for l in range(self.levels + 1)]
+        lv = [np.ascontiguousarray(dI[offs[l]:offs[l + 1]]) for l in range(self.levels)]
+        return lv, dI, ab, offs
+
+    def set_first(self, img, randomPattern, sparsityFactor=5):
+        """-> the updated global sparsityFactor. Level 0 is selected by a fresh PixelSelector (currentPotential 3): makeMaps(., 0.03*w*h, 1, false, 2)."""
+        lv, dI, ab, offs = self._pyr(img)
+        w, h = self.w, self.h
+        ag = [ab[offs[l]:offs[l + 1]] for l in range(3)]
+        m0, _, _ = pixsel_make_maps(lv[0], ag[0], ag[1], ag[2], w, h, randomPattern, np.float32(0.03) * w * h, 3, recursionsLeft=1, thFactor=2.0, kind=self.kind)
+        self.status0 = m0
+        arr = (c_fp * self.levels)(*[fp(x) for x in lv])
+        sf = np.array([sparsityFactor], np.int32)
+        self.L.orc_initf_set_first(self.h_, arr, fp(np.ascontiguousarray(m0, np.float32)), ip(sf))
+        return int(sf[0])
+
+    def track_frame(self, img, exposure_first=1.0, exposure_new=1.0):
+        lv, _, _, _ = self._pyr(img)
+        arr = (c_fp * self.levels)(*[fp(x) for x in lv])
+        return bool(self.L.orc_initf_track_frame(self.h_, arr, exposure_first, exposure_new))
+
+    def num(self, lvl):
+        return self.L.orc_initf_num(self.h_, lvl)
+
+    def get(self, lvl, field):
+        dt, m = self.FIELDS[field]
+        n = self.num(lvl)
+        out = np.zeros((n, m) if m > 1 else n, dt)
+        assert self.L.orc_initf_get(self.h_, lvl, field.encode(), out.ctypes.data_as(C.c_void_p)) == 0
+        return out
+
+    def state(self):
+        T, aff, st = np.zeros(12), np.zeros(2), np.zeros(4, np.int32)
+        self.L.orc_initf_get_state(self.h_, dp(T), dp(aff), ip(st))
+        return dict(thisToNext=T.reshape(3, 4), aff=aff, snapped=bool(st[0]), frameID=int(st[1]), snappedAt=int(st[2]), n_evals=int(st[3]))

@@ -12,6 +12,17 @@ def rel_err(a, b):
     return d / s
 
 
+def assert_fp32_faithful(gpu, o32, o64, factor=1.5, floor=1e-7):
+    """Per-row check against the ALL-FP64 evaluation of the same inputs: the GPU's fp32 result must be as close to that truth as the reference's own
+    fp32 arithmetic (the strict fp32 oracle, o32) is, at the median, the 99 % quantile and the maximum (x factor: FMA contraction / summation order
+    differ between the scalar CPU order and the device). Rows are scaled by their own largest fp64 entry."""
+    gpu, o32, o64 = (np.asarray(a, np.float64).reshape(len(a), -1) for a in (gpu, o32, o64))
+    s = np.maximum(np.abs(o64).max(1), 1e-300)
+    mine, ref = np.abs(gpu - o64).max(1) / s, np.abs(o32 - o64).max(1) / s
+    for q in (0.5, 0.99, 1.0):
+        assert np.quantile(mine, q) <= factor * np.quantile(ref, q) + floor, (q, np.quantile(mine, [0.5, 0.99, 1.0]), np.quantile(ref, [0.5, 0.99, 1.0]))
+
+
 def tracker_inputs(win, n=3000, seed=1):
     """Residuals targeting the newest keyframe (W-1): centerProjectedTo + HdiF, from the true depth."""
     rng = np.random.RandomState(seed)

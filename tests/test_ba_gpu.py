@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import orc
-from helpers import rel_err, pose_dist
+from helpers import rel_err, pose_dist, assert_fp32_faithful
 from nalo_slam_amd import binding, synth
 
 pytestmark = pytest.mark.gpu
@@ -22,11 +22,18 @@ def make_ctx(win, state6=None, aff=None):
     return c
 
 
+PAIR_AFF = [(0.0, 0.0), (0.01, 1.0), (-0.02, -2.0), (0.015, 0.5)]
+
+
+def pair_st6(win):
+    return synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+
+
 @pytest.fixture(scope="module")
 def pair(small_window):
     win = small_window
-    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
-    aff = [(0.0, 0.0), (0.01, 1.0), (-0.02, -2.0), (0.015, 0.5)]
+    st6 = pair_st6(win)
+    aff = PAIR_AFF
     orc.lib().orc_set_sum_mode(0)
     ba = orc.ba_from_window(win, "f32", state6=st6, aff=aff)
     c = make_ctx(win, st6, aff)
@@ -46,7 +53,16 @@ def test_linearize_states_and_jacobian_products(pair):
     assert ac.sum() > 500
     assert abs(E - E_o) / E_o < 1e-5
     m = ac.astype(bool)
-    assert rel_err(jp[m], jp_o[m]) < 2e-5
+    # JpJdF cancels (Jpdd near the epipole): the strict fp32 oracle itself sits 1.96e-5 (max-norm) from the all-fp64 evaluation of this window, so the
+    # bound is tied to that truth instead of to a fixed distance between two fp32 results (4e-5 here is the loose backstop)
+    orc.lib("f64").orc_set_sum_mode(0)
+    ba64 = orc.ba_from_window(win, "f64", state6=pair_st6(win), aff=PAIR_AFF)
+    ba64.linearize_all(False); ba64.apply_res()
+    _, ac64, jp64, _ = ba64.slots()
+    both = m & ac64.astype(bool)
+    assert both.sum() > 0.98 * m.sum()
+    assert_fp32_faithful(jp[both], jp_o[both], jp64[both])
+    assert rel_err(jp[m], jp_o[m]) < 4e-5
     nw = win.W - 1
     mm = (en_o[:, nw] >= 0) & (win.exists[:, nw] > 0)
     assert np.array_equal(mm, en[:, nw] >= 0)

@@ -1,0 +1,100 @@
+"""CPU side of the two-frame initialiser (oracle/orc_initfull.c).
+
+* The ONE piece of this path that is pinned by the reference itself: the oracle's k-d tree restatement against the reference's own util/nanoflann.h,
+  compiled from where it lies into oracle/_ref/libref_nanoflann.so behind our driver (oracle/ref_nanoflann.cpp; `make -C oracle`, only while
+  /root/reference exists — the prebuilt library travels to the GPU box). Neighbour INDICES must be identical including the order of equidistant points
+  (grid points + 0.1: most 10-NN sets end in a tie), and the fp32 squared distances bit-equal.
+* gridMaxSelection / makePixelStatus against closed-form properties (no reference vectors exist: parity unpinned).
+* The oracle's trackFrame recovers the direction of a known camera motion and snaps (sanity of the checker, not of the product)."""
+import numpy as np
+import pytest
+
+import orc
+from nalo_slam_amd import synth
+
+
+def _grid_cloud(rng, W, H, dens):
+    ys, xs = np.nonzero(rng.rand(H, W) < dens)
+    return (xs + 0.1).astype(np.float32), (ys + 0.1).astype(np.float32)
+
+
+@pytest.mark.parametrize("W,H,dens", [(80, 60, 0.3), (306, 92, 0.05), (40, 30, 1.0), (13, 11, 0.5), (612, 184, 0.03)])
+def test_kdtree_restatement_equals_reference_nanoflann(W, H, dens):
+    if orc.ref_nanoflann() is None:
+        pytest.fail("oracle/_ref/libref_nanoflann.so is missing: run `make -C oracle` where /root/reference exists")
+    rng = np.random.RandomState(W * 7 + H)
+    u, v = _grid_cloud(rng, W, H, dens)
+    i_o, d_o = orc.kdtree_knn(u, v, u, v, 10)
+    i_r, d_r = orc.ref_nanoflann_knn(u, v, u, v, 10)
+    assert np.array_equal(i_o, i_r) and np.array_equal(d_o, d_r)
+    # the self match comes first, and ties really occur (otherwise the test would not pin the traversal order)
+    assert np.array_equal(i_o[:, 0], np.arange(len(u)))
+    if len(u) > 11:                               # the 10th and 11th neighbours are often equidistant: WHICH one is kept is the traversal order being pinned
+        d11 = orc.ref_nanoflann_knn(u, v, u, v, 11)[1]
+        assert (d11[:, 9] == d11[:, 10]).mean() > 0.02
+    # the parent query of makeNN: nearest point of (u/2 - 0.25, v/2 - 0.25) in a coarser cloud
+    u2, v2 = _grid_cloud(rng, W // 2, H // 2, min(1.0, dens * 2))
+    qu, qv = u * np.float32(0.5) - np.float32(0.25), v * np.float32(0.5) - np.float32(0.25)
+    i_o, d_o = orc.kdtree_knn(u2, v2, qu, qv, 1)
+    i_r, d_r = orc.ref_nanoflann_knn(u2, v2, qu, qv, 1)
+    assert np.array_equal(i_o, i_r) and np.array_equal(d_o, d_r)
+
+
+def test_kdtree_random_clouds_and_outside_queries():
+    rng = np.random.RandomState(5)
+    u, v = (rng.rand(5000) * 100).astype(np.float32), (rng.rand(5000) * 50).astype(np.float32)
+    qu, qv = (rng.rand(3000) * 140 - 20).astype(np.float32), (rng.rand(3000) * 90 - 20).astype(np.float32)
+    for k in (1, 7, 10):
+        i_o, d_o = orc.kdtree_knn(u, v, qu, qv, k)
+        i_r, d_r = orc.ref_nanoflann_knn(u, v, qu, qv, k)
+        assert np.array_equal(i_o, i_r) and np.array_equal(d_o, d_r)
+    # against brute force: the distance lists are the k smallest (indices may differ only inside exact ties)
+    d2 = (qu[:200, None] - u[None]) ** 2 + (qv[:200, None] - v[None]) ** 2
+    assert np.array_equal(np.sort(d2, 1)[:, :10], orc.kdtree_knn(u, v, qu[:200], qv[:200], 10)[1])
+
+
+def test_grid_max_selection_properties():
+    win = synth.make_window(w=320, h=240, W=2, P=20, seed=1, n_extra=0)
+    dI, _ = orc.make_images(win.images[0], 1)
+    g = dI.reshape(240, 320, 3)
+    for pot in (1, 2, 3, 5, 8):
+        m, n = orc.grid_max_selection(dI, 320, 240, pot, 1.0)
+        assert n == int(m.sum()) and n > 0
+        ys, xs = np.nonzero(m)
+        assert ((g[ys, xs, 1] ** 2 + g[ys, xs, 2] ** 2) > (0.75 * 10.0) ** 2).all()
+        # at most four per cell, cells anchored at (1 + i*pot, 1 + j*pot)
+        cells = ((ys - 1) // pot) * 10000 + (xs - 1) // pot
+        assert np.bincount(np.unique(cells, return_inverse=True)[1]).max() <= 4
+        assert ys.min() >= 1 and xs.min() >= 1
+    # larger cells select fewer pixels; the adaptive wrapper lands near the requested density and reports the new sparsity
+    n1, n5 = orc.grid_max_selection(dI, 320, 240, 1)[1], orc.grid_max_selection(dI, 320, 240, 5)[1]
+    assert n5 < n1
+    m, n, sf = orc.make_pixel_status(dI, 320, 240, 0.05 * 320 * 240, 5)
+    assert 0.5 < n / (0.05 * 320 * 240) < 2.0 and sf >= 1
+
+
+def test_oracle_initializer_snaps_and_recovers_motion_direction():
+    win = synth.make_window(w=320, h=240, W=2, P=20, seed=3, n_extra=8, step_z=0.15, yaw_deg=0.1)
+    rp, _ = orc.pixsel_libc_tables(win.w * win.h)
+    ini = orc.Initializer(win.w, win.h, win.levels, win.K)
+    ini.set_first(win.images[0], rp)
+    n = [ini.num(l) for l in range(win.levels)]
+    assert n[0] > 500
+    for l in range(win.levels - 1):
+        par = ini.get(l, "parent")
+        assert par.min() >= 0 and par.max() < n[l + 1]
+        u, v, pu, pv = ini.get(l, "u"), ini.get(l, "v"), ini.get(l + 1, "u")[par], ini.get(l + 1, "v")[par]
+        assert np.median(np.hypot(u * 0.5 - 0.25 - pu, v * 0.5 - 0.25 - pv)) < 3
+        assert np.allclose(ini.get(l, "neighboursDist").sum(1), 10, rtol=1e-5)
+    rets = [ini.track_frame(win.images[i]) for i in range(1, 9)]
+    st = ini.state()
+    assert st["snapped"] and rets[-1] and not rets[0]
+    t = st["thisToNext"][:, 3]
+    Tt = synth.se3_mul(win.world_to_cam[8], synth.se3_inv(win.world_to_cam[0]))[:, 3]
+    assert np.dot(t, Tt) / (np.linalg.norm(t) * np.linalg.norm(Tt)) > 0.95
+    # the recovered inverse depths are positively rank-correlated with the true ones (1.2 m of baseline against a scene 3-40 m away: a weak, scale-free check)
+    u, v, iR, good = ini.get(0, "u"), ini.get(0, "v"), ini.get(0, "iR"), ini.get(0, "isGood").astype(bool)
+    idt = 1.0 / win.depth[0][v.astype(int), u.astype(int)]
+    ok = good & np.isfinite(idt)
+    from scipy.stats import spearmanr
+    assert spearmanr(iR[ok], idt[ok])[0] > 0.2

@@ -7,7 +7,8 @@ Two runs per image size:
   teacher-forced  before every keyframe the GPU back-end is handed the oracle's carried numbers (frames, calibration, HM/bM, inverse depths): what one
                   keyframe does to IDENTICAL carried state. Bar: window and tracked poses |log(T_gpu T_oracle^-1)| < 1e-5 (BASELINE.json) while every
                   residual decision agrees; a flipped borderline outlier decision (order-statistic threshold on fp32 energies) legitimately moves a
-                  keyframe's poses more than rounding does: 5e-5 then.
+                  keyframe's poses more than rounding does: 5e-5 then. Where the window is weakly constrained the reference's own fp32 arithmetic is
+                  farther than that from an all-fp64 evaluation (third back-end, same lock-step): the bar is then 1.5x that measured floor.
   closed loop     each back-end consumes its OWN numbers for the whole sequence. Two fp32 evaluations drift apart in a chaotic estimator: the strict
                   fp32 oracle against the all-fp64 oracle reaches 2e-5 .. 5e-5 over these sequences (measured, tests/seq_helpers.py dry run), which is
                   the noise floor of the reference's own arithmetic. Bar: 5e-5 per keyframe (2e-4 after a flipped decision).
@@ -23,22 +24,26 @@ pytestmark = pytest.mark.gpu
 
 
 def check(rec, drv, tol_state, tol_clean, tol_flipped):
-    fo, fg = rec["frames"]
+    fo, fg, f64 = rec["frames"]
     assert [f.fid for f in fo] == [f.fid for f in fg]
     flips = rec["state_mismatch"][1]
     tol_state["flips"] += flips
     tol = tol_clean if (tol_state["flips"] == 0 if not drv.teacher else flips == 0) else tol_flipped
-    if len(fo) < 5:                      # the first windows (2-4 frames, a few hundred points) are weakly constrained, like the toy window of test_ba_gpu.py
-        tol = max(tol, 3e-5)
+    # The third back-end is the ALL-FP64 oracle run in the same lock-step: its distance from the strict fp32 oracle on this keyframe is the noise floor of
+    # the reference's own arithmetic on this window. Weakly constrained windows have a high floor (the 4-frame window of the 640x480 sequence: 5.3e-5 between
+    # the two oracles); the GPU has to stay within 1.5x of it there, and within the fixed bar everywhere else.
+    floor = max(pose_dist(a.w2c, b.w2c) for a, b in zip(fo, f64))
+    tol = max(tol, 1.5 * floor)
     worst = max(pose_dist(a.w2c, b.w2c) for a, b in zip(fo, fg))
-    assert worst < tol, "keyframe %d: pose delta %.2e (flips %d, so far %d)" % (rec["k"], worst, flips, tol_state["flips"])
+    tol_state.setdefault("floor", []).append(floor)
+    assert worst < tol, "keyframe %d: pose delta %.2e, fp64-oracle floor %.2e (flips %d, so far %d)" % (rec["k"], worst, floor, flips, tol_state["flips"])
     for a, b in zip(fo, fg):
         assert np.abs(a.state - b.state).max() < 1e-4 * max(1.0, np.abs(a.state).max()) + 1e-7
         assert abs(a.th - b.th) < 1e-3 * a.th
     assert rel_err(rec["calib"][1], rec["calib"][0]) < 1e-6
-    ido, idg = rec["idepth"]
+    ido, idg = rec["idepth"][:2]
     assert np.median(np.abs(idg - ido) / np.abs(ido)) < 2e-5
-    (Ho, bo), (Hg, bg) = rec["prior"]
+    (Ho, bo), (Hg, bg) = rec["prior"][:2]
     assert Ho.shape == Hg.shape
     if np.abs(Ho).max() > 0:               # bM is a cancelling difference (M_b - Msc_b): its relative error is an order above H's
         assert rel_err(Hg, Ho) < (2e-4 if drv.teacher else 1e-3) and rel_err(bg, bo) < (2e-3 if drv.teacher else 1e-2), (rel_err(Hg, Ho), rel_err(bg, bo))
@@ -55,7 +60,7 @@ def check(rec, drv, tol_state, tol_clean, tol_flipped):
 @pytest.mark.parametrize("w,h,n_kf", [(640, 480, 12), (1224, 368, 11)])
 def test_keyframe_sequence(w, h, n_kf, teacher):
     win, kf = make_sequence(w=w, h=h, n_kf=n_kf)
-    B = [OracleBackend(win), GpuBackend(win)]
+    B = [OracleBackend(win), GpuBackend(win), OracleBackend(win, "f64")]
     drv = SequenceDriver(win, kf, B, teacher=teacher)
     tols = (1e-5, 5e-5) if teacher else (5e-5, 2e-4)
     tol_state = dict(flips=0)
@@ -69,5 +74,8 @@ def test_keyframe_sequence(w, h, n_kf, teacher):
     assert n_marg_frames >= 3 and n_marg_pts > 200
     assert max(len(r["fids"]) for r in drv.log) == 8
     assert np.abs(drv.log[-1]["prior"][1][0]).max() > 0
-    print("%dx%d %s: pose delta per keyframe:" % (w, h, "teacher-forced" if teacher else "closed loop"), ["%.1e" % x for x in worst], "flips", tol_state["flips"])
+    print("%dx%d %s: pose delta per keyframe:" % (w, h, "teacher-forced" if teacher else "closed loop"), ["%.1e" % x for x in worst], "flips", tol_state["flips"],
+          "fp64-oracle floor:", ["%.1e" % x for x in tol_state["floor"]])
+    if teacher:                                   # most keyframes sit at the fixed bar, whatever the floor allows on the weak ones
+        assert np.median(worst) < 1e-5
     B[1].close()
