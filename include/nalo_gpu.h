@@ -55,6 +55,27 @@ int nalo_sync(nalo_ctx* ctx);
 void* nalo_stream(nalo_ctx* ctx);                 /* hipStream_t every kernel of this ctx is launched on */
 
 /* ------------------------------------------------------------------------------------------------
+ * Settings of the reference that change the arithmetic of this path (util/settings.cpp). Defaults = the reference's; nalo_set_settings before
+ * nalo_ba_set_window / nalo_trk_track. Everything else in settings.cpp that this path reads is a compile-time constant here, as it is never changed by
+ * the reference's CLI (main_dso_pangolin.cpp:400-460 changes exactly these: mode=1 sets the affine modes to 0, mode=2 to -1).
+ *   forceAcceptStep   setting_forceAceptStep (:71, default 1). 0: FullSystem::optimize linearises WITHOUT applyRes, compares
+ *                     E + calcLEnergy + calcMEnergy against the last accepted values and either applies the step or restores the backup
+ *                     (FullSystemOptimize.cpp:511-541). Host-driven loop only (not with the sharded hooks / NALO_BA_DEVICE_GN: NALO_ERR_UNSUPPORTED).
+ *   affineOptModeA/B  setting_affineOptModeA / B (:128-129, defaults 1e12 / 1e8): >= 0 = prior on a / b of every frame but the first
+ *                     (FrameHessian::getPrior, HessianBlocks.h:286-312), < 0 = fixed: the prior becomes setting_initialAffAPrior / BPrior, JabF[0] / JabF[1]
+ *                     are zeroed (Residuals.cpp:241-242), the tracker solves the reduced 6x6 / 7x7 system (CoarseTracker.cpp:1140-1162, host LM loop) and
+ *                     zeroes the fixed output (:1255-1256); == 0 switches the tracker's plausibility test to relAff (:1249-1250).
+ *   minOptIterations  setting_minOptIterations (:74, default 1).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct nalo_settings {
+    int forceAcceptStep;
+    double affineOptModeA, affineOptModeB;
+    int minOptIterations;
+} nalo_settings;
+int nalo_get_settings(nalo_ctx* ctx, nalo_settings* out);
+int nalo_set_settings(nalo_ctx* ctx, const nalo_settings* in);
+
+/* ------------------------------------------------------------------------------------------------
  * a1  FrameHessian::makeImages (FullSystem/HessianBlocks.cpp:127-190), called at FullSystem.cpp:1065.
  * Uploads level-0 irradiance (w*h floats, 0..255), builds all pyramid levels {I,dx,dy} + absSquaredGrad
  * in HBM. mask (w*h floats) and bgr (3*w*h bytes) are optional (densemap=1 only); gammaB[256] optional
@@ -165,6 +186,14 @@ int nalo_ba_do_step(nalo_ctx* ctx, float stepfacC, float stepfacT, float stepfac
 /* FullSystem::optimize (FullSystemOptimize.cpp:398-602, call site FullSystem.cpp:1362). never_break != 0 disables
  * the early exit at :544 so a benchmark keyframe always runs mnumOptIts iterations. */
 int nalo_ba_optimize(nalo_ctx* ctx, int mnumOptIts, int never_break, double* rmse);
+/* a13  EnergyFunctional::calcLEnergyF_MT + calcLEnergyPt (EnergyFunctional.cpp:332-415) and calcMEnergyF (:320-329) at the CURRENT states, as
+ * FullSystem::calcLEnergy / calcMEnergy return them when setting_forceAceptStep is false (FullSystemOptimize.cpp:351, 371-379; they return 0 otherwise —
+ * these two entry points always compute). L = frame priors + calibration prior + per point deltaF^2 priorF (device reduction); the inner loop of
+ * calcLEnergyPt runs over linearised residuals, which never exist while optimize() runs (they live only inside nalo_ba_marginalize_points).
+ * M = delta . (2 bM + HM delta) on the host in fp64. *rejected (nalo_ba_optimize_stats) = steps the last nalo_ba_optimize restored from the backup. */
+int nalo_ba_calc_l_energy(nalo_ctx* ctx, double* E);
+int nalo_ba_calc_m_energy(nalo_ctx* ctx, double* E);
+int nalo_ba_optimize_stats(nalo_ctx* ctx, int* iterations, int* rejected);
 /* a13 + a7<2> + a9  flagPointsForRemoval's relinearise/fixLinearizationF (FullSystem.cpp:975-990,
  * EnergyFunctionalStructs.cpp:89-115) + EnergyFunctional::marginalizePointsF (EnergyFunctional.cpp:615-676).
  * flags[p] != 0 marks PS_MARGINALIZE. Adds 0.25*(M - Msc) into HM/bM and removes the points.

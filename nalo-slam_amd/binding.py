@@ -30,12 +30,17 @@ EXPORTS = [
     "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
-    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_get_frames", "nalo_ba_get_points",
+    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get",
 ]
+
+
+class Settings(C.Structure):
+    """nalo_settings (include/nalo_gpu.h)"""
+    _fields_ = [("forceAcceptStep", C.c_int), ("affineOptModeA", C.c_double), ("affineOptModeB", C.c_double), ("minOptIterations", C.c_int)]
 
 
 def lib_path():
@@ -109,6 +114,11 @@ def load():
     L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
                                             c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.nalo_init_do_step.argtypes = [vp, C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
+    L.nalo_ba_calc_l_energy.argtypes = [vp, c_dp]
+    L.nalo_ba_calc_m_energy.argtypes = [vp, c_dp]
+    L.nalo_ba_optimize_stats.argtypes = [vp, c_ip, c_ip]
+    L.nalo_get_settings.argtypes = [vp, C.POINTER(Settings)]
+    L.nalo_set_settings.argtypes = [vp, C.POINTER(Settings)]
     L.nalo_init_set_first.argtypes = [vp, C.c_int, c_ip, c_ip]
     L.nalo_init_track_frame.argtypes = [vp, C.c_int, C.c_float, C.c_float, c_ip]
     L.nalo_init_get_state.argtypes = [vp, c_dp, c_dp, c_ip, c_ip, c_ip, c_ip]
@@ -458,6 +468,31 @@ class Context:
         out = f(idepth_new).copy()
         self._ck(self.L.nalo_init_do_step(self.h_, len(out), _u8(np.ascontiguousarray(isGood, np.uint8)), _f(f(Jb)), _f(f(maxstep)), _f(f(idepth)), float(lam), _f(f(inc)), _f(out)))
         return out
+
+    def set_settings(self, force_accept_step=None, affine_opt_mode_a=None, affine_opt_mode_b=None, min_opt_iterations=None):
+        st = Settings()
+        self._ck(self.L.nalo_get_settings(self.h_, C.byref(st)))
+        if force_accept_step is not None: st.forceAcceptStep = int(force_accept_step)
+        if affine_opt_mode_a is not None: st.affineOptModeA = float(affine_opt_mode_a)
+        if affine_opt_mode_b is not None: st.affineOptModeB = float(affine_opt_mode_b)
+        if min_opt_iterations is not None: st.minOptIterations = int(min_opt_iterations)
+        self._ck(self.L.nalo_set_settings(self.h_, C.byref(st)))
+        return st
+
+    def ba_calc_l_energy(self):
+        e = np.zeros(1)
+        self._ck(self.L.nalo_ba_calc_l_energy(self.h_, _d(e)))
+        return float(e[0])
+
+    def ba_calc_m_energy(self):
+        e = np.zeros(1)
+        self._ck(self.L.nalo_ba_calc_m_energy(self.h_, _d(e)))
+        return float(e[0])
+
+    def ba_optimize_stats(self):
+        a = np.zeros(2, np.int32)
+        self._ck(self.L.nalo_ba_optimize_stats(self.h_, a[0:1].ctypes.data_as(C.POINTER(C.c_int)), a[1:2].ctypes.data_as(C.POINTER(C.c_int))))
+        return int(a[0]), int(a[1])
 
     def init_set_first(self, slot_first, sparsityFactor=5):
         """CoarseInitializer::setFirst -> (points per level, the updated global sparsityFactor)"""

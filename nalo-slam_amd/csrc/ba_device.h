@@ -59,6 +59,10 @@ struct BADev {
     const int* host_blk;                        // [W+1] point-block range of every host
     const int* sc_grp;                          // [W+1] ba_sc workgroup-group range of every host (groups of sc_bpw blocks)
     int sc_bpw, sc_groups;                      // blocks per group (1 when sc_split > 1), total groups
+    // settings (nalo_set_settings): setting_affineOptModeA / B < 0 zero JabF[0] / JabF[1] (Residuals.cpp:241-242)
+    int fix_a, fix_b;
+    int no_th;                                  // 1: this pass does not feed setNewFrameEnergyTH (the re-run that applies an accepted step, setting_forceAceptStep = false)
+    double* noapply_E;                          // [nblocks*lin_sub][W] energy partials of a linearisation that is NOT applied (FIX = 2)
 };
 
 // Device-side Gauss-Newton iteration (kernels_ba_gn.hip): constants of one optimize() call, the mutable frame / calibration states and the outputs it

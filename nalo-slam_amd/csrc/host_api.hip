@@ -287,7 +287,9 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
     // the host-driven loop below (a launch, a finish kernel and a polled flag per evaluation). NALO_TRK_HOST_LM=1 selects the host loop,
     // which is also what a caller gets by driving nalo_trk_eval itself.
     {
-        static const bool force_host = std::getenv("NALO_TRK_HOST_LM") != nullptr;
+        // a fixed affine parameter changes the system the LM solves (:1140-1162): those variants live in the host loop below
+        static const bool env_host = std::getenv("NALO_TRK_HOST_LM") != nullptr;
+        const bool force_host = env_host || c->set.affineOptModeA < 0 || c->set.affineOptModeB < 0;
         static const int dev_max_n = [] { const char* e = std::getenv("NALO_TRK_DEV_MAXN"); return e ? std::atoi(e) : (1 << 30); }();
         int stop = coarsestLvl + 1;
         while (stop > 0 && c->pc_n[stop - 1] <= dev_max_n) --stop;      // levels coarsestLvl..stop on the device
@@ -340,6 +342,21 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
             std::memcpy(Hl, H, sizeof(Hl));
             for (int i = 0; i < 8; ++i) { Hl[i * 8 + i] *= (1 + lambda); nb[i] = -b[i]; }
             ldlt_solve(8, Hl, nb, inc);
+            {                                                                  // :1140-1162: a and/or b fixed
+                const bool fa = c->set.affineOptModeA < 0, fb = c->set.affineOptModeB < 0;
+                if (fa && fb) { double H6[36], x6[6]; for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) H6[i * 6 + j] = Hl[i * 8 + j];
+                    ldlt_solve(6, H6, nb, x6); for (int i = 0; i < 6; ++i) inc[i] = x6[i]; inc[6] = inc[7] = 0; }
+                if (!fa && fb) { double H7[49], x7[7]; for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) H7[i * 7 + j] = Hl[i * 8 + j];
+                    ldlt_solve(7, H7, nb, x7); for (int i = 0; i < 7; ++i) inc[i] = x7[i]; inc[7] = 0; }
+                if (fa && !fb) {                                               // b takes a's slot: column 6 = column 7, then row 6 = row 7
+                    double Hs[64], bs[8], H7[49], x7[7]; std::memcpy(Hs, Hl, sizeof(Hs)); std::memcpy(bs, nb, sizeof(bs));
+                    for (int i = 0; i < 8; ++i) Hs[i * 8 + 6] = Hs[i * 8 + 7];
+                    for (int j = 0; j < 8; ++j) Hs[6 * 8 + j] = Hs[7 * 8 + j];
+                    bs[6] = bs[7];
+                    for (int i = 0; i < 7; ++i) for (int j = 0; j < 7; ++j) H7[i * 7 + j] = Hs[i * 8 + j];
+                    ldlt_solve(7, H7, bs, x7); for (int i = 0; i < 6; ++i) inc[i] = x7[i]; inc[6] = 0; inc[7] = x7[6];
+                }
+            }
             float extrapFac = 1;
             if (lambda < lambdaExtrapolationLimit) extrapFac = std::sqrt(std::sqrt(lambdaExtrapolationLimit / lambda));
             for (double& v : inc) v *= extrapFac;
@@ -373,7 +390,14 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
     if (n_evals) *n_evals = evals;
     if (!good) { *ok = 0; return NALO_OK; }
     std::memcpy(T_io, cur.m, sizeof(cur.m)); aff_io[0] = aff_cur[0]; aff_io[1] = aff_cur[1];
-    *ok = !(std::fabs((float)aff_io[0]) > 1.2f || std::fabs((float)aff_io[1]) > 200.f);   // :1243-1245 (affineOptMode != 0)
+    {                                                                          // :1243-1256
+        const double mA = c->set.affineOptModeA, mB = c->set.affineOptModeB;
+        bool fine = !((mA != 0 && std::fabs((float)aff_io[0]) > 1.2f) || (mB != 0 && std::fabs((float)aff_io[1]) > 200.f));
+        double rel[2]; aff_from_to(exposures[0], exposures[1], ref_aff[0], ref_aff[1], aff_io[0], aff_io[1], rel);
+        if ((mA == 0 && std::fabs(logf((float)rel[0])) > 1.5f) || (mB == 0 && std::fabs((float)rel[1]) > 200.f)) fine = false;
+        if (fine) { if (mA < 0) aff_io[0] = 0; if (mB < 0) aff_io[1] = 0; }
+        *ok = fine;
+    }
     return NALO_OK;
 }
 

@@ -23,6 +23,8 @@ void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
 void ba_launch_set_th(hipStream_t s, float* dst, const float* th, int W);
 void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int step);
+void ba_launch_lenergy(hipStream_t s, const BADev& B, double* partial);
+void ba_launch_load_backup(hipStream_t s, const BADev& B);
 
 struct HostFrame {
     int slot = 0, frameID = 0;
@@ -88,6 +90,8 @@ struct BAWindow {
     DevBuf<double> th_buf;                                          // a histogram as doubles (all-reduce payload)
     hipEvent_t ev_lin = nullptr, ev_th = nullptr; bool th_side_inflight = false;   // sharded windows run the quantile kernels on the side stream, under the SC kernel
     bool never_break = false;
+    DevBuf<double> noapply_E; std::vector<double> noapply_h;          // energy partials of a linearisation that is not applied (forceAcceptStep = false)
+    int opt_iterations = 0, opt_rejected = 0;
 };
 
 void ba_destroy(nalo_ctx* c) {
@@ -146,10 +150,10 @@ static void frame_set_state_zero(HostFrame& f, const double sz[10]) {     // Fra
     se3_log(P * inv, lp); se3_log(M * inv, lm);
     for (int r = 0; r < 6; ++r) f.ns_scale[r] = (lp[r] - lm[r]) / (2e-3);
 }
-static void frame_take_data(HostFrame& f) {                               // EFFrame::takeData + FrameHessian::getPrior
+static void frame_take_data(const nalo_settings& set, HostFrame& f) {     // EFFrame::takeData + FrameHessian::getPrior (HessianBlocks.h:286-312)
     double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (f.frameID == 0) { for (int i = 0; i < 3; ++i) p[i] = kInitialTransPrior; for (int i = 3; i < 6; ++i) p[i] = kInitialRotPrior; p[6] = kInitialAffPrior; p[7] = kInitialAffPrior; }
-    else { p[6] = kAffineOptModeA; p[7] = kAffineOptModeB; }
+    else { p[6] = set.affineOptModeA < 0 ? kInitialAffPrior : set.affineOptModeA; p[7] = set.affineOptModeB < 0 ? kInitialAffPrior : set.affineOptModeB; }
     for (int i = 0; i < 8; ++i) { f.prior[i] = p[i]; f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
 }
 
@@ -216,7 +220,7 @@ static int set_precalc(nalo_ctx* c) {
         }
     }
     for (int i = 0; i < 4; ++i) w.cDeltaF[i] = (float)(w.c_value[i] - w.c_value_zero[i]);
-    for (auto& f : w.frames) frame_take_data(f);
+    for (auto& f : w.frames) frame_take_data(c->set, f);
     const size_t nfl = (size_t)W * W * kPreStride;
     if (w.up_cap < nfl + 80) {                                             // [pre | calib 16 | xc 64 | xAd]; hipHostFree waits for copies in flight
         if (w.up_host) (void)hipHostFree(w.up_host);
@@ -286,8 +290,18 @@ static int flush_th(nalo_ctx* c) {
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }
-static int linearize_async(nalo_ctx* c, int mode, int fix) {
+// keep_th: the pass that APPLIES a step accepted by the energy test re-runs the linearisation the test was made on: same frameEnergyTH (no flush), and it
+// does not feed setNewFrameEnergyTH again (the untested pass already did)
+static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false) {
     BAWindow& w = *c->ba;
+    if (keep_th) {
+        w.dev.no_th = 1;
+        { ProfScope ps(c, "ba_linearize", true); ba_launch_linearize(c->stream, w.dev, mode, fix, ps.a, ps.b); }
+        w.dev.no_th = 0;
+        w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
+        NALO_HIP(c, hipGetLastError());
+        return NALO_OK;
+    }
     int rc = flush_th(c); if (rc) return rc;                          // frameEnergyTH of the previous pass feeds this one
     if (fix || mode == 2) NALO_HIP(c, hipMemsetAsync(w.pt_relbs.p, 0, (size_t)w.Ppad * 4, c->stream));
     {
@@ -330,9 +344,58 @@ static int linearize_async(nalo_ctx* c, int mode, int fix) {
             w.th_side_inflight = true;
         }
     } else if (mode == 0) w.th_pending = true;
-    w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
+    if (fix != 2) { w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false; }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
+}
+// linearizeAll(false) without applyRes: the energy of the current states (lastEnergyP), nothing else changes but state_NewEnergy and the threshold input
+static int linearize_noapply(nalo_ctx* c, double* E) {
+    BAWindow& w = *c->ba;
+    const size_t n = (size_t)w.nblocks * w.dev.lin_sub * w.W;
+    NALO_HIP(c, w.noapply_E.reserve(n));
+    w.dev.noapply_E = w.noapply_E.p;
+    NALO_HIP(c, hipMemsetAsync(w.noapply_E.p, 0, n * sizeof(double), c->stream));
+    int rc = linearize_async(c, 0, 2); if (rc) return rc;
+    w.noapply_h.resize(n);
+    NALO_HIP(c, hipMemcpyAsync(w.noapply_h.data(), w.noapply_E.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    double s = 0; for (double v : w.noapply_h) s += v;
+    *E = s;
+    return NALO_OK;
+}
+// calcLEnergyF_MT (EnergyFunctional.cpp:397-415) + calcLEnergyPt (:332-392); calcMEnergyF (:320-329)
+static int calc_l_energy(nalo_ctx* c, double* E) {
+    BAWindow& w = *c->ba;
+    double e = 0;
+    for (const auto& f : w.frames) for (int i = 0; i < 8; ++i) e += f.delta_prior[i] * f.prior[i] * f.delta_prior[i];
+    { float ec = 0; for (int i = 0; i < 4; ++i) ec += (w.cDeltaF[i] * (float)kInitialCalibHessian) * w.cDeltaF[i]; e += ec; }       // cDeltaF.cwiseProduct(cPriorF).dot(cDeltaF): floats
+    const int nb = (w.Ppad + 255) / 256;
+    NALO_HIP(c, w.noapply_E.reserve((size_t)std::max<size_t>(nb, (size_t)w.nblocks * w.dev.lin_sub * w.W)));
+    ba_launch_lenergy(c->stream, w.dev, w.noapply_E.p);
+    std::vector<double> part(nb);
+    NALO_HIP(c, hipMemcpyAsync(part.data(), w.noapply_E.p, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    double ep = 0; for (double v : part) ep += v;
+    *E = e + (double)(float)ep;                                       // E.finish(): Accumulator11 holds a float
+    return NALO_OK;
+}
+static double calc_m_energy(const BAWindow& w) {
+    const int n = w.n;
+    std::vector<double> d(n);
+    for (int i = 0; i < 4; ++i) d[i] = (double)w.cDeltaF[i];
+    for (int h = 0; h < w.W; ++h) for (int i = 0; i < 8; ++i) d[4 + 8 * h + i] = w.frames[h].delta[i];
+    double E = 0;
+    for (int i = 0; i < n; ++i) { double s = 0; for (int j = 0; j < n; ++j) s += w.HM[(size_t)i * n + j] * d[j]; E += d[i] * (2 * w.bM[i] + s); }
+    return E;
+}
+// FullSystem::loadSateBackup (FullSystemOptimize.cpp:352-369)
+static int load_state_backup(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    calib_set_value(w, w.c_value_backup);
+    for (auto& f : w.frames) frame_set_state(f, f.state_backup);
+    ba_launch_load_backup(c->stream, w.dev);
+    NALO_HIP(c, hipGetLastError());
+    return set_precalc(c);
 }
 static int sc_async(nalo_ctx* c, int shift, float margScale, int margOnly) {
     BAWindow& w = *c->ba;
@@ -631,10 +694,11 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
         frame_set_state(f, s.state_zero);
         frame_set_state_zero(f, z6);
         frame_set_state(f, s.state);
-        frame_take_data(f);
+        frame_take_data(c->set, f);
         w.dev.img[i] = c->slots[s.slot].dI[0];
     }
     w.dev.W = W; w.dev.w = c->w; w.dev.h = c->h;
+    w.dev.fix_a = c->set.affineOptModeA < 0; w.dev.fix_b = c->set.affineOptModeB < 0; w.dev.no_th = 0;
     NALO_HIP(c, w.th_hist.reserve(2 * 65536 + 16)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, (2 * 65536 + 16) * 4));
     w.dev.th_hist_hi = w.th_hist.p; w.dev.th_hist_lo = w.th_hist.p + 65536; w.dev.th_state = w.th_hist.p + 2 * 65536;
     if (w.HM.size() == (size_t)(w.n - 8) * (w.n - 8) && w.n > 12) {
@@ -971,14 +1035,56 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
     // (190 us per iteration in one workgroup against ~60 us for the host round trip incl. PCIe publish, poll, 17 us AVX2 LDL^T and launches). Kept as an
     // option; the default is the host-driven loop below.
     static const bool dev_loop = std::getenv("NALO_BA_DEVICE_GN") != nullptr;
-    if (dev_loop && (!w.hook || w.hook_stream_ordered)) {
+    if (dev_loop && c->set.forceAcceptStep && (!w.hook || w.hook_stream_ordered)) {
         int rc = optimize_device_loop(c, mnumOptIts, never_break); if (rc) return rc;
+        return optimize_epilogue(c, rmse);
+    }
+    w.opt_iterations = 0; w.opt_rejected = 0;
+    if (!c->set.forceAcceptStep) {
+        // setting_forceAceptStep = false: every linearisation is an energy evaluation first (FIX = 2: nothing but state_NewEnergy and the threshold input
+        // changes) and is applied only if E + E_L + E_M decreased; a rejected step restores the backup (:511-541). Host-driven, one sync per evaluation.
+        if (w.hook || w.th_on_side) return fail(c, NALO_ERR_UNSUPPORTED, "nalo_ba_optimize: forceAcceptStep = 0 is not offered on a sharded window");
+        ba_launch_reset_oob(c->stream, w.dev);
+        double lastE, lastL, lastM;
+        int rc = linearize_noapply(c, &lastE); if (rc) return rc;            // :436-438
+        rc = calc_l_energy(c, &lastL); if (rc) return rc;
+        lastM = calc_m_energy(w);
+        rc = linearize_async(c, 0, 0, true); if (rc) return rc;              // applyRes (:459-462)
+        double lambda = 1e-1;
+        for (int it = 0; it < mnumOptIts; ++it) {
+            backup_state(w);
+            rc = solve_system(c, it, lambda, nullptr, true); if (rc) return rc;
+            int canbreak = 0;
+            rc = do_step(c, 1, 1, 1, 1, 1, &canbreak); if (rc) return rc;
+            double newE, newL, newM;
+            rc = linearize_noapply(c, &newE); if (rc) return rc;             // :511-513
+            rc = calc_l_energy(c, &newL); if (rc) return rc;
+            newM = calc_m_energy(w);
+            ++w.opt_iterations;
+            if (newE + newL + newM < lastE + lastL + lastM) {                // :519-532
+                rc = linearize_async(c, 0, 0, true); if (rc) return rc;
+                lastE = newE; lastL = newL; lastM = newM;
+                lambda *= 0.25;
+            } else {                                                         // :534-541
+                rc = load_state_backup(c); if (rc) return rc;
+                rc = linearize_noapply(c, &lastE); if (rc) return rc;
+                rc = calc_l_energy(c, &lastL); if (rc) return rc;
+                lastM = calc_m_energy(w);
+                lambda *= 1e2;
+                ++w.opt_rejected;
+                // the accumulators, Jacobian products and residual states are still those of the last APPLIED linearisation (made at the restored
+                // states); only the systems stitched from them have to be rebuilt for the next solve
+                w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
+            }
+            if (canbreak && it >= c->set.minOptIterations && !never_break) break;
+        }
         return optimize_epilogue(c, rmse);
     }
     ba_launch_reset_oob(c->stream, w.dev);                                  // :412-429
     int rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :436 (+ applyRes :459-462)
     double lambda = 1e-1;
     for (int it = 0; it < mnumOptIts; ++it) {
+        ++w.opt_iterations;
         backup_state(w);                                                    // :482
         rc = solve_system(c, it, lambda, nullptr, true); if (rc) return rc; // :485 (+ the point part of doStepFromBackup)
         rc = do_step(c, 1, 1, 1, 1, 1, nullptr); if (rc) return rc;         // :501 (stepsize 1: no SOLVER_STEPMOMENTUM)
@@ -986,12 +1092,45 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
         lambda *= 0.25;
         // :544 `if(canbreak && iteration >= setting_minOptIterations) break;` — the step sums arrive with the next fetch, so the
         // test is made there; a loop that must break only costs one discarded accumulate+stitch, the state is untouched
-        if (!never_break && it >= 1 && it + 1 < mnumOptIts) {
+        if (!never_break && it >= c->set.minOptIterations && it + 1 < mnumOptIts) {
             rc = stitch_and_fetch_for_break(c); if (rc) return rc;
             if (w.last_canbreak) break;
         }
     }
     return optimize_epilogue(c, rmse);
+}
+
+int nalo_ba_calc_l_energy(nalo_ctx* c, double* E) {
+    NALO_BA_READY("nalo_ba_calc_l_energy")
+    if (!E) return fail(c, NALO_ERR_ARG, "nalo_ba_calc_l_energy: bad argument");
+    return calc_l_energy(c, E);
+}
+int nalo_ba_calc_m_energy(nalo_ctx* c, double* E) {
+    NALO_BA_READY("nalo_ba_calc_m_energy")
+    if (!E) return fail(c, NALO_ERR_ARG, "nalo_ba_calc_m_energy: bad argument");
+    *E = calc_m_energy(w);
+    return NALO_OK;
+}
+int nalo_ba_optimize_stats(nalo_ctx* c, int* iterations, int* rejected) {
+    if (!c || !c->ba) return fail(c, NALO_ERR_STATE, "nalo_ba_optimize_stats: no window");
+    if (iterations) *iterations = c->ba->opt_iterations;
+    if (rejected) *rejected = c->ba->opt_rejected;
+    return NALO_OK;
+}
+int nalo_get_settings(nalo_ctx* c, nalo_settings* out) {
+    if (!c || !out) return fail(c, NALO_ERR_ARG, "nalo_get_settings: bad argument");
+    *out = c->set;
+    return NALO_OK;
+}
+int nalo_set_settings(nalo_ctx* c, const nalo_settings* in) {
+    if (!c || !in) return fail(c, NALO_ERR_ARG, "nalo_set_settings: bad argument");
+    if (in->minOptIterations < 0 || !std::isfinite(in->affineOptModeA) || !std::isfinite(in->affineOptModeB)) return fail(c, NALO_ERR_ARG, "nalo_set_settings: bad value");
+    c->set = *in;
+    if (c->ba) {                                                             // a window that is already set picks the new priors / flags up at once
+        for (auto& f : c->ba->frames) frame_take_data(c->set, f);
+        c->ba->dev.fix_a = c->set.affineOptModeA < 0; c->ba->dev.fix_b = c->set.affineOptModeB < 0;
+    }
+    return NALO_OK;
 }
 
 int nalo_ba_marginalize_points(nalo_ctx* c, const uint8_t* flags, double* M, double* Mb, double* Msc, double* Mbsc) {

@@ -944,4 +944,30 @@ void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int
     }
 }
 
+// EnergyFunctional::calcLEnergyPt (EnergyFunctional.cpp:332-392), the per-point part that can be non-zero when FullSystem::optimize calls it: deltaF^2 priorF
+// (:388). Its inner loop runs over LINEARISED residuals, which exist only between flagPointsForRemoval and marginalizePointsF (FullSystem.cpp:975-990,1453),
+// never while optimize() runs. One fp64 partial per block, summed by the host in block order.
+__global__ __launch_bounds__(256) void ba_lenergy_kernel(BADev B, double* __restrict__ partial) {
+    __shared__ double sd[4];
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    double e = 0.0;
+    if (d < B.Ppad && (B.pt_flags[d] & PT_VALID)) {
+        const float4 geo = B.pt_geo[d];
+        const float deltaF = geo.z - geo.w;
+        e = (double)(deltaF * deltaF * B.pt_prior[d]);
+    }
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+}
+void ba_launch_lenergy(hipStream_t s, const BADev& B, double* partial) { ba_lenergy_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, partial); }
+
+// the point part of FullSystem::loadSateBackup (FullSystemOptimize.cpp:352-369): idepth = idepth_backup AND idepth_zero = idepth_backup
+__global__ __launch_bounds__(256) void ba_load_backup_kernel(BADev B) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < B.Ppad && (B.pt_flags[d] & PT_VALID)) { float4 geo = B.pt_geo[d]; geo.z = geo.w = B.pt_backup[d]; B.pt_geo[d] = geo; }
+}
+void ba_launch_load_backup(hipStream_t s, const BADev& B) { ba_load_backup_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B); }
+
 }  // namespace nalo

@@ -202,7 +202,7 @@ __device__ __forceinline__ void lin_setup(const BADev& B, const LinWhere& w, Lin
 
 // the photometric part of one pattern pixel (Residuals.cpp:183-245)
 template <int MODE>
-__device__ __forceinline__ void lin_pixel(LinRes& R, const float* pc, float hitI, float hitX, float hitY, float col, float wg) {
+__device__ __forceinline__ void lin_pixel(LinRes& R, const float* pc, float hitI, float hitX, float hitY, float col, float wg, bool fixA, bool fixB) {
     const float affLL0 = pc[24], affLL1 = pc[25], b0 = pc[26];
     const float residual = hitI - (affLL0 * col + affLL1);
     const float drdA = col - b0;
@@ -219,9 +219,12 @@ __device__ __forceinline__ void lin_pixel(LinRes& R, const float* pc, float hitI
     R.jab00 += jA * jI0; R.jab01 += jA * jI1; R.jab10 += jB * jI0; R.jab11 += jB * jI1;
     R.ab00 += jA * jA; R.ab01 += jA * jB; R.ab11 += jB * jB;
     R.wJI2_sum += hw * hw * (jI0 * jI0 + jI1 * jI1);                                               // on the hw-scaled gradient, as :215-239
+    // setting_affineOptModeA / B < 0: J->JabF[0] / [1] are zeroed AFTER the sums above (Residuals.cpp:241-242), so only what reads JabF itself sees it:
+    // res_toZeroF (EnergyFunctionalStructs.cpp:107-108) and Jab_r (AccumulatedTopHessian.cpp:108-109)
+    const float jAf = fixA ? 0.f : jA, jBf = fixB ? 0.f : jB;
     float ra = resF;                                                                                // mode 2: res_toZeroF (:103-111)
-    if (MODE == 2) ra = resF - jI0 * R.jx - jI1 * R.jy - jA * pc[33] - jB * pc[34];
-    R.JIr0 += ra * jI0; R.JIr1 += ra * jI1; R.Jabr0 += ra * jA; R.Jabr1 += ra * jB; R.rr += ra * ra;
+    if (MODE == 2) ra = resF - jI0 * R.jx - jI1 * R.jy - jAf * pc[33] - jBf * pc[34];
+    R.JIr0 += ra * jI0; R.JIr1 += ra * jI1; R.Jabr0 += ra * jAf; R.Jabr1 += ra * jBf; R.rr += ra * ra;
 }
 
 // energy threshold, applyRes(true), takeDataF, the per-slot stores (Residuals.cpp:260-273, 306-328; EnergyFunctionalStructs.cpp:39-50)
@@ -239,13 +242,17 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
             R.energy = R.energyLeft;
         }
     }
-    if (R.exists) {
+    if (FIX == 2) {
+        // linearizeAll(false) WITHOUT applyRes (setting_forceAceptStep = false, FullSystemOptimize.cpp:511-541): only state_NewEnergy is kept; state, Jacobian
+        // products and accumulators stay those of the last applied linearisation. An accepted step re-runs the pass with FIX = 0 at the same threshold.
+        if (R.exists) B.rs_energy[w.si] = R.en;
+    } else if (R.exists) {
         // ---- applyRes(true) (Residuals.cpp:306-328)
         bool active = false;
         if (R.state != 1) { active = (R.newState == 0); R.state = R.newState; R.en.x = R.en.y; }
         uint8_t st = (uint8_t)((R.st & ~(RS_STATE_MASK | RS_ACTIVE)) | R.state | (active ? RS_ACTIVE : 0));
         if (MODE == 2 && active) st |= RS_LINEARIZED;
-        if (FIX && !active) st &= ~(RS_EXISTS | RS_ACTIVE);                                      // toRemove (FullSystemOptimize.cpp:81-84,184-205)
+        if (FIX == 1 && !active) st &= ~(RS_EXISTS | RS_ACTIVE);                                      // toRemove (FullSystemOptimize.cpp:81-84,184-205)
         B.rs_state[w.si] = st;
         B.rs_energy[w.si] = R.en;
         if (active && R.full) {
@@ -261,7 +268,7 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
             // per-slot share of EFPoint::{bd,Hdd,Hcd}_acc (AccumulatedTopHessian.cpp:132-135); summed over the targets by ba_pt_acc_kernel
             B.rs_pp0[w.si] = make_float4(R.JIr0 * R.Jpdd0 + R.JIr1 * R.Jpdd1, a0 * R.Jpdd0 + a1 * R.Jpdd1, x[0] * a0 + y[0] * a1, x[1] * a0 + y[1] * a1);
             B.rs_pp1[w.si] = make_float2(x[2] * a0 + y[2] * a1, x[3] * a0 + y[3] * a1);
-            if (FIX || MODE == 2) {
+            if (FIX == 1 || MODE == 2) {
                 // relBS of FullSystemOptimize.cpp:69-71 + centerProjectedTo (makeCoarseDepthL0 input)
                 const float pu = R.pu, pv = R.pv, idepth = R.idepth;
                 const float i0 = pc[0] * pu + pc[1] * pv + pc[2], i1 = pc[3] * pu + pc[4] * pv + pc[5], i2 = pc[6] * pu + pc[7] * pv + pc[8];
@@ -276,7 +283,7 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
             R.a = R.bb = R.c = R.jab00 = R.jab01 = R.jab10 = R.jab11 = R.ab00 = R.ab01 = R.ab11 = R.JIr0 = R.JIr1 = R.Jabr0 = R.Jabr1 = R.rr = 0.f;
         }
     }
-    if (MODE == 0 && w.t == B.W - 1) {
+    if (MODE == 0 && w.t == B.W - 1 && !B.no_th) {
         B.en_new[w.d] = R.enew;
         if (R.enew >= 0.f) atomicAdd(&B.th_hist_hi[__float_as_uint(R.enew) >> 16], 1u);               // integer atomics: order independent
     }
@@ -321,9 +328,10 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
     const LinWhere w = lin_where<WG>(B, tid);
     if (w.skip) return;
     if (w.t == w.h) {                                                   // no self residuals; the newest frame's own points have no entry
-        if (MODE == 0 && w.t == B.W - 1) B.en_new[w.d] = -1.f;
+        if (MODE == 0 && w.t == B.W - 1 && !B.no_th) B.en_new[w.d] = -1.f;
         return;
     }
+    const bool fixA = B.fix_a != 0, fixB = B.fix_b != 0;
     LinRes R;
     lin_setup<MODE>(B, w, R);
     float color[8], wgt[8];
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
             float h0I, h0X, h0Y, h1I, h1X, h1Y;
             exchange(a0, a1, a2, a3, R.Kus[k0], R.Kvs[k0], h0I, h0X, h0Y);
             exchange(b0_, b1_, b2_, b3_, R.Kus[k1], R.Kvs[k1], h1I, h1X, h1Y);
-            if (R.need) { lin_pixel<MODE>(R, w.pc, h0I, h0X, h0Y, color[k0], wgt[k0]); lin_pixel<MODE>(R, w.pc, h1I, h1X, h1Y, color[k1], wgt[k1]); }
+            if (R.need) { lin_pixel<MODE>(R, w.pc, h0I, h0X, h0Y, color[k0], wgt[k0], fixA, fixB); lin_pixel<MODE>(R, w.pc, h1I, h1X, h1Y, color[k1], wgt[k1], fixA, fixB); }
         };
 #if NALO_LIN_COOP_NPB == 3
         // 3 + 3 + 2 pattern pixels: 12 loads in flight per lane
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
             exchange(a0, a1, a2, a3, R.Kus[k0], R.Kvs[k0], h0I, h0X, h0Y);
             exchange(b0_, b1_, b2_, b3_, R.Kus[k1], R.Kvs[k1], h1I, h1X, h1Y);
             exchange(c0_, c1_, c2_, c3_, R.Kus[k2], R.Kvs[k2], h2I, h2X, h2Y);
-            if (R.need) { lin_pixel<MODE>(R, w.pc, h0I, h0X, h0Y, color[k0], wgt[k0]); lin_pixel<MODE>(R, w.pc, h1I, h1X, h1Y, color[k1], wgt[k1]); lin_pixel<MODE>(R, w.pc, h2I, h2X, h2Y, color[k2], wgt[k2]); }
+            if (R.need) { lin_pixel<MODE>(R, w.pc, h0I, h0X, h0Y, color[k0], wgt[k0], fixA, fixB); lin_pixel<MODE>(R, w.pc, h1I, h1X, h1Y, color[k1], wgt[k1], fixA, fixB); lin_pixel<MODE>(R, w.pc, h2I, h2X, h2Y, color[k2], wgt[k2], fixA, fixB); }
         };
         batch3(std::integral_constant<int, 0>{}); batch3(std::integral_constant<int, 3>{}); batch(std::integral_constant<int, 3>{});
 #else
@@ -383,6 +391,21 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
 #endif
     }
     lin_commit<MODE, FIX>(B, w, R);
+    if (FIX == 2) {
+        // not applied: only the energy sum (stats[0] of linearizeAll_Reductor, a double sum of the float returns) leaves the workgroup
+        double e = (double)R.energy;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_down(e, o);
+        double* out = B.noapply_E + ((size_t)w.b * (kBlk / WG) + w.q) * B.W + w.t;
+        if (WG > 64) {
+            __syncthreads();                                                                       // the exchange buffer is dead
+            double* sd = reinterpret_cast<double*>(smem);
+            if ((tid & 63) == 0) sd[tid >> 6] = e;
+            __syncthreads();
+            if (tid == 0) { double s = 0; for (int i = 0; i < WG / 64; ++i) s += sd[i]; *out = s; }
+        } else if (tid == 0) *out = e;
+        return;
+    }
     // ---- the 93 reduced values: quad DPP adds -> LDS rows (one per quad) -> fp64 column sums -> this workgroup's partial
     lin_wave_sync();                                                                               // the rows alias the exchange buffer this wave has just read
     lin_stream(R, smem, tid);
@@ -409,10 +432,11 @@ void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix, hipEv
         if (ev_start) hipExtLaunchKernelGGL((ba_linearize_kernel<MODE_, FIX_, WG_>), dim3(grid), dim3(WG_), 0, s, ev_start, ev_stop, 0, B);         \
         else ba_linearize_kernel<MODE_, FIX_, WG_><<<grid, WG_, 0, s>>>(B);                                                                        \
     } while (0)
+    // fix: 0 = linearizeAll(false) + applyRes, 1 = linearizeAll(true), 2 = linearizeAll(false) without applyRes (energy only)
     if (sub == 4) {
-        if (mode == 2) NALO_LIN_LAUNCH(2, 0, 64); else if (fix) NALO_LIN_LAUNCH(0, 1, 64); else NALO_LIN_LAUNCH(0, 0, 64);
+        if (mode == 2) NALO_LIN_LAUNCH(2, 0, 64); else if (fix == 1) NALO_LIN_LAUNCH(0, 1, 64); else if (fix == 2) NALO_LIN_LAUNCH(0, 2, 64); else NALO_LIN_LAUNCH(0, 0, 64);
     } else {
-        if (mode == 2) NALO_LIN_LAUNCH(2, 0, 256); else if (fix) NALO_LIN_LAUNCH(0, 1, 256); else NALO_LIN_LAUNCH(0, 0, 256);
+        if (mode == 2) NALO_LIN_LAUNCH(2, 0, 256); else if (fix == 1) NALO_LIN_LAUNCH(0, 1, 256); else if (fix == 2) NALO_LIN_LAUNCH(0, 2, 256); else NALO_LIN_LAUNCH(0, 0, 256);
     }
 #undef NALO_LIN_LAUNCH
 }

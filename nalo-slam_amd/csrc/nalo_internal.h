@@ -92,6 +92,7 @@ struct nalo_ctx {
     nalo::PixSel* pixsel = nullptr;          // pixel selector state (kernels_pixsel.hip)
     void* rccl = nullptr;                    // RCCL communicators of the sharded BA (host_rccl.hip)
     nalo::Initializer* init = nullptr;       // two-frame initialiser state (host_init.hip)
+    nalo_settings set = {1, nalo::kAffineOptModeA, nalo::kAffineOptModeB, 1};   // util/settings.cpp:71,128-129,74
 
     // ---- host wall-clock accounting (NALO_HOST_TIMING=1 prints it at nalo_destroy)
     std::map<std::string, std::pair<double, long>> host_t;

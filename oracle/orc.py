@@ -315,6 +315,11 @@ def init_do_step(isGood, Jb, maxstep, idepth, lam, inc, idepth_new, kind="f32"):
 
 
 class Tracker:
+    def set_affine_modes(self, a, b):
+        """setting_affineOptModeA / B (< 0: fixed)"""
+        self.L.orc_trk_set_affine_modes.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        self.L.orc_trk_set_affine_modes(self.h_, float(a), float(b))
+
     def __init__(self, w, h, levels, K, kind="f32"):
         self.L = lib(kind)
         self.w, self.h, self.levels = w, h, levels
@@ -536,6 +541,23 @@ class BA:
 
     def set_options(self, nthreads=6, never_break=False):
         self.L.orc_ba_set_options(self.h_, nthreads, int(never_break))
+
+    def set_settings(self, force_accept_step=True, affine_opt_mode_a=1e12, affine_opt_mode_b=1e8, min_opt_iterations=1):
+        """setting_forceAceptStep / setting_affineOptModeA,B / setting_minOptIterations (util/settings.cpp:71,128-129,74)"""
+        self.L.orc_ba_set_settings.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
+        self.L.orc_ba_set_settings(self.h_, int(force_accept_step), float(affine_opt_mode_a), float(affine_opt_mode_b), int(min_opt_iterations))
+
+    def calc_l_energy(self):
+        self.L.orc_ba_calc_l_energy.argtypes = [C.c_void_p]; self.L.orc_ba_calc_l_energy.restype = C.c_double
+        return self.L.orc_ba_calc_l_energy(self.h_)
+
+    def calc_m_energy(self):
+        self.L.orc_ba_calc_m_energy.argtypes = [C.c_void_p]; self.L.orc_ba_calc_m_energy.restype = C.c_double
+        return self.L.orc_ba_calc_m_energy(self.h_)
+
+    def n_rejected(self):
+        self.L.orc_ba_n_rejected.argtypes = [C.c_void_p]; self.L.orc_ba_n_rejected.restype = C.c_int
+        return self.L.orc_ba_n_rejected(self.h_)
 
     def timers(self):
         t = np.zeros(4)

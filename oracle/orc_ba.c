@@ -61,11 +61,12 @@ static void frame_set_state_zero(OrcFrame* f, const double sz[10]) {
     f->ns_affine[1][0]=0; f->ns_affine[1][1]=expf((float)(sz[6]*SCALE_A))*f->ab_exposure;
 }
 /* FrameHessian::getPrior, HessianBlocks.h:321-350 */
-static void frame_take_data(OrcFrame* f) {
+static void frame_take_data(const OrcBA* ba, OrcFrame* f) {
     double p[8]={0,0,0,0,0,0,0,0};
     if (f->frameID==0) { for (int i=0;i<3;i++) p[i]=SETTING_INITIAL_TRANS_PRIOR; for (int i=3;i<6;i++) p[i]=SETTING_INITIAL_ROT_PRIOR;
         p[6]=SETTING_INITIAL_AFFA_PRIOR; p[7]=SETTING_INITIAL_AFFB_PRIOR; }
-    else { p[6]=SETTING_AFFINE_OPT_MODE_A; p[7]=SETTING_AFFINE_OPT_MODE_B; }
+    else { p[6]=ba->affine_opt_mode_a<0 ? SETTING_INITIAL_AFFA_PRIOR : ba->affine_opt_mode_a;            /* :292-302 */
+           p[7]=ba->affine_opt_mode_b<0 ? SETTING_INITIAL_AFFB_PRIOR : ba->affine_opt_mode_b; }
     for (int i=0;i<8;i++) { f->prior[i]=p[i]; f->delta[i]=f->state[i]-f->state_zero[i]; f->delta_prior[i]=f->state[i]; }
 }
 
@@ -100,6 +101,7 @@ OrcBA* orc_ba_create(int W, int P, int w, int h, double fx, double fy, double cx
     ba->nt_alloc=0; alloc_replicas(ba, ORC_NTHREADS);
     for (int i=0;i<4;i++) ba->cPrior[i]=SETTING_INITIAL_CALIB_HESSIAN;
     ba->nthreads_used=ORC_NTHREADS;
+    ba->force_accept_step=1; ba->affine_opt_mode_a=SETTING_AFFINE_OPT_MODE_A; ba->affine_opt_mode_b=SETTING_AFFINE_OPT_MODE_B; ba->min_opt_iterations=1;
     return ba;
 }
 void orc_ba_destroy(OrcBA* ba) {
@@ -123,7 +125,7 @@ void orc_ba_set_frame(OrcBA* ba, int i, const float* dI, const double evalPT[12]
     frame_set_state(f, st);
     frame_set_state_zero(f, f->state);
     if (state6) { for (int k=0;k<6;k++) st[k]=state6[k]; frame_set_state(f, st); }
-    frame_take_data(f);
+    frame_take_data(ba,f);
 }
 /* General form for a window that carries state between keyframes: evalPT (FEJ point), state and state_zero as the running system holds them
  * (FrameHessian::setStateZero / setState, HessianBlocks.h:208-255, HessianBlocks.cpp:73-106). Both are the UNSCALED 10-vectors. */
@@ -134,7 +136,7 @@ void orc_ba_set_frame_full(OrcBA* ba, int i, const float* dI, const double evalP
     frame_set_state(f, state_zero);
     frame_set_state_zero(f, state_zero);
     frame_set_state(f, state);
-    frame_take_data(f);
+    frame_take_data(ba,f);
 }
 /* PointHessian::idepth_zero differing from idepth (setIdepthZero / setIdepth are separate setters, HessianBlocks.h:449-460) */
 void orc_ba_set_idepth_zero(OrcBA* ba, const float* idepth_zero) {
@@ -218,7 +220,7 @@ static void set_delta(OrcBA* ba) {
             ba->adHTdeltaF[idx*8+j]=s1+s2; }
     }
     for (int i=0;i<4;i++) ba->cDeltaF[i]=(float)(ba->c_value[i]-ba->c_value_zero[i]);
-    for (int f=0;f<W;f++) frame_take_data(&ba->frames[f]);
+    for (int f=0;f<W;f++) frame_take_data(ba,&ba->frames[f]);
     for (int p=0;p<ba->P;p++) ba->pts[p].deltaF = ba->pts[p].idepth-ba->pts[p].idepth_zero;
 }
 /* FullSystem::setPrecalcValues, FullSystem.cpp:1694-1704 */
@@ -295,6 +297,8 @@ static double linearize(OrcBA* ba, int p, int t) {
         JabJIdx_00+=drdA*hw*hit[1]; JabJIdx_01+=drdA*hw*hit[2]; JabJIdx_10+=hw*hit[1]; JabJIdx_11+=hw*hit[2];
         JabJab_00+=drdA*drdA*hw*hw; JabJab_01+=drdA*hw*hw; JabJab_11+=hw*hw;
         wJI2_sum += hw*hw*(hit[1]*hit[1]+hit[2]*hit[2]);
+        if (ba->affine_opt_mode_a<0) J->JabF[0][idx]=0;                            /* Residuals.cpp:241-242 */
+        if (ba->affine_opt_mode_b<0) J->JabF[1][idx]=0;
     }
     J->JIdx2[0]=JIdxJIdx_00; J->JIdx2[1]=JIdxJIdx_10; J->JIdx2[2]=JIdxJIdx_10; J->JIdx2[3]=JIdxJIdx_11;
     J->JabJIdx[0]=JabJIdx_00; J->JabJIdx[1]=JabJIdx_01; J->JabJIdx[2]=JabJIdx_10; J->JabJIdx[3]=JabJIdx_11;
@@ -712,22 +716,73 @@ int orc_ba_do_step(OrcBA* ba, float stepfacC, float stepfacT, float stepfacR, fl
     return sqrtf(sumA)<0.0005*th && sqrtf(sumB)<0.00005*th && sqrtf(sumR)<0.00005*th && sqrtf(sumT)*sumNID<0.00005*th;
 }
 
+/* EnergyFunctional::calcLEnergyF_MT + calcLEnergyPt (EnergyFunctional.cpp:332-415): frame priors, calibration prior, and per point the linearised
+ * residuals' (2 res_toZeroF + J delta) . J delta plus deltaF^2 priorF. FullSystem::calcLEnergy returns 0 while setting_forceAceptStep (FullSystemOptimize.cpp:351). */
+double orc_ba_calc_l_energy(OrcBA* ba) {
+    int W=ba->W; double E=0;
+    for (int f=0;f<W;f++) for (int i=0;i<8;i++) E += ba->frames[f].delta_prior[i]*ba->frames[f].prior[i]*ba->frames[f].delta_prior[i];
+    { float e=0; for (int i=0;i<4;i++) e += (ba->cDeltaF[i]*(float)ba->cPrior[i])*ba->cDeltaF[i]; E += e; }      /* cDeltaF.cwiseProduct(cPriorF).dot(cDeltaF): floats */
+    double Ept=0;
+    for (int p=0;p<ba->P;p++) { OrcPoint* pt=&ba->pts[p]; if (pt->removed) continue;
+        real dd=pt->deltaF;
+        for (int t=0;t<W;t++) { OrcRes* r=RES(ba,p,t); if (!r->exists || !r->isLinearized || !r->isActive) continue;
+            const float* dp=ba->adHTdeltaF+(pt->host+W*t)*8; OrcJ* J=&r->J;
+            real jx=0, jy=0, cx_=0, cy_=0;
+            for (int i=0;i<6;i++) { jx+=J->Jpdxi[0][i]*(real)dp[i]; jy+=J->Jpdxi[1][i]*(real)dp[i]; }
+            for (int i=0;i<4;i++) { cx_+=J->Jpdc[0][i]*(real)ba->cDeltaF[i]; cy_+=J->Jpdc[1][i]*(real)ba->cDeltaF[i]; }
+            jx = jx + cx_ + J->Jpdd[0]*dd; jy = jy + cy_ + J->Jpdd[1]*dd;
+            for (int i=0;i<8;i++) {
+                real Jdelta = J->JIdx[0][i]*jx + J->JIdx[1][i]*jy + J->JabF[0][i]*(real)dp[6] + J->JabF[1][i]*(real)dp[7];
+                real r0 = r->res_toZeroF[i]; r0 = r0 + r0; r0 = r0 + Jdelta;
+                Ept += (double)(float)(Jdelta*r0);
+            } }
+        Ept += (double)(float)(pt->deltaF*pt->deltaF*pt->priorF); }
+    return E + (double)(float)Ept;
+}
+/* EnergyFunctional::calcMEnergyF (:320-329): delta . (2 bM + HM delta) with the stitched delta of getStitchedDeltaF (:938-945) */
+double orc_ba_calc_m_energy(OrcBA* ba) {
+    int W=ba->W, n=NDIM(ba); double* d=(double*)malloc(8*n); double E=0;
+    for (int i=0;i<4;i++) d[i]=(double)ba->cDeltaF[i];
+    for (int h=0;h<W;h++) for (int i=0;i<8;i++) d[ORC_CPARS+8*h+i]=ba->frames[h].delta[i];
+    for (int i=0;i<n;i++) { double s=0; for (int j=0;j<n;j++) s+=ba->HM[i*n+j]*d[j]; E += d[i]*(2*ba->bM[i]+s); }
+    free(d); return E;
+}
+/* FullSystem::loadSateBackup (FullSystemOptimize.cpp:352-369): note setIdepthZero(idepth_backup) */
+static void load_state_backup(OrcBA* ba) {
+    calib_set_value(ba,ba->c_value_backup);
+    for (int f=0;f<ba->W;f++) frame_set_state(&ba->frames[f],ba->frames[f].state_backup);
+    for (int p=0;p<ba->P;p++) { OrcPoint* ph=&ba->pts[p]; if (ph->removed) continue;
+        ph->idepth=ph->idepth_backup; ph->idepth_scaled=SCALE_IDEPTH*ph->idepth; ph->idepth_zero=ph->idepth_backup; ph->idepth_zero_scaled=SCALE_IDEPTH*ph->idepth_backup; }
+    orc_ba_set_precalc(ba);
+}
+
 /* ---------------------------------------------------------------- FullSystem::optimize, FullSystemOptimize.cpp:398-602 */
 double orc_ba_optimize(OrcBA* ba, int mnumOptIts) {
     if (ba->W<2) return 0; if (ba->W<3) mnumOptIts=20; if (ba->W<4) mnumOptIts=15;
     for (int p=0;p<ba->P;p++) for (int t=0;t<ba->W;t++) { OrcRes* r=RES(ba,p,t);        /* :412-429 resetOOB */
         if (r->exists && !r->isLinearized) { r->state_NewEnergy=r->state_energy=0; r->state_NewState=ORC_OUTLIER; r->state_state=ORC_IN; } }
+    const int force=ba->force_accept_step;
     double lastEnergy=orc_ba_linearize_all(ba,0);
+    double lastEnergyL = force ? 0 : orc_ba_calc_l_energy(ba), lastEnergyM = force ? 0 : orc_ba_calc_m_energy(ba);
     orc_ba_apply_res(ba);
     double lambda=1e-1;
+    ba->n_rejected=0;
     for (int it=0; it<mnumOptIts; it++) {
         backup_state(ba);
         orc_ba_solve_system(ba,it,lambda,0,0,0,0,0);
         int canbreak=orc_ba_do_step(ba,1,1,1,1,1);
         double newEnergy=orc_ba_linearize_all(ba,0);
-        orc_ba_apply_res(ba);                              /* setting_forceAceptStep = true */
-        lastEnergy=newEnergy; lambda*=0.25;
-        if (canbreak && it>=1 && !ba->never_break) break;  /* setting_minOptIterations = 1 */
+        double newEnergyL = force ? 0 : orc_ba_calc_l_energy(ba), newEnergyM = force ? 0 : orc_ba_calc_m_energy(ba);
+        if (force || (newEnergy + newEnergyL + newEnergyM < lastEnergy + lastEnergyL + lastEnergyM)) {      /* :519-532 */
+            orc_ba_apply_res(ba);
+            lastEnergy=newEnergy; lastEnergyL=newEnergyL; lastEnergyM=newEnergyM; lambda*=0.25;
+        } else {                                                                                          /* :534-541 */
+            load_state_backup(ba);
+            lastEnergy=orc_ba_linearize_all(ba,0);
+            lastEnergyL=orc_ba_calc_l_energy(ba); lastEnergyM=orc_ba_calc_m_energy(ba);
+            lambda*=1e2; ba->n_rejected++;
+        }
+        if (canbreak && it>=ba->min_opt_iterations && !ba->never_break) break;  /* setting_minOptIterations = 1 */
     }
     OrcFrame* nf=&ba->frames[ba->W-1];                     /* :550-557 */
     double nsz[10]={0,0,0,0,0,0,nf->state[6],nf->state[7],0,0};
@@ -861,6 +916,11 @@ void orc_ba_set_options(OrcBA* ba, int nthreads, int never_break) {
 /* 1 = linearizeAll chunked over the workers (upstream DSO; this fork runs it single-threaded, FullSystemOptimize.cpp:154-164): only for the
  * all-cores baseline line of bench.py */
 void orc_ba_set_linearize_mt(OrcBA* ba, int on) { ba->linearize_mt=on; }
+void orc_ba_set_settings(OrcBA* ba, int force_accept_step, double affA, double affB, int min_opt_iterations) {
+    ba->force_accept_step=force_accept_step; ba->affine_opt_mode_a=affA; ba->affine_opt_mode_b=affB; ba->min_opt_iterations=min_opt_iterations;
+    for (int f=0;f<ba->W;f++) frame_take_data(ba,&ba->frames[f]);
+}
+int orc_ba_n_rejected(OrcBA* ba) { return ba->n_rejected; }
 void orc_ba_get_timers(OrcBA* ba, double* t4) { t4[0]=ba->t_linearize; t4[1]=ba->t_accumulate; t4[2]=ba->t_solve; t4[3]=ba->t_other; }
 int orc_ba_counts(OrcBA* ba, int which) { return which==0?ba->resInA: which==1?ba->resInL: ba->resInM; }
 void orc_ba_set_idepth(OrcBA* ba, const float* idepth) { for (int p=0;p<ba->P;p++) { OrcPoint* pt=&ba->pts[p]; pt->idepth=idepth[p]; pt->idepth_scaled=idepth[p]; pt->idepth_zero=idepth[p]; pt->idepth_zero_scaled=idepth[p]; pt->deltaF=0; } }

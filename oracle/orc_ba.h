@@ -83,6 +83,8 @@ typedef struct OrcBA {
     int nthreads_used;                 /* 1 .. nt_alloc; 6 = the reference */
     int linearize_mt;                  /* 0 = single-threaded linearizeAll as in this fork (FullSystemOptimize.cpp:154-164); 1 = chunked over the workers (upstream DSO) */
     int never_break;
+    /* settings a caller may change (util/settings.cpp:71,128-129,74): defaults 1, 1e12, 1e8, 1 */
+    int force_accept_step; double affine_opt_mode_a, affine_opt_mode_b; int min_opt_iterations; int n_rejected;
     double t_linearize, t_accumulate, t_solve, t_other;   /* wall seconds, for the baseline report */
 } OrcBA;
 

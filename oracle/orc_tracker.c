@@ -76,6 +76,8 @@ typedef struct {
     const float* dI_ref;    /* borrowed: reference frame pyramid (AoS 3) */
     double lastResiduals[5], lastFlow[3];
     long n_calcres, n_calcgs;   /* call counters for the baseline report */
+    double affA, affB;          /* setting_affineOptModeA / B (util/settings.cpp:128-129); set by orc_trk_set_affine_modes, default 1e12 / 1e8 */
+    int aff_set;
 } OrcTracker;
 
 OrcTracker* orc_trk_create(int w, int h, int levels, float fx, float fy, float cx, float cy) {
@@ -337,7 +339,20 @@ int orc_trk_track(OrcTracker* T, const float* dI_new, double T_io[12], double af
         for (int it=0; it<maxIterations[lvl]; it++) {
             double Hl[64], nb[8], inc[8];
             memcpy(Hl,H,sizeof(Hl)); for (int i=0;i<8;i++) { Hl[i*8+i]*=(1+lambda); nb[i]=-b[i]; }
-            orc_ldlt_solve(8,Hl,nb,inc);       /* affineOptModeA/B >= 0: both a,b optimised (:1140-1162 variants not taken) */
+            orc_ldlt_solve(8,Hl,nb,inc);
+            {   /* :1140-1162: a and/or b fixed */
+                const double mA = T->aff_set ? T->affA : 1e12, mB = T->aff_set ? T->affB : 1e8;
+                if (mA < 0 && mB < 0) { double H6[36], x6[6]; for (int i=0;i<6;i++) for (int j=0;j<6;j++) H6[i*6+j]=Hl[i*8+j];
+                    orc_ldlt_solve(6,H6,nb,x6); for (int i=0;i<6;i++) inc[i]=x6[i]; inc[6]=inc[7]=0; }
+                if (!(mA < 0) && mB < 0) { double H7[49], x7[7]; for (int i=0;i<7;i++) for (int j=0;j<7;j++) H7[i*7+j]=Hl[i*8+j];
+                    orc_ldlt_solve(7,H7,nb,x7); for (int i=0;i<7;i++) inc[i]=x7[i]; inc[7]=0; }
+                if (mA < 0 && !(mB < 0)) { double Hs[64], bs[8], H7[49], x7[7]; memcpy(Hs,Hl,sizeof(Hs)); memcpy(bs,nb,sizeof(bs));
+                    for (int i=0;i<8;i++) Hs[i*8+6]=Hs[i*8+7];                       /* HlStitch.col(6) = col(7); then row(6) = row(7) */
+                    for (int j=0;j<8;j++) Hs[6*8+j]=Hs[7*8+j];
+                    bs[6]=bs[7];
+                    for (int i=0;i<7;i++) for (int j=0;j<7;j++) H7[i*7+j]=Hs[i*8+j];
+                    orc_ldlt_solve(7,H7,bs,x7); for (int i=0;i<6;i++) inc[i]=x7[i]; inc[6]=0; inc[7]=x7[6]; }
+            }
             float extrapFac=1;
             if (lambda < lambdaExtrapolationLimit) extrapFac = sqrt(sqrt(lambdaExtrapolationLimit/lambda));
             for (int i=0;i<8;i++) inc[i]*=extrapFac;
@@ -372,7 +387,15 @@ int orc_trk_track(OrcTracker* T, const float* dI_new, double T_io[12], double af
     for (int i=0;i<3;i++) lastFlow_out[i]=T->lastFlow[i];
     if (!ok) return 0;
     memcpy(T_io,cur,sizeof(cur)); aff_io[0]=aff_cur[0]; aff_io[1]=aff_cur[1];
-    if (fabsf((float)aff_io[0]) > 1.2f || fabsf((float)aff_io[1]) > 200) return 0;     /* :1243-1245, modes != 0 */
+    {   /* :1243-1256 */
+        const double mA = T->aff_set ? T->affA : 1e12, mB = T->aff_set ? T->affB : 1e8;
+        if ((mA != 0 && fabsf((float)aff_io[0]) > 1.2f) || (mB != 0 && fabsf((float)aff_io[1]) > 200)) return 0;
+        double rel[2]; orc_aff_from_to(exposures[0],exposures[1],ref_aff[0],ref_aff[1],aff_io[0],aff_io[1],rel);
+        if ((mA == 0 && fabsf(logf((float)rel[0])) > 1.5f) || (mB == 0 && fabsf((float)rel[1]) > 200)) return 0;
+        if (mA < 0) aff_io[0]=0;
+        if (mB < 0) aff_io[1]=0;
+    }
     return 1;
 }
+void orc_trk_set_affine_modes(OrcTracker* T, double affA, double affB) { T->affA=affA; T->affB=affB; T->aff_set=1; }
 long orc_trk_counter(OrcTracker* T, int which) { return which ? T->n_calcgs : T->n_calcres; }

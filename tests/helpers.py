@@ -45,23 +45,15 @@ def pose_dist(A, B):
 
 
 def sim3_aligned_dist(A, B):
-    """Largest distance between two monocular window trajectories A, B (lists of 3x4 worldToCam) after the best Sim(3) alignment of B onto A (Umeyama on
-    the camera centres; the rotation error after alignment is added as an angle). A monocular photometric window is held in place by priors only (frame 0's
-    pose prior, the depth priors, HM): a perturbation — a flipped outlier decision, closed-loop drift — moves it mostly ALONG that gauge, which is not an
-    error of the estimate. With fewer than 3 frames the raw distance is returned."""
+    """Largest distance between two monocular window trajectories A, B (lists of 3x4 worldToCam) modulo the Sim(3) gauge: poses are taken relative to the
+    window's first frame (removes the global SE(3)) and B's relative translations are rescaled by the least-squares scale factor onto A's. (An Umeyama fit
+    on the camera centres is degenerate for the forward-moving, nearly collinear trajectories of these sequences.) A monocular photometric window is held
+    in place by priors only (frame 0's pose prior, the depth priors, HM): a perturbation — a flipped outlier decision, closed-loop drift — moves it mostly
+    ALONG that gauge, which is not an error of the estimate. With fewer than 3 frames the raw distance is returned."""
     if len(A) < 3:
         return max(pose_dist(a, b) for a, b in zip(A, B))
-    ca = np.array([-(a[:, :3].T @ a[:, 3]) for a in A]); cb = np.array([-(b[:, :3].T @ b[:, 3]) for b in B])
-    ma, mb = ca.mean(0), cb.mean(0)
-    xa, xb = ca - ma, cb - mb
-    U, S, Vt = np.linalg.svd(xa.T @ xb / len(A))
-    D = np.eye(3); D[2, 2] = np.sign(np.linalg.det(U @ Vt))
-    R = U @ D @ Vt
-    s = np.trace(np.diag(S) @ D) / (xb ** 2).sum() * len(A)
-    t = ma - s * R @ mb
-    err = np.abs(ca - (s * (R @ cb.T).T + t)).max()
-    ang = 0.0
-    for a, b in zip(A, B):                      # camToWorld rotations align as Ra^T = R Rb^T, i.e. Ra R Rb^T = I
-        Rd = a[:, :3] @ R @ b[:, :3].T
-        ang = max(ang, np.arccos(np.clip((np.trace(Rd) - 1) / 2, -1, 1)))
-    return max(err, ang)
+    ra = [synth.se3_mul(a, synth.se3_inv(A[0])) for a in A[1:]]
+    rb = [synth.se3_mul(b, synth.se3_inv(B[0])) for b in B[1:]]
+    ta, tb = np.array([r[:, 3] for r in ra]), np.array([r[:, 3] for r in rb])
+    s = (ta * tb).sum() / max((tb * tb).sum(), 1e-300)
+    return max(pose_dist(x, np.c_[y[:, :3], s * y[:, 3]]) for x, y in zip(ra, rb))

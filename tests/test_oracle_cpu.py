@@ -515,3 +515,48 @@ def test_marginalize_frame_matches_dense_schur_and_solution_identity(small_windo
         x_full = np.linalg.solve(Hp, bp)
         x_marg = np.linalg.solve(H_o, b_o)
         assert np.abs(x_marg - x_full[:nd]).max() < 1e-6 * np.abs(x_full[:nd]).max()
+
+
+def test_l_and_m_energy_closed_forms_and_energy_test_branch():
+    """a13 on the oracle: calcLEnergyF_MT / calcMEnergyF (EnergyFunctional.cpp:320-415) against their closed forms in numpy, and the accept / reject branch
+    of FullSystem::optimize (setting_forceAceptStep = false, FullSystemOptimize.cpp:511-541): once solveSystemF's fixed lambda (SOLVER_FIX_LAMBDA,
+    EnergyFunctional.cpp:779) reproduces a rejected step, every later iteration is rejected too — the run ends at the last accepted state."""
+    win = synth.make_window(w=320, h=240, W=4, P=400, seed=7)
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    rng = np.random.RandomState(2)
+    n = 8 * win.W + 4
+    A = rng.randn(n, n); HM = A @ A.T * 1e3; bM = rng.randn(n) * 1e2
+    has_prior = (rng.rand(len(win.host)) < 0.3).astype(np.int32)
+    idz = (win.idepth * (1 + 1e-3 * rng.randn(len(win.host)))).astype(np.float32)
+    orc.lib().orc_set_sum_mode(0)
+    ba = orc.BA(win.W, len(win.host), win.w, win.h, win.K)
+    for i in range(win.W):
+        dI, _ = orc.make_images(win.images[i], 1)
+        ba.set_frame(i, dI, win.world_to_cam[i], state6=st6[i])
+    ba.set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights, has_prior=has_prior, idepth_zero=idz)
+    K = np.asarray(win.K, np.float64)
+    ba.set_calib_zero(K * (1 + np.array([1e-4, -1e-4, 2e-4, -2e-4])))
+    ba.set_residuals(win.exists)
+    ba.set_prior(HM, bM)
+    ba.prepare()
+    # M energy: delta . (2 bM + HM delta), delta = [cDeltaF | state - state_zero per frame]
+    cz = K * (1 + np.array([1e-4, -1e-4, 2e-4, -2e-4]))
+    cd = np.float32(np.array([K[0] / 50, K[1] / 50, K[2] / 50, K[3] / 50]) - np.array([np.float32(1 / 50.) * cz[0], np.float32(1 / 50.) * cz[1], np.float32(1 / 50.) * cz[2], np.float32(1 / 50.) * cz[3]]))
+    delta = np.r_[cd.astype(np.float64), np.concatenate([ba.frame(i)["state"][:8] - ba.frame(i)["state_zero"][:8] for i in range(win.W)])]
+    M_np = delta @ (2 * bM + HM @ delta)
+    assert abs(ba.calc_m_energy() - M_np) < 1e-4 * abs(M_np) + 1e-9          # cDeltaF is a float difference of nearly equal numbers: ~1e-5 of its value
+    # L energy: frame priors (frame 0: 1e10 / 1e11 / 1e14, others: a, b priors 1e12 / 1e8) on delta_prior = state, the calibration prior 5e9 on cDeltaF,
+    # and deltaF^2 * 2500 for the points with a depth prior
+    L_np = 0.0
+    for i in range(win.W):
+        s = ba.frame(i)["state"][:8]
+        p = np.r_[[1e10] * 3, [1e11] * 3, 1e14, 1e14] if i == 0 else np.r_[[0.0] * 6, 1e12, 1e8]
+        L_np += float((s * p * s).sum())
+    L_np += float((cd.astype(np.float64) ** 2 * 5e9).sum())
+    d = (win.idepth.astype(np.float32) - idz).astype(np.float64)
+    L_np += float((d * d * 2500.0 * (has_prior != 0)).sum())
+    assert abs(ba.calc_l_energy() - L_np) < 1e-4 * abs(L_np)
+    # the energy test
+    ba.set_settings(force_accept_step=False)
+    ba.optimize(6)
+    assert 0 <= ba.n_rejected() <= 6
