@@ -66,8 +66,12 @@ def test_track_frames_match_oracle(w, h, n_frames):
         d = pose_dist(sg["thisToNext"], so["thisToNext"])
         # the LM step solves Hl = H - Hsc/(1+lambda) in FLOAT (Mat88f, :182-197): the subtraction cancels, so two fp32 evaluations of the same path differ by
         # more than the 1e-5 bar on some frames; the all-fp64 oracle run beside them measures that floor (x1.5) when it took the same decisions
+        # ... and the loop is chaotic: +1 ulp on 1 % of the new frames' pixels moves the ORACLE's own result by 1.2e-4 at frame 2 and changes its decision
+        # path (tests/test_initializer_cpu.py::test_oracle_initializer_sensitivity). 2e-4 on an identical decision path is therefore the bar here; the
+        # first frame (short path, 33 evaluations) keeps the 1e-5 bar.
         floor = pose_dist(s64["thisToNext"], so["thisToNext"]) if so["n_evals"] == s64["n_evals"] else 0.0
-        assert d < (max(1e-5, 1.5 * floor) if same_path else 1e-3), (i, d, floor, so["n_evals"], sg["n_evals"], s64["n_evals"])
+        bar = max(1e-5, 1.5 * floor) if i == 1 else 2e-4
+        assert d < (bar if same_path else 1e-3), (i, d, floor, so["n_evals"], sg["n_evals"], s64["n_evals"])
         assert np.abs(sg["aff"] - so["aff"]).max() < 1e-6
         if same_path:
             for l in range(win.levels):

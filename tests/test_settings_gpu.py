@@ -99,7 +99,7 @@ def test_affine_modes_in_the_bundle_adjustment(carried, modes):
     assert rel_err(HA_g, HA_o) < 2e-5 and np.abs(bA_g - bA_o).max() < 5e-5 * np.abs(bA_o).max()
     HL_o, bL_o = ba.accumulate(1)
     HL_g, bL_g = c.ba_accumulate(1)
-    assert np.array_equal(HL_g, HL_o) and rel_err(bL_g, bL_o) < 1e-12            # the priors themselves: exact
+    assert np.array_equal(HL_g, HL_o) and rel_err(bL_g, bL_o) < 1e-6             # the priors themselves: exact; b_L = prior * delta (delta through fp32 states)
     # a fixed parameter leaves no gradient from the residuals in its slot (Jab_r uses the zeroed JabF) but keeps its Hessian entries
     W = win.W
     ia, ib = [4 + 8 * f + 6 for f in range(W)], [4 + 8 * f + 7 for f in range(W)]
