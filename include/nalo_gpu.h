@@ -90,6 +90,20 @@ int nalo_frame_upload(nalo_ctx* ctx, int slot, const float* irradiance, const fl
 int nalo_frame_upload_async(nalo_ctx* ctx, int slot, const float* irradiance, const float* mask, const uint8_t* bgr,
                             const float* gammaB);
 int nalo_frame_wait(nalo_ctx* ctx, int slot);
+/* The sensor frame as the dataset holds it: Undistort::undistort<T> (util/Undistort.cpp:435-530) = PhotometricUndistorter::processFrame
+ * (:214-251) + the bilinear remap, and the INTER_NEAREST resizes of Undistort::undistort_mask (:385-433, IOWrapper/OpenCV/ImageRW_OpenCV.cpp:55-85), fused
+ * in front of makeImages; call site ImageFolderReader::getImage_internal (util/DatasetReader.h:270-298) -> FullSystem::addActiveFrame.
+ * nalo_undist_set          the tables of the Undistort object, uploaded once: the response G (GDepth >= 256 entries, already rescaled to 0..255 as
+ *                          Undistort.cpp:101-103 does: nalo_io_read_pcalib), vignetteMapInv [wOrg*hOrg] (nalo_io_make_vignette; NULL without a vignette),
+ *                          photometricCalibration = setting_photometricCalibration (0 none, 1 response only, 2 response + vignette; util/settings.cpp:40),
+ *                          remapX / remapY [w*h] in original-image pixels, -1 = outside (Undistort.cpp:998-1010); NULL = passthrough (wOrg x hOrg = w x h).
+ * nalo_frame_upload_raw    raw = wOrg*hOrg pixels of bytes_per_px 1 (uchar) or 2 (ushort); exposure_time <= 0 disables the photometric part for this frame
+ *                          (data = factor * raw, :224-231); mask_org [wOrg*hOrg] / bgr_org [wOrg*hOrg*3] optional (dense=1 / densemap=1 inputs);
+ *                          gammaB as in nalo_frame_upload. The frame crosses PCIe at 1-2 B/px instead of 4. Synchronous like nalo_frame_upload. */
+int nalo_undist_set(nalo_ctx* ctx, int wOrg, int hOrg, const float* G, int GDepth, const float* vignetteMapInv, int photometricCalibration, const float* remapX,
+                    const float* remapY);
+int nalo_frame_upload_raw(nalo_ctx* ctx, int slot, const void* raw, int bytes_per_px, float exposure_time, float factor, const uint8_t* mask_org, const uint8_t* bgr_org,
+                          const float* gammaB);
 void* nalo_host_alloc(size_t bytes);
 void nalo_host_free(void* p);
 /* makeImages again from the level-0 irradiance already resident in the slot (asynchronous on the ctx stream): the

@@ -46,6 +46,26 @@ int nalo_io_read_pcalib(const char* path, int cap, float* G, int* n);
  * any stays zero. cap = capacity of both arrays. */
 int nalo_io_read_times(const char* path, int n_images, int cap, double* stamps, float* exposures, int* n_stamps, int* n_exposures);
 
+/* PNG images -- the reference reads them through cv::imread (IOWrapper/OpenCV/ImageRW_OpenCV.cpp:33-53, 88-175): a self-contained decoder on zlib's
+ * inflate (non-interlaced files; grey / grey+alpha / RGB / RGBA / palette; 1-16 bits), returning what the reference's wrappers return:
+ *   NALO_PNG_GRAY8     readImageBW_8U / readMask_8U  (cv::IMREAD_GRAYSCALE): 8-bit grey; 16-bit samples keep their high byte (png_set_strip_16), colour goes
+ *                      through libpng's png_set_rgb_to_gray(1, 0.299, 0.587) integer weights (9798 R + 19235 G + 3735 B + 16384) >> 15, alpha is dropped
+ *   NALO_PNG_BGR8      readImageRGB_8U               (cv::IMREAD_COLOR): 8-bit B,G,R triplets (grey is replicated)
+ *   NALO_PNG_UNCHANGED readImageBW_16U               (cv::IMREAD_UNCHANGED): samples as stored, 16-bit in host byte order; the wrapper accepts the file
+ *                      only if it is single-channel 16-bit -- check *channels == 1 && *depth == 16 as it does (:160-164)
+ * data: malloc'ed, w*h*channels samples of depth/8 bytes; free with nalo_io_free. */
+enum { NALO_PNG_GRAY8 = 0, NALO_PNG_BGR8 = 1, NALO_PNG_UNCHANGED = 2 };
+int nalo_io_read_png(const char* path, int mode, int* w, int* h, int* channels, int* depth, void** data);
+void nalo_io_free(void* p);
+
+/* vignette.png -- PhotometricUndistorter (util/Undistort.cpp:119-174): vignetteMap[i] = v[i] / max(v) (float division by the float maximum) from the
+ * 16-bit image when readImageBW_16U accepts the file, else from the 8-bit one; vignetteMapInv[i] = 1.0f / vignetteMap[i]. px: n samples of `depth` (8|16) bits. */
+int nalo_io_make_vignette(const void* px, int depth, int n, float* vignetteMap, float* vignetteMapInv);
+
+/* masks / colour images -- IOWrap::resizeMask / resizeColor (IOWrapper/OpenCV/ImageRW_OpenCV.cpp:55-85): cv::resize(.., INTER_NEAREST) of an 8-bit image with
+ * `channels` interleaved channels: dst(x, y) = src(min(floor(x * ifx), wOrg-1), min(floor(y * ify), hOrg-1)), ifx = 1 / ((double)w / wOrg) (OpenCV's resizeNN). */
+int nalo_io_resize_nearest_u8(const uint8_t* src, int wOrg, int hOrg, int channels, uint8_t* dst, int w, int h);
+
 #ifdef __cplusplus
 }
 #endif

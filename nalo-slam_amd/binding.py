@@ -26,7 +26,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 
 EXPORTS = [
     "nalo_create", "nalo_destroy", "nalo_last_error", "nalo_levels", "nalo_sync", "nalo_stream",
-    "nalo_frame_upload", "nalo_frame_upload_async", "nalo_frame_wait", "nalo_host_alloc", "nalo_host_free", "nalo_frame_rebuild", "nalo_frame_download",
+    "nalo_frame_upload", "nalo_frame_upload_raw", "nalo_undist_set", "nalo_frame_upload_async", "nalo_frame_wait", "nalo_host_alloc", "nalo_host_free", "nalo_frame_rebuild", "nalo_frame_download",
     "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
@@ -114,6 +114,8 @@ def load():
     L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
                                             c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.nalo_init_do_step.argtypes = [vp, C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
+    L.nalo_undist_set.argtypes = [vp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp]
+    L.nalo_frame_upload_raw.argtypes = [vp, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, c_u8p, c_u8p, c_fp]
     L.nalo_ba_calc_l_energy.argtypes = [vp, c_dp]
     L.nalo_ba_calc_m_energy.argtypes = [vp, c_dp]
     L.nalo_ba_optimize_stats.argtypes = [vp, c_ip, c_ip]
@@ -468,6 +470,32 @@ class Context:
         out = f(idepth_new).copy()
         self._ck(self.L.nalo_init_do_step(self.h_, len(out), _u8(np.ascontiguousarray(isGood, np.uint8)), _f(f(Jb)), _f(f(maxstep)), _f(f(idepth)), float(lam), _f(f(inc)), _f(out)))
         return out
+
+    def dense_make_map(self, slot, plane, mask_value, camToWorld, cap=100000):
+        """DenseMapping::updateMap bbox scan + makeMap -> dict(n, accept, rect, u, v, idepth, color, bgr)"""
+        rect = np.zeros(4, np.int32)
+        u, v = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        idp, col, bgr = np.zeros(cap, np.float32), np.zeros(cap, np.float32), np.zeros((cap, 3), np.uint8)
+        n, acc = np.zeros(1, np.int32), np.zeros(1, np.int32)
+        self._ck(self.L.nalo_dense_make_map(self.h_, slot, _f(np.ascontiguousarray(plane, np.float32)), C.c_float(mask_value), _d(np.ascontiguousarray(camToWorld, np.float64).reshape(-1)),
+                                            cap, _i(rect), _i(u), _i(v), _f(idp), _f(col), _u8(bgr), _i(n), _i(acc)))
+        k = min(int(n[0]), cap)
+        return dict(n=int(n[0]), accept=int(acc[0]), rect=rect, u=u[:k], v=v[:k], idepth=idp[:k], color=col[:k], bgr=bgr[:k])
+
+    def undist_set(self, wOrg, hOrg, G=None, vinv=None, photometric=0, remapX=None, remapY=None):
+        f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+        G, vinv, remapX, remapY = f(G), f(vinv), f(remapX), f(remapY)
+        self._ck(self.L.nalo_undist_set(self.h_, wOrg, hOrg, None if G is None else _f(G), 0 if G is None else G.size, None if vinv is None else _f(vinv), int(photometric),
+                                        None if remapX is None else _f(remapX), None if remapY is None else _f(remapY)))
+
+    def frame_upload_raw(self, slot, raw, exposure=1.0, factor=1.0, mask_org=None, bgr_org=None, gammaB=None):
+        raw = np.ascontiguousarray(raw)
+        assert raw.dtype in (np.uint8, np.uint16)
+        m = None if mask_org is None else np.ascontiguousarray(mask_org, np.uint8)
+        b = None if bgr_org is None else np.ascontiguousarray(bgr_org, np.uint8)
+        g = None if gammaB is None else np.ascontiguousarray(gammaB, np.float32)
+        self._ck(self.L.nalo_frame_upload_raw(self.h_, slot, raw.ctypes.data_as(C.c_void_p), raw.dtype.itemsize, C.c_float(exposure), C.c_float(factor),
+                                              None if m is None else _u8(m), None if b is None else _u8(b), None if g is None else _f(g)))
 
     def set_settings(self, force_accept_step=None, affine_opt_mode_a=None, affine_opt_mode_b=None, min_opt_iterations=None):
         st = Settings()

@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-lz"])
     return OUT
 
 

@@ -76,6 +76,7 @@ void nalo_destroy(nalo_ctx* c) {
     if (c->pinned_f) (void)hipHostFree(c->pinned_f);
     if (c->imm_host) (void)hipHostFree(c->imm_host);
     c->imm_dev.release(); c->imm_res.release();
+    c->und_G.release(); c->und_vinv.release(); c->und_rx.release(); c->und_ry.release(); c->und_raw.release(); c->und_mask.release(); c->und_bgr.release();
     for (auto& kv : c->prof) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
@@ -140,6 +141,57 @@ int nalo_frame_upload_async(nalo_ctx* c, int slot, const float* irradiance, cons
     s.valid = true;
     return NALO_OK;
 }
+// Undistort / PhotometricUndistorter tables (util/Undistort.cpp:49-190 builds G and vignetteMapInv, :637-1018 remapX / remapY): device resident after this call
+int nalo_undist_set(nalo_ctx* c, int wOrg, int hOrg, const float* G, int GDepth, const float* vignetteMapInv, int photometricCalibration, const float* remapX, const float* remapY) {
+    if (!c || wOrg <= 1 || hOrg <= 1 || photometricCalibration < 0 || photometricCalibration > 2 || (!remapX) != (!remapY)) return fail(c, NALO_ERR_ARG, "nalo_undist_set: bad argument");
+    if (photometricCalibration > 0 && (!G || GDepth < 256)) return fail(c, NALO_ERR_ARG, "nalo_undist_set: the response G needs >= 256 entries (Undistort.cpp:83-87)");
+    if (photometricCalibration == 2 && !vignetteMapInv) return fail(c, NALO_ERR_ARG, "nalo_undist_set: photometricCalibration 2 needs the vignette");
+    if (!remapX && (wOrg != c->w || hOrg != c->h)) return fail(c, NALO_ERR_ARG, "nalo_undist_set: passthrough needs wOrg x hOrg = w x h");
+    NALO_HIP(c, hipSetDevice(c->device));
+    const size_t no = (size_t)wOrg * hOrg, n = (size_t)c->w * c->h;
+    if (G) { NALO_HIP(c, c->und_G.reserve(GDepth)); NALO_HIP(c, hipMemcpy(c->und_G.p, G, (size_t)GDepth * 4, hipMemcpyHostToDevice)); }
+    if (vignetteMapInv) { NALO_HIP(c, c->und_vinv.reserve(no)); NALO_HIP(c, hipMemcpy(c->und_vinv.p, vignetteMapInv, no * 4, hipMemcpyHostToDevice)); }
+    if (remapX) {
+        // the four taps of every output pixel must lie inside the original image (the reference's makeOptimalK_crop / the remap construction guarantee it:
+        // out-of-image entries are -1, Undistort.cpp:998-1010); checked here because a violated table is an out-of-bounds device read
+        for (size_t i = 0; i < n; ++i) if (!(remapX[i] < 0) && !(remapX[i] >= 0 && remapY[i] >= 0 && (int)remapX[i] + 1 < wOrg && (int)remapY[i] + 1 < hOrg))
+            return fail(c, NALO_ERR_ARG, "nalo_undist_set: remap entry outside the original image");
+        NALO_HIP(c, c->und_rx.reserve(n)); NALO_HIP(c, c->und_ry.reserve(n));
+        NALO_HIP(c, hipMemcpy(c->und_rx.p, remapX, n * 4, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(c->und_ry.p, remapY, n * 4, hipMemcpyHostToDevice));
+    }
+    c->und_wOrg = wOrg; c->und_hOrg = hOrg; c->und_photometric = photometricCalibration; c->und_GDepth = GDepth; c->und_remap = remapX != nullptr; c->und_vig = vignetteMapInv != nullptr;
+    c->und_set = true;
+    return NALO_OK;
+}
+
+int nalo_frame_upload_raw(nalo_ctx* c, int slot, const void* raw, int bytes_per_px, float exposure_time, float factor, const uint8_t* mask_org, const uint8_t* bgr_org,
+                          const float* gammaB) {
+    if (!c || !raw || slot < 0 || slot >= (int)c->slots.size() || (bytes_per_px != 1 && bytes_per_px != 2)) return fail(c, NALO_ERR_ARG, "nalo_frame_upload_raw: bad argument");
+    if (!c->und_set) return fail(c, NALO_ERR_STATE, "nalo_frame_upload_raw: nalo_undist_set has not run");
+    NALO_HIP(c, hipSetDevice(c->device));
+    FrameSlot& s = c->slots[slot];
+    const size_t no = (size_t)c->und_wOrg * c->und_hOrg, n0 = (size_t)c->w * c->h;
+    // processFrame: `if(!valid || exposure_time <= 0 || setting_photometricCalibration==0)` -> data = factor * image_in (:224-231)
+    int photometric = c->und_photometric;
+    if (exposure_time <= 0) photometric = 0;
+    if (photometric > 0 && bytes_per_px == 2 && c->und_GDepth < 65536) return fail(c, NALO_ERR_ARG, "nalo_frame_upload_raw: 16-bit frames index G beyond its depth");
+    NALO_HIP(c, c->und_raw.reserve(no * 2));
+    NALO_HIP(c, hipMemcpyAsync(c->und_raw.p, raw, no * bytes_per_px, hipMemcpyHostToDevice, c->stream));
+    if (mask_org) { NALO_HIP(c, c->und_mask.reserve(no)); NALO_HIP(c, hipMemcpyAsync(c->und_mask.p, mask_org, no, hipMemcpyHostToDevice, c->stream)); if (!s.mask) NALO_HIP(c, hipMalloc((void**)&s.mask, n0 * 4)); }
+    if (bgr_org) { NALO_HIP(c, c->und_bgr.reserve(no * 3)); NALO_HIP(c, hipMemcpyAsync(c->und_bgr.p, bgr_org, no * 3, hipMemcpyHostToDevice, c->stream)); if (!s.bgr) NALO_HIP(c, hipMalloc((void**)&s.bgr, n0 * 3)); }
+    const float* gdev = nullptr;
+    if (gammaB) { NALO_HIP(c, c->upload_tmp.reserve(256)); NALO_HIP(c, hipMemcpyAsync(c->upload_tmp.p, gammaB, 256 * 4, hipMemcpyHostToDevice, c->stream)); gdev = c->upload_tmp.p; }
+    int rc = ingest_launch(c, c->stream, c->und_raw.p, bytes_per_px, c->und_wOrg, c->und_hOrg, c->und_G.p, c->und_vig ? c->und_vinv.p : nullptr, c->und_remap ? c->und_rx.p : nullptr,
+                           c->und_remap ? c->und_ry.p : nullptr, photometric, factor, mask_org ? c->und_mask.p : nullptr, bgr_org ? c->und_bgr.p : nullptr, s.I[0], s.mask, s.bgr);
+    if (rc) return rc;
+    rc = pyramid_build(c, s, gdev);
+    if (rc) return rc;
+    pixsel_invalidate_hists(c, slot);
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    s.valid = true;
+    return NALO_OK;
+}
+
 int nalo_frame_wait(nalo_ctx* c, int slot) {
     if (!c || slot < 0 || slot >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_frame_wait: bad slot");
     if (c->slots[slot].ev_up) NALO_HIP(c, hipEventSynchronize(c->slots[slot].ev_up));

@@ -10,6 +10,9 @@
 #include <sstream>
 #include <string>
 #include <vector>
+#include <cmath>
+#include <cstdlib>
+#include <zlib.h>
 
 namespace {
 
@@ -154,6 +157,139 @@ int nalo_io_read_times(const char* path, int n_images, int cap, double* stamps, 
     if ((int)ts.size() > cap || (int)ex.size() > cap) return NALO_IO_ERR_ARG;
     std::copy(ts.begin(), ts.end(), stamps); std::copy(ex.begin(), ex.end(), exposures);
     *n_stamps = (int)ts.size(); *n_exposures = (int)ex.size();
+    return NALO_IO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ PNG
+namespace {
+inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+inline int paeth(int a, int b, int c) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+}
+
+int nalo_io_read_png(const char* path, int mode, int* w_out, int* h_out, int* channels_out, int* depth_out, void** data_out) {
+    if (!path || !w_out || !h_out || !channels_out || !depth_out || !data_out || mode < 0 || mode > 2) return NALO_IO_ERR_ARG;
+    std::ifstream f(path, std::ios::binary);
+    if (!f.good()) return NALO_IO_ERR_FILE;
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (file.size() < 8 + 25 || std::memcmp(file.data(), sig, 8)) return NALO_IO_ERR_FORMAT;
+    int w = 0, h = 0, bitdepth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte;
+    size_t pos = 8; bool have_hdr = false, done = false;
+    while (!done && pos + 12 <= file.size()) {
+        const uint32_t len = be32(&file[pos]); const uint8_t* type = &file[pos + 4];
+        if (pos + 12 + (size_t)len > file.size()) return NALO_IO_ERR_FORMAT;
+        const uint8_t* d = &file[pos + 8];
+        if (!std::memcmp(type, "IHDR", 4)) {
+            if (len != 13) return NALO_IO_ERR_FORMAT;
+            w = (int)be32(d); h = (int)be32(d + 4); bitdepth = d[8]; ctype = d[9]; interlace = d[12]; have_hdr = true;
+            if (d[10] != 0 || d[11] != 0) return NALO_IO_ERR_FORMAT;
+        } else if (!std::memcmp(type, "PLTE", 4)) plte.assign(d, d + len);
+        else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
+        else if (!std::memcmp(type, "IEND", 4)) done = true;
+        pos += 12 + (size_t)len;
+    }
+    if (!have_hdr || w <= 0 || h <= 0 || interlace != 0) return NALO_IO_ERR_FORMAT;             // Adam7 files are not supported
+    int nch;
+    switch (ctype) { case 0: nch = 1; break; case 2: nch = 3; break; case 3: nch = 1; break; case 4: nch = 2; break; case 6: nch = 4; break; default: return NALO_IO_ERR_FORMAT; }
+    if (!(bitdepth == 8 || bitdepth == 16 || ((ctype == 0 || ctype == 3) && (bitdepth == 1 || bitdepth == 2 || bitdepth == 4))) || (ctype == 3 && bitdepth == 16)) return NALO_IO_ERR_FORMAT;
+    if (ctype == 3 && plte.size() < 3) return NALO_IO_ERR_FORMAT;
+    const size_t bpp_bits = (size_t)nch * bitdepth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
+    std::vector<uint8_t> rawbuf((stride + 1) * (size_t)h);
+    {
+        z_stream zs; std::memset(&zs, 0, sizeof(zs));
+        if (inflateInit(&zs) != Z_OK) return NALO_IO_ERR_FORMAT;
+        zs.next_in = idat.data(); zs.avail_in = (uInt)idat.size(); zs.next_out = rawbuf.data(); zs.avail_out = (uInt)rawbuf.size();
+        const int zr = inflate(&zs, Z_FINISH);
+        const size_t got = rawbuf.size() - zs.avail_out;
+        inflateEnd(&zs);
+        if ((zr != Z_STREAM_END && zr != Z_OK && zr != Z_BUF_ERROR) || got != rawbuf.size()) return NALO_IO_ERR_FORMAT;
+    }
+    // un-filter (PNG specification, 9.2)
+    std::vector<uint8_t> img(stride * (size_t)h);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t ft = rawbuf[(stride + 1) * y]; const uint8_t* in = &rawbuf[(stride + 1) * y + 1];
+        uint8_t* cur = &img[stride * y]; const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+            int v = in[i];
+            switch (ft) { case 0: break; case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) >> 1; break; case 4: v += paeth(a, b, c); break; default: return NALO_IO_ERR_FORMAT; }
+            cur[i] = (uint8_t)v;
+        }
+    }
+    // samples -> 16-bit working values per channel (palette and sub-byte depths expanded the way libpng's png_set_expand does)
+    const size_t npx = (size_t)w * h;
+    int och = nch; const int odepth = bitdepth == 16 ? 16 : 8;
+    std::vector<uint16_t> px;
+    if (ctype == 3) {
+        och = 3; px.resize(npx * 3);
+        for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+            const uint8_t* row = &img[stride * y]; unsigned idx;
+            if (bitdepth == 8) idx = row[x]; else { const int per = 8 / bitdepth, sh = (per - 1 - x % per) * bitdepth; idx = (row[x / per] >> sh) & ((1u << bitdepth) - 1); }
+            if ((size_t)idx * 3 + 2 >= plte.size()) return NALO_IO_ERR_FORMAT;
+            for (int k = 0; k < 3; ++k) px[((size_t)y * w + x) * 3 + k] = plte[idx * 3 + k];
+        }
+    } else {
+        px.resize(npx * nch);
+        for (int y = 0; y < h; ++y) {
+            const uint8_t* row = &img[stride * y];
+            for (int x = 0; x < w; ++x) for (int k = 0; k < nch; ++k) {
+                uint16_t v;
+                if (bitdepth == 16) v = (uint16_t)((row[((size_t)x * nch + k) * 2] << 8) | row[((size_t)x * nch + k) * 2 + 1]);
+                else if (bitdepth == 8) v = row[(size_t)x * nch + k];
+                else { const int per = 8 / bitdepth, sh = (per - 1 - x % per) * bitdepth; const unsigned s = (row[x / per] >> sh) & ((1u << bitdepth) - 1); v = (uint16_t)(s * 255u / ((1u << bitdepth) - 1)); }
+                px[((size_t)y * w + x) * nch + k] = v;
+            }
+        }
+    }
+    void* out = nullptr; int rch, rdepth;
+    if (mode == NALO_PNG_UNCHANGED) {
+        rch = och; rdepth = odepth;
+        if (rdepth == 16) { uint16_t* o = (uint16_t*)std::malloc(npx * rch * 2); if (!o) return NALO_IO_ERR_FILE; std::memcpy(o, px.data(), npx * rch * 2); out = o; }
+        else { uint8_t* o = (uint8_t*)std::malloc(npx * rch); if (!o) return NALO_IO_ERR_FILE; for (size_t i = 0; i < npx * rch; ++i) o[i] = (uint8_t)px[i]; out = o; }
+        if (rdepth == 8 && rch >= 3) { uint8_t* o = (uint8_t*)out; for (size_t i = 0; i < npx; ++i) std::swap(o[i * rch], o[i * rch + 2]); }      // OpenCV stores B,G,R(,A)
+        if (rdepth == 16 && rch >= 3) { uint16_t* o = (uint16_t*)out; for (size_t i = 0; i < npx; ++i) std::swap(o[i * rch], o[i * rch + 2]); }
+    } else {
+        const int sh = odepth == 16 ? 8 : 0;                                                       // png_set_strip_16: the high byte
+        const bool colour = och >= 3;
+        rdepth = 8; rch = mode == NALO_PNG_GRAY8 ? 1 : 3;
+        uint8_t* o = (uint8_t*)std::malloc(npx * rch); if (!o) return NALO_IO_ERR_FILE;
+        for (size_t i = 0; i < npx; ++i) {
+            const uint16_t* p = &px[i * och];
+            if (mode == NALO_PNG_GRAY8) {
+                if (colour) { const unsigned r = p[0] >> sh, g = p[1] >> sh, b = p[2] >> sh; o[i] = (uint8_t)((9798u * r + 19235u * g + 3735u * b + 16384u) >> 15); }
+                else o[i] = (uint8_t)(p[0] >> sh);
+            } else {
+                if (colour) { o[3 * i] = (uint8_t)(p[2] >> sh); o[3 * i + 1] = (uint8_t)(p[1] >> sh); o[3 * i + 2] = (uint8_t)(p[0] >> sh); }
+                else o[3 * i] = o[3 * i + 1] = o[3 * i + 2] = (uint8_t)(p[0] >> sh);
+            }
+        }
+        out = o;
+    }
+    *w_out = w; *h_out = h; *channels_out = rch; *depth_out = rdepth; *data_out = out;
+    return NALO_IO_OK;
+}
+void nalo_io_free(void* p) { std::free(p); }
+
+int nalo_io_make_vignette(const void* px, int depth, int n, float* vignetteMap, float* vignetteMapInv) {
+    if (!px || (depth != 8 && depth != 16) || n <= 0 || !vignetteMap || !vignetteMapInv) return NALO_IO_ERR_ARG;
+    float maxV = 0;                                                                              // Undistort.cpp:137-142 / 156-161
+    for (int i = 0; i < n; ++i) { const float v = depth == 16 ? (float)((const uint16_t*)px)[i] : (float)((const uint8_t*)px)[i]; if (v > maxV) maxV = v; }
+    for (int i = 0; i < n; ++i) { const float v = depth == 16 ? (float)((const uint16_t*)px)[i] : (float)((const uint8_t*)px)[i]; vignetteMap[i] = v / maxV; }
+    for (int i = 0; i < n; ++i) vignetteMapInv[i] = 1.0f / vignetteMap[i];                       // :176-177
+    return NALO_IO_OK;
+}
+
+int nalo_io_resize_nearest_u8(const uint8_t* src, int wOrg, int hOrg, int channels, uint8_t* dst, int w, int h) {
+    if (!src || !dst || wOrg <= 0 || hOrg <= 0 || w <= 0 || h <= 0 || channels <= 0) return NALO_IO_ERR_ARG;
+    const double ifx = 1.0 / ((double)w / wOrg), ify = 1.0 / ((double)h / hOrg);
+    for (int y = 0; y < h; ++y) {
+        const int sy = std::min((int)std::floor(y * ify), hOrg - 1);
+        for (int x = 0; x < w; ++x) {
+            const int sx = std::min((int)std::floor(x * ifx), wOrg - 1);
+            for (int k = 0; k < channels; ++k) dst[((size_t)y * w + x) * channels + k] = src[((size_t)sy * wOrg + sx) * channels + k];
+        }
+    }
     return NALO_IO_OK;
 }
 

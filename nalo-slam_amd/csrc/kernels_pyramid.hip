@@ -106,6 +106,69 @@ __global__ __launch_bounds__(256) void pyr_grad_all_kernel(PyrLevels P, const fl
     P.absg[l][idx] = ab;
 }
 
+// Raw-frame ingest: PhotometricUndistorter::processFrame (reference src/util/Undistort.cpp:214-251) + the remap loop of Undistort::undistort (:435-530) +
+// the INTER_NEAREST resizes of Undistort::undistort_mask (:385-433; IOWrapper/OpenCV/ImageRW_OpenCV.cpp:55-85) in ONE pass over the rectified image:
+// the 8- or 16-bit sensor frame crosses PCIe as it is (1-2 B/px instead of the 4 B/px float image the host path uploads) and
+//   data[p] = G[raw[p]] * vignetteMapInv[p]      (photometricCalibration 2; 1: no vignette; disabled: factor * raw[p])
+// is evaluated at the (up to) four taps of every output pixel instead of being materialised: out = bilinear(data, remapX, remapY), 0 where remapX < 0
+// (passthrough: out = data). Each product and the weighted sum are rounded as the reference's float code does (this file: -ffp-contract=off).
+struct IngestParams {
+    const void* raw; int bpp;                       // 1 or 2 bytes per pixel
+    int wOrg, hOrg, w, h;
+    const float *G, *vinv, *remapX, *remapY;        // G [GDepth]; vinv [wOrg*hOrg] or null; remap [w*h] or null (passthrough)
+    int photometric;                                // 0: data = factor * raw, 1: G only, 2: G * vignetteMapInv
+    float factor;
+    const uint8_t *mask_org, *bgr_org;              // [wOrg*hOrg], [wOrg*hOrg*3] or null
+    float* out_I; float* out_mask; uint8_t* out_bgr;
+    double ifx, ify;                                // cv::resize: 1 / ((double)w / wOrg)
+};
+__device__ __forceinline__ float ingest_tap(const IngestParams& P, int p) {
+    const unsigned v = P.bpp == 1 ? (unsigned)reinterpret_cast<const uint8_t*>(P.raw)[p] : (unsigned)reinterpret_cast<const uint16_t*>(P.raw)[p];
+    if (P.photometric == 0) return P.factor * (float)v;
+    float d = P.G[v];
+    if (P.photometric == 2) d *= P.vinv[p];
+    return d;
+}
+__global__ __launch_bounds__(256) void ingest_kernel(IngestParams P) {
+    const int n = P.w * P.h;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        float o;
+        if (!P.remapX) o = ingest_tap(P, idx);
+        else {
+            float xx = P.remapX[idx], yy = P.remapY[idx];
+            if (xx < 0) o = 0.f;
+            else {
+                const int xxi = (int)xx, yyi = (int)yy;
+                xx -= xxi; yy -= yyi;
+                const float xxyy = xx * yy;
+                const int p = xxi + yyi * P.wOrg;
+                o = xxyy * ingest_tap(P, p + 1 + P.wOrg) + (yy - xxyy) * ingest_tap(P, p + P.wOrg) + (xx - xxyy) * ingest_tap(P, p + 1) + (1 - xx - yy + xxyy) * ingest_tap(P, p);
+            }
+        }
+        P.out_I[idx] = o;
+        if (P.mask_org || P.bgr_org) {                     // cv::resize(.., INTER_NEAREST): sx = min(floor(x * ifx), wOrg - 1)
+            const int y = idx / P.w, x = idx - y * P.w;
+            int sx = (int)floor(x * P.ifx), sy = (int)floor(y * P.ify);
+            sx = sx < P.wOrg - 1 ? sx : P.wOrg - 1; sy = sy < P.hOrg - 1 ? sy : P.hOrg - 1;
+            const int sp = sx + sy * P.wOrg;
+            if (P.mask_org) P.out_mask[idx] = (float)P.mask_org[sp] * 1.0f;
+            if (P.bgr_org) { P.out_bgr[3 * idx] = P.bgr_org[3 * sp]; P.out_bgr[3 * idx + 1] = P.bgr_org[3 * sp + 1]; P.out_bgr[3 * idx + 2] = P.bgr_org[3 * sp + 2]; }
+        }
+    }
+}
+int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float* remapX, const float* remapY, int photometric,
+                  float factor, const uint8_t* mask_org, const uint8_t* bgr_org, float* out_I, float* out_mask, uint8_t* out_bgr) {
+    IngestParams P;
+    P.raw = raw; P.bpp = bpp; P.wOrg = wOrg; P.hOrg = hOrg; P.w = c->w; P.h = c->h; P.G = G; P.vinv = vinv; P.remapX = remapX; P.remapY = remapY; P.photometric = photometric;
+    P.factor = factor; P.mask_org = mask_org; P.bgr_org = bgr_org; P.out_I = out_I; P.out_mask = out_mask; P.out_bgr = out_bgr;
+    P.ifx = 1.0 / ((double)c->w / wOrg); P.ify = 1.0 / ((double)c->h / hOrg);
+    const int n = c->w * c->h;
+    ProfScope ps(c, "ingest");
+    ingest_kernel<<<std::min((n + 255) / 256, 4096), 256, 0, st>>>(P);
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+
 int pyramid_build(nalo_ctx* c, FrameSlot& s, const float* gammaB_dev) {
     ProfScope ps(c, "pyramid");
     PyrLevels P;

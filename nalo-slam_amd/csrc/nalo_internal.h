@@ -67,6 +67,9 @@ struct nalo_ctx {
     hipStream_t stream = nullptr, side = nullptr, copy = nullptr;   // copy: H2D frame uploads of nalo_frame_upload_async (overlap the kernels of `stream`)
     hipEvent_t ev_main = nullptr;            // main-stream marker the copy stream waits on before it overwrites a slot that has been used
     float* gamma_dev = nullptr;              // 256-entry gamma table of the asynchronous upload path
+    // raw-frame ingest (nalo_undist_set / nalo_frame_upload_raw): photometric + geometric undistortion tables, raw staging
+    int und_wOrg = 0, und_hOrg = 0, und_photometric = 0, und_GDepth = 0; bool und_set = false, und_remap = false, und_vig = false;
+    nalo::DevBuf<float> und_G, und_vinv, und_rx, und_ry; nalo::DevBuf<uint8_t> und_raw, und_mask, und_bgr;
     std::string err;
     std::vector<nalo::FrameSlot> slots;
 
@@ -181,6 +184,8 @@ int init_calc_launch(nalo_ctx* c, const float4* colorRef, const float4* colorNew
 int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float* inc, float* idepth_new);
 // kernels_pyramid.hip
 int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
+int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float* remapX, const float* remapY, int photometric,
+                  float factor, const uint8_t* mask_org, const uint8_t* bgr_org, float* out_I, float* out_mask, uint8_t* out_bgr);
 // kernels_tracker.hip
 int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const float* dId, const float* dHdi);
 int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], const float t[3], const float Ki[9],

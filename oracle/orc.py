@@ -703,3 +703,28 @@ class Initializer:
         T, aff, st = np.zeros(12), np.zeros(2), np.zeros(4, np.int32)
         self.L.orc_initf_get_state(self.h_, dp(T), dp(aff), ip(st))
         return dict(thisToNext=T.reshape(3, 4), aff=aff, snapped=bool(st[0]), frameID=int(st[1]), snappedAt=int(st[2]), n_evals=int(st[3]))
+
+
+# ------------------------------------------------------------------ image side of the dataset reader (orc_undist.c)
+def undistort(raw, G, vinv, photometric, factor, remapX, remapY, w, h, kind="f32"):
+    """Undistort::undistort<T>: raw [hOrg, wOrg] uint8 / uint16 -> float32 [h, w]"""
+    raw = np.ascontiguousarray(raw)
+    hOrg, wOrg = raw.shape
+    out = np.zeros((h, w), np.float32)
+    f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    G, vinv, remapX, remapY = f(G), f(vinv), f(remapX), f(remapY)
+    L = lib(kind)
+    L.orc_undistort.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_int, C.c_float, c_fp, c_fp, C.c_int, C.c_int, c_fp]
+    L.orc_undistort(raw.ctypes.data_as(C.c_void_p), raw.dtype.itemsize, wOrg, hOrg, fp(G), fp(vinv), int(photometric), float(factor), fp(remapX), fp(remapY), w, h, fp(out))
+    return out
+
+
+def resize_nearest_u8(src, w, h, kind="f32"):
+    src = np.ascontiguousarray(src, np.uint8)
+    hOrg, wOrg = src.shape[:2]
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.zeros((h, w) if src.ndim == 2 else (h, w, ch), np.uint8)
+    L = lib(kind)
+    L.orc_resize_nearest_u8.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, c_u8p, C.c_int, C.c_int]
+    L.orc_resize_nearest_u8(u8p(src), wOrg, hOrg, ch, u8p(dst), w, h)
+    return dst

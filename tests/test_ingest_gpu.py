@@ -1,0 +1,100 @@
+"""Raw-frame ingest on the device: nalo_undist_set + nalo_frame_upload_raw = PhotometricUndistorter::processFrame
+(util/Undistort.cpp:214-251) + the remap of Undistort::undistort (:435-530) + the INTER_NEAREST mask / colour resizes of undistort_mask
+(:385-433) fused in front of makeImages, against the CPU oracle (orc_undist.c) followed by the oracle's makeImages. Every product and the bilinear sum
+are fp32 operations in the reference's order (the kernel is built without FMA contraction): level-0 irradiance and the whole pyramid are BIT-EXACT."""
+import numpy as np
+import pytest
+
+import orc
+from nalo_slam_amd import binding
+
+pytestmark = pytest.mark.gpu
+
+
+def radial_remap(w, h, wo, ho, k1=-0.12):
+    """a plausible rectification table: radial distortion around the image centre; pixels whose four taps do not fit the original image are -1"""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    nx, ny = (x - w / 2) / (0.6 * w), (y - h / 2) / (0.6 * w)
+    r2 = nx * nx + ny * ny
+    rx = ((nx * (1 + k1 * r2)) * 0.6 * w + wo / 2).astype(np.float32)
+    ry = ((ny * (1 + k1 * r2)) * 0.6 * w + ho / 2).astype(np.float32)
+    bad = ~((rx >= 0) & (ry >= 0) & (rx.astype(int) + 1 < wo) & (ry.astype(int) + 1 < ho))
+    rx[bad] = -1; ry[bad] = -1
+    rx[0, :7] = -1; ry[0, :7] = -1                       # a few explicit outside entries
+    return rx, ry
+
+
+@pytest.mark.parametrize("dtype,photometric,remap", [(np.uint8, 2, True), (np.uint8, 1, True), (np.uint8, 0, True), (np.uint16, 2, True), (np.uint8, 2, False)],
+                         ids=["u8_full", "u8_response_only", "u8_none", "u16_full", "passthrough"])
+def test_raw_ingest_bit_exact(dtype, photometric, remap):
+    rng = np.random.RandomState(11)
+    w, h = 640, 480
+    wo, ho = (672, 512) if remap else (w, h)
+    depth = 256 if dtype == np.uint8 else 65536
+    raw = rng.randint(0, depth, (ho, wo)).astype(dtype)
+    G = np.cumsum(rng.rand(depth) + 0.05).astype(np.float32)
+    G = (255.0 * (G - G[0]) / (G[-1] - G[0])).astype(np.float32)
+    yy, xx = np.mgrid[0:ho, 0:wo]
+    vmap = (1.0 - 0.4 * (((xx - wo / 2) / wo) ** 2 + ((yy - ho / 2) / ho) ** 2)).astype(np.float32)
+    vinv = (np.float32(1.0) / vmap).astype(np.float32)
+    rx, ry = radial_remap(w, h, wo, ho) if remap else (None, None)
+    K = (0.52 * w, 0.52 * w, (w - 1) / 2.0, (h - 1) / 2.0)
+    c = binding.Context(w, h, K, n_slots=2)
+    c.undist_set(wo, ho, G, vinv if photometric == 2 else None, photometric, rx, ry)
+    for exposure in (0.02, 0.0):                         # exposure <= 0 switches the photometric part off for that frame (factor * raw)
+        c.frame_upload_raw(0, raw, exposure=exposure, factor=0.5)
+        ph = photometric if exposure > 0 else 0
+        img = orc.undistort(raw, G, vinv if ph == 2 else None, ph, 0.5, rx, ry, w, h)
+        dI_o, ab_o = orc.make_images(img, c.levels)
+        L = orc.lib()
+        for lvl in range(c.levels):
+            o0, o1 = L.orc_pyr_offset(w, h, lvl), L.orc_pyr_offset(w, h, lvl + 1)
+            dI_g, ab_g = c.frame_download(0, lvl)
+            assert np.array_equal(dI_g, dI_o[o0:o1]), (exposure, lvl)
+            assert np.array_equal(ab_g, ab_o[o0:o1])
+    if remap:
+        assert (img == 0).sum() >= 7 and (img != 0).mean() > 0.9
+    c.close()
+
+
+def test_ingest_rejects_bad_tables():
+    w, h = 320, 240
+    c = binding.Context(w, h, (160.0, 160.0, 159.5, 119.5), n_slots=1)
+    G = np.linspace(0, 255, 256).astype(np.float32)
+    rx = np.full((h, w), 10.0, np.float32); ry = np.full((h, w), 10.0, np.float32)
+    rx[5, 5] = 400.0                                     # taps outside a 330-wide original
+    with pytest.raises(binding.NaloError):
+        c.undist_set(330, 250, G, None, 1, rx, ry)
+    with pytest.raises(binding.NaloError):
+        c.undist_set(330, 250, G, None, 1, None, None)   # passthrough with a different size
+    with pytest.raises(binding.NaloError):
+        c.frame_upload_raw(0, np.zeros((250, 330), np.uint8))   # tables not set
+    with pytest.raises(binding.NaloError):
+        c.undist_set(330, 250, G[:100], None, 1, np.full((h, w), 3.0, np.float32), np.full((h, w), 3.0, np.float32))
+    c.close()
+
+
+def test_ingest_mask_and_colour_feed_the_dense_map():
+    """resizeMask / resizeColor on the device: a frame ingested with original-size mask + colour produces the same makeMap output as a frame uploaded with the
+    host-resized (oracle) mask and colour"""
+    rng = np.random.RandomState(2)
+    w, h, wo, ho = 640, 480, 660, 496
+    raw = rng.randint(0, 256, (ho, wo)).astype(np.uint8)
+    rx, ry = radial_remap(w, h, wo, ho, k1=-0.05)
+    mask_o = np.zeros((ho, wo), np.uint8); mask_o[300:470, 80:600] = 7; mask_o[100:200, 50:300] = 3
+    bgr_o = rng.randint(0, 256, (ho, wo, 3)).astype(np.uint8)
+    K = (0.52 * w, 0.52 * w, (w - 1) / 2.0, (h - 1) / 2.0)
+    G = np.linspace(0, 255, 256).astype(np.float32)
+    c = binding.Context(w, h, K, n_slots=2)
+    c.undist_set(wo, ho, G, None, 1, rx, ry)
+    c.frame_upload_raw(0, raw, mask_org=mask_o, bgr_org=bgr_o)
+    img = orc.undistort(raw, G, None, 1, 1.0, rx, ry, w, h)
+    c.frame_upload(1, img, mask=orc.resize_nearest_u8(mask_o, w, h).astype(np.float32), bgr=orc.resize_nearest_u8(bgr_o, w, h))
+    plane = np.array([0.0, -1.0, 0.05, 1.6], np.float32)
+    T = np.eye(4)[:3]
+    a = c.dense_make_map(0, plane, 7.0, T, cap=200000)
+    b = c.dense_make_map(1, plane, 7.0, T, cap=200000)
+    assert a["n"] == b["n"] and a["n"] > 1000
+    for k in ("u", "v", "idepth", "color", "bgr", "rect"):
+        assert np.array_equal(a[k], b[k]), k
+    c.close()

@@ -84,7 +84,7 @@ def test_track_frames_match_oracle(w, h, n_frames):
                     a, b, t = g[k][m64], ini.get(l, k)[m64], ini64.get(l, k)[m64]
                     sc = np.maximum(np.abs(t), 1e-3)
                     mine, ref = np.abs(a - t) / sc, np.abs(b - t) / sc
-                    if so["n_evals"] == s64["n_evals"]:                  # the fp64 run took the same decisions: its distance from the fp32 oracle is the floor
+                    if i == 1 and so["n_evals"] == s64["n_evals"]:       # first frame, same decisions in fp64: its distance from the fp32 oracle is the floor (later frames: chaotic, see above)
                         for q in (0.5, 0.99):
                             assert np.quantile(mine, q) < 2 * np.quantile(ref, q) + 1e-6, (i, l, k, q, np.quantile(mine, q), np.quantile(ref, q))
                     d = np.abs(a - b) / np.maximum(np.abs(b), 1e-3)

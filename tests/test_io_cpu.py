@@ -112,3 +112,134 @@ def test_pcalib_and_times(lib, tmp_path):
     (tmp_path / "times2.txt").write_text("0 1.5\n1 1.6\n")
     assert lib.nalo_io_read_times(str(tmp_path / "times2.txt").encode(), 2, 16, dp(st), fpp(ex), C.byref(ns), C.byref(ne)) == 0
     assert ns.value == 2 and ne.value == 0                                   # no exposure anywhere: exposures dropped, stamps kept
+
+
+# ------------------------------------------------------------------------------------------------ PNG / vignette / nearest resize
+def _png_bytes(arr, ctype, bitdepth, filters=(0, 1, 2, 3, 4), palette=None, idat_split=3):
+    """a PNG writer for the tests: arr [h, w] or [h, w, c] of uint8 / uint16 samples (sub-byte depths: values < 2^bitdepth), rows filtered with the given
+    filter types in rotation (all five PNG filters get exercised), the zlib stream split over several IDAT chunks"""
+    import struct, zlib
+    h, w = arr.shape[:2]
+    nch = 1 if arr.ndim == 2 else arr.shape[2]
+    if bitdepth == 16:
+        rows = [arr[y].astype(">u2").tobytes() for y in range(h)]
+    elif bitdepth == 8:
+        rows = [arr[y].astype(np.uint8).tobytes() for y in range(h)]
+    else:
+        per = 8 // bitdepth
+        rows = []
+        for y in range(h):
+            r = arr[y].astype(np.uint8)
+            pad = (-w) % per
+            r = np.r_[r, np.zeros(pad, np.uint8)].reshape(-1, per)
+            rows.append(bytes(int(sum(int(v) << ((per - 1 - k) * bitdepth) for k, v in enumerate(g))) for g in r))
+    bpp = max(1, nch * bitdepth // 8)
+    out, prev = b"", bytes(len(rows[0]))
+    for y, row in enumerate(rows):
+        ft = filters[y % len(filters)]
+        f = bytearray(len(row))
+        for i in range(len(row)):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: p = 0
+            elif ft == 1: p = a
+            elif ft == 2: p = b
+            elif ft == 3: p = (a + b) >> 1
+            else:
+                pp = a + b - c; pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            f[i] = (row[i] - p) & 255
+        out += bytes([ft]) + bytes(f)
+        prev = row
+    z = zlib.compress(out, 6)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bitdepth, ctype, 0, 0, 0))
+    if palette is not None:
+        png += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    n = max(1, len(z) // idat_split)
+    for i in range(0, len(z), n):
+        png += chunk(b"IDAT", z[i:i + n])
+    return png + chunk(b"IEND", b"")
+
+
+def _read_png(lib, path, mode):
+    w, h, ch, dep = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    data = C.c_void_p()
+    lib.nalo_io_read_png.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    rc = lib.nalo_io_read_png(str(path).encode(), mode, C.byref(w), C.byref(h), C.byref(ch), C.byref(dep), C.byref(data))
+    if rc:
+        return rc, None
+    n = w.value * h.value * ch.value
+    buf = (C.c_uint16 * n).from_address(data.value) if dep.value == 16 else (C.c_uint8 * n).from_address(data.value)
+    a = np.array(buf).reshape((h.value, w.value) if ch.value == 1 else (h.value, w.value, ch.value))
+    lib.nalo_io_free.argtypes = [C.c_void_p]
+    lib.nalo_io_free(data)
+    return 0, a
+
+
+def test_png_reader_all_sample_formats(lib, tmp_path):
+    rng = np.random.RandomState(3)
+    w, h = 37, 23                                        # odd sizes: sub-byte rows end in padding bits
+    g8 = rng.randint(0, 256, (h, w)).astype(np.uint8)
+    g16 = rng.randint(0, 65536, (h, w)).astype(np.uint16)
+    rgb = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    rgba = rng.randint(0, 256, (h, w, 4)).astype(np.uint8)
+    ga = rng.randint(0, 256, (h, w, 2)).astype(np.uint8)
+    pal = rng.randint(0, 256, (16, 3)).astype(np.uint8)
+    idx4 = rng.randint(0, 16, (h, w)).astype(np.uint8)
+    g2 = rng.randint(0, 4, (h, w)).astype(np.uint8)
+    files = dict(g8=_png_bytes(g8, 0, 8), g16=_png_bytes(g16, 0, 16), rgb=_png_bytes(rgb, 2, 8), rgba=_png_bytes(rgba, 6, 8), ga=_png_bytes(ga, 4, 8),
+                 pal=_png_bytes(idx4, 3, 4, palette=pal), g2=_png_bytes(g2, 0, 2))
+    for k, b in files.items():
+        (tmp_path / (k + ".png")).write_bytes(b)
+    GRAY, BGR, UNCH = 0, 1, 2
+    gray_w = lambda c: ((9798 * c[..., 0].astype(np.int64) + 19235 * c[..., 1].astype(np.int64) + 3735 * c[..., 2].astype(np.int64) + 16384) >> 15).astype(np.uint8)
+    # 8-bit grey: identical in every mode that returns grey
+    assert np.array_equal(_read_png(lib, tmp_path / "g8.png", GRAY)[1], g8)
+    assert np.array_equal(_read_png(lib, tmp_path / "g8.png", UNCH)[1], g8)
+    assert np.array_equal(_read_png(lib, tmp_path / "g8.png", BGR)[1], np.repeat(g8[..., None], 3, 2))
+    # 16-bit grey: unchanged keeps the samples (vignette path), greyscale keeps the high byte
+    assert np.array_equal(_read_png(lib, tmp_path / "g16.png", UNCH)[1], g16)
+    assert np.array_equal(_read_png(lib, tmp_path / "g16.png", GRAY)[1], (g16 >> 8).astype(np.uint8))
+    # colour: B,G,R order, integer grey weights, alpha dropped
+    assert np.array_equal(_read_png(lib, tmp_path / "rgb.png", BGR)[1], rgb[..., ::-1])
+    assert np.array_equal(_read_png(lib, tmp_path / "rgb.png", GRAY)[1], gray_w(rgb))
+    assert np.array_equal(_read_png(lib, tmp_path / "rgba.png", BGR)[1], rgba[..., 2::-1])
+    assert np.array_equal(_read_png(lib, tmp_path / "ga.png", GRAY)[1], ga[..., 0])
+    # palette and sub-byte grey are expanded
+    assert np.array_equal(_read_png(lib, tmp_path / "pal.png", BGR)[1], pal[idx4][..., ::-1])
+    assert np.array_equal(_read_png(lib, tmp_path / "g2.png", GRAY)[1], (g2 * 85).astype(np.uint8))
+    # malformed input is refused, never crashes
+    (tmp_path / "bad.png").write_bytes(files["g8"][:60])
+    assert _read_png(lib, tmp_path / "bad.png", GRAY)[0] == -3
+    (tmp_path / "nopng.png").write_bytes(b"P5 2 2 255 abcd")
+    assert _read_png(lib, tmp_path / "nopng.png", GRAY)[0] == -3
+    assert _read_png(lib, tmp_path / "missing.png", GRAY)[0] == -2
+
+
+def test_vignette_and_nearest_resize(lib):
+    import orc
+    rng = np.random.RandomState(5)
+    v16 = rng.randint(20000, 65536, 5000).astype(np.uint16)
+    vm, vi = np.zeros(5000, np.float32), np.zeros(5000, np.float32)
+    lib.nalo_io_make_vignette.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    assert lib.nalo_io_make_vignette(v16.ctypes.data_as(C.c_void_p), 16, 5000, fpp(vm), fpp(vi)) == 0
+    ref = v16.astype(np.float32) / np.float32(v16.max())
+    assert np.array_equal(vm, ref) and np.array_equal(vi, np.float32(1.0) / ref) and vm.max() == 1.0
+    v8 = rng.randint(60, 256, 300).astype(np.uint8)
+    assert lib.nalo_io_make_vignette(v8.ctypes.data_as(C.c_void_p), 8, 300, fpp(vm), fpp(vi)) == 0
+    assert np.array_equal(vm[:300], v8.astype(np.float32) / np.float32(v8.max()))
+    # nearest resize: the KITTI case (1241x376 -> 1224x368) and an upscale, 1 and 3 channels, against the oracle's restatement of cv::resize
+    lib.nalo_io_resize_nearest_u8.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int]
+    for (wo, ho, w, h) in [(1241, 376, 1224, 368), (320, 240, 640, 480), (100, 37, 33, 19)]:
+        for ch in (1, 3):
+            src = rng.randint(0, 256, (ho, wo) if ch == 1 else (ho, wo, ch)).astype(np.uint8)
+            dst = np.zeros((h, w) if ch == 1 else (h, w, ch), np.uint8)
+            assert lib.nalo_io_resize_nearest_u8(src.ctypes.data_as(C.POINTER(C.c_ubyte)), wo, ho, ch, dst.ctypes.data_as(C.POINTER(C.c_ubyte)), w, h) == 0
+            assert np.array_equal(dst, orc.resize_nearest_u8(src, w, h))
+            # closed form: source index = floor(x * wo / w) clipped
+            sx = np.minimum(np.floor(np.arange(w) * (1.0 / (w / wo))).astype(int), wo - 1); sy = np.minimum(np.floor(np.arange(h) * (1.0 / (h / ho))).astype(int), ho - 1)
+            assert np.array_equal(dst, src[sy][:, sx])

@@ -51,8 +51,8 @@ def check(rec, drv, tol_state, tol_clean, tol_flipped):
     print("  kf %2d W=%d: gpu-vs-fp32-oracle %.1e (raw %.1e), fp64-vs-fp32 oracle (floor) %.1e, flips gpu %d / fp64 %d, residuals %d" % (rec["k"], len(fo), worst, raw, floor, flips, rec["state_mismatch"][2], rec["n_res"]))
     assert worst < tol, "keyframe %d: pose delta %.2e, fp64-oracle floor %.2e (flips %d, so far %d)" % (rec["k"], worst, floor, flips, tol_state["flips"])
     for a, b in zip(fo, fg):
-        # (closed loop: the raw states carry the gauge drift the aligned comparison above removes)
-        assert np.abs(a.state - b.state).max() < (1e-4 if drv.teacher else 1e-3) * max(1.0, np.abs(a.state).max()) + 1e-7
+        if drv.teacher:                  # closed loop: each back-end's state is relative to ITS OWN linearisation point (evalPT), not comparable
+            assert np.abs(a.state - b.state).max() < 1e-4 * max(1.0, np.abs(a.state).max()) + 1e-7
         assert abs(a.th - b.th) < 1e-3 * a.th
     assert rel_err(rec["calib"][1], rec["calib"][0]) < 1e-6
     ido, idg = rec["idepth"][:2]
