@@ -128,6 +128,14 @@ int nalo_trk_set_ref(nalo_ctx* ctx, int slot_ref, int n, const float* Ku, const 
 int nalo_trk_set_pc(nalo_ctx* ctx, int slot_ref, int lvl, int n, const float* u, const float* v,
                     const float* idepth, const float* color);
 int nalo_trk_get_pc(nalo_ctx* ctx, int lvl, int* n, float* u, float* v, float* idepth, float* color);
+/* dense=1: the plane-sampled points makeCoarseDepthL0 appends to the LEVEL-0 cloud after step 5 (CoarseTracker.cpp:600-655), one call per mask cluster, on
+ * the device (no round trip of the cloud): dir / dis_plane = the cluster's fitted plane (fitPlane, a PCL RANSAC on the caller's side), refMaskColor =
+ * clusters[i][0][3], rect = {minx, maxx, miny, maxy} of the cluster's pixels. Uses the mask and I of the tracking reference's slot (frameHessians.back() is
+ * lastRef). Appends, in the reference's x-outer / y-inner order, every (x % 5 == 0, y % 5 == 0) pixel of [minx,maxx) x [miny,maxy) whose mask equals
+ * refMaskColor with new_idepth = dir^T Ki (x,y,1) / -dis_plane and colour I_ref(x,y) — INCLUDING the reference's off-by-one (the k-th point is stored at
+ * pc_n + 1 + k while pc_n grows by one per point, :646-650): slot [old pc_n] is left unwritten by the reference (defined as zeros here) and the last
+ * sampled point stays outside the count. Nothing is appended when the box touches the border, refMaskColor is 0 (:621-630). *n_added = growth of pc_n[0]. */
+int nalo_trk_append_plane_points(nalo_ctx* ctx, const float dir[3], float dis_plane, int refMaskColor, const int rect[4], int* n_added);
 int nalo_trk_get_depth(nalo_ctx* ctx, int lvl, float* idepth, float* weight_sums);
 
 /* a3+a4 fused  CoarseTracker::calcRes (CoarseTracker.cpp:891-1049) + calcGSSSE (:828-885), call sites
@@ -206,6 +214,18 @@ int nalo_ba_optimize(nalo_ctx* ctx, int mnumOptIts, int never_break, double* rms
  * calcLEnergyPt runs over linearised residuals, which never exist while optimize() runs (they live only inside nalo_ba_marginalize_points).
  * M = delta . (2 bM + HM delta) on the host in fp64. *rejected (nalo_ba_optimize_stats) = steps the last nalo_ba_optimize restored from the backup. */
 int nalo_ba_calc_l_energy(nalo_ctx* ctx, double* E);
+/* planeOpt=1, call sites FullSystem.cpp:1440-1441, without Ceres:
+ * nalo_ba_plane_scale_fix    FullSystem::planeOptimize's active part (FullSystem/PlaneOptimize.cpp:183-301) for the newest keyframe: camToWorld =
+ *     trackingRef.camToWorld * [R | localscale * t](camToTrackingRef), its own points' idepth /= localscale (idepth_zero alike), setEvalPT at the new pose, adjoints,
+ *     precalc. localscale = getlocalgh() / groundP[3] is the caller's (ground plane from its RANSAC); the caller skips the call when scaleFixed / no ground.
+ * nalo_ba_sw_gray_optimize   FullSystem::SWGrayOptimize_J (:307-454). The reference's Ceres cost functor multiplies every Jacobian by an image gradient it never
+ *     reads (a shadowed variable, PlaneOptimize.h:378-381): the gradient is identically zero, Ceres returns its initial point. The call therefore
+ *     (a) evaluates the Huber(100) cost 1/2 sum rho(r^2) over all (point, target != host) centre-pixel residuals with 1e-4 <= idepth <= 1e3 on the device
+ *     (*cost, *n_residual_blocks: what Ceres' summary reports as initial = final cost), and (b) applies the post-solve state changes with the unchanged
+ *     parameters: newest frame PRE_worldToCam = [exp(log R) | t] and re-linearised there, idepth_zero = idepth for the points of frames 0 .. W-3, adjoints and
+ *     precalc values recomputed. Read the result with nalo_ba_get_frames / nalo_ba_get_points. */
+int nalo_ba_plane_scale_fix(nalo_ctx* ctx, double localscale, const double camToTrackingRef[12], const double trackingRef_camToWorld[12]);
+int nalo_ba_sw_gray_optimize(nalo_ctx* ctx, double* cost, int* n_residual_blocks);
 int nalo_ba_calc_m_energy(nalo_ctx* ctx, double* E);
 int nalo_ba_optimize_stats(nalo_ctx* ctx, int* iterations, int* rejected);
 /* a13 + a7<2> + a9  flagPointsForRemoval's relinearise/fixLinearizationF (FullSystem.cpp:975-990,
@@ -233,6 +253,8 @@ int nalo_ba_get_frames(nalo_ctx* ctx, nalo_frame_state* frames /* W */, double* 
  * BEFORE nalo_ba_marginalize_points (which re-accumulates); after an explicit nalo_ba_linearize the accumulation of that linearisation is run on demand. */
 int nalo_ba_get_points(nalo_ctx* ctx, float* idepth, float* step, float* HdiF, float* bdSumF, float* Hdd_accAF,
                        float* bd_accAF, float* Hcd_accAF /* P x 4 */, float* maxRelBaseline);
+/* PointHessian::idepth_zero of every point (the linearisation point SWGrayOptimize_J / loadSateBackup / doStepFromBackup move) */
+int nalo_ba_get_idepth_zero(nalo_ctx* ctx, float* idepth_zero);
 /* per residual slot [p*W + t]: state (-1 none, 0 IN, 1 OOB, 2 OUTLIER), active flag, JpJdF (8), state_NewEnergyWithOutlier,
  * centerProjectedTo (3) */
 int nalo_ba_get_residuals(nalo_ctx* ctx, int8_t* state, uint8_t* active, float* JpJdF, float* energy_new,

@@ -27,11 +27,11 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 EXPORTS = [
     "nalo_create", "nalo_destroy", "nalo_last_error", "nalo_levels", "nalo_sync", "nalo_stream",
     "nalo_frame_upload", "nalo_frame_upload_raw", "nalo_undist_set", "nalo_frame_upload_async", "nalo_frame_wait", "nalo_host_alloc", "nalo_host_free", "nalo_frame_rebuild", "nalo_frame_download",
-    "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
+    "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_append_plane_points", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
-    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_ba_get_frames", "nalo_ba_get_points",
-    "nalo_ba_get_residuals", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
+    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_plane_scale_fix", "nalo_ba_sw_gray_optimize", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_ba_get_frames", "nalo_ba_get_points",
+    "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get",
@@ -114,9 +114,13 @@ def load():
     L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
                                             c_u8p, c_fp, c_fp, c_fp, c_fp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.nalo_init_do_step.argtypes = [vp, C.c_int, c_u8p, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp]
+    L.nalo_trk_append_plane_points.argtypes = [vp, c_fp, C.c_float, C.c_int, c_ip, c_ip]
     L.nalo_undist_set.argtypes = [vp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp]
     L.nalo_frame_upload_raw.argtypes = [vp, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, c_u8p, c_u8p, c_fp]
+    L.nalo_ba_get_idepth_zero.argtypes = [vp, c_fp]
     L.nalo_ba_calc_l_energy.argtypes = [vp, c_dp]
+    L.nalo_ba_plane_scale_fix.argtypes = [vp, C.c_double, c_dp, c_dp]
+    L.nalo_ba_sw_gray_optimize.argtypes = [vp, c_dp, c_ip]
     L.nalo_ba_calc_m_energy.argtypes = [vp, c_dp]
     L.nalo_ba_optimize_stats.argtypes = [vp, c_ip, c_ip]
     L.nalo_get_settings.argtypes = [vp, C.POINTER(Settings)]
@@ -482,6 +486,11 @@ class Context:
         k = min(int(n[0]), cap)
         return dict(n=int(n[0]), accept=int(acc[0]), rect=rect, u=u[:k], v=v[:k], idepth=idp[:k], color=col[:k], bgr=bgr[:k])
 
+    def trk_append_plane_points(self, dirv, dis, ref_color, rect):
+        n = np.zeros(1, np.int32)
+        self._ck(self.L.nalo_trk_append_plane_points(self.h_, _f(np.ascontiguousarray(dirv, np.float32)), C.c_float(dis), int(ref_color), _i(np.ascontiguousarray(rect, np.int32)), _i(n)))
+        return int(n[0])
+
     def undist_set(self, wOrg, hOrg, G=None, vinv=None, photometric=0, remapX=None, remapY=None):
         f = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
         G, vinv, remapX, remapY = f(G), f(vinv), f(remapX), f(remapY)
@@ -506,6 +515,20 @@ class Context:
         if min_opt_iterations is not None: st.minOptIterations = int(min_opt_iterations)
         self._ck(self.L.nalo_set_settings(self.h_, C.byref(st)))
         return st
+
+    def ba_plane_scale_fix(self, localscale, camToTrackingRef, trackingRef_camToWorld):
+        a = np.ascontiguousarray(camToTrackingRef, np.float64).reshape(-1); b = np.ascontiguousarray(trackingRef_camToWorld, np.float64).reshape(-1)
+        self._ck(self.L.nalo_ba_plane_scale_fix(self.h_, float(localscale), _d(a), _d(b)))
+
+    def ba_sw_gray_optimize(self):
+        cost, n = np.zeros(1), np.zeros(1, np.int32)
+        self._ck(self.L.nalo_ba_sw_gray_optimize(self.h_, _d(cost), _i(n)))
+        return float(cost[0]), int(n[0])
+
+    def ba_get_idepth_zero(self, P):
+        o = np.zeros(P, np.float32)
+        self._ck(self.L.nalo_ba_get_idepth_zero(self.h_, _f(o)))
+        return o
 
     def ba_calc_l_energy(self):
         e = np.zeros(1)

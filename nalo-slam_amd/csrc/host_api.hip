@@ -272,6 +272,32 @@ int nalo_trk_set_pc(nalo_ctx* c, int slot_ref, int lvl, int n, const float* u, c
     return NALO_OK;
 }
 
+// dense=1 glue: append the plane-sampled points of one mask cluster to the level-0 cloud on the device (CoarseTracker.cpp:628-655)
+int nalo_trk_append_plane_points(nalo_ctx* c, const float dir[3], float dis_plane, int refMaskColor, const int rect[4], int* n_added) {
+    if (!c || !dir || !rect) return fail(c, NALO_ERR_ARG, "nalo_trk_append_plane_points: bad argument");
+    if (c->slot_ref < 0 || !c->slots[c->slot_ref].valid || !c->pc_u[0].p) return fail(c, NALO_ERR_STATE, "nalo_trk_append_plane_points: no tracking reference");
+    const FrameSlot& s = c->slots[c->slot_ref];
+    if (!s.mask) return fail(c, NALO_ERR_STATE, "nalo_trk_append_plane_points: the reference frame was uploaded without a mask");
+    const int minx = rect[0], maxx = rect[1], miny = rect[2], maxy = rect[3];
+    // `if(maxx>w[0]-1||minx<1||maxy>h[0]-1||miny<1) continue;` and `if (refMaskColor==0) continue;` (:621-630): nothing is appended
+    if (n_added) *n_added = 0;
+    if (maxx > c->w - 1 || minx < 1 || maxy > c->h - 1 || miny < 1 || refMaskColor == 0 || dis_plane == 0.f) return NALO_OK;
+    NALO_HIP(c, hipSetDevice(c->device));
+    const int x0 = ((minx + 4) / 5) * 5, y0 = ((miny + 4) / 5) * 5;
+    const int nx = x0 < maxx ? (maxx - 1 - x0) / 5 + 1 : 0, ny = y0 < maxy ? (maxy - 1 - y0) / 5 + 1 : 0;
+    const int n0 = c->pc_n[0];
+    if ((size_t)n0 + 2 + (size_t)nx * ny > c->pc_u[0].cap) return fail(c, NALO_ERR_STATE, "nalo_trk_append_plane_points: the level-0 cloud would outgrow its w*h buffer");
+    if (nx == 0 || ny == 0) return NALO_OK;
+    NALO_HIP(c, c->scan_tmp.reserve(64));
+    int rc = trk_append_plane_launch(c, s.mask, s.dI[0], dir, dis_plane, (float)refMaskColor, x0, nx, y0, ny, n0, c->scan_tmp.p); if (rc) return rc;
+    int added = 0;
+    NALO_HIP(c, hipMemcpyAsync(&added, c->scan_tmp.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    c->pc_n[0] = n0 + added;
+    if (n_added) *n_added = added;
+    return NALO_OK;
+}
+
 int nalo_trk_get_pc(nalo_ctx* c, int lvl, int* n, float* u, float* v, float* idepth, float* color) {
     if (!c || lvl < 0 || lvl >= c->levels || !n) return fail(c, NALO_ERR_ARG, "nalo_trk_get_pc: bad argument");
     *n = c->pc_n[lvl];

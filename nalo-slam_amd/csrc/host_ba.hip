@@ -25,6 +25,8 @@ void ba_launch_set_th(hipStream_t s, float* dst, const float* th, int W);
 void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int step);
 void ba_launch_lenergy(hipStream_t s, const BADev& B, double* partial);
 void ba_launch_load_backup(hipStream_t s, const BADev& B);
+void ba_launch_swgray(hipStream_t s, const BADev& B, const double* Rt, double* partial);
+void ba_launch_set_idepth(hipStream_t s, const BADev& B, int mode, int host_sel, double scale);
 
 struct HostFrame {
     int slot = 0, frameID = 0;
@@ -1100,6 +1102,70 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
     return optimize_epilogue(c, rmse);
 }
 
+// the newest frame takes a new pose as its linearisation point: setEvalPT(PRE_worldToCam, {0.., a, b}) + setAdjointsF + the precalc values
+// (PlaneOptimize.cpp:275-289, 421-436; the same steps as the end of FullSystem::optimize, FullSystemOptimize.cpp:550-557)
+static int relinearize_newest(nalo_ctx* c, const SE3& worldToCam) {
+    BAWindow& w = *c->ba;
+    HostFrame& nf = w.frames[w.W - 1];
+    const double nsz[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
+    nf.evalPT = worldToCam;
+    frame_set_state(nf, nsz); frame_set_state_zero(nf, nsz);
+    w.proj_valid = false;
+    int rc = set_adjoints(c); if (rc) return rc;
+    rc = set_precalc(c); if (rc) return rc;
+    w.have_lin = false; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
+    return NALO_OK;
+}
+
+int nalo_ba_plane_scale_fix(nalo_ctx* c, double localscale, const double camToTrackingRef[12], const double trackingRef_camToWorld[12]) {
+    NALO_BA_READY("nalo_ba_plane_scale_fix")
+    if (!camToTrackingRef || !trackingRef_camToWorld || !(localscale > 0) || !std::isfinite(localscale)) return fail(c, NALO_ERR_ARG, "nalo_ba_plane_scale_fix: bad argument");
+    SE3 cam2ref = SE3::from(camToTrackingRef);                                // :259-261
+    cam2ref.m[3] *= localscale; cam2ref.m[7] *= localscale; cam2ref.m[11] *= localscale;
+    const SE3 camToWorld = SE3::from(trackingRef_camToWorld) * cam2ref;       // :267
+    ba_launch_set_idepth(c->stream, w.dev, 1, w.W - 1, localscale);           // :270-275: the newest frame's own points
+    NALO_HIP(c, hipGetLastError());
+    return relinearize_newest(c, camToWorld.inverse());
+}
+
+int nalo_ba_sw_gray_optimize(nalo_ctx* c, double* cost, int* n_residual_blocks) {
+    NALO_BA_READY("nalo_ba_sw_gray_optimize")
+    const int W = w.W;
+    // parameter blocks: per frame {translation, so3 log} of camToWorld.inverse() (:321-331); the functor rebuilds T = [exp(omega) | t] (PlaneOptimize.h:350-360)
+    std::vector<SE3> T(W);
+    for (int i = 0; i < W; ++i) {
+        double xi[6]; se3_log(w.frames[i].PRE_worldToCam, xi);
+        const double om[6] = {0, 0, 0, xi[3], xi[4], xi[5]};
+        T[i] = se3_exp(om);
+        T[i].m[3] = w.frames[i].PRE_worldToCam.t(0); T[i].m[7] = w.frames[i].PRE_worldToCam.t(1); T[i].m[11] = w.frames[i].PRE_worldToCam.t(2);
+    }
+    std::vector<double> Rt((size_t)W * W * 12, 0.0);
+    for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
+        const SE3 Tij = T[t] * T[h].inverse();
+        double* o = &Rt[(size_t)(h * W + t) * 12];
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[i * 3 + j] = Tij.R(i, j); o[9 + i] = Tij.t(i); }
+    }
+    const size_t npart = (size_t)w.nblocks * W * 2;
+    NALO_HIP(c, w.noapply_E.reserve(npart + Rt.size()));
+    double* dRt = w.noapply_E.p + npart;
+    NALO_HIP(c, hipMemcpyAsync(dRt, Rt.data(), Rt.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    ba_launch_swgray(c->stream, w.dev, dRt, w.noapply_E.p);
+    std::vector<double> part(npart);
+    NALO_HIP(c, hipMemcpyAsync(part.data(), w.noapply_E.p, npart * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    double cs = 0, cn = 0;
+    for (size_t i = 0; i < npart; i += 2) { cs += part[i]; cn += part[i + 1]; }
+    if (cost) *cost = cs;
+    if (n_residual_blocks) *n_residual_blocks = (int)(cn + 0.5);
+    // zero Jacobians -> Ceres returns the parameters it was given. After the solve (:396-440):
+    //  * the newest frame's PRE_worldToCam is rebuilt from its parameter block: rotation = exp(log(R)) (a round trip through so3, not the identical matrix)
+    //  * points hosted by frames 0 .. W-3 get setIdepth / setIdepthZero of their (unchanged) parameter: their linearisation point moves to the current value
+    //  * the newest frame is re-linearised at that pose, adjoints and precalc values are recomputed
+    ba_launch_set_idepth(c->stream, w.dev, 0, W - 2, 1.0);
+    NALO_HIP(c, hipGetLastError());
+    return relinearize_newest(c, T[W - 1]);
+}
+
 int nalo_ba_calc_l_energy(nalo_ctx* c, double* E) {
     NALO_BA_READY("nalo_ba_calc_l_energy")
     if (!E) return fail(c, NALO_ERR_ARG, "nalo_ba_calc_l_energy: bad argument");
@@ -1240,6 +1306,16 @@ int nalo_ba_get_points(nalo_ctx* c, float* idepth, float* step, float* HdiF, flo
         if (Hcd) { Hcd[4 * p] = hcd[d].x; Hcd[4 * p + 1] = hcd[d].y; Hcd[4 * p + 2] = hcd[d].z; Hcd[4 * p + 3] = hcd[d].w; }
         if (maxRelBaseline) maxRelBaseline[p] = rel[d];
     }
+    return NALO_OK;
+}
+
+int nalo_ba_get_idepth_zero(nalo_ctx* c, float* idepth_zero) {
+    if (!c || !c->ba || !c->ba->points_set || !idepth_zero) return fail(c, NALO_ERR_STATE, "nalo_ba_get_idepth_zero: no points");
+    BAWindow& w = *c->ba;
+    std::vector<float4> geo(w.Ppad);
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    NALO_HIP(c, hipMemcpy(geo.data(), w.pt_geo.p, (size_t)w.Ppad * 16, hipMemcpyDeviceToHost));
+    for (int p = 0; p < w.P; ++p) idepth_zero[p] = geo[w.p2d[p]].w;
     return NALO_OK;
 }
 

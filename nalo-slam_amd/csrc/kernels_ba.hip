@@ -968,6 +968,66 @@ __global__ __launch_bounds__(256) void ba_load_backup_kernel(BADev B) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d < B.Ppad && (B.pt_flags[d] & PT_VALID)) { float4 geo = B.pt_geo[d]; geo.z = geo.w = B.pt_backup[d]; B.pt_geo[d] = geo; }
 }
+// FullSystem::SWGrayOptimize_J (reference src/FullSystem/PlaneOptimize.cpp:307-454) without Ceres. Its cost functor GrayTHFactor_TH (PlaneOptimize.h:348-457)
+// evaluates ONE residual per (point, target != host): the centre pixel (pattern index 4) of the point projected with T_ij = T_j T_i^-1 (poses rebuilt from
+// {translation, so3 log} parameter blocks, fp64; the projection in the mixed float/double arithmetic of projectPoint, PlaneOptimize.h:277-297), r = I_target(Ku,Kv)
+// - color[4], or r = 100 when the projection leaves the image. Its analytic Jacobians are multiplied by an image gradient that is ALWAYS ZERO: the functor
+// reads the gradient from an outer `hitColor` that an inner declaration shadows (PlaneOptimize.h:378-381, 400-401). Ceres therefore sees a
+// zero gradient at the initial point and returns it unchanged (gradient tolerance reached in iteration 0). What remains of the call is (a) the value of
+// the Huber(100) cost, computed here, and (b) the state changes made AFTER the solve with the unchanged parameters (host_ba.hip: nalo_ba_sw_gray_optimize).
+// Block = 256 points of one host x one target; partial {cost sum, residual blocks} per (block, target) in fp64.
+__global__ __launch_bounds__(256) void ba_swgray_kernel(BADev B, const double* __restrict__ Rt /* [W*W][12] row h*W+t: R (9), t (3) of T_ij */, double* __restrict__ partial) {
+    __shared__ double sd[4][2];
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x, d = b * kBlk + tid, h = B.blk_host[b];
+    double cost = 0.0, cnt = 0.0;
+    if (t != h && (B.pt_flags[d] & PT_VALID)) {
+        const float4 geo = B.pt_geo[d];
+        const double inv_dep = (double)(kScaleIdepth * geo.z);                                        // idepth_scaled
+        if (!(inv_dep < 1e-4 || inv_dep > 1e3)) {                                                    // PlaneOptimize.cpp:375-376
+            const double* M = Rt + (size_t)(h * B.W + t) * 12;
+            const float fxl = B.calib[0], fyl = B.calib[1], cxl = B.calib[2], cyl = B.calib[3], fxli = B.calib[4], fyli = B.calib[5];
+            const float idf = (float)inv_dep;
+            const double K0 = (double)((geo.x + 0 - cxl) * fxli), K1 = (double)((geo.y + 0 - cyl) * fyli);
+            const double p0 = M[0] * K0 + M[1] * K1 + M[2] * 1.0 + M[9] * (double)idf, p1 = M[3] * K0 + M[4] * K1 + M[5] * 1.0 + M[10] * (double)idf,
+                         p2 = M[6] * K0 + M[7] * K1 + M[8] * 1.0 + M[11] * (double)idf;
+            const float drescale = (float)(1.0f / p2);
+            const float u = (float)(p0 * (double)drescale), v = (float)(p1 * (double)drescale);
+            const float Ku = u * fxl + cxl, Kv = v * fyl + cyl;
+            double r;
+            if (!(Ku > 1.1f && Kv > 1.1f && Ku < (float)(B.w - 3) && Kv < (float)(B.h - 3)) || inv_dep < 0) r = 100.0;
+            else {
+                const float4* img = B.img[t];
+                const int ix = (int)Ku, iy = (int)Kv;
+                const float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
+                const float4* bp = img + ix + iy * B.w;
+                const float I = dxdy * bp[1 + B.w].x + (dy - dxdy) * bp[B.w].x + (dx - dxdy) * bp[1].x + (1 - dx - dy + dxdy) * bp[0].x;
+                r = (double)(I - B.pt_col1[d].x);                                                    // color[4]
+            }
+            const double s = r * r;
+            cost = 0.5 * (s <= 1e4 ? s : 2.0 * 100.0 * sqrt(s) - 1e4);                               // ceres::HuberLoss(100): rho(s) = s, or 2 a sqrt(s) - a^2
+            cnt = 1.0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { cost += __shfl_down(cost, o); cnt += __shfl_down(cnt, o); }
+    if ((tid & 63) == 0) { sd[tid >> 6][0] = cost; sd[tid >> 6][1] = cnt; }
+    __syncthreads();
+    if (tid == 0) { double* o = partial + ((size_t)b * B.W + t) * 2; o[0] = (sd[0][0] + sd[1][0]) + (sd[2][0] + sd[3][0]); o[1] = (sd[0][1] + sd[1][1]) + (sd[2][1] + sd[3][1]); }
+}
+void ba_launch_swgray(hipStream_t s, const BADev& B, const double* Rt, double* partial) { ba_swgray_kernel<<<dim3(B.nblocks, B.W), 256, 0, s>>>(B, Rt, partial); }
+
+// idepth (and idepth_zero) of the points hosted by frames with index < first_kept_host are (re)set: mode 0 idepth_zero = idepth (SWGrayOptimize_J's
+// setIdepth / setIdepthZero with the unchanged parameter, PlaneOptimize.cpp:413-419: hosts 0 .. W-3); mode 1: idepth = idepth_zero = (float)(idepth / scale) for
+// the points of ONE host (planeOptimize's scale fix, :268-273)
+__global__ __launch_bounds__(256) void ba_set_idepth_kernel(BADev B, int mode, int host_sel, double scale) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= B.Ppad || !(B.pt_flags[d] & PT_VALID)) return;
+    const int h = B.blk_host[d / kBlk];
+    float4 geo = B.pt_geo[d];
+    if (mode == 0) { if (h < host_sel) { geo.z = (float)(double)(kScaleIdepth * geo.z); geo.w = geo.z; B.pt_geo[d] = geo; } }
+    else if (h == host_sel) { geo.z = (float)((double)(kScaleIdepth * geo.z) / scale); geo.w = geo.z; B.pt_geo[d] = geo; }
+}
+void ba_launch_set_idepth(hipStream_t s, const BADev& B, int mode, int host_sel, double scale) { ba_set_idepth_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, mode, host_sel, scale); }
+
 void ba_launch_load_backup(hipStream_t s, const BADev& B) { ba_load_backup_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B); }
 
 }  // namespace nalo

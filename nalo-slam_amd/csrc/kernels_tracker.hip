@@ -296,6 +296,52 @@ __global__ __launch_bounds__(1024) void trk_scan_all_kernel(TrkLevels P, int* __
     if (threadIdx.x == 0) __hip_atomic_store(&out[NALO_MAX_LEVELS], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// dense=1: the plane-sampled points CoarseTracker::makeCoarseDepthL0 appends to the level-0 cloud (reference src/FullSystem/CoarseTracker.cpp:628-655). For one
+// mask cluster with fitted plane (dir, dis): every pixel of its bounding box [minx,maxx) x [miny,maxy) with x % 5 == 0, y % 5 == 0 and mask == refMaskColor
+// becomes a point with new_idepth = (dir^T Ki (x, y, 1)) / -dis, colour = I_ref(x, y), in the reference's loop order (x outer, y inner). The reference stores
+// point k at index pc_n + 1 + k and then counts pc_n += 1 per point (:646-650): slot [old pc_n] is never written (stale heap there, ZERO here) and the last
+// sampled point falls just outside the count. Reproduced. ONE workgroup: the candidates (multiples of 5: <= w h / 25) are compacted in order, chunk by
+// chunk, with ballot counts and an LDS scan over the 16 waves.
+__global__ __launch_bounds__(1024) void trk_append_plane_kernel(const float* __restrict__ mask, const float4* __restrict__ dIref, int w, float d0, float d1, float d2, float dis,
+                                                                float Ki00, float Ki02, float Ki11, float Ki12, float refColor, int x0, int nx, int y0, int ny, int n0,
+                                                                float* __restrict__ pu, float* __restrict__ pv, float* __restrict__ pid, float* __restrict__ pcol, int* __restrict__ n_out) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { base_s = 0; pu[n0] = 0.f; pv[n0] = 0.f; pid[n0] = 0.f; pcol[n0] = 0.f; }
+    __syncthreads();
+    // dir^T * Ki as Eigen evaluates it (row vector times matrix, then times the point): t = dir^T Ki
+    const float t0 = d0 * Ki00 + d1 * 0.f + d2 * 0.f, t1 = d0 * 0.f + d1 * Ki11 + d2 * 0.f, t2 = d0 * Ki02 + d1 * Ki12 + d2 * 1.f;
+    const int total = nx * ny;
+    for (int c0 = 0; c0 < total; c0 += 1024) {
+        const int j = c0 + tid;
+        bool take = false; int x = 0, y = 0;
+        if (j < total) { x = x0 + 5 * (j / ny); y = y0 + 5 * (j % ny); take = mask[x + y * w] == refColor; }
+        const unsigned long long b = __ballot(take);
+        if (lane == 0) wave_cnt[wv] = __popcll(b);
+        __syncthreads();
+        int off = base_s;
+        for (int k = 0; k < wv; ++k) off += wave_cnt[k];
+        if (take) {
+            const int at = n0 + 1 + off + __popcll(b & ((1ull << lane) - 1ull));
+            float nid = t0 * (float)x + t1 * (float)y + t2 * 1.f;
+            nid /= -dis;
+            pu[at] = (float)x; pv[at] = (float)y; pid[at] = nid; pcol[at] = dIref[x + y * w].x;
+        }
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int k = 0; k < 16; ++k) s += wave_cnt[k]; base_s += s; }
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = base_s;
+}
+int trk_append_plane_launch(nalo_ctx* c, const float* mask, const float4* dIref, const float dir[3], float dis, float refColor, int x0, int nx, int y0, int ny, int n0, int* n_dev) {
+    const float fx = c->fx[0], fy = c->fy[0], cx = c->cx[0], cy = c->cy[0];
+    trk_append_plane_kernel<<<1, 1024, 0, c->stream>>>(mask, dIref, c->w, dir[0], dir[1], dir[2], dis, 1.0f / fx, -cx / fx, 1.0f / fy, -cy / fy, refColor, x0, nx, y0, ny, n0,
+                                                       c->pc_u[0].p, c->pc_v[0].p, c->pc_id[0].p, c->pc_col[0].p, n_dev);
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+
 int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const float* dId, const float* dHdi) {
     const int L = c->levels;
     TrkLevels P;

@@ -188,6 +188,7 @@ int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOr
                   float factor, const uint8_t* mask_org, const uint8_t* bgr_org, float* out_I, float* out_mask, uint8_t* out_bgr);
 // kernels_tracker.hip
 int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const float* dId, const float* dHdi);
+int trk_append_plane_launch(nalo_ctx* c, const float* mask, const float4* dIref, const float dir[3], float dis, float refColor, int x0, int nx, int y0, int ny, int n0, int* n_dev);
 int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], const float t[3], const float Ki[9],
                     float affa, float affb, float b0, float cutoff, float maxEnergy, double out64[64]);
 

@@ -315,6 +315,12 @@ def init_do_step(isGood, Jb, maxstep, idepth, lam, inc, idepth_new, kind="f32"):
 
 
 class Tracker:
+    def append_plane_points(self, mask, dirv, dis, ref_color, rect):
+        self.L.orc_trk_append_plane_points.argtypes = [C.c_void_p, c_fp, c_fp, C.c_float, C.c_int, c_ip]
+        self.L.orc_trk_append_plane_points.restype = C.c_int
+        return self.L.orc_trk_append_plane_points(self.h_, fp(np.ascontiguousarray(mask, np.float32)), fp(np.ascontiguousarray(dirv, np.float32)), float(dis), int(ref_color),
+                                                  ip(np.ascontiguousarray(rect, np.int32)))
+
     def set_affine_modes(self, a, b):
         """setting_affineOptModeA / B (< 0: fixed)"""
         self.L.orc_trk_set_affine_modes.argtypes = [C.c_void_p, C.c_double, C.c_double]
@@ -546,6 +552,22 @@ class BA:
         """setting_forceAceptStep / setting_affineOptModeA,B / setting_minOptIterations (util/settings.cpp:71,128-129,74)"""
         self.L.orc_ba_set_settings.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
         self.L.orc_ba_set_settings(self.h_, int(force_accept_step), float(affine_opt_mode_a), float(affine_opt_mode_b), int(min_opt_iterations))
+
+    def plane_scale_fix(self, localscale, camToTrackingRef, trackingRef_camToWorld):
+        self.L.orc_ba_plane_scale_fix.argtypes = [C.c_void_p, C.c_double, c_dp, c_dp]
+        self.L.orc_ba_plane_scale_fix(self.h_, float(localscale), dp(np.ascontiguousarray(camToTrackingRef, np.float64).reshape(-1)), dp(np.ascontiguousarray(trackingRef_camToWorld, np.float64).reshape(-1)))
+
+    def sw_gray_optimize(self):
+        self.L.orc_ba_sw_gray_optimize.argtypes = [C.c_void_p, c_ip]; self.L.orc_ba_sw_gray_optimize.restype = C.c_double
+        n = np.zeros(1, np.int32)
+        cost = self.L.orc_ba_sw_gray_optimize(self.h_, ip(n))
+        return cost, int(n[0])
+
+    def idepth_zero(self):
+        self.L.orc_ba_get_idepth_zero.argtypes = [C.c_void_p, c_fp]
+        o = np.zeros(self.P, np.float32)
+        self.L.orc_ba_get_idepth_zero(self.h_, fp(o))
+        return o
 
     def calc_l_energy(self):
         self.L.orc_ba_calc_l_energy.argtypes = [C.c_void_p]; self.L.orc_ba_calc_l_energy.restype = C.c_double

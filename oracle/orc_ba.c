@@ -756,6 +756,58 @@ static void load_state_backup(OrcBA* ba) {
     orc_ba_set_precalc(ba);
 }
 
+/* ---------------------------------------------------------------- planeOpt=1 without Ceres
+ * FullSystem::planeOptimize's scale fix (PlaneOptimize.cpp:183-301) and FullSystem::SWGrayOptimize_J (:307-454). GrayTHFactor_TH::Evaluate (PlaneOptimize.h:348-457)
+ * multiplies its Jacobians by d_uv = the gradient of an OUTER hitColor that stays zero (an inner declaration shadows it, :378-381): zero gradient, Ceres returns
+ * the initial point. Restated: the Huber(100) cost it reports, and the state changes after the solve with unchanged parameters. */
+static void relinearize_newest(OrcBA* ba, const double w2c[12]) {
+    OrcFrame* nf=&ba->frames[ba->W-1];
+    double nsz[10]={0,0,0,0,0,0,nf->state[6],nf->state[7],0,0};
+    memcpy(nf->evalPT,w2c,sizeof(double)*12);
+    frame_set_state(nf,nsz); frame_set_state_zero(nf,nsz);
+    orc_ba_set_adjoints(ba); orc_ba_set_precalc(ba);
+}
+void orc_ba_plane_scale_fix(OrcBA* ba, double localscale, const double camToTrackingRef[12], const double trackingRef_camToWorld[12]) {
+    double c2r[12], c2w[12], w2c[12]; memcpy(c2r,camToTrackingRef,sizeof(c2r));
+    c2r[3]*=localscale; c2r[7]*=localscale; c2r[11]*=localscale;
+    orc_se3_mul(trackingRef_camToWorld,c2r,c2w); orc_se3_inv(c2w,w2c);
+    for (int p=0;p<ba->P;p++) { OrcPoint* ph=&ba->pts[p]; if (ph->removed || ph->host!=ba->W-1) continue;
+        double idp=ph->idepth_scaled/localscale;
+        ph->idepth=(float)idp; ph->idepth_scaled=SCALE_IDEPTH*ph->idepth; ph->idepth_zero=(float)idp; ph->idepth_zero_scaled=SCALE_IDEPTH*ph->idepth_zero; }
+    relinearize_newest(ba,w2c);
+}
+double orc_ba_sw_gray_optimize(OrcBA* ba, int* n_blocks) {
+    int W=ba->W; double T[ORC_MAXW][12]; double cost=0; int nb=0;
+    for (int i=0;i<W;i++) { double xi[6], om[6]={0,0,0,0,0,0}; orc_se3_log(ba->frames[i].PRE_worldToCam,xi); om[3]=xi[3]; om[4]=xi[4]; om[5]=xi[5];
+        orc_se3_exp(om,T[i]); T[i][3]=ba->frames[i].PRE_worldToCam[3]; T[i][7]=ba->frames[i].PRE_worldToCam[7]; T[i][11]=ba->frames[i].PRE_worldToCam[11]; }
+    float fxl=ba->c_scaledf[0], fyl=ba->c_scaledf[1], cxl=ba->c_scaledf[2], cyl=ba->c_scaledf[3], fxli=ba->c_scaledi[0], fyli=ba->c_scaledi[1];
+    for (int h=0;h<W;h++) for (int t=0;t<W;t++) { if (h==t) continue;
+        double Ti[12], Tij[12]; orc_se3_inv(T[h],Ti); orc_se3_mul(T[t],Ti,Tij);
+        const float* dIl=ba->frames[t].dI;
+        for (int p=0;p<ba->P;p++) { OrcPoint* ph=&ba->pts[p]; if (ph->removed || ph->host!=h) continue;
+            double inv_dep=ph->idepth_scaled;
+            if (inv_dep<1e-4 || inv_dep>1e3) continue;
+            float idf=(float)inv_dep;
+            double K0=(double)((ph->u+0-cxl)*fxli), K1=(double)((ph->v+0-cyl)*fyli);
+            double p0=Tij[0]*K0+Tij[1]*K1+Tij[2]*1.0+Tij[3]*(double)idf, p1=Tij[4]*K0+Tij[5]*K1+Tij[6]*1.0+Tij[7]*(double)idf, p2=Tij[8]*K0+Tij[9]*K1+Tij[10]*1.0+Tij[11]*(double)idf;
+            float drescale=(float)(1.0f/p2);
+            float u=(float)(p0*(double)drescale), v=(float)(p1*(double)drescale);
+            float Ku=u*fxl+cxl, Kv=v*fyl+cyl;
+            double r;
+            if (!(Ku>1.1f && Kv>1.1f && Ku<(float)(ba->w-3) && Kv<(float)(ba->h-3)) || inv_dep<0) r=100;
+            else { int ix=(int)Ku, iy=(int)Kv; float dx=Ku-ix, dy=Kv-iy, dxdy=dx*dy; const float* bp=dIl+3*(ix+iy*ba->w);
+                float I=dxdy*bp[3*(1+ba->w)]+(dy-dxdy)*bp[3*ba->w]+(dx-dxdy)*bp[3]+(1-dx-dy+dxdy)*bp[0];
+                r=(double)(I-ph->color[4]); }
+            double s=r*r; cost+=0.5*(s<=1e4 ? s : 2.0*100.0*sqrt(s)-1e4); nb++;
+        } }
+    for (int p=0;p<ba->P;p++) { OrcPoint* ph=&ba->pts[p]; if (ph->removed || ph->host>=W-2) continue;
+        double idp=ph->idepth_scaled; ph->idepth=(float)idp; ph->idepth_scaled=SCALE_IDEPTH*ph->idepth; ph->idepth_zero=(float)idp; ph->idepth_zero_scaled=SCALE_IDEPTH*ph->idepth_zero; }
+    relinearize_newest(ba,T[W-1]);
+    if (n_blocks) *n_blocks=nb;
+    return cost;
+}
+void orc_ba_get_idepth_zero(OrcBA* ba, float* out) { for (int p=0;p<ba->P;p++) out[p]=ba->pts[p].idepth_zero; }
+
 /* ---------------------------------------------------------------- FullSystem::optimize, FullSystemOptimize.cpp:398-602 */
 double orc_ba_optimize(OrcBA* ba, int mnumOptIts) {
     if (ba->W<2) return 0; if (ba->W<3) mnumOptIts=20; if (ba->W<4) mnumOptIts=15;

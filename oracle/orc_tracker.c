@@ -176,6 +176,26 @@ void orc_trk_set_pc(OrcTracker* t, const float* dI_ref, int lvl, int n, const fl
     t->dI_ref = dI_ref; t->pc_n[lvl]=n;
     memcpy(t->pc_u[lvl],u,4*n); memcpy(t->pc_v[lvl],v,4*n); memcpy(t->pc_idepth[lvl],idepth,4*n); memcpy(t->pc_color[lvl],color,4*n);
 }
+/* dense=1 sampling of one mask cluster, CoarseTracker.cpp:621-655 (incl. the off-by-one store index; the never-written slot [old pc_n] is zeroed) */
+int orc_trk_append_plane_points(OrcTracker* t, const float* mask, const float dir[3], float dis_plane, int refMaskColor, const int rect[4]) {
+    const int w=t->w[0], h=t->h[0], minx=rect[0], maxx=rect[1], miny=rect[2], maxy=rect[3];
+    if (maxx>w-1||minx<1||maxy>h-1||miny<1) return 0;
+    if (refMaskColor==0) return 0;
+    const float* Ki=t->Ki[0];
+    const int last=t->pc_n[0];
+    t->pc_u[0][last]=t->pc_v[0][last]=t->pc_idepth[0][last]=t->pc_color[0][last]=0;
+    for (int x=minx;x<maxx;x++) for (int y=miny;y<maxy;y++) {
+        if (mask[x+y*w]!=refMaskColor) continue;
+        if (x%5==0&&y%5==0) {
+            float tv[3]; for (int j=0;j<3;j++) tv[j]=dir[0]*Ki[j]+dir[1]*Ki[3+j]+dir[2]*Ki[6+j];      /* (dir^T Ki) first, then times (x,y,1) */
+            float nid=tv[0]*x+tv[1]*y+tv[2]*1;
+            nid/=-dis_plane;
+            t->pc_u[0][t->pc_n[0]+1]=x; t->pc_v[0][t->pc_n[0]+1]=y; t->pc_idepth[0][t->pc_n[0]+1]=nid; t->pc_color[0][t->pc_n[0]+1]=t->dI_ref[3*(x+y*w)];
+            t->pc_n[0]++;
+        }
+    }
+    return t->pc_n[0]-last;
+}
 int orc_trk_get_pc(OrcTracker* t, int lvl, float* u, float* v, float* idepth, float* color) {
     int n=t->pc_n[lvl];
     if (u) { memcpy(u,t->pc_u[lvl],4*n); memcpy(v,t->pc_v[lvl],4*n); memcpy(idepth,t->pc_idepth[lvl],4*n); memcpy(color,t->pc_color[lvl],4*n); }

@@ -1,0 +1,65 @@
+"""dense=1 tracker glue (VERDICT r1 missing #6): the plane-sampled points CoarseTracker::makeCoarseDepthL0 appends to the level-0 cloud
+(reference src/FullSystem/CoarseTracker.cpp:600-655) are generated ON THE DEVICE by nalo_trk_append_plane_points — no round trip of the cloud through
+nalo_trk_get_pc / nalo_trk_set_pc. Against the CPU oracle on the KITTI frame shape: indices, order (x outer, y inner), the reference's off-by-one store
+position and counts EQUAL, inverse depths 1e-6; then the tracker runs on the enlarged cloud and lands on the oracle's pose (< 1e-5)."""
+import numpy as np
+import pytest
+
+import orc
+from helpers import pose_dist, tracker_inputs, true_rel_pose
+from nalo_slam_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (1224, 368)])
+def test_plane_points_appended_on_device(w, h):
+    win = synth.make_window(w=w, h=h, W=3, P=300, seed=4)
+    ref, new = win.W - 1, win.W
+    Ku, Kv, nid, hdi = tracker_inputs(win, n=2500, seed=2)
+    # ground-plane mask clusters on the reference keyframe: cluster values 7 and 3, one box touching the border (must be refused), one with colour 0
+    mask = np.zeros((h, w), np.float32)
+    gy0 = int(0.62 * h)
+    mask[gy0:h - 12, 30:w - 40] = 7.0
+    mask[gy0 + 20:gy0 + 60, w // 3:w // 2] = 3.0
+    rects = {7: [30, w - 40, gy0, h - 12], 3: [w // 3, w // 2, gy0 + 20, gy0 + 60]}
+    # the true ground plane of the synthetic scene in the reference camera: y = 1.6 - camera height ... use a fitted-looking plane (values only need to agree)
+    planes = {7: (np.array([0.01, -0.999, 0.03], np.float32), 1.58), 3: (np.array([-0.02, -0.998, 0.05], np.float32), 1.61)}
+    c = binding.Context(w, h, win.K, n_slots=win.W + 1)
+    for i in range(win.W + 1):
+        c.frame_upload(i, win.images[i], mask=mask if i == ref else None)
+    c.trk_set_ref(ref, Ku, Kv, nid, hdi)
+    trk = orc.Tracker(w, h, win.levels, win.K)
+    dI_ref, _ = orc.make_images(win.images[ref], win.levels)
+    dI_new, _ = orc.make_images(win.images[new], win.levels)
+    trk.set_ref(dI_ref, Ku, Kv, nid, hdi)
+    n_before = c.trk_get_pc(0)[0].shape[0]
+    assert n_before == trk.get_pc(0)[0].shape[0]
+    total = 0
+    for col in (7, 3):
+        d, dis = planes[col]
+        a_g = c.trk_append_plane_points(d, dis, col, rects[col])
+        a_o = trk.append_plane_points(mask, d, dis, col, rects[col])
+        assert a_g == a_o and a_o > 50
+        total += a_o
+    # refused boxes: touching the border, mask colour 0
+    assert c.trk_append_plane_points(planes[7][0], planes[7][1], 7, [0, w - 40, gy0, h - 12]) == 0
+    assert trk.append_plane_points(mask, planes[7][0], planes[7][1], 7, [0, w - 40, gy0, h - 12]) == 0
+    assert c.trk_append_plane_points(planes[7][0], planes[7][1], 0, rects[7]) == 0
+    ug, vg, ig, cg = c.trk_get_pc(0)
+    uo, vo, io_, co = trk.get_pc(0)
+    assert len(ug) == len(uo) == n_before + total
+    assert np.array_equal(ug, uo) and np.array_equal(vg, vo) and np.array_equal(cg, co)
+    assert np.allclose(ig, io_, rtol=1e-6, atol=0)
+    # the slot the reference never writes is defined as zero on both sides; the appended coordinates are multiples of 5 inside the mask cluster
+    assert ug[n_before] == 0 and ig[n_before] == 0
+    app = slice(n_before + 1, None)
+    assert np.all(ug[app] % 5 == 0) and np.all(vg[app] % 5 == 0)
+    assert np.all(np.isin(mask[vg[app].astype(int), ug[app].astype(int)], (7.0, 3.0)))
+    # and tracking on the enlarged level-0 cloud agrees with the oracle
+    T0 = orc.se3_exp(orc.se3_log(true_rel_pose(win, ref, new)) * 0.9)
+    ok_g, T_g = c.trk_track(new, T0, [0, 0], [0, 0], [1, 1], c.levels - 1)[:2]
+    ok_o, T_o = trk.track(dI_new, T0, [0, 0], [0, 0], [1, 1], win.levels - 1)[:2]
+    assert ok_g == ok_o
+    assert pose_dist(T_g, T_o) < 1e-5
+    c.close()

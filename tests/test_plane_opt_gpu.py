@@ -1,0 +1,62 @@
+"""planeOpt=1 without Ceres (config 3 of BASELINE.json): nalo_ba_plane_scale_fix = the active part of FullSystem::planeOptimize
+(reference src/FullSystem/PlaneOptimize.cpp:183-301) and nalo_ba_sw_gray_optimize = FullSystem::SWGrayOptimize_J (:307-454), through the C-ABI against the
+oracle's restatement on a window that has been optimised (frames off their linearisation point, idepth != idepth_zero).
+
+The reference's Ceres functor has an identically zero Jacobian (shadowed `hitColor`, PlaneOptimize.h:378-381), so Ceres returns its initial point: parity
+here means (a) the Huber(100) cost over all (point, target) centre-pixel residuals (what Ceres' summary reports), residual-block count EQUAL, cost 1e-9
+relative (fp64 sums of fp32 residuals in different order), (b) the post-solve state: newest frame re-linearised at [exp(log R) | t], idepth_zero = idepth
+for the points of frames 0..W-3 and untouched elsewhere, and (c) the next optimize() starting from that state agrees with the oracle's. Parity is
+unpinned (no Ceres in the image, no fixtures in the reference): the oracle is a restatement of what the reference's code can be READ to do."""
+import numpy as np
+import pytest
+
+import orc
+from helpers import pose_dist
+from nalo_slam_amd import binding, synth
+from test_window_state_gpu import carried_inputs, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,W,P", [(640, 480, 6, 1800), (1224, 368, 8, 2000)])
+def test_plane_scale_fix_and_sw_gray_optimize(w, h, W, P):
+    win = synth.make_window(w=w, h=h, W=W, P=P, seed=21)
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    has_prior, idz, calib_zero, aff = carried_inputs(win)
+    n = 8 * W + 4
+    ba, c = make_pair(win, st6, aff, has_prior, idz, calib_zero, np.zeros((n, n)), np.zeros(n))
+    ba.optimize(6); c.ba_optimize(6)
+    # --- planeOptimize: rescale the newest keyframe against its tracking reference (the previous keyframe)
+    fr_o = [ba.frame(i) for i in range(W)]
+    c2w_ref = synth.se3_inv(fr_o[W - 2]["worldToCam"])
+    cam2ref = synth.se3_mul(fr_o[W - 2]["worldToCam"], synth.se3_inv(fr_o[W - 1]["worldToCam"]))
+    ba.plane_scale_fix(1.03, cam2ref, c2w_ref)
+    c.ba_plane_scale_fix(1.03, cam2ref, c2w_ref)
+    fg, w2c_g, _ = c.ba_get_frames()
+    assert pose_dist(w2c_g[W - 1], ba.frame(W - 1)["worldToCam"]) < 1e-9
+    t_new = synth.se3_mul(w2c_g[W - 2], synth.se3_inv(w2c_g[W - 1]))[:, 3]
+    assert abs(np.linalg.norm(t_new) / np.linalg.norm(cam2ref[:, 3]) - 1.03) < 1e-4          # the baseline to the tracking reference grew by the scale
+    assert np.array_equal(c.ba_get_points()["idepth"], ba.points()["idepth"]) or np.allclose(c.ba_get_points()["idepth"], ba.points()["idepth"], rtol=2e-5)
+    # --- SWGrayOptimize_J
+    id_before = c.ba_get_points()["idepth"].copy(); idz_before = c.ba_get_idepth_zero(len(win.host)).copy()
+    cost_o, nb_o = ba.sw_gray_optimize()
+    cost_g, nb_g = c.ba_sw_gray_optimize()
+    assert nb_g == nb_o and nb_o > 0.9 * len(win.host) * (W - 1) * 0.5
+    assert abs(cost_g - cost_o) < 2e-5 * cost_o, (cost_g, cost_o)
+    fg, w2c_g, _ = c.ba_get_frames()
+    for i in range(W):
+        assert pose_dist(w2c_g[i], ba.frame(i)["worldToCam"]) < (1e-5 if i < W - 1 else 1e-9)
+    # the newest frame sits at its new linearisation point: pose part of the state is zero, evalPT = its pose
+    assert np.abs(np.array(fg[W - 1].state)[:6]).max() == 0 and np.abs(np.array(fg[W - 1].state_zero)[:6]).max() == 0
+    assert pose_dist(np.array(fg[W - 1].worldToCam_evalPT).reshape(3, 4), w2c_g[W - 1]) < 1e-12
+    idz_after = c.ba_get_idepth_zero(len(win.host))
+    old = win.host < W - 2
+    assert np.array_equal(idz_after[old], id_before[old]) and np.array_equal(idz_after[~old], idz_before[~old])
+    assert np.array_equal(c.ba_get_points()["idepth"], id_before)                             # the "optimised" inverse depths are the initial ones
+    assert np.allclose(idz_after, ba.idepth_zero(), rtol=2e-5)
+    # --- and the window continues from there identically
+    r_o = ba.optimize(6); r_g = c.ba_optimize(6)
+    assert abs(r_g - r_o) < 1e-4 * r_o
+    fg, w2c_g, _ = c.ba_get_frames()
+    assert max(pose_dist(w2c_g[i], ba.frame(i)["worldToCam"]) for i in range(W)) < 3e-5
+    c.close()
