@@ -10,10 +10,16 @@ OUT = os.path.join(HERE, "libnalo_gpu.so")
 NO_CONTRACT = {"kernels_pyramid.hip", "kernels_imm.hip", "kernels_init.hip", "kernels_pixsel.hip", "host_init.hip"}   # a1 is bit-exact vs the reference's scalar fp32 code: no FMA contraction
 
 
+# per-file flags (experiments). Measured in round 2 and NOT adopted: kernels_ba_lin.hip with -fno-hip-fp32-correctly-rounded-divide-sqrt (v_rcp-based fp32
+# division: 2330 -> 2049 vector instructions per lane) runs the stress250k pass in 195.1 us against 195.4 us with IEEE division - the kernel waits on its
+# gathers, not on the vector ALU - and flips residual state decisions against the oracle. NALO_LIN_FAST_DIV=1 rebuilds it that way.
+PER_FILE = {"kernels_ba_lin.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]} if os.environ.get("NALO_LIN_FAST_DIV") else {}
+
+
 def build(force=False, verbose=False):
     csrc = os.path.join(HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in SRC if os.path.exists(os.path.join(csrc, s))]
-    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "nalo_gpu.h"), os.path.join(HERE, "..", "include", "nalo_io.h")]
+    deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "nalo_gpu.h"), os.path.join(HERE, "..", "include", "nalo_io.h"), os.path.abspath(__file__)]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     objs = []
@@ -21,7 +27,7 @@ def build(force=False, verbose=False):
     procs = []
     for s in srcs:
         # the object name carries the flag set, so moving a file in/out of NO_CONTRACT (or changing NALO_CXXFLAGS) rebuilds it
-        tag = ("nc" if os.path.basename(s) in NO_CONTRACT else "fc") + ("%08x" % (zlib.crc32(os.environ.get("NALO_CXXFLAGS", "").encode()) & 0xFFFFFFFF) if os.environ.get("NALO_CXXFLAGS") else "")
+        tag = ("nc" if os.path.basename(s) in NO_CONTRACT else "fc") + ("d" if os.path.basename(s) in PER_FILE else "") + ("%08x" % (zlib.crc32(os.environ.get("NALO_CXXFLAGS", "").encode()) & 0xFFFFFFFF) if os.environ.get("NALO_CXXFLAGS") else "")
         o = os.path.join(HERE, "build", os.path.basename(s) + "." + tag + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [s] + deps[len(srcs):]):
@@ -30,6 +36,8 @@ def build(force=False, verbose=False):
         cmd += os.environ.get("NALO_CXXFLAGS", "").split()
         if os.path.basename(s) in NO_CONTRACT:
             cmd += ["-ffp-contract=off"]
+        if os.path.basename(s) in PER_FILE:
+            cmd += PER_FILE[os.path.basename(s)]
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
         procs.append((s, subprocess.Popen(cmd)))

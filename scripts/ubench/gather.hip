@@ -69,12 +69,48 @@ __global__ __launch_bounds__(256) void gatherD(const float4* __restrict__ img, c
     acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8); acc += __shfl_xor(acc, 16);
     if ((t & 31) == 0) out[i] = acc;
 }
+// E / F: 64-byte FOOTPRINT RECORDS — for every pixel the four {I,dx,dy} texels of its bilinear footprint stored together (4 x 16 B, one cache line half):
+//   E: quad-cooperative like C, lane q loads 16-byte chunk q of the pixel's record: the quad reads ONE contiguous 64-byte block (1 line instead of 2 half rows)
+//   F: one residual per lane like A, its four taps are four 16-byte loads from ONE record (same line)
+__global__ __launch_bounds__(256) void gatherE(const float4* __restrict__ rec, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 2, q = t & 3;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+        const int ix = (int)x, iy = (int)y;
+        const float4 a = rec[(size_t)(ix + iy * w) * 4 + q];
+        acc += a.x + a.y;
+    }
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+    if (q == 0) out[i] = acc;
+}
+__global__ __launch_bounds__(256) void gatherF(const float4* __restrict__ rec, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+        const int ix = (int)x, iy = (int)y;
+        const float4* b = rec + (size_t)(ix + iy * w) * 4;
+        const float4 a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3];
+        acc += a0.x + a1.y + a2.z + a3.x;
+    }
+    out[i] = acc;
+}
 static uint32_t part1by1(uint32_t x) { x &= 0xffff; x = (x | (x << 8)) & 0x00FF00FF; x = (x | (x << 4)) & 0x0F0F0F0F; x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; }
 int main(int argc, char** argv) {
     const int w = 1920, h = 1072, W = 8, P = argc > 1 ? atoi(argv[1]) : 250000;
     const int per = P / W;
     std::vector<float4*> imgs(W);
     for (int f = 0; f < W; ++f) { CK(hipMalloc(&imgs[f], (size_t)w * h * 16)); CK(hipMemset(imgs[f], 0, (size_t)w * h * 16)); }
+    std::vector<float4*> recs(W);
+    for (int f = 0; f < W; ++f) { CK(hipMalloc(&recs[f], (size_t)w * h * 64)); CK(hipMemset(recs[f], 0, (size_t)w * h * 64)); }
     // residual list: for each target t, for each host h != t, the host's points (Morton order) reprojected with a small shift
     std::vector<float2> uv; std::vector<int> tgt_start(W + 1, 0);
     srand(1);
@@ -92,7 +128,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&duv, nmax * W * 8)); CK(hipMalloc(&dout, nmax * W * 4));
     for (int t = 0; t < W; ++t) CK(hipMemcpy(duv + t * nmax, per_target[t].data(), nmax * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 4; ++variant) {
+    for (int variant = 0; variant < 6; ++variant) {
         float best = 1e9;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
@@ -101,13 +137,15 @@ int main(int argc, char** argv) {
                 if (variant == 0) gatherA<<<(n + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
                 else if (variant == 1) gatherB<<<(n * 8 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
                 else if (variant == 2) gatherC<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
-                else gatherD<<<(unsigned)(((size_t)n * 32 + 255) / 256), 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else if (variant == 3) gatherD<<<(unsigned)(((size_t)n * 32 + 255) / 256), 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else if (variant == 4) gatherE<<<(n * 4 + 255) / 256, 256>>>(recs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else gatherF<<<(n + 255) / 256, 256>>>(recs[t], duv + t * nmax, n, w, dout + t * nmax);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
         }
         const double taps = (double)nmax * W * 32;
-        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", "ABCD"[variant], nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
+        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", "ABCDEF"[variant], nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
     }
     return 0;
 }
