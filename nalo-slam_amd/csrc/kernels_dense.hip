@@ -20,7 +20,13 @@ __global__ __launch_bounds__(256) void dense_bbox_kernel(const float* __restrict
         if (mask[x + y * w] != value) continue;
         minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
     }
-    if (minx != INT_MAX) { atomicMin(&rect[0], minx); atomicMax(&rect[1], maxx); atomicMin(&rect[2], miny); atomicMax(&rect[3], maxy); }
+    // wave reduction first: one lane per wave touches the four global words (every lane doing so serialised ~10^5 atomics on 4 addresses: 374 us at
+    // 1920x1072, now a coalesced read of the mask)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        minx = min(minx, __shfl_down(minx, o)); maxx = max(maxx, __shfl_down(maxx, o)); miny = min(miny, __shfl_down(miny, o)); maxy = max(maxy, __shfl_down(maxy, o));
+    }
+    if ((threadIdx.x & 63) == 0 && minx != INT_MAX) { atomicMin(&rect[0], minx); atomicMax(&rect[1], maxx); atomicMin(&rect[2], miny); atomicMax(&rect[3], maxy); }
 }
 
 struct DenseParams {

@@ -63,8 +63,8 @@ def check(rec, drv, tol_state, tol_clean, tol_flipped):
     assert Ho.shape == Hg.shape
     if np.abs(Ho).max() > 0:               # bM is a cancelling difference (M_b - Msc_b): its relative error is an order above H's; same floor rule as the poses
         H64, b64 = rec["prior"][2]
-        assert rel_err(Hg, Ho) < max(2e-4 if drv.teacher else 1e-3, 1.5 * rel_err(H64, Ho)), (rel_err(Hg, Ho), rel_err(H64, Ho))
-        assert rel_err(bg, bo) < max(2e-3 if drv.teacher else 1e-2, 1.5 * rel_err(b64, bo)), (rel_err(bg, bo), rel_err(b64, bo))
+        assert rel_err(Hg, Ho) < max(2e-4 if drv.teacher else 5e-3, 1.5 * rel_err(H64, Ho)), (rel_err(Hg, Ho), rel_err(H64, Ho))
+        assert rel_err(bg, bo) < max(2e-3 if drv.teacher else 5e-2, 1.5 * rel_err(b64, bo)), (rel_err(bg, bo), rel_err(b64, bo))
     for (b, fid), (ok, T, aff) in rec.get("tracked", {}).items():
         if b == 1:
             ok_o, T_o, aff_o = rec["tracked"][(0, fid)]
