@@ -575,12 +575,15 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
 
 def load_traffic(workload):
     """HBM bytes per ba_linearize launch from the committed PMC summary (profiles/traffic_*.json), or None."""
-    p = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get(workload)
-        except Exception:
-            return None
+    for name in ("traffic_r02.json", "traffic_r01.json"):          # the newest committed measurement wins
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                v = json.load(open(p)).get(workload)
+                if v is not None:
+                    return v
+            except Exception:
+                pass
     return None
 
 

@@ -32,10 +32,10 @@
 #include "reduce.h"
 
 #ifndef NALO_LIN_COOP_NPB
-#define NALO_LIN_COOP_NPB 3        // pattern pixels per gather batch: 3+3+2 (12 loads in flight per lane) measured best on stress250k; 2: +2 %, 4: spills
-#endif
+#define NALO_LIN_COOP_NPB 2        // pattern pixels per gather batch: 2 (8 loads in flight per lane) x 4 waves per SIMD. Round-2 sweep (profiles/r02_tune_lin.log):
+#endif                             // 3 waves x 3+3+2 pixels 207.6 / 919.9 us (stress250k / shard1m), 4 x 2: 208.4 / 871.4, 4 x 3 (spills) 228.6 / 958.7, 5 x 2: 237.1 / 975.5
 #ifndef NALO_LIN_COOP_WAVES
-#define NALO_LIN_COOP_WAVES 3      // waves per SIMD the gather kernel's register allocation leaves room for
+#define NALO_LIN_COOP_WAVES 4      // waves per SIMD the gather kernel's register allocation leaves room for (128 VGPRs)
 #endif
 
 namespace nalo {
@@ -82,7 +82,6 @@ __device__ __forceinline__ void lin_wave_sync() {
 // ---------------------------------------------------------------------------------------------------------------- the residual, per lane
 struct LinRes {
     // everything the accumulation needs; stays zero unless this lane ends with an active (IN) residual
-    float x[10], y[10];
     float a, bb, c, jab00, jab01, jab10, jab11, ab00, ab01, ab11;
     float JIr0, JIr1, Jabr0, Jabr1, rr, cnt, energy, enew;
     // geometry / state
@@ -118,14 +117,38 @@ __device__ __forceinline__ LinWhere lin_where(const BADev& B, int tid) {
     return w;
 }
 
+// x = (Jpdc[0], Jpdxi[0]), y = (Jpdc[1], Jpdxi[1]) of a residual (Residuals.cpp:108-156) from the point and the precalc record. A function of its own so that the
+// twenty values are NOT alive across the gather phase: they are (re)computed where they are consumed (takeDataF and the accumulation, after the last tap),
+// which is what lets the kernel fit 128 vector registers = four waves per SIMD (the gathers are latency bound: more waves, more loads in flight).
+__device__ __forceinline__ void lin_geometry(const BADev& B, const LinWhere& w, float pu, float pv, float idz, float* __restrict__ x, float* __restrict__ y) {
+    const float* pc = w.pc;
+    const float cal_fxl = B.calib[0], cal_fyl = B.calib[1], cal_cxl = B.calib[2], cal_cyl = B.calib[3], cal_fxli = B.calib[4], cal_fyli = B.calib[5];
+    const float KliP0 = (pu - cal_cxl) * cal_fxli, KliP1 = (pv - cal_cyl) * cal_fyli;
+    const float p0 = pc[12] * KliP0 + pc[13] * KliP1 + pc[14] + pc[21] * idz;
+    const float p1 = pc[15] * KliP0 + pc[16] * KliP1 + pc[17] + pc[22] * idz;
+    const float p2 = pc[18] * KliP0 + pc[19] * KliP1 + pc[20] + pc[23] * idz;
+    const float drescale = 1.0f / p2, new_idepth = idz * drescale;
+    const float u = p0 * drescale, vv = p1 * drescale;
+    x[2] = drescale * (pc[18] * u - pc[12]);                                                        // :123-156
+    x[3] = cal_fxl * drescale * (pc[19] * u - pc[13]) * cal_fyli;
+    x[0] = KliP0 * x[2]; x[1] = KliP1 * x[3];
+    y[2] = cal_fyl * drescale * (pc[18] * vv - pc[15]) * cal_fxli;
+    y[3] = drescale * (pc[19] * vv - pc[16]);
+    y[0] = KliP0 * y[2]; y[1] = KliP1 * y[3];
+    x[0] = (x[0] + u) * kScaleF; x[1] *= kScaleF; x[2] = (x[2] + 1) * kScaleC; x[3] *= kScaleC;
+    y[0] *= kScaleF; y[1] = (y[1] + vv) * kScaleF; y[2] *= kScaleC; y[3] = (y[3] + 1) * kScaleC;
+    x[4] = new_idepth * cal_fxl; x[5] = 0.f; x[6] = -new_idepth * u * cal_fxl;
+    x[7] = -u * vv * cal_fxl; x[8] = (1 + u * u) * cal_fxl; x[9] = -vv * cal_fxl;
+    y[4] = 0.f; y[5] = new_idepth * cal_fyl; y[6] = -new_idepth * vv * cal_fyl;
+    y[7] = -(1 + vv * vv) * cal_fyl; y[8] = u * vv * cal_fyl; y[9] = u * cal_fyl;
+}
+
 // phase A: state, the two projections, geometric Jacobians (Residuals.cpp:78-170, ResidualProjections.h:47-87). Sets R.need when the residual takes its taps.
 template <int MODE>
 __device__ __forceinline__ void lin_setup(const BADev& B, const LinWhere& w, LinRes& R) {
     const float* pc = w.pc;
     // CalibHessian::value_scaledf / value_scaledi live in device memory (uniform scalar loads): the GN step may be taken on the device
     const float cal_fxl = B.calib[0], cal_fyl = B.calib[1], cal_cxl = B.calib[2], cal_cyl = B.calib[3], cal_fxli = B.calib[4], cal_fyli = B.calib[5];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) { R.x[i] = 0.f; R.y[i] = 0.f; }
     R.a = R.bb = R.c = R.jab00 = R.jab01 = R.jab10 = R.jab11 = R.ab00 = R.ab01 = R.ab11 = 0.f;
     R.JIr0 = R.JIr1 = R.Jabr0 = R.Jabr1 = R.rr = R.cnt = R.energy = 0.f; R.enew = -1.f;
     R.pu = R.pv = R.idepth = R.idz = 0.f; R.en = make_float2(0.f, 0.f);
@@ -174,21 +197,9 @@ __device__ __forceinline__ void lin_setup(const BADev& B, const LinWhere& w, Lin
     const float t0x = pc[21], t0y = pc[22], t0z = pc[23];
     R.Jpdd0 = drescale * (t0x - t0z * u) * kScaleIdepth * cal_fxl;                                   // Residuals.cpp:116-117
     R.Jpdd1 = drescale * (t0y - t0z * vv) * kScaleIdepth * cal_fyl;
-    float* x = R.x; float* y = R.y;
-    // x = (Jpdc[0], Jpdxi[0]), y = (Jpdc[1], Jpdxi[1])                                          :123-156
-    x[2] = drescale * (pc[18] * u - pc[12]);
-    x[3] = cal_fxl * drescale * (pc[19] * u - pc[13]) * cal_fyli;
-    x[0] = KliP0 * x[2]; x[1] = KliP1 * x[3];
-    y[2] = cal_fyl * drescale * (pc[18] * vv - pc[15]) * cal_fxli;
-    y[3] = drescale * (pc[19] * vv - pc[16]);
-    y[0] = KliP0 * y[2]; y[1] = KliP1 * y[3];
-    x[0] = (x[0] + u) * kScaleF; x[1] *= kScaleF; x[2] = (x[2] + 1) * kScaleC; x[3] *= kScaleC;
-    y[0] *= kScaleF; y[1] = (y[1] + vv) * kScaleF; y[2] *= kScaleC; y[3] = (y[3] + 1) * kScaleC;
-    x[4] = new_idepth * cal_fxl; x[5] = 0.f; x[6] = -new_idepth * u * cal_fxl;
-    x[7] = -u * vv * cal_fxl; x[8] = (1 + u * u) * cal_fxl; x[9] = -vv * cal_fxl;
-    y[4] = 0.f; y[5] = new_idepth * cal_fyl; y[6] = -new_idepth * vv * cal_fyl;
-    y[7] = -(1 + vv * vv) * cal_fyl; y[8] = u * vv * cal_fyl; y[9] = u * cal_fyl;
     if (MODE == 2) {                                                                                // Jp*delta (EnergyFunctionalStructs.cpp:94-99)
+        float x[10], y[10];
+        lin_geometry(B, w, R.pu, R.pv, R.idz, x, y);
         const float dd = idepth - idz;
         float jx = 0.f, jy = 0.f;
 #pragma unroll
@@ -257,7 +268,8 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
         B.rs_energy[w.si] = R.en;
         if (active && R.full) {
             R.cnt = 1.f;
-            const float* x = R.x; const float* y = R.y;
+            float x[10], y[10];
+            lin_geometry(B, w, R.pu, R.pv, R.idz, x, y);
             // ---- takeDataF (EnergyFunctionalStructs.cpp:39-50)
             const float a0 = R.a * R.Jpdd0 + R.bb * R.Jpdd1, a1 = R.bb * R.Jpdd0 + R.c * R.Jpdd1;
             float4 j0, j1;
@@ -290,9 +302,14 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
 }
 
 // AccumulatorApprox::update / updateTopRight / updateBotRight (AccumulatedTopHessian.cpp:115-129) of this lane's residual, streamed into the LDS row of its quad
-__device__ __forceinline__ void lin_stream(const LinRes& R, float* rows, int tid) {
+__device__ __forceinline__ void lin_stream(const BADev& B, const LinWhere& w, const LinRes& R, float* rows, int tid) {
     QuadStream qs(rows, tid);
-    const float* x = R.x; const float* y = R.y;
+    float x[10], y[10];
+    if (R.cnt != 0.f) lin_geometry(B, w, R.pu, R.pv, R.idz, x, y);                                 // only lanes that end with an active residual contribute
+    else {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { x[i] = 0.f; y[i] = 0.f; }
+    }
     {
         float ax[10], cy[10];
 #pragma unroll
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
     }
     // ---- the 93 reduced values: quad DPP adds -> LDS rows (one per quad) -> fp64 column sums -> this workgroup's partial
     lin_wave_sync();                                                                               // the rows alias the exchange buffer this wave has just read
-    lin_stream(R, smem, tid);
+    lin_stream(B, w, R, smem, tid);
     if (WG > 64) __syncthreads(); else lin_wave_sync();
     double* out = B.top_partial + (((size_t)w.b * (kBlk / WG) + w.q) * B.W + w.t) * kTopStride;
     constexpr int ROWS = WG / 4;

@@ -1,17 +1,17 @@
 """Per-launch HBM traffic of ba_linearize from the rocprofv3 --pmc passes of scripts/prof_pmc.sh.
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of 16-B-per-lane loads at 64 B
-(MI355X_MICROARCH.md, HBM section), so the read side is doubled. Writes profiles/traffic_r01.json (read by bench.py)."""
+(MI355X_MICROARCH.md, HBM section), so the read side is doubled. Writes profiles/traffic_r02.json (read by bench.py; NALO_TRAFFIC_OUT overrides the path)."""
 import csv, glob, json, os, sys
 
 def mean_counter(tag, ctr, kernel):
     vals = []
     for f in glob.glob(f"gpurun_out/{tag}/{ctr}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel_Name"] and "<0, 0>" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+            if kernel in r["Kernel_Name"] and ("<0, 0>" in r["Kernel_Name"] or "<0, 0, " in r["Kernel_Name"]) and r["Counter_Name"] == ctr:
                 vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
-out_path = "profiles/traffic_r01.json"
+out_path = os.environ.get("NALO_TRAFFIC_OUT", "profiles/traffic_r02.json")
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for tag, wl in [a.split(":") for a in sys.argv[1:]]:
     f, nf = mean_counter(tag, "FETCH_SIZE", "ba_linearize")

@@ -147,5 +147,19 @@ int main(int argc, char** argv) {
         const double taps = (double)nmax * W * 32;
         printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", "ABCDEF"[variant], nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
     }
+    // occupancy sweep of layout C: dynamic LDS per 256-thread block caps the blocks per CU (160 KB of LDS), i.e. waves per SIMD, with 8 loads in flight per lane:
+    // does the gather rate depend on the loads in flight (latency bound) or not (bound by the miss path of the memory system)?
+    for (int wps : {1, 2, 3, 4, 6, 8}) {
+        const size_t lds = (size_t)(160 * 1024 / wps) - 2048;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gatherC), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        float best = 1e9;
+        for (int rep = 0; rep < 5; ++rep) {
+            CK(hipEventRecord(e0));
+            for (int t = 0; t < W; ++t) { const int n = (int)nmax; gatherC<<<(n * 4 + 255) / 256, 256, lds>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax); }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
+        }
+        printf("layout C at %d waves/SIMD (8 loads in flight per lane): %.1f us\n", wps, best * 1e3);
+    }
     return 0;
 }
