@@ -452,6 +452,12 @@ def main():
                 except Exception as e:
                     out["pixel_selector"] = {"error": repr(e)}
                 log("pixel selector leg done")
+                leg_state["leg"] = "initializer"
+                try:
+                    out["initializer"] = init_leg(cpu=not args.no_cpu_baseline)
+                except Exception as e:
+                    out["initializer"] = {"error": repr(e)}
+                log("initializer leg done")
                 # The KITTI-sized launch moves 6 MB (0.8 us at 8 TB/s): it is launch-latency bound by construction. The kernel's
                 # roofline position is therefore reported on the largest single-GPU window of this same run (configs[3]);
                 # the figure of the headline workload stays next to it.
@@ -460,6 +466,10 @@ def main():
                     out["roofline_kitti00_8kf"] = out["roofline"]
                     out["roofline"] = dict(kernel="ba_linearize", workload="stress250k", note="the KITTI-sized launch is latency bound (see roofline_kitti00_8kf, same kernel, measured over the timed region); "
                                            "this is the same kernel on the largest single-GPU window (configs[3]) inside this run",
+                                           ceiling=dict(what="pure 16-byte tap gathers of the same residual list, nothing else (scripts/ubench/gather.hip layout C, profiles/r02_ubench_gather.log)",
+                                                        gather_only_us=175.0, frac_of_hbm_roofline=round(768e6 / 175e-6 / 1e9 / HBM_PEAK_GBS, 3),
+                                                        note="the gather rate saturates at 3-4 waves/SIMD (1: 252, 2: 199, 3: 180, 4: 176, 8: 175 us): bound by the miss path of sparse 16-B gathers (31 k points per 2 Mpx frame), not by latency, "
+                                                             "vector ALU (IEEE vs rcp division: same time) or HBM (traffic < algorithmic bytes)"),
                                            bound="hbm", achieved=sl["achieved_GBs"], peak=HBM_PEAK_GBS,
                                            unit="GB/s", frac=sl["frac"], traffic=load_traffic("stress250k"), avg_us=sl["avg_us"],
                                            launches=sl["launches"], alg_bytes=sl["alg_bytes"])
@@ -697,7 +707,56 @@ def frontend_legs(rounds=30):
     res["dense_map"] = timed("dense_map", dm, 11.0 * bbox_px + 24.0 * n.value, n_rounds=10)
     res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="count + scan + write launches of makeMap; the D2H copy of the point list is not in avg_us")
     res["dense_bbox"] = timed("dense_bbox", dm, 4.0 * (w - 4) * (h - 4), n_rounds=10)
+    # ---- raw-frame ingest (photometric undistortion + remap fused in front of makeImages): an 8-bit sensor frame slightly larger than the rectified image
+    wo, ho = w + 64, h + 48
+    raw = rng.randint(0, 256, (ho, wo)).astype(np.uint8)
+    G = np.linspace(0, 255, 256).astype(np.float32)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    rx, ry = (xx * np.float32((wo - 2.0) / w) + 0.3).astype(np.float32), (yy * np.float32((ho - 2.0) / h) + 0.3).astype(np.float32)
+    vinv = np.ones((ho, wo), np.float32)
+    c.undist_set(wo, ho, G, vinv, 2, rx, ry)
+    alg_ing = 1.0 * wo * ho + 4.0 * wo * ho + 8.0 * w * h + 4.0 * w * h          # raw bytes + vignette + remap tables + irradiance out
+    res["ingest"] = timed("ingest", lambda: c.frame_upload_raw(1, raw, exposure=0.02), alg_ing, n_rounds=10)
+    res["ingest"]["note"] = ("nalo_frame_upload_raw: G[raw] * vignetteMapInv at the four taps of every rectified pixel (bilinear remap), one pass; the frame crosses PCIe "
+                             "at 1 B/px (%.2f MB) instead of 4 B/px; avg_us is the kernel, the call also pays the copy and the pyramid" % (wo * ho / 1e6))
     c.close()
+    return res
+
+
+def init_leg(w=1224, h=368, frames=3, cpu=True):
+    """the two-frame initialiser behind the C-ABI (setFirst + trackFrame) on the KITTI frame shape, wall clock per call, next to the CPU port"""
+    import time
+    from nalo_slam_amd import binding, synth
+    win = synth.make_window(w=w, h=h, W=2, P=20, seed=3, n_extra=frames - 1, step_z=0.15, yaw_deg=0.1)
+    rp = None
+    try:
+        import orc
+        rp, _ = orc.pixsel_libc_tables(w * h)
+    except Exception:
+        rng = np.random.RandomState(1); rp = rng.randint(0, 256, w * h).astype(np.uint8)
+    c = binding.Context(w, h, win.K, n_slots=frames + 1)
+    for i in range(frames + 1):
+        c.frame_upload(i, win.images[i])
+    c.pixsel_set_random(rp)
+    c.init_set_first(0)
+    t0 = time.perf_counter(); num, _ = c.init_set_first(0); t_first = time.perf_counter() - t0
+    ev0 = c.init_state()["n_evals"]; t_tr = []
+    for i in range(1, frames + 1):
+        t0 = time.perf_counter(); c.init_track_frame(i); t_tr.append(time.perf_counter() - t0)
+    evals = c.init_state()["n_evals"] - ev0
+    res = {"image": "%dx%d" % (w, h), "points_per_level": [int(x) for x in num], "set_first_ms": round(t_first * 1e3, 2), "track_frame_ms": round(float(np.mean(t_tr)) * 1e3, 2),
+           "calc_res_and_gs_evaluations_per_frame": round(evals / frames, 1),
+           "note": "setFirst = selection kernels of every level + host k-d tree (makeNN, sequential by construction); trackFrame = ~45 device evaluations + the host Gauss-Seidel sweeps"}
+    c.close()
+    if cpu:
+        import orc
+        ini = orc.Initializer(w, h, win.levels, win.K, "fast")
+        t0 = time.perf_counter(); ini.set_first(win.images[0], rp); res["set_first_cpu_port_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+        t = []
+        for i in range(1, frames + 1):
+            t0 = time.perf_counter(); ini.track_frame(win.images[i]); t.append(time.perf_counter() - t0)
+        res["track_frame_cpu_port_ms"] = round(float(np.mean(t)) * 1e3, 2)
+        res["cpu_cores"] = 1
     return res
 
 
