@@ -707,6 +707,8 @@ def frontend_legs(rounds=30):
     res["dense_map"] = timed("dense_map", dm, 11.0 * bbox_px + 24.0 * n.value, n_rounds=10)
     res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="count + scan + write launches of makeMap; the D2H copy of the point list is not in avg_us")
     res["dense_bbox"] = timed("dense_bbox", dm, 4.0 * (w - 4) * (h - 4), n_rounds=10)
+    res["dense_extent"] = timed("dense_extent", dm, 2 * 24.0 * n.value, n_rounds=10)
+    res["dense_extent"]["note"] = "the accept test of MapPoint.cpp:403 with the reference's order-dependent maxy / maxz: two passes over the world points (24 B each)"
     # ---- raw-frame ingest (photometric undistortion + remap fused in front of makeImages): an 8-bit sensor frame slightly larger than the rectified image
     wo, ho = w + 64, h + 48
     raw = rng.randint(0, 256, (ho, wo)).astype(np.uint8)

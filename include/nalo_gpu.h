@@ -417,7 +417,7 @@ int nalo_init_get_points(nalo_ctx* ctx, int lvl, int cap, int* n, float* u, floa
 
 /* ------------------------------------------------------------------------------------------------
  * Profiling: per-kernel HIP-event timing on the ctx stream. Names: "trk_eval", "ba_linearize",
- * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize", "pixsel", "dist_bfs", "dense_bbox", "dense_map", "ingest". Enable, run, then query (sync inside).
+ * "ba_sc", "ba_reduce", "ba_resub", "pyramid", "trk_lm", "imm_trace", "imm_optimize", "pixsel", "dist_bfs", "dense_bbox", "dense_map", "dense_extent", "ingest". Enable, run, then query (sync inside).
  * nalo_profile_select(ctx, name) restricts the brackets to ONE scope (NULL = all): a recorded event pair costs ~10 us of pipeline bubbles on a
  * latency-bound window, so a timed run brackets only the kernel it reports ("ba_linearize" carries its timestamps in the dispatch itself).
  * ------------------------------------------------------------------------------------------------ */

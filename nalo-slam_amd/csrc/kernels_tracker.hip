@@ -140,10 +140,11 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
 }
 
 // ------------------------------------------------------------------------------------------------ a2
-// step 1 (CoarseTracker.cpp:388-405): weighted scatter. Two points on one pixel commute exactly; three or more
-// (rare) make the fp32 sum order-dependent, as in any parallel scatter.
+// step 1 (CoarseTracker.cpp:388-405): weighted scatter. Two points on one pixel commute exactly in fp32; three or more (rare) would make the sum depend on
+// the arrival order of the atomics while the reference adds them serially, in residual order. The scatter therefore also counts the hits per pixel, and
+// trk_scatter_fix_kernel redoes the pixels with >= 3 hits in ascending residual index: the result is the serial loop's, bit for bit, run to run.
 __global__ __launch_bounds__(256) void trk_scatter_kernel(const float* __restrict__ Ku, const float* __restrict__ Kv, const float* __restrict__ nid,
-                                                          const float* __restrict__ HdiF, int n, int w0, int h0, float* __restrict__ idepth, float* __restrict__ wsum) {
+                                                          const float* __restrict__ HdiF, int n, int w0, int h0, float* __restrict__ idepth, float* __restrict__ wsum, int* __restrict__ cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int u = (int)(Ku[i] + 0.5f), v = (int)(Kv[i] + 0.5f);
@@ -151,6 +152,67 @@ __global__ __launch_bounds__(256) void trk_scatter_kernel(const float* __restric
     const float weight = sqrtf((float)(1e-3 / ((double)HdiF[i] + 1e-12)));
     atomicAdd(idepth + u + w0 * v, nid[i] * weight);
     atomicAdd(wsum + u + w0 * v, weight);
+    atomicAdd(cnt + u + w0 * v, 1);
+}
+// ONE workgroup. Pass 1 lists (in ascending index: ordered ballot compaction) the residuals whose pixel took three or more hits and zeroes those pixels;
+// pass 2 adds them back one listed residual per pixel and round, always the lowest remaining index first (owner[] = LDS-free: the pixel's count word is
+// reused as the "next index allowed" gate). Usually the list is empty and the kernel is one read of the counts.
+constexpr int kScatterFixCap = 4096;
+__global__ __launch_bounds__(1024) void trk_scatter_fix_kernel(const float* __restrict__ Ku, const float* __restrict__ Kv, const float* __restrict__ nid, const float* __restrict__ HdiF,
+                                                               int n, int w0, int h0, float* __restrict__ idepth, float* __restrict__ wsum, int* __restrict__ cnt) {
+    __shared__ int list[kScatterFixCap];
+    __shared__ int wave_cnt[16];
+    __shared__ int total;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) total = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        bool hot = false;
+        if (i < n) {
+            const int u = (int)(Ku[i] + 0.5f), v = (int)(Kv[i] + 0.5f);
+            hot = !(u < 0 || v < 0 || u >= w0 || v >= h0) && cnt[u + w0 * v] >= 3;
+        }
+        const unsigned long long b = __ballot(hot);
+        if (lane == 0) wave_cnt[wv] = __popcll(b);
+        __syncthreads();
+        int off = total;
+        for (int k = 0; k < wv; ++k) off += wave_cnt[k];
+        if (hot) { const int at = off + __popcll(b & ((1ull << lane) - 1ull)); if (at < kScatterFixCap) list[at] = i; }
+        __syncthreads();
+        if (tid == 0) { int s = 0; for (int k = 0; k < 16; ++k) s += wave_cnt[k]; total += s; }
+        __syncthreads();
+    }
+    const int m = total;
+    if (m == 0 || m > kScatterFixCap) return;            // (more than 4096 colliding residuals — never seen —: the atomic sums stay)
+    for (int k = tid; k < m; k += 1024) {
+        const int i = list[k], p = (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f);
+        idepth[p] = 0.f; wsum[p] = 0.f; cnt[p] = 0x7fffffff;                                       // gate = lowest listed index of the pixel, found next
+    }
+    __syncthreads();
+    for (int k = tid; k < m; k += 1024) { const int i = list[k]; atomicMin(cnt + (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f), i); }
+    __syncthreads();
+    // rounds: a listed residual adds itself when the gate of its pixel shows its index, then passes the gate to the next listed index of that pixel
+    for (int round = 0; round < m; ++round) {
+        bool any = false;
+        for (int k = tid; k < m; k += 1024) {
+            const int i = list[k];
+            if (i < 0) continue;
+            const int p = (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f);
+            if (cnt[p] == i) {
+                const float weight = sqrtf((float)(1e-3 / ((double)HdiF[i] + 1e-12)));
+                idepth[p] += nid[i] * weight; wsum[p] += weight;
+                list[k] = -1 - i;                                                                   // done (kept negative so that the gate search can skip it)
+            } else any = true;
+        }
+        __syncthreads();
+        if (!__syncthreads_or(any)) break;
+        // next gate per pixel: the lowest not-yet-added listed index
+        for (int k = tid; k < m; k += 1024) { const int i = list[k]; if (i < 0) { const int j = -1 - i, p = (int)(Ku[j] + 0.5f) + w0 * (int)(Kv[j] + 0.5f); if (cnt[p] == j) cnt[p] = 0x7fffffff; } }
+        __syncthreads();
+        for (int k = tid; k < m; k += 1024) { const int i = list[k]; if (i >= 0) atomicMin(cnt + (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f), i); }
+        __syncthreads();
+    }
 }
 // All levels of steps 2-5 go through ONE launch per step (the per-level launches were ~30 dependent kernels of a few microseconds each).
 struct TrkLevels {
@@ -162,9 +224,9 @@ struct TrkLevels {
     int scan0[NALO_MAX_LEVELS + 1];                                               // counts/offsets base per level inside scan_tmp ([nb counts | nb+1 offsets])
     int L;
 };
-__global__ __launch_bounds__(256) void trk_zero2_kernel(float* __restrict__ a, float* __restrict__ b, int n) {
+__global__ __launch_bounds__(256) void trk_zero2_kernel(float* __restrict__ a, float* __restrict__ b, int* __restrict__ cnt, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { a[i] = 0.f; b[i] = 0.f; }
+    if (i < n) { a[i] = 0.f; b[i] = 0.f; cnt[i] = 0; }
 }
 // step 2 (:408-433): 2x2 SUM pyramid, every level from one pass over level 0. A block owns a 32x32 level-0 tile = 16x16 level-1 pixels, and
 // walks up through LDS (8x8, 4x4, 2x2, 1); each parent is a + b + c + d of its four children in the reference's order, so the values
@@ -365,8 +427,12 @@ int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const 
     dil0[L] = dil_blocks; cmp0[L] = cmp_blocks; P.scan0[L] = scan_total;
     NALO_HIP(c, c->scan_tmp.reserve((size_t)scan_total));
     const int n0 = c->wl[0] * c->hl[0];
-    trk_zero2_kernel<<<(n0 + 255) / 256, 256, 0, c->stream>>>(P.id[0], P.ws[0], n0);
-    if (n > 0) trk_scatter_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(dKu, dKv, dId, dHdi, n, c->wl[0], c->hl[0], P.id[0], P.ws[0]);
+    NALO_HIP(c, c->trk_cnt.reserve((size_t)n0));
+    trk_zero2_kernel<<<(n0 + 255) / 256, 256, 0, c->stream>>>(P.id[0], P.ws[0], c->trk_cnt.p, n0);
+    if (n > 0) {
+        trk_scatter_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(dKu, dKv, dId, dHdi, n, c->wl[0], c->hl[0], P.id[0], P.ws[0], c->trk_cnt.p);
+        trk_scatter_fix_kernel<<<1, 1024, 0, c->stream>>>(dKu, dKv, dId, dHdi, n, c->wl[0], c->hl[0], P.id[0], P.ws[0], c->trk_cnt.p);
+    }
     if (L > 1) trk_sum_down_all_kernel<<<((c->wl[1] + 15) / 16) * ((c->hl[1] + 15) / 16), 256, 0, c->stream>>>(P);
     for (int l = 0; l <= L; ++l) P.blk0[l] = dil0[l];
     trk_dilate_all_kernel<<<dil_blocks, 256, 0, c->stream>>>(P);

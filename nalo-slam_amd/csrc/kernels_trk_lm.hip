@@ -1,15 +1,14 @@
 // Device-resident CoarseTracker::trackNewestCoarse (reference src/FullSystem/CoarseTracker.cpp:1073-1259) for gfx950.
 //
-// The reference's LM loop does up to ~180 calcRes/calcGSSSE evaluations per frame with an 8x8 solve and an SE3::exp in
-// between. Driven from the host every evaluation costs a launch + a completion round trip (~25-30 us) although the kernel
-// itself runs ~10 us on a KITTI-sized point cloud: the loop is latency bound. Here ONE persistent workgroup (1024 lanes,
-// one CU) runs the whole pyramid descent: fused calcRes+calcGS over the level's points, block reduction (DPP quad adds ->
-// LDS rows -> fp64 column sums), then lane 0 plays the host: fp64 LDL^T, SE3::exp, accept/reject, lambda schedule, level
-// cutoff repeat — exactly the control flow of the host mirror in host_api.hip. One CU only has the memory parallelism for a few
-// thousand points, so this kernel takes the COARSE levels (n <= 8192: most of the iterations happen there) and hands the state
-// (pose, affine, haveRepeated) back; the host mirror continues on the fine levels with the multi-block trk_eval kernel.
-// NALO_TRK_HOST_LM=1 forces the host loop for every level. Every wave reaches every barrier: the loop state lives
-// in LDS and all branches on it are block-uniform.
+// The reference's LM loop does up to ~180 calcRes/calcGSSSE evaluations per frame with an 8x8 solve and an SE3::exp in between. Driven from the host every
+// evaluation costs a launch + a completion round trip (~19 us) although the kernels themselves run a few microseconds on a KITTI-sized point cloud: the loop
+// is latency bound. Here ONE persistent launch of up to NALO_LM_MAX_BLOCKS (64) workgroups of 256 lanes runs the whole pyramid descent, ALL levels:
+// every workgroup evaluates its share of the level's points (fused calcRes + calcGS), reduces it (DPP quad adds -> LDS rows -> fp64 column sums) and
+// publishes the partial as 8-byte {fp32 value, tag} words (agent-scope atomics: the data is the arrival flag, double-buffered by evaluation parity, bounded
+// poll); then EVERY workgroup sums the partials in a fixed order and replays the control flow on its wave 0: 8x8 LDL^T with one matrix row per lane and
+// v_readlane broadcasts, SE3::exp, accept / reject, lambda schedule, cutoff repeat, level descent - exactly the control flow of the host mirror in
+// host_api.hip (NALO_TRK_HOST_LM=1 selects that one, and so do the fixed-affine settings). The workgroups must be co-resident (no cooperative launch is
+// used: 64 workgroups of 256 lanes fit 256 CUs by a wide margin; a violation ends in the bounded poll's error, not in a hang).
 #include "nalo_internal.h"
 #include "reduce.h"
 

@@ -85,6 +85,7 @@ struct nalo_ctx {
     nalo::DevBuf<unsigned long long> lm_partial;   // persistent LM kernel: [2][blocks][64] block partials {fp32, tag}
     unsigned long long lm_launches = 0;
     nalo::DevBuf<int> scan_tmp;              // compaction counts
+    nalo::DevBuf<int> trk_cnt;               // hits per level-0 pixel of the reference scatter (ordered redo of pixels with >= 3 hits)
     nalo::DevBuf<float> upload_tmp;
     float* pinned_f = nullptr; size_t pinned_f_cap = 0;
     float* imm_host = nullptr; nalo::DevBuf<float> imm_dev; size_t imm_cap = 0;   // immature-point staging (pinned / device)

@@ -52,6 +52,35 @@ def test_coarse_depth_and_point_clouds(ctx, small_window):
         assert rel_err(ib, ia) < 1e-6 and rel_err(wb, wa) < 1e-6
 
 
+def test_scatter_collisions_are_summed_in_residual_order(ctx, small_window):
+    """a2 step 1 with MANY residuals on the same pixels (3 .. 40 hits): the reference adds them serially in residual order; the device redoes every pixel with
+    >= 3 hits in ascending index (trk_scatter_fix_kernel), so level 0's idepth / weightSums equal the oracle's BIT FOR BIT and repeat exactly"""
+    win = small_window
+    rng = np.random.RandomState(9)
+    Ku, Kv, nid, hdi = tracker_inputs(win, n=2000, seed=3)
+    hot_u, hot_v = rng.randint(20, win.w - 20, 60), rng.randint(20, win.h - 20, 60)
+    reps = rng.randint(3, 41, 60)
+    eu = np.concatenate([np.full(r, u) + rng.uniform(-0.45, 0.45, r) for u, r in zip(hot_u, reps)]).astype(np.float32)
+    ev = np.concatenate([np.full(r, v) + rng.uniform(-0.45, 0.45, r) for v, r in zip(hot_v, reps)]).astype(np.float32)
+    en = (10.0 ** rng.uniform(-2.5, 0.5, len(eu))).astype(np.float32)            # inverse depths over three decades: the order of the fp32 adds matters
+    eh = (10.0 ** rng.uniform(-7, -2, len(eu))).astype(np.float32)
+    perm = rng.permutation(len(Ku) + len(eu))
+    Ku, Kv, nid, hdi = [np.concatenate([a, b])[perm] for a, b in ((Ku, eu), (Kv, ev), (nid, en), (hdi, eh))]
+    trk = orc.Tracker(win.w, win.h, win.levels, win.K)
+    dI_ref, _ = orc.make_images(win.images[win.W - 1], win.levels)
+    trk.set_ref(dI_ref, Ku, Kv, nid, hdi)
+    ia, wa = trk.get_depth(0)
+    runs = []
+    for _ in range(3):
+        ctx.trk_set_ref(win.W - 1, Ku, Kv, nid, hdi)
+        runs.append(ctx.trk_get_depth(0))
+    for ib, wb in runs:
+        assert np.array_equal(ib, ia) and np.array_equal(wb, wa)
+    for l in range(win.levels):
+        a, b = trk.get_pc(l), ctx.trk_get_pc(l)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and rel_err(b[2], a[2]) < 1e-6
+
+
 @pytest.mark.parametrize("lvl", [0, 1, 3])
 def test_fused_eval_matches_oracle(ctx, small_window, lvl):
     """a3+a4: stats6, H (8x8), b (8). fp32 pointwise, fp32 block partials, fp64 finish vs the fp64-sum oracle:
