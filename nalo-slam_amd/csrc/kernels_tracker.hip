@@ -187,7 +187,9 @@ __global__ __launch_bounds__(1024) void trk_scatter_fix_kernel(const float* __re
     if (m == 0 || m > kScatterFixCap) return;            // (more than 4096 colliding residuals — never seen —: the atomic sums stay)
     for (int k = tid; k < m; k += 1024) {
         const int i = list[k], p = (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f);
-        idepth[p] = 0.f; wsum[p] = 0.f; cnt[p] = 0x7fffffff;                                       // gate = lowest listed index of the pixel, found next
+        // every access to the pixel's words below goes to L2 (atomics / agent-scope loads): the atomics of the scatter and of the gate bypass this CU's L1,
+        // a plain load could return a stale line
+        atomicExch(idepth + p, 0.f); atomicExch(wsum + p, 0.f); atomicExch(cnt + p, 0x7fffffff);       // gate = lowest listed index of the pixel, found next
     }
     __syncthreads();
     for (int k = tid; k < m; k += 1024) { const int i = list[k]; atomicMin(cnt + (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f), i); }
@@ -199,16 +201,16 @@ __global__ __launch_bounds__(1024) void trk_scatter_fix_kernel(const float* __re
             const int i = list[k];
             if (i < 0) continue;
             const int p = (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f);
-            if (cnt[p] == i) {
+            if (__hip_atomic_load(cnt + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == i) {
                 const float weight = sqrtf((float)(1e-3 / ((double)HdiF[i] + 1e-12)));
-                idepth[p] += nid[i] * weight; wsum[p] += weight;
+                atomicAdd(idepth + p, __fmul_rn(nid[i], weight)); atomicAdd(wsum + p, weight);         // one adder per pixel and round: the order is the index order
                 list[k] = -1 - i;                                                                   // done (kept negative so that the gate search can skip it)
             } else any = true;
         }
         __syncthreads();
         if (!__syncthreads_or(any)) break;
         // next gate per pixel: the lowest not-yet-added listed index
-        for (int k = tid; k < m; k += 1024) { const int i = list[k]; if (i < 0) { const int j = -1 - i, p = (int)(Ku[j] + 0.5f) + w0 * (int)(Kv[j] + 0.5f); if (cnt[p] == j) cnt[p] = 0x7fffffff; } }
+        for (int k = tid; k < m; k += 1024) { const int i = list[k]; if (i < 0) { const int j = -1 - i, p = (int)(Ku[j] + 0.5f) + w0 * (int)(Kv[j] + 0.5f); atomicCAS(cnt + p, j, 0x7fffffff); } }
         __syncthreads();
         for (int k = tid; k < m; k += 1024) { const int i = list[k]; if (i >= 0) atomicMin(cnt + (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f), i); }
         __syncthreads();
