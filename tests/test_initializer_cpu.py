@@ -124,3 +124,35 @@ def test_oracle_initializer_sensitivity():
     d = [np.linalg.norm(orc.se3_log(synth.se3_mul(a, synth.se3_inv(b)))) for a, b in zip(base, pert)]
     assert d[0] < 1e-5                 # the first frame is still tame
     assert max(d[1:]) > 3e-5           # later frames amplify a 1-ulp perturbation beyond the BA's 1e-5 pose bar
+
+
+def _golden_nanoflann():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_nanoflann_r02.npz"))
+
+
+def test_oracle_kdtree_against_reference_generated_fixture():
+    """tests/golden/golden_nanoflann_r02.npz holds outputs of the REFERENCE's nanoflann.h (tests/golden/make_golden_nanoflann.py): needs neither
+    /root/reference nor oracle/_ref at run time, so it also pins the oracle on the GPU box"""
+    g = _golden_nanoflann()
+    L = int(g["levels"])
+    for l in range(L):
+        u, v = g["u%d" % l], g["v%d" % l]
+        idx, dist = orc.kdtree_knn(u, v, u, v, 10)
+        assert np.array_equal(idx, g["nn_idx%d" % l]) and np.array_equal(dist, g["nn_dist%d" % l])
+        if l + 1 < L:
+            pi, pd = orc.kdtree_knn(g["u%d" % (l + 1)], g["v%d" % (l + 1)], u * np.float32(0.5) - np.float32(0.25), v * np.float32(0.5) - np.float32(0.25), 1)
+            assert np.array_equal(pi[:, 0], g["parent_idx%d" % l]) and np.array_equal(pd[:, 0], g["parent_dist%d" % l])
+    # and the oracle's setFirst reproduces the fixture's point sets and turns those distances into its neighbour weights
+    win = synth.make_window(w=320, h=240, W=2, P=20, seed=3, n_extra=0)
+    rp, _ = orc.pixsel_libc_tables(win.w * win.h)
+    ini = orc.Initializer(win.w, win.h, win.levels, win.K)
+    ini.set_first(win.images[0], rp)
+    for l in range(L):
+        assert np.array_equal(ini.get(l, "u"), g["u%d" % l]) and np.array_equal(ini.get(l, "v"), g["v%d" % l])
+        assert np.array_equal(ini.get(l, "neighbours"), g["nn_idx%d" % l])
+        df = np.exp(-g["nn_dist%d" % l] * np.float32(0.05)).astype(np.float32)
+        w = ini.get(l, "neighboursDist")
+        assert np.allclose(w, df * (10.0 / df.sum(1, keepdims=True)), rtol=2e-6)
+        if l + 1 < L:
+            assert np.array_equal(ini.get(l, "parent"), g["parent_idx%d" % l])
