@@ -46,6 +46,15 @@ int nalo_io_read_pcalib(const char* path, int cap, float* G, int* n);
  * any stays zero. cap = capacity of both arrays. */
 int nalo_io_read_times(const char* path, int n_images, int cap, double* stamps, float* exposures, int* n_stamps, int* n_exposures);
 
+/* Rectification -- the part of Undistort::readFromFile that follows the parse (util/Undistort.cpp:911-1005) with makeOptimalK_crop (:637-757) and the five
+ * distortCoordinates models (:1018-1292: FOV, RadTan, EquiDistant, KannalaBrandt, Pinhole): from a parsed camera.txt to the rectified camera matrix
+ * K_out = {fx, fy, cx, cy} and the per-pixel lookup remapX / remapY [w*h] (position in the original image, -1 = outside) that Undistort::undistort and
+ * nalo_undist_set consume. rect_mode crop: the largest axis-aligned normalised rectangle whose border stays inside the original image (the reference's
+ * 0.995 shrink iteration, <= 500 rounds); explicit: K = out_calib scaled by w, h (-0.5 on the centre); none: K = parsOrg, *passthrough = 1 (no table is needed;
+ * remap is still filled). full (makeOptimalK_full) is an assert(false) in the reference: NALO_IO_ERR_FORMAT. The reference's two slips in the border
+ * clean-up are kept (`if(iy == hOrg-1) ix = hOrg-1.001` and the `iy < wOrg-1` test, :981-984). */
+int nalo_io_make_rectification(const nalo_camera_file* cam, double K_out[4], float* remapX, float* remapY, int* passthrough);
+
 /* PNG images -- the reference reads them through cv::imread (IOWrapper/OpenCV/ImageRW_OpenCV.cpp:33-53, 88-175): a self-contained decoder on zlib's
  * inflate (non-interlaced files; grey / grey+alpha / RGB / RGBA / palette; 1-16 bits), returning what the reference's wrappers return:
  *   NALO_PNG_GRAY8     readImageBW_8U / readMask_8U  (cv::IMREAD_GRAYSCALE): 8-bit grey; 16-bit samples keep their high byte (png_set_strip_16), colour goes

@@ -293,4 +293,118 @@ int nalo_io_resize_nearest_u8(const uint8_t* src, int wOrg, int hOrg, int channe
     return NALO_IO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ rectification tables
+namespace {
+struct Rectifier {
+    int model; float p[8]; double K[4];                       // parsOrg as floats (VecX parsOrg holds doubles; every model casts to float first), K = fx fy cx cy
+    void distort(const float* in_x, const float* in_y, float* out_x, float* out_y, int n) const {
+        const float fx = p[0], fy = p[1], cx = p[2], cy = p[3];
+        const float ofx = (float)K[0], ofy = (float)K[1], ocx = (float)K[2], ocy = (float)K[3];
+        for (int i = 0; i < n; ++i) {
+            float ix = (in_x[i] - ocx) / ofx, iy = (in_y[i] - ocy) / ofy;
+            switch (model) {
+            case NALO_CAM_FOV: {                                                                 // Undistort.cpp:1018-1055
+                const float dist = p[4], d2t = 2.0f * tan(dist / 2.0f);
+                const float r = sqrtf(ix * ix + iy * iy);
+                const float fac = (r == 0 || dist == 0) ? 1 : atanf(r * d2t) / (dist * r);
+                out_x[i] = fx * fac * ix + cx; out_y[i] = fy * fac * iy + cy;
+            } break;
+            case NALO_CAM_RADTAN: {                                                              // :1074-1116 (2.0 literals: double intermediate)
+                const float k1 = p[4], k2 = p[5], r1 = p[6], r2 = p[7];
+                const float mx2 = ix * ix, my2 = iy * iy, mxy = ix * iy, rho2 = mx2 + my2;
+                const float rad = k1 * rho2 + k2 * rho2 * rho2;
+                const float xd = ix + ix * rad + 2.0 * r1 * mxy + r2 * (rho2 + 2.0 * mx2);
+                const float yd = iy + iy * rad + 2.0 * r2 * mxy + r1 * (rho2 + 2.0 * my2);
+                out_x[i] = fx * xd + cx; out_y[i] = fy * yd + cy;
+            } break;
+            case NALO_CAM_EQUIDISTANT: {                                                         // :1134-1176 (sqrt / atan: double functions of float arguments)
+                const float k1 = p[4], k2 = p[5], k3 = p[6], k4 = p[7];
+                const float r = sqrt(ix * ix + iy * iy);
+                const float theta = atan(r), t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+                const float thetad = theta * (1 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8);
+                const float scaling = (r > 1e-8) ? thetad / r : 1.0;
+                out_x[i] = fx * ix * scaling + cx; out_y[i] = fy * iy * scaling + cy;
+            } break;
+            case NALO_CAM_KANNALABRANDT: {                                                       // :1193-1240
+                const float k0 = p[4], k1 = p[5], k2 = p[6], k3 = p[7];
+                const float ss = ix * ix + iy * iy, sq = sqrtf(ss);
+                const float theta = atan2f(sq, 1), t2 = theta * theta, t3 = t2 * theta, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+                const float r = theta + k0 * t3 + k1 * t5 + k2 * t7 + k3 * t9;
+                if (sq < 1e-6) { out_x[i] = fx * ix + cx; out_y[i] = fy * iy + cy; }
+                else { out_x[i] = (r / sq) * fx * ix + cx; out_y[i] = (r / sq) * fy * iy + cy; }
+            } break;
+            default:                                                                             // Pinhole :1258-1283
+                out_x[i] = fx * ix + cx; out_y[i] = fy * iy + cy;
+            }
+        }
+    }
+};
+}  // namespace
+
+int nalo_io_make_rectification(const nalo_camera_file* cam, double K_out[4], float* remapX, float* remapY, int* passthrough) {
+    if (!cam || !K_out || !remapX || !remapY || cam->w <= 1 || cam->h <= 1 || cam->w_org <= 1 || cam->h_org <= 1) return NALO_IO_ERR_ARG;
+    Rectifier R; R.model = cam->model;
+    for (int i = 0; i < 8; ++i) R.p[i] = (float)cam->pars[i];
+    const int w = cam->w, h = cam->h, wOrg = cam->w_org, hOrg = cam->h_org;
+    int pass = 0;
+    if (cam->rect_mode == -1) {                                                                    // makeOptimalK_crop (:637-757)
+        R.K[0] = R.K[1] = 1; R.K[2] = R.K[3] = 0;                                                  // K.setIdentity()
+        std::vector<float> tgX(100000), tgY(100000);
+        float minX = 0, maxX = 0, minY = 0, maxY = 0;
+        for (int x = 0; x < 100000; ++x) { tgX[x] = (x - 50000.0f) / 10000.0f; tgY[x] = 0; }
+        R.distort(tgX.data(), tgY.data(), tgX.data(), tgY.data(), 100000);
+        for (int x = 0; x < 100000; ++x) if (tgX[x] > 0 && tgX[x] < wOrg - 1) { if (minX == 0) minX = (x - 50000.0f) / 10000.0f; maxX = (x - 50000.0f) / 10000.0f; }
+        for (int y = 0; y < 100000; ++y) { tgY[y] = (y - 50000.0f) / 10000.0f; tgX[y] = 0; }
+        R.distort(tgX.data(), tgY.data(), tgX.data(), tgY.data(), 100000);
+        for (int y = 0; y < 100000; ++y) if (tgY[y] > 0 && tgY[y] < hOrg - 1) { if (minY == 0) minY = (y - 50000.0f) / 10000.0f; maxY = (y - 50000.0f) / 10000.0f; }
+        minX *= 1.01; maxX *= 1.01; minY *= 1.01; maxY *= 1.01;
+        bool oobLeft = true, oobRight = true, oobTop = true, oobBottom = true;
+        int iteration = 0;
+        while (oobLeft || oobRight || oobTop || oobBottom) {
+            oobLeft = oobRight = oobTop = oobBottom = false;
+            for (int y = 0; y < h; ++y) { remapX[y * 2] = minX; remapX[y * 2 + 1] = maxX; remapY[y * 2] = remapY[y * 2 + 1] = minY + (maxY - minY) * (float)y / ((float)h - 1.0f); }
+            R.distort(remapX, remapY, remapX, remapY, 2 * h);
+            for (int y = 0; y < h; ++y) {
+                if (!(remapX[2 * y] > 0 && remapX[2 * y] < wOrg - 1)) oobLeft = true;
+                if (!(remapX[2 * y + 1] > 0 && remapX[2 * y + 1] < wOrg - 1)) oobRight = true;
+            }
+            for (int x = 0; x < w; ++x) { remapY[x * 2] = minY; remapY[x * 2 + 1] = maxY; remapX[x * 2] = remapX[x * 2 + 1] = minX + (maxX - minX) * (float)x / ((float)w - 1.0f); }
+            R.distort(remapX, remapY, remapX, remapY, 2 * w);
+            for (int x = 0; x < w; ++x) {
+                if (!(remapY[2 * x] > 0 && remapY[2 * x] < hOrg - 1)) oobTop = true;
+                if (!(remapY[2 * x + 1] > 0 && remapY[2 * x + 1] < hOrg - 1)) oobBottom = true;
+            }
+            if ((oobLeft || oobRight) && (oobTop || oobBottom)) { if ((maxX - minX) > (maxY - minY)) oobBottom = oobTop = false; else oobLeft = oobRight = false; }
+            if (oobLeft) minX *= 0.995;
+            if (oobRight) maxX *= 0.995;
+            if (oobTop) minY *= 0.995;
+            if (oobBottom) maxY *= 0.995;
+            if (++iteration > 500) return NALO_IO_ERR_FORMAT;                                     // the reference exit(1)s here
+        }
+        R.K[0] = ((float)w - 1.0f) / (maxX - minX); R.K[1] = ((float)h - 1.0f) / (maxY - minY);
+        R.K[2] = -minX * R.K[0]; R.K[3] = -minY * R.K[1];
+    } else if (cam->rect_mode == -2) return NALO_IO_ERR_FORMAT;                                   // makeOptimalK_full: assert(false)
+    else if (cam->rect_mode == -3) {
+        if (w != wOrg || h != hOrg) return NALO_IO_ERR_FORMAT;
+        for (int i = 0; i < 4; ++i) R.K[i] = cam->pars[i];
+        pass = 1;
+    } else {
+        R.K[0] = cam->out_calib[0] * w; R.K[1] = cam->out_calib[1] * h; R.K[2] = cam->out_calib[2] * w - 0.5; R.K[3] = cam->out_calib[3] * h - 0.5;
+    }
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) { remapX[x + y * w] = x; remapY[x + y * w] = y; }
+    R.distort(remapX, remapY, remapX, remapY, h * w);
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {                                     // "make rounding resistant" (:972-996), slips included
+        float ix = remapX[x + y * w], iy = remapY[x + y * w];
+        if (ix == 0) ix = 0.001;
+        if (iy == 0) iy = 0.001;
+        if (ix == wOrg - 1) ix = wOrg - 1.001;
+        if (iy == hOrg - 1) ix = hOrg - 1.001;
+        if (ix > 0 && iy > 0 && ix < wOrg - 1 && iy < wOrg - 1) { remapX[x + y * w] = ix; remapY[x + y * w] = iy; }
+        else { remapX[x + y * w] = -1; remapY[x + y * w] = -1; }
+    }
+    for (int i = 0; i < 4; ++i) K_out[i] = R.K[i];
+    if (passthrough) *passthrough = pass;
+    return NALO_IO_OK;
+}
+
 }  // extern "C"

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert sorted(set(binding.EXPORTS)) == [s for s in syms if s in binding.EXPORTS]
     assert set(binding.EXPORTS) == set(syms)
     io_syms = declared_symbols("nalo_io.h")
-    assert len(io_syms) == 9 and not [s for s in io_syms if not hasattr(lib, s)]
+    assert len(io_syms) == 10 and not [s for s in io_syms if not hasattr(lib, s)]
 
 
 def test_no_cpu_fallback():

@@ -243,3 +243,59 @@ def test_vignette_and_nearest_resize(lib):
             # closed form: source index = floor(x * wo / w) clipped
             sx = np.minimum(np.floor(np.arange(w) * (1.0 / (w / wo))).astype(int), wo - 1); sy = np.minimum(np.floor(np.arange(h) * (1.0 / (h / ho))).astype(int), ho - 1)
             assert np.array_equal(dst, src[sy][:, sx])
+
+
+def _rectify(lib, cf):
+    K = np.zeros(4); rx = np.zeros((cf.h, cf.w), np.float32); ry = np.zeros((cf.h, cf.w), np.float32); pt = C.c_int(0)
+    lib.nalo_io_make_rectification.argtypes = [C.POINTER(CameraFile), C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    rc = lib.nalo_io_make_rectification(C.byref(cf), dp(K), fpp(rx), fpp(ry), C.byref(pt))
+    return rc, K, rx, ry, pt.value
+
+
+def _rectify_oracle(cf):
+    import orc
+    L = orc.lib()
+    K = np.zeros(4); rx = np.zeros((cf.h, cf.w), np.float32); ry = np.zeros((cf.h, cf.w), np.float32); pt = np.zeros(1, np.int32)
+    L.orc_make_rectification.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    pars = np.array(list(cf.pars)); oc = np.array(list(cf.out_calib), np.float32)
+    rc = L.orc_make_rectification(cf.model, dp(pars), cf.w_org, cf.h_org, cf.w, cf.h, cf.rect_mode, fpp(oc), dp(K), fpp(rx), fpp(ry), pt.ctypes.data_as(C.POINTER(C.c_int)))
+    return rc, K, rx, ry, int(pt[0])
+
+
+def test_rectification_tables_all_models(lib, tmp_path):
+    """camera.txt -> K and remapX / remapY (Undistort::readFromFile + makeOptimalK_crop + distortCoordinates, util/Undistort.cpp:637-757, 911-1292): the product's
+    host code against the oracle's restatement (EQUAL: same float operations), plus properties that do not depend on either: a pinhole crop is an affine map
+    whose corners land inside the original image, and a distortion model maps the rectified principal point onto the original one."""
+    cases = {
+        "kitti": "Pinhole 0.5812 1.9225 0.4964 0.4689 0\n1241 376\ncrop\n1224 368\n",
+        "radtan": "RadTan 458.654 457.296 367.215 248.375 -0.28340811 0.07395907 0.00019359 1.76187114e-05\n752 480\ncrop\n640 480\n",
+        "fov": "0.535719308086809 0.669566858850269 0.493248545285398 0.500408664348414 0.897966326944875\n1280 1024\n0.4 0.53 0.5 0.5 0\n640 480\n",
+        "kb": "KannalaBrandt 380.8 380.9 320.1 239.9 -0.01 0.02 -0.03 0.004\n640 480\nnone\n640 480\n",
+        "equi": "EquiDistant 190.9 190.9 254.9 256.8 0.003 0.0007 -0.002 0.0002\n512 512\ncrop\n480 480\n",
+    }
+    for name, txt in cases.items():
+        p = tmp_path / (name + ".txt"); p.write_text(txt)
+        cf = CameraFile(); assert lib.nalo_io_read_camera(str(p).encode(), C.byref(cf)) == 0
+        rc, K, rx, ry, pt = _rectify(lib, cf)
+        rc_o, K_o, rx_o, ry_o, pt_o = _rectify_oracle(cf)
+        assert rc == 0 and rc_o == 0 and pt == pt_o == (1 if name == "kb" else 0), name
+        assert np.array_equal(K, K_o) and np.array_equal(rx, rx_o) and np.array_equal(ry, ry_o), name
+        inside = rx >= 0
+        assert inside.mean() > 0.9, name                  # (the explicit FOV calibration leaves its corners outside the original image)
+        assert (rx[inside] < cf.w_org - 1).all() and (ry[inside] > 0).all()
+        if name == "kitti":                       # pinhole: remap = original intrinsics applied to the rectified rays: affine in (x, y)
+            fx, fy, cx, cy = list(cf.pars)[:4]
+            yy, xx = np.mgrid[0:cf.h, 0:cf.w]
+            assert np.allclose(rx, fx * (xx - K[2]) / K[0] + cx, atol=2e-3) and np.allclose(ry, fy * (yy - K[3]) / K[1] + cy, atol=2e-3)
+            assert 0 < rx[0, 0] < 20 and cf.w_org - 21 < rx[0, -1] < cf.w_org - 1          # the crop keeps (almost) the whole width
+        else:                                     # the rectified principal point looks along the optical axis: it maps to the original principal point
+            x0, y0 = int(round(K[2])), int(round(K[3]))
+            assert abs(rx[y0, x0] - cf.pars[2]) < 1.5 * abs(cf.pars[0] / K[0]) + 1e-3 and abs(ry[y0, x0] - cf.pars[3]) < 1.5 * abs(cf.pars[1] / K[1]) + 1e-3
+    # the modes the reference refuses
+    (tmp_path / "full.txt").write_text("EquiDistant 190.9 190.9 254.9 256.8 0.003 0.0007 -0.002 0.0002\n512 512\nfull\n512 512\n")
+    cf = CameraFile(); lib.nalo_io_read_camera(str(tmp_path / "full.txt").encode(), C.byref(cf))
+    assert _rectify(lib, cf)[0] == -3
+    (tmp_path / "none_resized.txt").write_text("Pinhole 500 500 320 240 0\n640 480\nnone\n320 240\n")
+    cf = CameraFile(); lib.nalo_io_read_camera(str(tmp_path / "none_resized.txt").encode(), C.byref(cf))
+    assert _rectify(lib, cf)[0] == -3
