@@ -96,6 +96,17 @@ class GpuJob:
         self.last_T = [None] * TRACKED_PER_KF                           # tracked poses of the last step (pose_delta_vs_oracle)
         self._pinned = None
 
+    def enable_raw_uploads(self):
+        """page-locked 8-bit copies of the tracked frames + an identity response (photometricCalibration 1, passthrough geometry): step(upload="raw") then
+        feeds the SENSOR format through nalo_frame_upload_raw_async — 1 B/px over PCIe, photometric undistortion fused in front of the pyramid"""
+        W = self.win.W
+        self.ctx.undist_set(self.win.w, self.win.h, np.arange(256, dtype=np.float32), None, 1, None, None)
+        self._pinned_raw = []
+        for k in range(TRACKED_PER_KF):
+            a = self.ctx.pinned_array((self.win.h, self.win.w), np.uint8)
+            a[:] = np.clip(np.rint(self.win.images[W + k]), 0, 255).astype(np.uint8)
+            self._pinned_raw.append(a)
+
     def enable_uploads(self):
         """page-locked copies of the tracked frames: step(upload=True) then pays the per-frame PCIe copy through nalo_frame_upload_async (what a running
         system does per frame, FullSystem.cpp:1053-1065) instead of rebuilding the pyramid from HBM-resident irradiance"""
@@ -126,7 +137,10 @@ class GpuJob:
             self._prepare_calls()
         c.ba_restore()
         if track:
-            if upload:                                                       # all three copies go to the copy stream at once: the first one is exposed,
+            if upload == "raw":
+                for k in range(TRACKED_PER_KF):
+                    c.frame_upload_raw_async(W + k, self._pinned_raw[k], exposure=1.0)
+            elif upload:                                                     # all three copies go to the copy stream at once: the first one is exposed,
                 for k in range(TRACKED_PER_KF):                              # the others run under the tracking of the frame before
                     c.frame_upload_async(W + k, self._pinned[k])
             for k in range(TRACKED_PER_KF):
@@ -386,6 +400,23 @@ def main():
             out["with_frame_uploads"] = dict(value=round(1.0 / dtu, 3), unit="keyframes/s", ms_per_step=round(dtu * 1e3, 4), steps=nup,
                                             note="same step, but the %d tracked frames arrive through nalo_frame_upload_async from pinned host memory "
                                                  "(%.2f MB each over PCIe, copy stream overlapped with tracking) instead of HBM-resident irradiance" % (TRACKED_PER_KF, win.w * win.h * 4 / 1e6))
+            try:
+                job.enable_raw_uploads()
+                for _ in range(2):
+                    job.step(True, upload="raw")
+                job.ctx.sync()
+                t1 = time.perf_counter()
+                for _ in range(nup):
+                    job.step(True, upload="raw")
+                job.ctx.sync()
+                dtr = (time.perf_counter() - t1) / nup
+                out["with_raw_frame_uploads"] = dict(value=round(1.0 / dtr, 3), unit="keyframes/s", ms_per_step=round(dtr * 1e3, 4), steps=nup,
+                                                    note="same step, the %d tracked frames arrive as 8-bit sensor frames through nalo_frame_upload_raw_async (%.2f MB each over PCIe, "
+                                                         "photometric undistortion on the device in front of makeImages; the frames are the 8-bit roundings of the synthetic images)" % (TRACKED_PER_KF, win.w * win.h / 1e6))
+                for k in range(TRACKED_PER_KF):                              # back to the float frames for the legs below
+                    job.ctx.frame_upload(win.W + k, win.images[win.W + k])
+            except Exception as e:
+                out["with_raw_frame_uploads"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             info = cpu_info()
             out["cpu_baseline"] = cpu_baseline(win, st6, trk, track=do_track)

@@ -104,6 +104,9 @@ int nalo_undist_set(nalo_ctx* ctx, int wOrg, int hOrg, const float* G, int GDept
                     const float* remapY);
 int nalo_frame_upload_raw(nalo_ctx* ctx, int slot, const void* raw, int bytes_per_px, float exposure_time, float factor, const uint8_t* mask_org, const uint8_t* bgr_org,
                           const float* gammaB);
+/* asynchronous form for tracked (non-key) frames, as nalo_frame_upload_async: the raw copy runs on the copy stream, ingest + pyramid are queued behind it; returns
+ * at once, raw must stay untouched until nalo_frame_wait(ctx, slot) (pinned memory: nalo_host_alloc). No mask / colour (keyframe inputs). */
+int nalo_frame_upload_raw_async(nalo_ctx* ctx, int slot, const void* raw, int bytes_per_px, float exposure_time, float factor, const float* gammaB);
 void* nalo_host_alloc(size_t bytes);
 void nalo_host_free(void* p);
 /* makeImages again from the level-0 irradiance already resident in the slot (asynchronous on the ctx stream): the

@@ -26,7 +26,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 
 EXPORTS = [
     "nalo_create", "nalo_destroy", "nalo_last_error", "nalo_levels", "nalo_sync", "nalo_stream",
-    "nalo_frame_upload", "nalo_frame_upload_raw", "nalo_undist_set", "nalo_frame_upload_async", "nalo_frame_wait", "nalo_host_alloc", "nalo_host_free", "nalo_frame_rebuild", "nalo_frame_download",
+    "nalo_frame_upload", "nalo_frame_upload_raw", "nalo_frame_upload_raw_async", "nalo_undist_set", "nalo_frame_upload_async", "nalo_frame_wait", "nalo_host_alloc", "nalo_host_free", "nalo_frame_rebuild", "nalo_frame_download",
     "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_append_plane_points", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
@@ -117,6 +117,7 @@ def load():
     L.nalo_trk_append_plane_points.argtypes = [vp, c_fp, C.c_float, C.c_int, c_ip, c_ip]
     L.nalo_undist_set.argtypes = [vp, C.c_int, C.c_int, c_fp, C.c_int, c_fp, C.c_int, c_fp, c_fp]
     L.nalo_frame_upload_raw.argtypes = [vp, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, c_u8p, c_u8p, c_fp]
+    L.nalo_frame_upload_raw_async.argtypes = [vp, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, c_fp]
     L.nalo_ba_get_idepth_zero.argtypes = [vp, c_fp]
     L.nalo_ba_calc_l_energy.argtypes = [vp, c_dp]
     L.nalo_ba_plane_scale_fix.argtypes = [vp, C.c_double, c_dp, c_dp]
@@ -505,6 +506,11 @@ class Context:
         g = None if gammaB is None else np.ascontiguousarray(gammaB, np.float32)
         self._ck(self.L.nalo_frame_upload_raw(self.h_, slot, raw.ctypes.data_as(C.c_void_p), raw.dtype.itemsize, C.c_float(exposure), C.c_float(factor),
                                               None if m is None else _u8(m), None if b is None else _u8(b), None if g is None else _f(g)))
+
+    def frame_upload_raw_async(self, slot, raw, exposure=1.0, factor=1.0):
+        """raw: a contiguous uint8 / uint16 array that stays alive and untouched until frame_wait(slot) (pinned: pinned_array(..., dtype))"""
+        assert raw.flags.c_contiguous and raw.dtype in (np.uint8, np.uint16)
+        self._ck(self.L.nalo_frame_upload_raw_async(self.h_, slot, raw.ctypes.data_as(C.c_void_p), raw.dtype.itemsize, C.c_float(exposure), C.c_float(factor), None))
 
     def set_settings(self, force_accept_step=None, affine_opt_mode_a=None, affine_opt_mode_b=None, min_opt_iterations=None):
         st = Settings()

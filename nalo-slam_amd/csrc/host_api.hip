@@ -66,6 +66,7 @@ void nalo_destroy(nalo_ctx* c) {
         for (int l = 0; l < NALO_MAX_LEVELS; ++l) { if (s.I[l]) (void)hipFree(s.I[l]); if (s.dI[l]) (void)hipFree(s.dI[l]); if (s.absg[l]) (void)hipFree(s.absg[l]); }
         if (s.mask) (void)hipFree(s.mask);
         if (s.bgr) (void)hipFree(s.bgr);
+        if (s.raw) (void)hipFree(s.raw);
     }
     for (int l = 0; l < NALO_MAX_LEVELS; ++l) {
         c->trk_idepth[l].release(); c->trk_wsum[l].release(); c->trk_wbak[l].release();
@@ -188,6 +189,40 @@ int nalo_frame_upload_raw(nalo_ctx* c, int slot, const void* raw, int bytes_per_
     if (rc) return rc;
     pixsel_invalidate_hists(c, slot);
     NALO_HIP(c, hipStreamSynchronize(c->stream));
+    s.valid = true;
+    return NALO_OK;
+}
+
+// The per-frame entry of a running pipeline for SENSOR frames: the 1-2 B/px raw image is copied on the copy stream (under the tracking of the previous frame),
+// the ingest + pyramid kernels are queued on the main stream behind the copy's event. raw must stay untouched until nalo_frame_wait (pinned memory for a truly
+// asynchronous copy). Mask / colour are not taken here (keyframe-only inputs: use nalo_frame_upload_raw for those frames).
+int nalo_frame_upload_raw_async(nalo_ctx* c, int slot, const void* raw, int bytes_per_px, float exposure_time, float factor, const float* gammaB) {
+    if (!c || !raw || slot < 0 || slot >= (int)c->slots.size() || (bytes_per_px != 1 && bytes_per_px != 2)) return fail(c, NALO_ERR_ARG, "nalo_frame_upload_raw_async: bad argument");
+    if (!c->und_set) return fail(c, NALO_ERR_STATE, "nalo_frame_upload_raw_async: nalo_undist_set has not run");
+    NALO_HIP(c, hipSetDevice(c->device));
+    FrameSlot& s = c->slots[slot];
+    const size_t no = (size_t)c->und_wOrg * c->und_hOrg;
+    int photometric = c->und_photometric;
+    if (exposure_time <= 0) photometric = 0;
+    if (photometric > 0 && bytes_per_px == 2 && c->und_GDepth < 65536) return fail(c, NALO_ERR_ARG, "nalo_frame_upload_raw_async: 16-bit frames index G beyond its depth");
+    if (!c->copy) { NALO_HIP(c, hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking)); NALO_HIP(c, hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming)); }
+    if (!s.ev_up) NALO_HIP(c, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+    if (s.raw_cap < no * 2) { if (s.raw) { NALO_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(s.raw); } s.raw = nullptr; s.raw_cap = 0; NALO_HIP(c, hipMalloc((void**)&s.raw, no * 2)); s.raw_cap = no * 2; }
+    if (gammaB && !c->gamma_dev) NALO_HIP(c, hipMalloc((void**)&c->gamma_dev, 256 * 4));
+    if (s.valid) {                                                   // kernels already queued on the main stream may still read this slot (incl. its raw buffer)
+        NALO_HIP(c, hipEventRecord(c->ev_main, c->stream));
+        NALO_HIP(c, hipStreamWaitEvent(c->copy, c->ev_main, 0));
+    }
+    NALO_HIP(c, hipMemcpyAsync(s.raw, raw, no * bytes_per_px, hipMemcpyHostToDevice, c->copy));
+    if (gammaB) NALO_HIP(c, hipMemcpyAsync(c->gamma_dev, gammaB, 256 * 4, hipMemcpyHostToDevice, c->copy));
+    NALO_HIP(c, hipEventRecord(s.ev_up, c->copy));
+    NALO_HIP(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
+    int rc = ingest_launch(c, c->stream, s.raw, bytes_per_px, c->und_wOrg, c->und_hOrg, c->und_G.p, c->und_vig ? c->und_vinv.p : nullptr, c->und_remap ? c->und_rx.p : nullptr,
+                           c->und_remap ? c->und_ry.p : nullptr, photometric, factor, nullptr, nullptr, s.I[0], nullptr, nullptr);
+    if (rc) return rc;
+    rc = pyramid_build(c, s, gammaB ? c->gamma_dev : nullptr);
+    if (rc) return rc;
+    pixsel_invalidate_hists(c, slot);
     s.valid = true;
     return NALO_OK;
 }

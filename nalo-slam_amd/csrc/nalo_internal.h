@@ -47,6 +47,7 @@ struct FrameSlot {
     uint8_t* bgr = nullptr;
     bool valid = false;
     hipEvent_t ev_up = nullptr;              // nalo_frame_upload_async: the slot's H2D copies (copy stream) have completed
+    uint8_t* raw = nullptr; size_t raw_cap = 0;   // nalo_frame_upload_raw_async: this slot's sensor frame as uploaded (several frames may be in flight)
 };
 
 struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };

@@ -98,3 +98,32 @@ def test_ingest_mask_and_colour_feed_the_dense_map():
     for k in ("u", "v", "idepth", "color", "bgr", "rect"):
         assert np.array_equal(a[k], b[k]), k
     c.close()
+
+
+def test_raw_ingest_async_equals_sync():
+    """nalo_frame_upload_raw_async (copy stream + event, several frames in flight, each slot with its own raw buffer) produces the pyramids of the synchronous
+    entry point, whatever the order the frames are waited for"""
+    rng = np.random.RandomState(5)
+    w, h, wo, ho = 640, 480, 672, 512
+    G = np.cumsum(rng.rand(256) + 0.05).astype(np.float32); G = (255.0 * (G - G[0]) / (G[-1] - G[0])).astype(np.float32)
+    rx, ry = radial_remap(w, h, wo, ho)
+    c = binding.Context(w, h, (0.52 * w, 0.52 * w, (w - 1) / 2.0, (h - 1) / 2.0), n_slots=4)
+    c.undist_set(wo, ho, G, None, 1, rx, ry)
+    raws = [rng.randint(0, 256, (ho, wo)).astype(np.uint8) for _ in range(3)]
+    ref = []
+    for r in raws:
+        c.frame_upload_raw(3, r, exposure=0.01)
+        ref.append([c.frame_download(3, l)[0].copy() for l in range(c.levels)])
+    pinned = []
+    for k, r in enumerate(raws):
+        a = c.pinned_array((ho, wo), np.uint8); a[:] = r; pinned.append(a)
+    for rep in range(2):                                 # twice: the second round overwrites slots that kernels may still be reading
+        for k in range(3):
+            c.frame_upload_raw_async(k, pinned[k], exposure=0.01)
+        for k in (2, 0, 1):
+            c.frame_wait(k)
+        c.sync()
+        for k in range(3):
+            for l in range(c.levels):
+                assert np.array_equal(c.frame_download(k, l)[0], ref[k][l]), (rep, k, l)
+    c.close()
