@@ -166,8 +166,13 @@ inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint3
 inline int paeth(int a, int b, int c) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
 }
 
+static int read_png_impl(const char* path, int mode, int* w_out, int* h_out, int* channels_out, int* depth_out, void** data_out);
 int nalo_io_read_png(const char* path, int mode, int* w_out, int* h_out, int* channels_out, int* depth_out, void** data_out) {
     if (!path || !w_out || !h_out || !channels_out || !depth_out || !data_out || mode < 0 || mode > 2) return NALO_IO_ERR_ARG;
+    try { return read_png_impl(path, mode, w_out, h_out, channels_out, depth_out, data_out); }
+    catch (...) { return NALO_IO_ERR_FORMAT; }                                                   // no exception crosses the C ABI (a damaged header can ask for any size)
+}
+static int read_png_impl(const char* path, int mode, int* w_out, int* h_out, int* channels_out, int* depth_out, void** data_out) {
     std::ifstream f(path, std::ios::binary);
     if (!f.good()) return NALO_IO_ERR_FILE;
     std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -195,6 +200,8 @@ int nalo_io_read_png(const char* path, int mode, int* w_out, int* h_out, int* ch
     if (!(bitdepth == 8 || bitdepth == 16 || ((ctype == 0 || ctype == 3) && (bitdepth == 1 || bitdepth == 2 || bitdepth == 4))) || (ctype == 3 && bitdepth == 16)) return NALO_IO_ERR_FORMAT;
     if (ctype == 3 && plte.size() < 3) return NALO_IO_ERR_FORMAT;
     const size_t bpp_bits = (size_t)nch * bitdepth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
+    // a damaged IHDR must not turn into a huge allocation: deflate cannot expand beyond ~1032:1, and frames here are far below 2^15 pixels a side
+    if (w > 32768 || h > 32768 || (stride + 1) * (size_t)h > idat.size() * 1100 + 4096) return NALO_IO_ERR_FORMAT;
     std::vector<uint8_t> rawbuf((stride + 1) * (size_t)h);
     {
         z_stream zs; std::memset(&zs, 0, sizeof(zs));

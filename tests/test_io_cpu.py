@@ -299,3 +299,34 @@ def test_rectification_tables_all_models(lib, tmp_path):
     (tmp_path / "none_resized.txt").write_text("Pinhole 500 500 320 240 0\n640 480\nnone\n320 240\n")
     cf = CameraFile(); lib.nalo_io_read_camera(str(tmp_path / "none_resized.txt").encode(), C.byref(cf))
     assert _rectify(lib, cf)[0] == -3
+
+
+def test_png_reader_survives_damaged_files(lib, tmp_path):
+    """400 mutated / truncated PNGs (byte flips, cut files, overwritten header words incl. absurd sizes): every call returns a code, none crashes or throws
+    across the C ABI (a damaged IHDR used to ask for a multi-gigabyte buffer)"""
+    import random
+    rng = np.random.RandomState(0)
+    base = [_png_bytes(rng.randint(0, 256, (23, 37)).astype(np.uint8), 0, 8), _png_bytes(rng.randint(0, 65536, (23, 37)).astype(np.uint16), 0, 16),
+            _png_bytes(rng.randint(0, 256, (23, 37, 3)).astype(np.uint8), 2, 8), _png_bytes(rng.randint(0, 16, (23, 37)).astype(np.uint8), 3, 4, palette=rng.randint(0, 256, (16, 3)))]
+    random.seed(1)
+    p = tmp_path / "f.png"
+    codes = set()
+    for it in range(400):
+        b = bytearray(random.choice(base))
+        kind = random.random()
+        if kind < 0.4:
+            for _ in range(random.randint(1, 6)):
+                b[random.randrange(len(b))] = random.randrange(256)
+        elif kind < 0.7:
+            b = b[:random.randrange(8, len(b))]
+        else:
+            i = random.randrange(8, len(b) - 4); b[i:i + 4] = random.getrandbits(32).to_bytes(4, "big")
+        p.write_bytes(bytes(b))
+        rc, a = _read_png(lib, p, random.randrange(3))
+        codes.add(rc)
+        assert rc in (0, -3)
+    # the classic: a valid file whose IHDR claims 2^31 x 2^31 pixels
+    b = bytearray(base[0]); b[16:24] = (0x7fffffff).to_bytes(4, "big") * 2
+    p.write_bytes(bytes(b))
+    assert _read_png(lib, p, 0)[0] == -3
+    assert -3 in codes
