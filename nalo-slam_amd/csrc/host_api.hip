@@ -67,6 +67,7 @@ void nalo_destroy(nalo_ctx* c) {
         if (s.mask) (void)hipFree(s.mask);
         if (s.bgr) (void)hipFree(s.bgr);
         if (s.raw) (void)hipFree(s.raw);
+        if (s.dI0t) (void)hipFree(s.dI0t);
     }
     for (int l = 0; l < NALO_MAX_LEVELS; ++l) {
         c->trk_idepth[l].release(); c->trk_wsum[l].release(); c->trk_wbak[l].release();

@@ -169,7 +169,29 @@ int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOr
     return NALO_OK;
 }
 
+// Level 0 once more in 4x2-texel tiles: a 128-byte cache line then holds a 4 wide x 2 high block of {I,dx,dy,0} texels instead of 8 texels of one row, so the
+// 2x2 bilinear footprints of ba_linearize touch fewer lines (6x6 pattern footprint: ~7.9 lines instead of ~9.8). Measured on the gather microbenchmark
+// (scripts/ubench/gather.hip, layouts C vs G): 174 -> 153 us on the stress250k residual list, 350 -> 317 us at 1M points; 2x4 tiles 155 / 335, 8x8-tile
+// super-blocks on top: no further gain. tile index = ((y >> 1) * (w >> 2) + (x >> 2)) * 8 + ((y & 1) << 2) + (x & 3). Needs w % 4 == 0 and h % 2 == 0.
+__global__ __launch_bounds__(256) void tile_level0_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int w, int h) {
+    const int n = w * h, wt = w >> 2;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < n; o += gridDim.x * blockDim.x) {      // o = OUTPUT index: coalesced stores, 64-byte runs of loads
+        const int tile = o >> 3, in = o & 7, ty = tile / wt, tx = tile - ty * wt;
+        const int x = (tx << 2) + (in & 3), y = (ty << 1) + (in >> 2);
+        dst[o] = src[x + y * w];
+    }
+}
+int frame_tile_level0(nalo_ctx* c, FrameSlot& s) {
+    const size_t n = (size_t)c->w * c->h;
+    if (!s.dI0t) NALO_HIP(c, hipMalloc((void**)&s.dI0t, n * sizeof(float4)));
+    tile_level0_kernel<<<std::min((int)((n + 255) / 256), 4096), 256, 0, c->stream>>>(s.dI[0], s.dI0t, c->w, c->h);
+    NALO_HIP(c, hipGetLastError());
+    s.tiled_valid = true;
+    return NALO_OK;
+}
+
 int pyramid_build(nalo_ctx* c, FrameSlot& s, const float* gammaB_dev) {
+    s.tiled_valid = false;
     ProfScope ps(c, "pyramid");
     PyrLevels P;
     P.L = c->levels;

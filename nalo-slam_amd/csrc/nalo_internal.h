@@ -48,6 +48,7 @@ struct FrameSlot {
     bool valid = false;
     hipEvent_t ev_up = nullptr;              // nalo_frame_upload_async: the slot's H2D copies (copy stream) have completed
     uint8_t* raw = nullptr; size_t raw_cap = 0;   // nalo_frame_upload_raw_async: this slot's sensor frame as uploaded (several frames may be in flight)
+    float4* dI0t = nullptr; bool tiled_valid = false;   // level 0 again in 4x2-texel tiles of 128 bytes (ba_linearize's gathers), made on demand (frame_tile_level0)
 };
 
 struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
@@ -186,6 +187,7 @@ int init_calc_launch(nalo_ctx* c, const float4* colorRef, const float4* colorNew
 int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float* inc, float* idepth_new);
 // kernels_pyramid.hip
 int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
+int frame_tile_level0(nalo_ctx* c, nalo::FrameSlot& s);
 int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float* remapX, const float* remapY, int photometric,
                   float factor, const uint8_t* mask_org, const uint8_t* bgr_org, float* out_I, float* out_mask, uint8_t* out_bgr);
 // kernels_tracker.hip

@@ -142,6 +142,28 @@ __global__ __launch_bounds__(256) void gatherH(const float4* __restrict__ img, c
     acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
     if (q == 0) out[i] = acc;
 }
+// I: 4x2 tiles as in G, the tiles themselves in 8x8-tile super-blocks (32 x 16 pixels = 8 KB contiguous): locality beyond the line (pages, L2 sets)
+__device__ __forceinline__ size_t tiled_index_sb(int x, int y, int wsb) {
+    const int tx = x >> 2, ty = y >> 1;
+    return (((size_t)(ty >> 3) * wsb + (tx >> 3)) * 64 + ((ty & 7) << 3) + (tx & 7)) * 8 + ((y & 1) << 2) + (x & 3);
+}
+__global__ __launch_bounds__(256) void gatherI(const float4* __restrict__ img, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 2, q = t & 3;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    const int wsb = (w >> 2) >> 3;
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+        const int ix = (int)x + (q & 1), iy = (int)y + (q >> 1);
+        const float4 a = img[tiled_index_sb(ix, iy, wsb)];
+        acc += a.x + a.y;
+    }
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+    if (q == 0) out[i] = acc;
+}
 static uint32_t part1by1(uint32_t x) { x &= 0xffff; x = (x | (x << 8)) & 0x00FF00FF; x = (x | (x << 4)) & 0x0F0F0F0F; x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; }
 int main(int argc, char** argv) {
     const int w = 1920, h = 1072, W = 8, P = argc > 1 ? atoi(argv[1]) : 250000;
@@ -167,7 +189,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&duv, nmax * W * 8)); CK(hipMalloc(&dout, nmax * W * 4));
     for (int t = 0; t < W; ++t) CK(hipMemcpy(duv + t * nmax, per_target[t].data(), nmax * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 8; ++variant) {
+    for (int variant = 0; variant < 9; ++variant) {
         float best = 1e9;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
@@ -180,13 +202,14 @@ int main(int argc, char** argv) {
                 else if (variant == 4) gatherE<<<(n * 4 + 255) / 256, 256>>>(recs[t], duv + t * nmax, n, w, dout + t * nmax);
                 else if (variant == 5) gatherF<<<(n + 255) / 256, 256>>>(recs[t], duv + t * nmax, n, w, dout + t * nmax);
                 else if (variant == 6) gatherG<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
-                else gatherH<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else if (variant == 7) gatherH<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else gatherI<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
         }
         const double taps = (double)nmax * W * 32;
-        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", "ABCDEFGH"[variant], nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
+        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", "ABCDEFGHI"[variant], nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
     }
     // occupancy sweep of layout C: dynamic LDS per 256-thread block caps the blocks per CU (160 KB of LDS), i.e. waves per SIMD, with 8 loads in flight per lane:
     // does the gather rate depend on the loads in flight (latency bound) or not (bound by the miss path of the memory system)?
