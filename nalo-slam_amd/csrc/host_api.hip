@@ -403,7 +403,7 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
     {
         // a fixed affine parameter changes the system the LM solves (:1140-1162): those variants live in the host loop below
         static const bool env_host = std::getenv("NALO_TRK_HOST_LM") != nullptr;
-        const bool force_host = env_host || c->set.affineOptModeA < 0 || c->set.affineOptModeB < 0;
+        const bool force_host = env_host || c->lm_host_only || c->set.affineOptModeA < 0 || c->set.affineOptModeB < 0;
         static const int dev_max_n = [] { const char* e = std::getenv("NALO_TRK_DEV_MAXN"); return e ? std::atoi(e) : (1 << 30); }();
         int stop = coarsestLvl + 1;
         while (stop > 0 && c->pc_n[stop - 1] <= dev_max_n) --stop;      // levels coarsestLvl..stop on the device
@@ -412,6 +412,12 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
                 return fail(c, NALO_ERR_STATE, "nalo_trk_track: no reference / empty frame slot");
             double o[32];
             int rc = trk_lm_launch(c, slot_new, T_io, aff_io, ref_aff, exposures, coarsestLvl, stop, minResForAbort, o);
+            if (rc == NALO_LM_LOST_BLOCK) {
+                // the persistent kernel's workgroups were not co-resident (another context holds the CUs): nothing was written back, so the frame is
+                // redone by the host-driven loop below (same kernels per evaluation, same results to 1e-5), and so is every later frame of this context
+                c->lm_host_only = true;
+                std::fprintf(stderr, "[nalo] trk_lm_kernel: a workgroup's partial never arrived; this context now drives the tracker's LM loop from the host\n");
+            } else {
             if (rc) return rc;
             for (int l = stop; l <= coarsestLvl && l < 5; ++l) lastRes[l] = o[14 + l];
             flow[0] = o[19]; flow[1] = o[20]; flow[2] = o[21];
@@ -426,6 +432,7 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
             cur = SE3::from(o); aff_cur[0] = o[12]; aff_cur[1] = o[13];
             haveRepeated = o[25] != 0.0;
             start_lvl = (int)o[24];                                         // next level to process (-1: pyramid finished)
+            }
         }
     }
     static const int maxIterations[5] = {10, 20, 50, 50, 50};

@@ -8,7 +8,8 @@
 // poll); then EVERY workgroup sums the partials in a fixed order and replays the control flow on its wave 0: 8x8 LDL^T with one matrix row per lane and
 // v_readlane broadcasts, SE3::exp, accept / reject, lambda schedule, cutoff repeat, level descent - exactly the control flow of the host mirror in
 // host_api.hip (NALO_TRK_HOST_LM=1 selects that one, and so do the fixed-affine settings). The workgroups must be co-resident (no cooperative launch is
-// used: 64 workgroups of 256 lanes fit 256 CUs by a wide margin; a violation ends in the bounded poll's error, not in a hang).
+// used: 64 workgroups of 256 lanes fit 256 CUs by a wide margin; a violation - the CUs held by another context's long kernel - ends in the bounded poll, not in
+// a hang: the launch returns NALO_LM_LOST_BLOCK and nalo_trk_track redoes the frame with the host-driven loop and keeps to it for this context).
 #include "nalo_internal.h"
 #include "reduce.h"
 
@@ -507,7 +508,8 @@ int trk_lm_launch(nalo_ctx* c, int slot_new, const double T0[12], const double a
 #ifdef NALO_LM_TICKS
     { const double* t = c->trk_out_host + 64 + 26; fprintf(stderr, "[lm ticks] evals=%d eval=%.0f blockred=%.0f gridsum=%.0f lane0=%.0f (shader clocks per eval)\n", (int)out24[23], t[0] / out24[23], t[1] / out24[23], t[2] / out24[23], t[3] / out24[23]); }
 #endif
-    if (out24[22] < 0) return fail(c, NALO_ERR_HIP, "trk_lm_kernel: a workgroup's partial never arrived (timeout)");
+    static const bool test_timeout = std::getenv("NALO_LM_TEST_TIMEOUT") != nullptr;          // tests: exercise the caller's degraded path once per context
+    if (out24[22] < 0 || (test_timeout && c->lm_launches == 1)) return NALO_LM_LOST_BLOCK;
     return NALO_OK;
 }
 

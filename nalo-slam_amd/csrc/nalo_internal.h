@@ -86,6 +86,7 @@ struct nalo_ctx {
     unsigned long long trk_seq = 0;
     nalo::DevBuf<unsigned long long> lm_partial;   // persistent LM kernel: [2][blocks][64] block partials {fp32, tag}
     unsigned long long lm_launches = 0;
+    bool lm_host_only = false;                 // latched when a trk_lm launch lost a workgroup (CUs taken by another context): the host-driven LM loop from then on
     nalo::DevBuf<int> scan_tmp;              // compaction counts
     nalo::DevBuf<int> trk_cnt;               // hits per level-0 pixel of the reference scatter (ordered redo of pixels with >= 3 hits)
     nalo::DevBuf<float> upload_tmp;
@@ -186,6 +187,7 @@ int init_calc_launch(nalo_ctx* c, const float4* colorRef, const float4* colorNew
                      float alphaOpt, float couplingWeight, const float* base, float* outw, double* sums91);
 int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float* inc, float* idepth_new);
 // kernels_pyramid.hip
+constexpr int NALO_LM_LOST_BLOCK = 1000;     // trk_lm_launch only (never crosses the C ABI): the persistent kernel's workgroups were not co-resident
 int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
 int frame_tile_level0(nalo_ctx* c, nalo::FrameSlot& s);
 int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float* remapX, const float* remapY, int photometric,

@@ -162,3 +162,49 @@ def test_track_abort_and_exposure_paths(small_window):
     top = win.levels - 1
     assert abs(lr[top] - lr_o[top]) < 1e-4 * lr_o[top] and np.isnan(lr[:top]).all() and np.isnan(lr_o[:top]).all()
     c.close()
+
+
+_LOST_BLOCK_SCRIPT = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests"); sys.path.insert(0, sys.argv[1] + "/oracle")
+import nalo_pkg
+nalo_pkg.load()
+from helpers import tracker_inputs
+from nalo_slam_amd import binding, synth
+win = synth.make_window(w=640, h=480, W=4, P=400, seed=7)
+c = binding.Context(win.w, win.h, win.K, n_slots=2)
+c.frame_upload(0, win.images[win.W - 1]); c.frame_upload(1, win.images[win.W])
+Ku, Kv, nid, hdi = tracker_inputs(win)
+c.trk_set_ref(0, Ku, Kv, nid, hdi)
+T0 = np.asarray(json.loads(sys.argv[2]))
+out = []
+for _ in range(2):                                   # frame 1: the launch is reported lost and redone from the host; frame 2: host loop straight away
+    ok, T, aff, lr, lf, nev = c.trk_track(1, T0, [0, 0], [0, 0], [1, 1], win.levels - 1)
+    out.append(dict(ok=int(ok), T=np.asarray(T).tolist(), aff=np.asarray(aff).tolist(), nev=int(nev)))
+c.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_lost_workgroup_degrades_to_the_host_driven_loop(ctx, small_window, tmp_path):
+    """Hygiene item of the round-1 review: trk_lm_kernel needs its workgroups co-resident. When one never arrives (CUs held by another context) the launch ends
+    in its bounded poll and nalo_trk_track REDOES the frame with the host-driven LM loop (the same fused evaluation kernel per step - still the HIP path) and keeps
+    to it for the context. NALO_LM_TEST_TIMEOUT makes a context's first launch report the loss; the env is read once per process, hence the child process."""
+    import json, os, subprocess, sys
+    win = small_window
+    Ku, Kv, nid, hdi = tracker_inputs(win)
+    ctx.trk_set_ref(win.W - 1, Ku, Kv, nid, hdi)
+    T0 = orc.se3_exp(orc.se3_log(true_rel_pose(win, win.W - 1, win.W)) * 0.8)
+    ok, T, aff, lr, lf, nev = ctx.trk_track(win.W, T0, [0, 0], [0, 0], [1, 1], win.levels - 1)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "lost_block.py"
+    script.write_text(_LOST_BLOCK_SCRIPT)
+    env = dict(os.environ, NALO_LM_TEST_TIMEOUT="1")
+    p = subprocess.run([sys.executable, str(script), root, json.dumps(np.asarray(T0).tolist())], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "drives the tracker's LM loop from the host" in p.stderr
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for r in res:
+        assert r["ok"] == ok == 1
+        assert pose_dist(np.asarray(r["T"]), T) < 1e-5 and np.abs(np.asarray(r["aff"]) - aff).max() < 1e-3
+    assert p.stderr.count("drives the tracker's LM loop from the host") == 1          # latched: the second frame did not try the persistent kernel again
