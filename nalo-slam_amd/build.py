@@ -20,10 +20,14 @@ def build(force=False, verbose=False):
     csrc = os.path.join(HERE, "csrc")
     srcs = [os.path.join(csrc, s) for s in SRC if os.path.exists(os.path.join(csrc, s))]
     deps = srcs + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "nalo_gpu.h"), os.path.join(HERE, "..", "include", "nalo_io.h"), os.path.abspath(__file__)]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    # the library is up to date only if it was linked from objects built with the SAME flag set (tuning scripts switch NALO_CXXFLAGS back and forth)
+    flags = os.environ.get("NALO_CXXFLAGS", "") + "|" + ("fastdiv" if PER_FILE else "")
+    stamp = os.path.join(HERE, "build", ".flags")
+    same = os.path.exists(stamp) and open(stamp).read() == flags
+    if not force and same and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     objs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     procs = []
     for s in srcs:
         # the object name carries the flag set, so moving a file in/out of NO_CONTRACT (or changing NALO_CXXFLAGS) rebuilds it
@@ -45,6 +49,8 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-lz"])
+    with open(stamp, "w") as f:
+        f.write(flags)
     return OUT
 
 
