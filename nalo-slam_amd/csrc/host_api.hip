@@ -390,7 +390,9 @@ int nalo_trk_eval(nalo_ctx* c, int slot_new, int lvl, const double R[9], const d
 int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2], const double ref_aff[2], const float exposures[2],
                    int coarsestLvl, const double minResForAbort[5], double lastResiduals[5], double lastFlow[3], int* ok, int* n_evals) {
     if (!c || !T_io || !aff_io || !ref_aff || !exposures || !ok) return fail(c, NALO_ERR_ARG, "nalo_trk_track: bad argument");
-    if (!(coarsestLvl < 5 && coarsestLvl < c->levels)) return fail(c, NALO_ERR_ARG, "nalo_trk_track: coarsestLvl out of range");
+    if (!(coarsestLvl >= 0 && coarsestLvl < 5 && coarsestLvl < c->levels)) return fail(c, NALO_ERR_ARG, "nalo_trk_track: coarsestLvl out of range");
+    if (slot_new < 0 || slot_new >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_trk_track: frame slot out of range");
+    if (c->slot_ref < 0 || !c->slots[slot_new].valid) return fail(c, NALO_ERR_STATE, "nalo_trk_track: no reference (nalo_trk_set_ref) / empty frame slot");
     HostTimer ht(c, "trk_track");   // assert at :1083
     double lastRes[5] = {NAN, NAN, NAN, NAN, NAN}, flow[3] = {1000, 1000, 1000};
     SE3 cur = SE3::from(T_io);
