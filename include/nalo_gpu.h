@@ -429,6 +429,12 @@ int nalo_profile_select(nalo_ctx* ctx, const char* kernel);
 int nalo_profile_reset(nalo_ctx* ctx);
 int nalo_profile_get(nalo_ctx* ctx, const char* kernel, double* total_ms, int* launches);
 
+/* Calibration of the roofline's denominator on THIS device ("fraction of the box's measured device-copy / triad bandwidth from a calibration
+ * kernel in the same run"; no reference counterpart). Runs `iters` timed passes (after one untimed) of a streaming kernel over `bytes`-sized buffers on the
+ * context's stream, timed with HIP events: copy_GBs = 2 * bytes / t (b[i] = a[i], 16 B per lane, grid-stride), triad_GBs = 3 * bytes / t (c[i] = a[i] + s * b[i]).
+ * bytes is rounded down to a multiple of 16; >= 1 MiB. Either output may be NULL. */
+int nalo_hbm_calibrate(nalo_ctx* ctx, size_t bytes, int iters, double* copy_GBs, double* triad_GBs);
+
 #ifdef __cplusplus
 }
 #endif

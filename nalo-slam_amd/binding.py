@@ -34,7 +34,7 @@ EXPORTS = [
     "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
-    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get",
+    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get", "nalo_hbm_calibrate",
 ]
 
 
@@ -149,6 +149,7 @@ def load():
     L.nalo_profile_reset.argtypes = [vp]
     L.nalo_profile_select.argtypes = [vp, C.c_char_p]
     L.nalo_profile_get.argtypes = [vp, C.c_char_p, c_dp, c_ip]
+    L.nalo_hbm_calibrate.argtypes = [vp, C.c_size_t, C.c_int, c_dp, c_dp]
     _LIB = L
     return L
 
@@ -707,6 +708,12 @@ class Context:
         self._ck(self.L.nalo_ba_rccl_init(self.h_, int(nranks), int(rank), id_main, id_side))
 
     # ---- profiling
+    def hbm_calibrate(self, nbytes=1 << 30, iters=10):
+        """measured streaming bandwidth of this device (GB/s): (copy, triad) - the roofline's denominator next to the nominal 8 TB/s"""
+        a, b = C.c_double(0), C.c_double(0)
+        self._ck(self.L.nalo_hbm_calibrate(self.h_, C.c_size_t(nbytes), iters, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def profile_enable(self, on=True):
         self._ck(self.L.nalo_profile_enable(self.h_, int(on)))
 

@@ -742,4 +742,30 @@ int nalo_profile_get(nalo_ctx* c, const char* kernel, double* total_ms, int* lau
     return NALO_OK;
 }
 
+int nalo_hbm_calibrate(nalo_ctx* c, size_t bytes, int iters, double* copy_GBs, double* triad_GBs) {
+    bytes &= ~(size_t)15;
+    if (!c || bytes < ((size_t)1 << 20) || iters < 1) return fail(c, NALO_ERR_ARG, "nalo_hbm_calibrate: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    float4 *a = nullptr, *b = nullptr, *d = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto done = [&](int rc) { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (d) (void)hipFree(d); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); return rc; };
+    if (hipMalloc((void**)&a, bytes) != hipSuccess || hipMalloc((void**)&b, bytes) != hipSuccess || hipMalloc((void**)&d, bytes) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(fail(c, NALO_ERR_HIP, "nalo_hbm_calibrate: allocation failed"));
+    if (hipMemsetAsync(a, 0, bytes, c->stream) != hipSuccess || hipMemsetAsync(b, 0, bytes, c->stream) != hipSuccess) return done(fail(c, NALO_ERR_HIP, "nalo_hbm_calibrate: memset failed"));
+    const size_t n = bytes / 16;
+    for (int which = 0; which < 2; ++which) {
+        double* out = which ? triad_GBs : copy_GBs;
+        if (!out) continue;
+        hbm_stream_launch(c->stream, a, b, d, n, which);                               // untimed: first touch, clocks
+        (void)hipEventRecord(e0, c->stream);
+        for (int i = 0; i < iters; ++i) hbm_stream_launch(c->stream, a, b, d, n, which);
+        (void)hipEventRecord(e1, c->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) return done(fail(c, NALO_ERR_HIP, "nalo_hbm_calibrate: kernel failed"));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *out = (which ? 3.0 : 2.0) * (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
+    }
+    return done(NALO_OK);
+}
+
 }  // extern "C"

@@ -13,12 +13,13 @@
 namespace nalo {
 
 __global__ __launch_bounds__(256) void dense_bbox_kernel(const float* __restrict__ mask, int w, int h, float value, int* __restrict__ rect /* minx,maxx,miny,maxy */) {
-    const int iw = w - 4, total = iw * (h - 4);
     int minx = INT_MAX, maxx = INT_MIN, miny = INT_MAX, maxy = INT_MIN;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int y = e / iw + 2, x = e % iw + 2;
-        if (mask[x + y * w] != value) continue;
-        minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
+    for (int y = 2 + blockIdx.x; y < h - 2; y += gridDim.x) {              // a workgroup walks whole rows: no division per pixel, coalesced row segments
+        const float* row = mask + (size_t)y * w;
+        for (int x = 2 + threadIdx.x; x < w - 2; x += blockDim.x) {
+            if (row[x] != value) continue;
+            minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
+        }
     }
     // wave, then workgroup reduction: ONE lane per workgroup touches the four global words, and the grid has at most 512 workgroups. Every lane (then every
     // wave) doing so serialised 10^4..10^5 atomics on four addresses: 374 / 365 us at 1920x1072 against a 8 MB read of the mask.
@@ -175,8 +176,7 @@ extern "C" int nalo_dense_make_map(nalo_ctx* c, int slot, const float plane[4], 
     NALO_HIP(c, c->scan_tmp.reserve(8));
     const int init[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
     NALO_HIP(c, hipMemcpyAsync(c->scan_tmp.p, init, 16, hipMemcpyHostToDevice, c->stream));
-    const int total0 = (c->w - 4) * (c->h - 4);
-    { ProfScope ps(c, "dense_bbox"); dense_bbox_kernel<<<std::min((total0 + 255) / 256, 512), 256, 0, c->stream>>>(s.mask, c->w, c->h, mask_value, c->scan_tmp.p); }
+    { ProfScope ps(c, "dense_bbox"); dense_bbox_kernel<<<std::max(1, std::min(c->h - 4, 512)), 256, 0, c->stream>>>(s.mask, c->w, c->h, mask_value, c->scan_tmp.p); }
     int rect[4];
     NALO_HIP(c, hipMemcpyAsync(rect, c->scan_tmp.p, 16, hipMemcpyDeviceToHost, c->stream));
     NALO_HIP(c, hipStreamSynchronize(c->stream));

@@ -190,6 +190,7 @@ int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* 
 constexpr int NALO_LM_LOST_BLOCK = 1000;     // trk_lm_launch only (never crosses the C ABI): the persistent kernel's workgroups were not co-resident
 int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
 int frame_tile_level0(nalo_ctx* c, nalo::FrameSlot& s);
+void hbm_stream_launch(hipStream_t st, const float4* a, const float4* b, float4* d, size_t n, int triad);
 int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float* remapX, const float* remapY, int photometric,
                   float factor, const uint8_t* mask_org, const uint8_t* bgr_org, float* out_I, float* out_mask, uint8_t* out_bgr);
 // kernels_tracker.hip

@@ -101,3 +101,14 @@ def test_bundle_adjustment_call_order_and_arguments(small_window):
     # marginalising a frame that is not in the window
     assert L.nalo_ba_marginalize_frame(h, win.W + 2) == ERR_ARG
     c.close()
+
+
+def test_hbm_calibration_leg():
+    """nalo_hbm_calibrate (the measured denominator of bench.py's roofline): plausible on an MI355X (HBM3E, 8 TB/s nominal) and rejects nonsense"""
+    c = binding.Context(64, 64, (50, 50, 31.5, 31.5), n_slots=1)
+    copy, triad = c.hbm_calibrate(256 << 20, 5)
+    assert 1000.0 < copy < 8000.0 and 1000.0 < triad < 8000.0, (copy, triad)
+    a = C.c_double(0)
+    assert c.L.nalo_hbm_calibrate(c.h_, C.c_size_t(1024), 5, C.byref(a), None) == ERR_ARG          # below 1 MiB
+    assert c.L.nalo_hbm_calibrate(c.h_, C.c_size_t(1 << 24), 0, C.byref(a), None) == ERR_ARG
+    c.close()
