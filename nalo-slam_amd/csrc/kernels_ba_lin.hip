@@ -117,6 +117,29 @@ __device__ __forceinline__ LinWhere lin_where(const BADev& B, int tid) {
     return w;
 }
 
+// The per-residual outputs (JpJdF, the point-sum shares, the energies: 64 B per residual, 114 MB on stress250k) are written once here and read once by the
+// next kernels: stored with the nontemporal hint they do not evict image lines from the L2 the gathers live in (stress250k: 203.0 -> 193.3 us on one box, back to
+// back; shard1m unchanged). The same hint on the point-record LOADS costs 3-5 % (they are re-read per target frame and do hit) - not used.
+#ifndef NALO_LIN_NT_STORES
+#define NALO_LIN_NT_STORES 1
+#endif
+typedef float lin_f4 __attribute__((ext_vector_type(4)));
+typedef float lin_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lin_store(float4* p, const float4& v) {
+#if NALO_LIN_NT_STORES
+    lin_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<lin_f4*>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void lin_store(float2* p, const float2& v) {
+#if NALO_LIN_NT_STORES
+    lin_f2 t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<lin_f2*>(p));
+#else
+    *p = v;
+#endif
+}
+
 // x = (Jpdc[0], Jpdxi[0]), y = (Jpdc[1], Jpdxi[1]) of a residual (Residuals.cpp:108-156) from the point and the precalc record. A function of its own so that the
 // twenty values are NOT alive across the gather phase: they are (re)computed where they are consumed (takeDataF and the accumulation, after the last tap),
 // which is what lets the kernel fit 128 vector registers = four waves per SIMD (the gathers are latency bound: more waves, more loads in flight).
@@ -265,7 +288,7 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
         if (MODE == 2 && active) st |= RS_LINEARIZED;
         if (FIX == 1 && !active) st &= ~(RS_EXISTS | RS_ACTIVE);                                      // toRemove (FullSystemOptimize.cpp:81-84,184-205)
         B.rs_state[w.si] = st;
-        B.rs_energy[w.si] = R.en;
+        lin_store(&B.rs_energy[w.si], R.en);
         if (active && R.full) {
             R.cnt = 1.f;
             float x[10], y[10];
@@ -276,10 +299,10 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
             j0.x = x[4] * a0 + y[4] * a1; j0.y = x[5] * a0 + y[5] * a1; j0.z = x[6] * a0 + y[6] * a1; j0.w = x[7] * a0 + y[7] * a1;
             j1.x = x[8] * a0 + y[8] * a1; j1.y = x[9] * a0 + y[9] * a1;
             j1.z = R.jab00 * R.Jpdd0 + R.jab01 * R.Jpdd1; j1.w = R.jab10 * R.Jpdd0 + R.jab11 * R.Jpdd1;
-            B.rs_jp0[w.si] = j0; B.rs_jp1[w.si] = j1;
+            lin_store(&B.rs_jp0[w.si], j0); lin_store(&B.rs_jp1[w.si], j1);
             // per-slot share of EFPoint::{bd,Hdd,Hcd}_acc (AccumulatedTopHessian.cpp:132-135); summed over the targets by ba_pt_acc_kernel
-            B.rs_pp0[w.si] = make_float4(R.JIr0 * R.Jpdd0 + R.JIr1 * R.Jpdd1, a0 * R.Jpdd0 + a1 * R.Jpdd1, x[0] * a0 + y[0] * a1, x[1] * a0 + y[1] * a1);
-            B.rs_pp1[w.si] = make_float2(x[2] * a0 + y[2] * a1, x[3] * a0 + y[3] * a1);
+            lin_store(&B.rs_pp0[w.si], make_float4(R.JIr0 * R.Jpdd0 + R.JIr1 * R.Jpdd1, a0 * R.Jpdd0 + a1 * R.Jpdd1, x[0] * a0 + y[0] * a1, x[1] * a0 + y[1] * a1));
+            lin_store(&B.rs_pp1[w.si], make_float2(x[2] * a0 + y[2] * a1, x[3] * a0 + y[3] * a1));
             if (FIX == 1 || MODE == 2) {
                 // relBS of FullSystemOptimize.cpp:69-71 + centerProjectedTo (makeCoarseDepthL0 input)
                 const float pu = R.pu, pv = R.pv, idepth = R.idepth;
