@@ -27,8 +27,8 @@ struct BADev {
     const float* calib;                         // [10] {fxl, fyl, cxl, cyl, fxli, fyli (CalibHessian::value_scaledf / value_scaledi), cDeltaF[4] (EnergyFunctional)}
     const int* stop;                            // device-side GN loop: 1 = the loop has terminated, every kernel returns at once
     const float4* img[16];                      // level-0 {I,dx,dy,0} of every window frame (row major)
-    const float4* img_t[16];                    // the same texels in 4x2 tiles of 128 bytes (ba_linearize gathers from these when wt != 0)
-    int wt;                                     // tiles per tile row (w >> 2), 0 = no tiled copies (w % 4 or h % 2 non-zero): gather from img
+    const float* img_t[16];                     // the same texels, 12 bytes each, in 5x2 tiles of 128 bytes (frame_tile_level0): what ba_linearize gathers from
+    int wt;                                     // tiles per tile row = ceil(w / 5)
     int lin_sub;                                // ba_linearize workgroups (= fp64 partials) per point block: 1 = 256 threads, 4 = one wave each (small windows)
     const float* pre;                           // [W*W][kPreStride], index h*W + t
     float* frameTH;                             // [W] frameEnergyTH (device resident, updated by the quantile kernel)

@@ -297,14 +297,12 @@ static int flush_th(nalo_ctx* c) {
 // the tiled level-0 copies ba_linearize gathers from: made on demand, remade when a window frame's pyramid was rebuilt since
 static int ensure_tiled(nalo_ctx* c) {
     BAWindow& w = *c->ba;
-    static const bool off = std::getenv("NALO_LIN_ROWMAJOR") != nullptr;
-    if (off || (c->w & 3) || (c->h & 1)) { w.dev.wt = 0; return NALO_OK; }
     for (int i = 0; i < w.W; ++i) {
         FrameSlot& s = c->slots[w.frames[i].slot];
         if (!s.tiled_valid) { int rc = frame_tile_level0(c, s); if (rc) return rc; }
         w.dev.img_t[i] = s.dI0t;
     }
-    w.dev.wt = c->w >> 2;
+    w.dev.wt = (c->w + 4) / 5;
     return NALO_OK;
 }
 static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false) {

@@ -381,15 +381,15 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         wgt[0] = w0.x; wgt[1] = w0.y; wgt[2] = w0.z; wgt[3] = w0.w; wgt[4] = w1.x; wgt[5] = w1.y; wgt[6] = w1.z; wgt[7] = w1.w;
     }
     {
-        const bool tiled = B.wt != 0;                                      // workgroup-uniform
-        const float4* __restrict__ img = tiled ? B.img_t[w.t] : B.img[w.t];
+        // the target frame's level 0 as 12-byte texels in 5x2 tiles of 128 bytes (frame_tile_level0): fewer cache lines per bilinear footprint, 25 % more image per line
+        const float* __restrict__ img = B.img_t[w.t];
         const int lane = tid & 63, q = lane & 3, Q = lane >> 2;
-        const int qx = q & 1, qy = q >> 1, wt = B.wt, wrow = B.w;
-        // texel address of tap q of the pixel whose integer position a quad lane broadcast as ix | iy << 16: row major, or the 4x2-tile layout of
-        // frame_tile_level0 (a 128-byte line = a 4 wide x 2 high block of texels: fewer lines per bilinear footprint)
-        auto tap = [&](int packed) __attribute__((always_inline)) -> int {
-            const int x = (packed & 0xffff) + qx, y = (packed >> 16) + qy;
-            return tiled ? ((((y >> 1) * wt + (x >> 2)) << 3) + ((y & 1) << 2) + (x & 3)) : (x + y * wrow);
+        const int qx = q & 1, qy = q >> 1, wt = B.wt;
+        // tap q of the pixel whose integer position a quad lane broadcast as ix | iy << 16
+        auto tap = [&](int packed) __attribute__((always_inline)) -> float4 {
+            const int x = (packed & 0xffff) + qx, y = (packed >> 16) + qy, tx = (x * 52429) >> 18;          // x / 5, exact below 43690
+            const float* p = img + (((y >> 1) * wt + tx) << 5) + ((y & 1) * 5 + (x - tx * 5)) * 3;
+            return make_float4(p[0], p[1], p[2], 0.f);
         };
         // exchange buffer of this wave: [residual r of the quad][quad Q][tap q], rows padded by one texel (bank spread). It aliases the 16 reduction rows
         // this wave alone writes at the end of the kernel (QuadStream: row = tid >> 2), so it costs no LDS of its own
@@ -411,8 +411,8 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         auto batch = [&](auto HALF) __attribute__((always_inline)) {
             constexpr int k0 = 2 * decltype(HALF)::value, k1 = k0 + 1;
             const int o0 = R.need ? ((int)R.Kus[k0] | ((int)R.Kvs[k0] << 16)) : 0, o1 = R.need ? ((int)R.Kus[k1] | ((int)R.Kvs[k1] << 16)) : 0;
-            const float4 a0 = img[tap(lin_quad_bcast<0>(o0))], a1 = img[tap(lin_quad_bcast<1>(o0))], a2 = img[tap(lin_quad_bcast<2>(o0))], a3 = img[tap(lin_quad_bcast<3>(o0))];
-            const float4 b0_ = img[tap(lin_quad_bcast<0>(o1))], b1_ = img[tap(lin_quad_bcast<1>(o1))], b2_ = img[tap(lin_quad_bcast<2>(o1))], b3_ = img[tap(lin_quad_bcast<3>(o1))];
+            const float4 a0 = tap(lin_quad_bcast<0>(o0)), a1 = tap(lin_quad_bcast<1>(o0)), a2 = tap(lin_quad_bcast<2>(o0)), a3 = tap(lin_quad_bcast<3>(o0));
+            const float4 b0_ = tap(lin_quad_bcast<0>(o1)), b1_ = tap(lin_quad_bcast<1>(o1)), b2_ = tap(lin_quad_bcast<2>(o1)), b3_ = tap(lin_quad_bcast<3>(o1));
             float h0I, h0X, h0Y, h1I, h1X, h1Y;
             exchange(a0, a1, a2, a3, R.Kus[k0], R.Kvs[k0], h0I, h0X, h0Y);
             exchange(b0_, b1_, b2_, b3_, R.Kus[k1], R.Kvs[k1], h1I, h1X, h1Y);
@@ -423,9 +423,9 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         auto batch3 = [&](auto FIRST) __attribute__((always_inline)) {
             constexpr int k0 = decltype(FIRST)::value, k1 = k0 + 1, k2 = k0 + 2;
             const int o0 = R.need ? ((int)R.Kus[k0] | ((int)R.Kvs[k0] << 16)) : 0, o1 = R.need ? ((int)R.Kus[k1] | ((int)R.Kvs[k1] << 16)) : 0, o2 = R.need ? ((int)R.Kus[k2] | ((int)R.Kvs[k2] << 16)) : 0;
-            const float4 a0 = img[tap(lin_quad_bcast<0>(o0))], a1 = img[tap(lin_quad_bcast<1>(o0))], a2 = img[tap(lin_quad_bcast<2>(o0))], a3 = img[tap(lin_quad_bcast<3>(o0))];
-            const float4 b0_ = img[tap(lin_quad_bcast<0>(o1))], b1_ = img[tap(lin_quad_bcast<1>(o1))], b2_ = img[tap(lin_quad_bcast<2>(o1))], b3_ = img[tap(lin_quad_bcast<3>(o1))];
-            const float4 c0_ = img[tap(lin_quad_bcast<0>(o2))], c1_ = img[tap(lin_quad_bcast<1>(o2))], c2_ = img[tap(lin_quad_bcast<2>(o2))], c3_ = img[tap(lin_quad_bcast<3>(o2))];
+            const float4 a0 = tap(lin_quad_bcast<0>(o0)), a1 = tap(lin_quad_bcast<1>(o0)), a2 = tap(lin_quad_bcast<2>(o0)), a3 = tap(lin_quad_bcast<3>(o0));
+            const float4 b0_ = tap(lin_quad_bcast<0>(o1)), b1_ = tap(lin_quad_bcast<1>(o1)), b2_ = tap(lin_quad_bcast<2>(o1)), b3_ = tap(lin_quad_bcast<3>(o1));
+            const float4 c0_ = tap(lin_quad_bcast<0>(o2)), c1_ = tap(lin_quad_bcast<1>(o2)), c2_ = tap(lin_quad_bcast<2>(o2)), c3_ = tap(lin_quad_bcast<3>(o2));
             float h0I, h0X, h0Y, h1I, h1X, h1Y, h2I, h2X, h2Y;
             exchange(a0, a1, a2, a3, R.Kus[k0], R.Kvs[k0], h0I, h0X, h0Y);
             exchange(b0_, b1_, b2_, b3_, R.Kus[k1], R.Kvs[k1], h1I, h1X, h1Y);

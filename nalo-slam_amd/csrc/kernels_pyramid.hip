@@ -169,22 +169,25 @@ int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOr
     return NALO_OK;
 }
 
-// Level 0 once more in 4x2-texel tiles: a 128-byte cache line then holds a 4 wide x 2 high block of {I,dx,dy,0} texels instead of 8 texels of one row, so the
-// 2x2 bilinear footprints of ba_linearize touch fewer lines (6x6 pattern footprint: ~7.9 lines instead of ~9.8). Measured on the gather microbenchmark
-// (scripts/ubench/gather.hip, layouts C vs G): 174 -> 153 us on the stress250k residual list, 350 -> 317 us at 1M points; 2x4 tiles 155 / 335, 8x8-tile
-// super-blocks on top: no further gain. tile index = ((y >> 1) * (w >> 2) + (x >> 2)) * 8 + ((y & 1) << 2) + (x & 3). Needs w % 4 == 0 and h % 2 == 0.
-__global__ __launch_bounds__(256) void tile_level0_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int w, int h) {
-    const int n = w * h, wt = w >> 2;
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;                   // o = OUTPUT index: coalesced stores, 64-byte runs of loads; one texel per lane, consecutive
-    if (o >= n) return;                                                    // workgroups on consecutive memory (a grid-stride loop streams ~25 % slower: scripts/ubench/copy.hip)
-    const int tile = o >> 3, in = o & 7, ty = tile / wt, tx = tile - ty * wt;
-    const int x = (tx << 2) + (in & 3), y = (ty << 1) + (in >> 2);
-    dst[o] = src[x + y * w];
+// Level 0 once more, for ba_linearize's gathers: 12-byte texels {I,dx,dy} (the 16-byte texel spends a quarter of every cache line on padding) in tiles of
+// 5 wide x 2 high texels = 120 bytes, padded to one 128-byte cache line. A line then holds a 5x2 block of texels instead of 8 texels of one row: a 2x2 bilinear
+// footprint lies in one line with probability 2/5 instead of never, the 6x6 footprint of a residual in ~7.0 lines instead of ~9.8, and the same lines hold 25 % more
+// image. Pure gathers of the stress250k residual list (scripts/ubench/gather.hip, profiles/r02_ubench_gather_12B.log): row-major 16-B texels 174.6 us, 4x2 tiles
+// of 16-B texels 153.3, row-major 12-B texels 151.6, **5x2 tiles of 12-B texels 131.5**.
+// float index of texel (x, y): ((y >> 1) * wt + x / 5) * 32 + ((y & 1) * 5 + x % 5) * 3, wt = ceil(w / 5); any w, h (the last tile column / row is partly unused).
+__global__ __launch_bounds__(256) void tile_level0_kernel(const float4* __restrict__ src, float* __restrict__ dst, int w, int h, int wt) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;                   // one source texel per lane, consecutive workgroups on consecutive memory
+    if (o >= w * h) return;
+    const int y = o / w, x = o - y * w, tx = x / 5;
+    const float4 t = src[o];
+    float* d = dst + ((size_t)(y >> 1) * wt + tx) * 32 + ((y & 1) * 5 + (x - tx * 5)) * 3;
+    d[0] = t.x; d[1] = t.y; d[2] = t.z;
 }
 int frame_tile_level0(nalo_ctx* c, FrameSlot& s) {
+    const int wt = (c->w + 4) / 5, ht = (c->h + 1) / 2;
     const size_t n = (size_t)c->w * c->h;
-    if (!s.dI0t) NALO_HIP(c, hipMalloc((void**)&s.dI0t, n * sizeof(float4)));
-    tile_level0_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(s.dI[0], s.dI0t, c->w, c->h);
+    if (!s.dI0t) NALO_HIP(c, hipMalloc((void**)&s.dI0t, (size_t)wt * ht * 128 + 16));         // + 16: the 12-byte load of a tile's last texel may be issued as 16
+    tile_level0_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(s.dI[0], s.dI0t, c->w, c->h, wt);
     NALO_HIP(c, hipGetLastError());
     s.tiled_valid = true;
     return NALO_OK;

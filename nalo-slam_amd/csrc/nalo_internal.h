@@ -48,7 +48,7 @@ struct FrameSlot {
     bool valid = false;
     hipEvent_t ev_up = nullptr;              // nalo_frame_upload_async: the slot's H2D copies (copy stream) have completed
     uint8_t* raw = nullptr; size_t raw_cap = 0;   // nalo_frame_upload_raw_async: this slot's sensor frame as uploaded (several frames may be in flight)
-    float4* dI0t = nullptr; bool tiled_valid = false;   // level 0 again in 4x2-texel tiles of 128 bytes (ba_linearize's gathers), made on demand (frame_tile_level0)
+    float* dI0t = nullptr; bool tiled_valid = false;    // level 0 again as 12-byte texels in 5x2 tiles of 128 bytes (ba_linearize's gathers), made on demand (frame_tile_level0)
 };
 
 struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };

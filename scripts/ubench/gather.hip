@@ -164,6 +164,46 @@ __global__ __launch_bounds__(256) void gatherI(const float4* __restrict__ img, c
     acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
     if (q == 0) out[i] = acc;
 }
+// J: 12-byte texels {I,dx,dy} (the 16-byte texel wastes a quarter of every cache line on padding) in 5x2-texel tiles padded to 128 bytes: a line holds 10 useful
+// texels instead of 8, a 6x6 footprint ~7.0 lines instead of ~7.9. Loads are global_load_dwordx3 (4-byte aligned). x / 5 by multiply-shift.
+struct f3 { float x, y, z; };
+__device__ __forceinline__ size_t tiled_index52(int x, int y, int wt) { const int tx = (x * 52429) >> 18; return ((size_t)(y >> 1) * wt + tx) * 32 + ((y & 1) * 5 + (x - tx * 5)) * 3; }   // in floats
+__global__ __launch_bounds__(256) void gatherJ(const float4* __restrict__ img, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 2, q = t & 3;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    const int wt = (w + 4) / 5;
+    const float* base = reinterpret_cast<const float*>(img);
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+        const int ix = (int)x + (q & 1), iy = (int)y + (q >> 1);
+        const f3 a = *reinterpret_cast<const f3*>(base + tiled_index52(ix, iy, wt));
+        acc += a.x + a.y;
+    }
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+    if (q == 0) out[i] = acc;
+}
+// K: 12-byte texels, row major (no tiles): how much of J is the texel size alone
+__global__ __launch_bounds__(256) void gatherK(const float4* __restrict__ img, const float2* __restrict__ uv, int n, int w, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t >> 2, q = t & 3;
+    if (i >= n) return;
+    const float2 p = uv[i];
+    const float* base = reinterpret_cast<const float*>(img);
+    float acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float x = p.x + pat[k][0] * 1.1f, y = p.y + pat[k][1] * 1.1f;
+        const int ix = (int)x + (q & 1), iy = (int)y + (q >> 1);
+        const f3 a = *reinterpret_cast<const f3*>(base + ((size_t)iy * w + ix) * 3);
+        acc += a.x + a.y;
+    }
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+    if (q == 0) out[i] = acc;
+}
 static uint32_t part1by1(uint32_t x) { x &= 0xffff; x = (x | (x << 8)) & 0x00FF00FF; x = (x | (x << 4)) & 0x0F0F0F0F; x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; }
 int main(int argc, char** argv) {
     const int w = 1920, h = 1072, W = 8, P = argc > 1 ? atoi(argv[1]) : 250000;
@@ -189,7 +229,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&duv, nmax * W * 8)); CK(hipMalloc(&dout, nmax * W * 4));
     for (int t = 0; t < W; ++t) CK(hipMemcpy(duv + t * nmax, per_target[t].data(), nmax * 8, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int variant = 0; variant < 9; ++variant) {
+    for (int variant = 0; variant < 11; ++variant) {
         float best = 1e9;
         for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0));
@@ -203,13 +243,15 @@ int main(int argc, char** argv) {
                 else if (variant == 5) gatherF<<<(n + 255) / 256, 256>>>(recs[t], duv + t * nmax, n, w, dout + t * nmax);
                 else if (variant == 6) gatherG<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
                 else if (variant == 7) gatherH<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
-                else gatherI<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else if (variant == 8) gatherI<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else if (variant == 9) gatherJ<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
+                else gatherK<<<(n * 4 + 255) / 256, 256>>>(imgs[t], duv + t * nmax, n, w, dout + t * nmax);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
         }
         const double taps = (double)nmax * W * 32;
-        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", "ABCDEFGHI"[variant], nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
+        printf("variant %c: %zu residuals, %.1f us, %.2f TB/s of 16-B taps, %.2f Gtaps/s\n", "ABCDEFGHIJK"[variant], nmax * W, best * 1e3, taps * 16 / (best * 1e-3) / 1e12, taps / (best * 1e-3) / 1e9);
     }
     // occupancy sweep of layout C: dynamic LDS per 256-thread block caps the blocks per CU (160 KB of LDS), i.e. waves per SIMD, with 8 loads in flight per lane:
     // does the gather rate depend on the loads in flight (latency bound) or not (bound by the miss path of the memory system)?
