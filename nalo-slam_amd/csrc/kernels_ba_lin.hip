@@ -384,11 +384,17 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         // the target frame's level 0 as 12-byte texels in 5x2 tiles of 128 bytes (frame_tile_level0): fewer cache lines per bilinear footprint, 25 % more image per line
         const float* __restrict__ img = B.img_t[w.t];
         const int lane = tid & 63, q = lane & 3, Q = lane >> 2;
-        const int qx = q & 1, qy = q >> 1, wt = B.wt;
-        // tap q of the pixel whose integer position a quad lane broadcast as ix | iy << 16
+        const int wt = B.wt;
+        // The lane that owns a residual resolves its pixel once: float index of tap (0,0) plus two flags - does x + 1 / y + 1 leave the tile -, packed into one word
+        // (index < 2^30); the quad's lanes then only add their tap's offset to the word a quad lane broadcast (6 instead of 13 vector instructions per tap).
+        auto pack = [&](float Ku, float Kv) __attribute__((always_inline)) -> int {
+            const int x = (int)Ku, y = (int)Kv, tx = (x * 52429) >> 18, rx = x - tx * 5, ry = y & 1;         // x / 5, exact below 43690
+            return ((((y >> 1) * wt + tx) << 5) + (ry * 5 + rx) * 3) | (rx == 4 ? 1 << 30 : 0) | (int)((unsigned)ry << 31);
+        };
+        const int ox0 = (q & 1) ? 3 : 0, ox1 = (q & 1) ? 20 : 0;                   // x + 1: next texel (+3 floats), or texel 0 of the next tile (+32 - 12)
+        const int oy0 = (q >> 1) ? 15 : 0, oy1 = (q >> 1) ? wt * 32 - 15 : 0;      // y + 1: second row of the tile (+15), or first row of the tile below
         auto tap = [&](int packed) __attribute__((always_inline)) -> float4 {
-            const int x = (packed & 0xffff) + qx, y = (packed >> 16) + qy, tx = (x * 52429) >> 18;          // x / 5, exact below 43690
-            const float* p = img + (((y >> 1) * wt + tx) << 5) + ((y & 1) * 5 + (x - tx * 5)) * 3;
+            const float* p = img + ((packed & 0x3fffffff) + ((packed & (1 << 30)) ? ox1 : ox0) + (packed < 0 ? oy1 : oy0));
             return make_float4(p[0], p[1], p[2], 0.f);
         };
         // exchange buffer of this wave: [residual r of the quad][quad Q][tap q], rows padded by one texel (bank spread). It aliases the 16 reduction rows
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         // a batch = two pattern pixels: 8 sixteen-byte loads in flight per lane, then the two exchanges, then (per lane) their photometric part
         auto batch = [&](auto HALF) __attribute__((always_inline)) {
             constexpr int k0 = 2 * decltype(HALF)::value, k1 = k0 + 1;
-            const int o0 = R.need ? ((int)R.Kus[k0] | ((int)R.Kvs[k0] << 16)) : 0, o1 = R.need ? ((int)R.Kus[k1] | ((int)R.Kvs[k1] << 16)) : 0;
+            const int o0 = R.need ? pack(R.Kus[k0], R.Kvs[k0]) : 0, o1 = R.need ? pack(R.Kus[k1], R.Kvs[k1]) : 0;
             const float4 a0 = tap(lin_quad_bcast<0>(o0)), a1 = tap(lin_quad_bcast<1>(o0)), a2 = tap(lin_quad_bcast<2>(o0)), a3 = tap(lin_quad_bcast<3>(o0));
             const float4 b0_ = tap(lin_quad_bcast<0>(o1)), b1_ = tap(lin_quad_bcast<1>(o1)), b2_ = tap(lin_quad_bcast<2>(o1)), b3_ = tap(lin_quad_bcast<3>(o1));
             float h0I, h0X, h0Y, h1I, h1X, h1Y;
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         // 3 + 3 + 2 pattern pixels: 12 loads in flight per lane
         auto batch3 = [&](auto FIRST) __attribute__((always_inline)) {
             constexpr int k0 = decltype(FIRST)::value, k1 = k0 + 1, k2 = k0 + 2;
-            const int o0 = R.need ? ((int)R.Kus[k0] | ((int)R.Kvs[k0] << 16)) : 0, o1 = R.need ? ((int)R.Kus[k1] | ((int)R.Kvs[k1] << 16)) : 0, o2 = R.need ? ((int)R.Kus[k2] | ((int)R.Kvs[k2] << 16)) : 0;
+            const int o0 = R.need ? pack(R.Kus[k0], R.Kvs[k0]) : 0, o1 = R.need ? pack(R.Kus[k1], R.Kvs[k1]) : 0, o2 = R.need ? pack(R.Kus[k2], R.Kvs[k2]) : 0;
             const float4 a0 = tap(lin_quad_bcast<0>(o0)), a1 = tap(lin_quad_bcast<1>(o0)), a2 = tap(lin_quad_bcast<2>(o0)), a3 = tap(lin_quad_bcast<3>(o0));
             const float4 b0_ = tap(lin_quad_bcast<0>(o1)), b1_ = tap(lin_quad_bcast<1>(o1)), b2_ = tap(lin_quad_bcast<2>(o1)), b3_ = tap(lin_quad_bcast<3>(o1));
             const float4 c0_ = tap(lin_quad_bcast<0>(o2)), c1_ = tap(lin_quad_bcast<1>(o2)), c2_ = tap(lin_quad_bcast<2>(o2)), c3_ = tap(lin_quad_bcast<3>(o2));
