@@ -516,10 +516,10 @@ def main():
                     out["roofline_kitti00_8kf"] = out["roofline"]
                     out["roofline"] = dict(kernel="ba_linearize", workload="stress250k", note="the KITTI-sized launch is latency bound (see roofline_kitti00_8kf, same kernel, measured over the timed region); "
                                            "this is the same kernel on the largest single-GPU window (configs[3]) inside this run",
-                                           ceiling=dict(what="pure 16-byte tap gathers of the same residual list, nothing else, from the 4x2-tiled texel layout the kernel uses (scripts/ubench/gather.hip layout G, profiles/r02_ubench_gather_tiled.log; "
-                                                             "row-major layout C: 175 us)",
-                                                        gather_only_us=153.0, frac_of_hbm_roofline=round(768e6 / 153e-6 / 1e9 / HBM_PEAK_GBS, 3),
-                                                        note="the gather rate saturates at 3-4 waves/SIMD (row major: 1: 252, 2: 199, 3: 180, 4: 176, 8: 175 us): bound by the miss path of sparse 16-B gathers (31 k points per 2 Mpx frame), not by latency, "
+                                           ceiling=dict(what="pure tap gathers of the same residual list, nothing else, from the layout the kernel uses: 12-byte texels in 5x2 tiles of 128 bytes (scripts/ubench/gather.hip layout J, "
+                                                             "profiles/r02_ubench_gather_12B.log; 16-byte texels row major: 175 us, in 4x2 tiles: 153 us, 12-byte row major: 152 us)",
+                                                        gather_only_us=131.5, frac_of_hbm_roofline=round(768e6 / 131.5e-6 / 1e9 / HBM_PEAK_GBS, 3),
+                                                        note="the gather rate saturates at 3-4 waves/SIMD (row major: 1: 252, 2: 199, 3: 180, 4: 176, 8: 175 us): bound by the miss path of sparse gathers (31 k points per 2 Mpx frame), not by latency, "
                                                              "vector ALU (IEEE vs rcp division: same time) or HBM (traffic < algorithmic bytes); the kernel's waves spend ~40 % of their life outside the gather phase, "
                                                              "which is the distance to this ceiling (DESIGN.md 3)"),
                                            bound="hbm", achieved=sl["achieved_GBs"], peak=HBM_PEAK_GBS,
