@@ -73,6 +73,8 @@ struct QuadStream {
     }
 };
 
+struct alignas(16) LinTexel { float x, y, z; };           // {I, dx, dy}: a 12-byte texel in a 16-byte LDS slot
+
 // wave-scope ordering of LDS traffic: the hardware keeps one wave's LDS operations in order; the fences keep the COMPILER from moving a lane's reads above
 // other lanes' writes (for this lane provably non-aliasing) or the next writes above these reads
 __device__ __forceinline__ void lin_wave_sync() {
@@ -393,19 +395,19 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         };
         const int ox0 = (q & 1) ? 3 : 0, ox1 = (q & 1) ? 20 : 0;                   // x + 1: next texel (+3 floats), or texel 0 of the next tile (+32 - 12)
         const int oy0 = (q >> 1) ? 15 : 0, oy1 = (q >> 1) ? wt * 32 - 15 : 0;      // y + 1: second row of the tile (+15), or first row of the tile below
-        auto tap = [&](int packed) __attribute__((always_inline)) -> float4 {
+        auto tap = [&](int packed) __attribute__((always_inline)) -> LinTexel {
             const float* p = img + ((packed & 0x3fffffff) + ((packed & (1 << 30)) ? ox1 : ox0) + (packed < 0 ? oy1 : oy0));
-            return make_float4(p[0], p[1], p[2], 0.f);
+            return LinTexel{p[0], p[1], p[2]};
         };
         // exchange buffer of this wave: [residual r of the quad][quad Q][tap q], rows padded by one texel (bank spread). It aliases the 16 reduction rows
         // this wave alone writes at the end of the kernel (QuadStream: row = tid >> 2), so it costs no LDS of its own
-        float4* xb = reinterpret_cast<float4*>(smem + (tid >> 6) * 16 * kTopStride);
+        LinTexel* xb = reinterpret_cast<LinTexel*>(smem + (tid >> 6) * 16 * kTopStride);       // 16-byte slots, 12 bytes used: ds_write_b96 / ds_read_b96 straight from / to the load's registers
         // one pixel's exchange: the four texels this lane loaded (tap q of residuals 0..3 of its quad) go out, the four taps of its own residual come back
-        auto exchange = [&](const float4& t0, const float4& t1, const float4& t2, const float4& t3, float xk, float yk, float& oI, float& oX, float& oY) __attribute__((always_inline)) {
+        auto exchange = [&](const LinTexel& t0, const LinTexel& t1, const LinTexel& t2, const LinTexel& t3, float xk, float yk, float& oI, float& oX, float& oY) __attribute__((always_inline)) {
             lin_wave_sync();
             xb[0 * 65 + Q * 4 + q] = t0; xb[1 * 65 + Q * 4 + q] = t1; xb[2 * 65 + Q * 4 + q] = t2; xb[3 * 65 + Q * 4 + q] = t3;
             lin_wave_sync();
-            const float4 p00 = xb[q * 65 + Q * 4], p10 = xb[q * 65 + Q * 4 + 1], p01 = xb[q * 65 + Q * 4 + 2], p11 = xb[q * 65 + Q * 4 + 3];
+            const LinTexel p00 = xb[q * 65 + Q * 4], p10 = xb[q * 65 + Q * 4 + 1], p01 = xb[q * 65 + Q * 4 + 2], p11 = xb[q * 65 + Q * 4 + 3];
             const int ix = (int)xk, iy = (int)yk;                 // util/globalFuncs.h:75-89
             const float dx = xk - ix, dy = yk - iy, dxdy = dx * dy;
             const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
@@ -417,8 +419,8 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         auto batch = [&](auto HALF) __attribute__((always_inline)) {
             constexpr int k0 = 2 * decltype(HALF)::value, k1 = k0 + 1;
             const int o0 = R.need ? pack(R.Kus[k0], R.Kvs[k0]) : 0, o1 = R.need ? pack(R.Kus[k1], R.Kvs[k1]) : 0;
-            const float4 a0 = tap(lin_quad_bcast<0>(o0)), a1 = tap(lin_quad_bcast<1>(o0)), a2 = tap(lin_quad_bcast<2>(o0)), a3 = tap(lin_quad_bcast<3>(o0));
-            const float4 b0_ = tap(lin_quad_bcast<0>(o1)), b1_ = tap(lin_quad_bcast<1>(o1)), b2_ = tap(lin_quad_bcast<2>(o1)), b3_ = tap(lin_quad_bcast<3>(o1));
+            const LinTexel a0 = tap(lin_quad_bcast<0>(o0)), a1 = tap(lin_quad_bcast<1>(o0)), a2 = tap(lin_quad_bcast<2>(o0)), a3 = tap(lin_quad_bcast<3>(o0));
+            const LinTexel b0_ = tap(lin_quad_bcast<0>(o1)), b1_ = tap(lin_quad_bcast<1>(o1)), b2_ = tap(lin_quad_bcast<2>(o1)), b3_ = tap(lin_quad_bcast<3>(o1));
             float h0I, h0X, h0Y, h1I, h1X, h1Y;
             exchange(a0, a1, a2, a3, R.Kus[k0], R.Kvs[k0], h0I, h0X, h0Y);
             exchange(b0_, b1_, b2_, b3_, R.Kus[k1], R.Kvs[k1], h1I, h1X, h1Y);
@@ -429,9 +431,9 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
         auto batch3 = [&](auto FIRST) __attribute__((always_inline)) {
             constexpr int k0 = decltype(FIRST)::value, k1 = k0 + 1, k2 = k0 + 2;
             const int o0 = R.need ? pack(R.Kus[k0], R.Kvs[k0]) : 0, o1 = R.need ? pack(R.Kus[k1], R.Kvs[k1]) : 0, o2 = R.need ? pack(R.Kus[k2], R.Kvs[k2]) : 0;
-            const float4 a0 = tap(lin_quad_bcast<0>(o0)), a1 = tap(lin_quad_bcast<1>(o0)), a2 = tap(lin_quad_bcast<2>(o0)), a3 = tap(lin_quad_bcast<3>(o0));
-            const float4 b0_ = tap(lin_quad_bcast<0>(o1)), b1_ = tap(lin_quad_bcast<1>(o1)), b2_ = tap(lin_quad_bcast<2>(o1)), b3_ = tap(lin_quad_bcast<3>(o1));
-            const float4 c0_ = tap(lin_quad_bcast<0>(o2)), c1_ = tap(lin_quad_bcast<1>(o2)), c2_ = tap(lin_quad_bcast<2>(o2)), c3_ = tap(lin_quad_bcast<3>(o2));
+            const LinTexel a0 = tap(lin_quad_bcast<0>(o0)), a1 = tap(lin_quad_bcast<1>(o0)), a2 = tap(lin_quad_bcast<2>(o0)), a3 = tap(lin_quad_bcast<3>(o0));
+            const LinTexel b0_ = tap(lin_quad_bcast<0>(o1)), b1_ = tap(lin_quad_bcast<1>(o1)), b2_ = tap(lin_quad_bcast<2>(o1)), b3_ = tap(lin_quad_bcast<3>(o1));
+            const LinTexel c0_ = tap(lin_quad_bcast<0>(o2)), c1_ = tap(lin_quad_bcast<1>(o2)), c2_ = tap(lin_quad_bcast<2>(o2)), c3_ = tap(lin_quad_bcast<3>(o2));
             float h0I, h0X, h0Y, h1I, h1X, h1Y, h2I, h2X, h2Y;
             exchange(a0, a1, a2, a3, R.Kus[k0], R.Kvs[k0], h0I, h0X, h0Y);
             exchange(b0_, b1_, b2_, b3_, R.Kus[k1], R.Kvs[k1], h1I, h1X, h1Y);
