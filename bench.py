@@ -457,7 +457,7 @@ def main():
         # The extra legs must never cost the main line: they run under a deadline (a collective that never completes on some fabric would otherwise
         # hang every rank). On expiry rank 0 prints the line it has, marked, and every rank leaves.
         import threading
-        deadline_s = float(os.environ.get("NALO_BENCH_EXTRA_DEADLINE", "420"))
+        deadline_s = float(os.environ.get("NALO_BENCH_EXTRA_DEADLINE", "420" if world == 1 else "240"))   # N > 1 runs only the sharded leg (~30 s): a blocked collective must not hold the node for long
 
         leg_state = {"leg": "shard1m"}                # which extra leg (hence which kernel / collective) was in flight when the deadline hit
 
