@@ -427,9 +427,11 @@ void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NP
 #define STITCH_TICK(i) do { } while (0)
 #endif
 constexpr int kAdRow = 9, kAdMat = 73;        // padded 8x8 adjoint in LDS
-template <bool FAST, typename Put>
-__device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, int a, Put put) {
-    const int W = D.W, n1 = D.n1, n = n1 - 1, NPL = D.NPL, tid = threadIdx.x, NT = blockDim.x, cb = 8 * (W - 1);
+// WC: the window size as a compile-time constant (0 = run time). With it the 2 x (W - 1) x 8-term sums of phase 2 and the 56-term sums of phase 1 unroll, and
+// their LDS loads are issued in batches instead of one dependent group per loop trip (W = 8, headline window: phase 2 9.4 -> see DESIGN 5).
+template <bool FAST, int WC, typename Put>
+__device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, int a, int r0, int nr, Put put) {      // rows r0 .. r0 + nr - 1 of frame a's eight
+    const int W = WC ? WC : D.W, n1 = WC ? 8 * WC + 5 : D.n1, n = n1 - 1, NPL = WC ? 16 * ((8 * (WC - 1) + 5 + 15) / 16) : D.NPL, tid = threadIdx.x, NT = blockDim.x, cb = 8 * (W - 1);
 #ifdef NALO_STITCH_TICKS
     long long tk[5] = {0, 0, 0, 0, 0};
 #endif
@@ -453,10 +455,11 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
         }
         __syncthreads();
         STITCH_TICK(1);
-        for (int e = tid; e < W * 8 * NPL; e += NT) {
-            const int i = e / (8 * NPL), o = e - i * 8 * NPL, r = o / NPL, l = o - r * NPL;
+        for (int e = tid; e < W * nr * NPL; e += NT) {
+            const int i = e / (nr * NPL), o = e - i * nr * NPL, r = r0 + o / NPL, l = o % NPL;
             double s = 0;
             if (i == a) {
+#pragma unroll
                 for (int g2 = 0; g2 < W - 1; ++g2) {
                     const double* A = Ah + (g2 < a ? g2 : g2 + 1) * 64 + r * 8;
 #pragma unroll
@@ -467,7 +470,7 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) s += A[k] * Gi[(i * 8 + k) * NPL + l];
             }
-            U[e] = s;
+            U[(i * 8 + r) * NPL + l] = s;
         }
         __syncthreads();
         STITCH_TICK(2);
@@ -476,8 +479,8 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
         __syncthreads();
         STITCH_TICK(3);
     } else {
-        for (int e = tid; e < W * 8 * NPL; e += NT) {
-            const int i = e / (8 * NPL), o = e - i * 8 * NPL, r = o / NPL, l = o - r * NPL;
+        for (int e = tid; e < W * nr * NPL; e += NT) {
+            const int i = e / (nr * NPL), o = e - i * nr * NPL, r = r0 + o / NPL, l = o % NPL;
             const double* __restrict__ G = D.M_sc + (size_t)i * NPL * NPL;
             double s = 0;
             if (i == a) {
@@ -491,13 +494,13 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) s += A[k] * G[(size_t)(8 * (a < i ? a : a - 1) + k) * NPL + l];
             }
-            U[e] = s;
+            U[(i * 8 + r) * NPL + l] = s;
         }
         __syncthreads();
     }
     auto phase2 = [&](const double* adH, const double* adT, const int MS, const int RS) {
-        for (int e = tid; e < 8 * n1; e += NT) {
-            const int r = e / n1, c = e - r * n1;
+        for (int e = tid; e < nr * n1; e += NT) {
+            const int r = r0 + e / n1, c = e % n1;
             double s = 0;
             if (c < 4) { for (int i = 0; i < W; ++i) s += U[(i * 8 + r) * NPL + cb + c]; }
             else if (c == n) { for (int i = 0; i < W; ++i) s += U[(i * 8 + r) * NPL + cb + 4]; }
@@ -506,11 +509,13 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
                 const int j = (c - 4) >> 3, cp = (c - 4) & 7;
                 const double* Uj = U + (j * 8 + r) * NPL;
                 double s4[4] = {0, 0, 0, 0};                                   // four chains: fp64 FMA latency is 4x its issue rate
+#pragma unroll
                 for (int g2 = 0; g2 < W - 1; ++g2) {                           // host j itself: every slot of its G, through adHost(j, .)
                     const double* A = adH + (j + (g2 < j ? g2 : g2 + 1) * W) * MS + cp * RS;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) s4[k & 3] += Uj[8 * g2 + k] * A[k];
                 }
+#pragma unroll
                 for (int i = 0; i < W; ++i) {                                  // the other hosts: frame j's slot, through adTarget(i, j)
                     if (i == j) continue;
                     const double* Ui = U + (i * 8 + r) * NPL + 8 * (j < i ? j : j - 1);
@@ -536,7 +541,10 @@ __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, 
     __shared__ int is_last;
     if (D.stop && D.stop[0]) return;
     const int W = D.W, n1 = D.n1, n = n1 - 1, NPL = D.NPL, tid = threadIdx.x, NT = blockDim.x;
-    const int sys = blockIdx.x / (W + 1), g = blockIdx.x - sys * (W + 1);
+    // workgroups: [0, W] the top system (W frame rows + the corner), then 2 W for the Schur-complement system - TWO per frame, four of its eight rows each (phase 2
+    // is bound by LDS bandwidth: 2 x 112 fp64 operands per output; two workgroups on two CUs halve it: 18 -> 11 us at W = 8) - then its corner
+    const int sys = blockIdx.x > W ? 1 : 0;
+    const int gb = blockIdx.x - (W + 1), g = sys ? (gb < 2 * W ? gb >> 1 : W) : (int)blockIdx.x, r0 = sys ? (gb & 1) * 4 : 0;
     const double* __restrict__ adH = D.AD;
     const double* __restrict__ adT = D.AD + (size_t)W * W * 64;
     double* Hs = D.H + (size_t)sys * n1 * n1;
@@ -604,7 +612,8 @@ __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, 
                 put(ri < 4 ? ri : n, ci < 4 ? ci : n, s);
             }
         } else if (g < W) {
-            if (ad_in_lds) stitch_sc_rows<true>(D, lds, g, put); else stitch_sc_rows<false>(D, lds, g, put);
+            if (ad_in_lds) { if (D.W == 8) stitch_sc_rows<true, 8>(D, lds, g, r0, 4, put); else stitch_sc_rows<true, 0>(D, lds, g, r0, 4, put); }
+            else stitch_sc_rows<false, 0>(D, lds, g, r0, 4, put);
         } else {
             const int cb = 8 * (W - 1);
             for (int e = tid; e < W * 25; e += NT) {
@@ -651,7 +660,7 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
         if (hipFuncSetAttribute((const void*)ba_stitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         lds_allowed = lds;
     }
-    ba_stitch_kernel<<<2 * (D.W + 1), 1024, lds, s>>>(D, mask, ad_in_lds, mapped, ntail, seq);
+    ba_stitch_kernel<<<3 * D.W + 2, 1024, lds, s>>>(D, mask, ad_in_lds, mapped, ntail, seq);
     return 0;
 }
 
