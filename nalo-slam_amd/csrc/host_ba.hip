@@ -79,6 +79,10 @@ struct BAWindow {
     float* up_host2 = nullptr;                                      // second precalc staging block: set_precalc alternates between the two, each guarded by
     hipEvent_t ev_up[2] = {nullptr, nullptr}; int up_idx = 0;       // the event of its last H2D copy (a copy queued behind a long kernel may still be pending)
     size_t up_cap = 0;
+    // small windows: the precalc records are not copied at all - ba_linearize reads them (scalar loads, one record per workgroup) straight from mapped host
+    // memory; four rotating blocks, a block is rewritten only after the host has seen the stream drain past its last reader (pre_synced)
+    float* pre_map[4] = {nullptr, nullptr, nullptr, nullptr}; float* pre_map_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pre_map_cap = 0; long pre_pos = 0, pre_synced = 0;
     bool have_lin = false, have_sc = false, stitched_top = false, stitched_sc = false, points_set = false, res_set = false;
     bool pt_acc_on_read = false;                                    // nalo_ba_get_points may run the per-point accumulation of an explicit nalo_ba_linearize
     int sc_shift = -1;
@@ -111,6 +115,7 @@ void ba_destroy(nalo_ctx* c) {
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
     if (w->up_host2) (void)hipHostFree(w->up_host2);
+    for (float* p : w->pre_map) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : w->ev_up) if (e) (void)hipEventDestroy(e);
     if (w->gn_host) (void)hipHostFree(w->gn_host);
     w->gn_d.release(); w->gn_f.release(); w->gn_i.release();
@@ -232,12 +237,34 @@ static int set_precalc(nalo_ctx* c) {
         NALO_HIP(c, hipHostMalloc((void**)&w.up_host2, (nfl + 16) * 4));
         w.up_cap = nfl + 80;
     }
+    // Small windows (the KITTI-sized ones, latency bound): no copy. The H2D blit of these 8 KB sat between the back-substitution and the next linearisation
+    // with ~10 us of pipeline gaps around it plus ~5 us of runtime calls on the host; the kernels read the records from mapped host memory instead (scalar
+    // loads, a few hundred bytes per workgroup over PCIe: +2 us inside ba_linearize). Large windows keep the device copy (thousands of workgroups).
+    static const bool force_blit = std::getenv("NALO_BA_PRE_BLIT") != nullptr;
+    const bool direct = !force_blit && w.points_set && w.Ppad <= 32768;
+    float* rec;
+    if (direct) {
+        if (w.pre_map_cap < nfl + 16) {
+            NALO_HIP(c, hipStreamSynchronize(c->stream));
+            for (int i = 0; i < 4; ++i) {
+                if (w.pre_map[i]) (void)hipHostFree(w.pre_map[i]);
+                w.pre_map[i] = nullptr;
+                NALO_HIP(c, hipHostMalloc((void**)&w.pre_map[i], (nfl + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+                NALO_HIP(c, hipHostGetDevicePointer((void**)&w.pre_map_dev[i], w.pre_map[i], 0));
+            }
+            w.pre_map_cap = nfl + 16; w.pre_synced = w.pre_pos;
+        }
+        ++w.pre_pos;
+        if (w.pre_pos - 4 > w.pre_synced) { NALO_HIP(c, hipStreamSynchronize(c->stream)); w.pre_synced = w.pre_pos - 1; }   // the block's last readers may still run
+        rec = w.pre_map[w.pre_pos & 3];
+    } else {
     // the records are rewritten while the previous copy may still be queued behind a kernel (optimize: do_step -> set_precalc, then the epilogue's
     // set_precalc with no wait in between; nalo_ba_restore likewise): alternate two staging blocks, each guarded by the event of its last copy
     w.up_idx ^= 1;
     if (!w.ev_up[w.up_idx]) NALO_HIP(c, hipEventCreateWithFlags(&w.ev_up[w.up_idx], hipEventDisableTiming));
     else NALO_HIP(c, hipEventSynchronize(w.ev_up[w.up_idx]));
-    float* rec = w.up_idx ? w.up_host2 : w.up_host;
+    rec = w.up_idx ? w.up_host2 : w.up_host;
+    }
     const float fx = w.c_scaledf[0], fy = w.c_scaledf[1], cx = w.c_scaledf[2], cy = w.c_scaledf[3];
     const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1.0f / fx, 0, -cx / fx, 0, 1.0f / fy, -cy / fy, 0, 0, 1};
     for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
@@ -259,7 +286,8 @@ static int set_precalc(nalo_ctx* c) {
     float* cal = rec + nfl;                                               // CalibHessian::value_scaledf / value_scaledi + cDeltaF travel with the records
     cal[0] = fx; cal[1] = fy; cal[2] = cx; cal[3] = cy; cal[4] = w.c_scaledi[0]; cal[5] = w.c_scaledi[1];
     for (int i = 0; i < 4; ++i) cal[6 + i] = w.cDeltaF[i];
-    NALO_HIP(c, w.pre.reserve(nfl + 16));
+    NALO_HIP(c, w.pre.reserve(nfl + 16));                                  // (the device-resident GN loop, NALO_BA_DEVICE_GN, writes its records here either way)
+    if (direct) { w.dev.pre = w.pre_map_dev[w.pre_pos & 3]; w.dev.calib = w.dev.pre + nfl; return NALO_OK; }
     NALO_HIP(c, hipMemcpyAsync(w.pre.p, rec, (nfl + 16) * 4, hipMemcpyHostToDevice, c->stream));
     NALO_HIP(c, hipEventRecord(w.ev_up[w.up_idx], c->stream));
     w.dev.pre = w.pre.p; w.dev.calib = w.pre.p + nfl;
@@ -468,6 +496,7 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
         } else if (sep_publish && !misc_only) ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq, w.st_ticket.p + 1);
         { int rc = flush_th(c); if (rc) return rc; }                  // behind the publish: overlaps the host's solve
         if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
+        w.pre_synced = w.pre_pos;                               // everything launched on the main stream so far has run (the side stream reads no precalc record)
         if (w.step_pending) {                                   // finish doStepFromBackup's break test with the sums of the last step
             const double* s3 = w.stitched_host + 2 * blk + 2 * W * W;
             const float numID = (float)s3[2];
