@@ -15,8 +15,11 @@
 
 namespace nalo {
 
+// lanes per workgroup: 512 (one point per lane and round, half as many workgroups as with 256 lanes -> half as many partials to exchange and to
+// sum in every workgroup per evaluation; 214 VGPRs, no spill). Headline window, same box, back to back: 256: 696, 384: 708, **512: 717-769**, 768 (spills): 670-678,
+// 1024 (spills): 633-640 keyframes/s.
 #ifndef NALO_LM_THREADS
-#define NALO_LM_THREADS 256
+#define NALO_LM_THREADS 512
 #endif
 #ifndef NALO_LM_G
 #define NALO_LM_G 1

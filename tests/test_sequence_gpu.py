@@ -63,8 +63,11 @@ def check(rec, drv, tol_state, tol_clean, tol_flipped):
     assert Ho.shape == Hg.shape
     if np.abs(Ho).max() > 0:               # bM is a cancelling difference (M_b - Msc_b): its relative error is an order above H's; same floor rule as the poses
         H64, b64 = rec["prior"][2]
-        assert rel_err(Hg, Ho) < max(2e-4 if drv.teacher else 5e-3, 1.5 * rel_err(H64, Ho)), (rel_err(Hg, Ho), rel_err(H64, Ho))
-        assert rel_err(bg, bo) < max(2e-3 if drv.teacher else 5e-2, 1.5 * rel_err(b64, bo)), (rel_err(bg, bo), rel_err(b64, bo))
+        # a flipped residual decision (an order statistic of fp32 energies decides: inherent) moves a marginalised point's whole contribution
+        # in or out of the prior: 2e-3 of max|H| measured for ONE flip of 9897 on the 1224x368 run; without flips the teacher-forced prior agrees to 2e-4
+        tight = drv.teacher and tol_state["flips"] == 0
+        assert rel_err(Hg, Ho) < max(2e-4 if tight else 5e-3, 1.5 * rel_err(H64, Ho)), (rel_err(Hg, Ho), rel_err(H64, Ho), flips)
+        assert rel_err(bg, bo) < max(2e-3 if tight else 5e-2, 1.5 * rel_err(b64, bo)), (rel_err(bg, bo), rel_err(b64, bo), flips)
     for (b, fid), (ok, T, aff) in rec.get("tracked", {}).items():
         if b == 1:
             ok_o, T_o, aff_o = rec["tracked"][(0, fid)]
