@@ -62,7 +62,7 @@ struct BAWindow {
     DevBuf<float4> rs_pp0;
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
     DevBuf<int> blk_host, host_blk, blk_order, sc_grp;
-    DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 16
+    DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 64 (state, arrival counters, workgroup totals)
     // device-side Gauss-Newton loop (kernels_ba_gn.hip): constants + states of one optimize() call
     DevBuf<double> gn_d; DevBuf<float> gn_f; DevBuf<int> gn_i; GNDev gn{};
     double* gn_host = nullptr; size_t gn_host_cap = 0;              // pinned staging (doubles; the float part follows)
@@ -742,7 +742,7 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     }
     w.dev.W = W; w.dev.w = c->w; w.dev.h = c->h;
     w.dev.fix_a = c->set.affineOptModeA < 0; w.dev.fix_b = c->set.affineOptModeB < 0; w.dev.no_th = 0;
-    NALO_HIP(c, w.th_hist.reserve(2 * 65536 + 16)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, (2 * 65536 + 16) * 4));
+    NALO_HIP(c, w.th_hist.reserve(2 * 65536 + 64)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, (2 * 65536 + 64) * 4));
     w.dev.th_hist_hi = w.th_hist.p; w.dev.th_hist_lo = w.th_hist.p + 65536; w.dev.th_state = w.th_hist.p + 2 * 65536;
     if (w.HM.size() == (size_t)(w.n - 8) * (w.n - 8) && w.n > 12) {
         // one frame appended to a window that carries a prior = EnergyFunctional::insertFrame (EnergyFunctional.cpp:437-442): conservativeResize, the new

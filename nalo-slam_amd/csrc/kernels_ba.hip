@@ -798,50 +798,78 @@ void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partia
 // that target the newest frame, by a two-level 16+16-bit radix select on the float bit patterns (monotone for x >= 0):
 // the high-half histogram is filled by ba_linearize_kernel itself (integer atomics), then find-hi -> low-half histogram of the
 // matching entries -> find-lo + the threshold formula (:130-133). Runs on the side stream, overlapped with SC/reduce/stitch.
-__global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new, const int* __restrict__ stop) {
+// 16 workgroups of 256 lanes, one launch: workgroup g owns bins [4096 g, 4096 (g + 1)) in registers (wave w of it: 1024 bins = 4 rounds of coalesced 16-byte
+// loads), publishes its total, and after a 16-party arrival counter (the workgroups are co-resident: 16 x 256 lanes; the spin is bounded) the ONE workgroup whose
+// range holds the k-th entry locates the bin wave -> round -> lane -> bin with shuffles only. (Was: one workgroup of 1024 lanes pulling all 256 KB through one CU,
+// 13 us per search, two searches per pass: on the critical path of every sharded iteration.) state[4] = generation (selects the counter), state[5..6] = the two
+// arrival counters (the idle one is cleared by workgroup 0), state[16..31] = the totals.
+constexpr int kThWG = 16;
+__global__ __launch_bounds__(256) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new, const int* __restrict__ stop) {
     if (stop && stop[0]) return;
-    // wave w owns bins [4096 w, 4096 (w+1)): 16 rounds of coalesced 16-byte loads (round i, lane l = bins 4096 w + 256 i + 4 l ..+3), everything stays in
-    // registers. The bin whose running count passes k is then located wave -> round -> lane -> bin with shuffles only.
-    __shared__ unsigned wsum[16];
-    __shared__ unsigned s_bin, s_run;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint4* h4 = reinterpret_cast<uint4*>(hist + wave * 4096) + lane;
-    uint4 q[16];
-    unsigned ls[16], sum = 0;
+    __shared__ unsigned wsum[4], tot[kThWG];
+    __shared__ unsigned s_bin, s_run, s_gen;
+    __shared__ int s_ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    uint4* h4 = reinterpret_cast<uint4*>(hist + wg * 4096 + wave * 1024) + lane;
+    uint4 q[4];
+    unsigned ls[4], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { q[i] = h4[i * 64]; ls[i] = q[i].x + q[i].y + q[i].z + q[i].w; sum += ls[i]; }
+    for (int i = 0; i < 4; ++i) { q[i] = h4[i * 64]; ls[i] = q[i].x + q[i].y + q[i].z + q[i].w; sum += ls[i]; }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) h4[i * 64] = make_uint4(0u, 0u, 0u, 0u);                // ready for the next pass
+    for (int i = 0; i < 4; ++i) h4[i * 64] = make_uint4(0u, 0u, 0u, 0u);                 // ready for the next pass
     unsigned wtot = sum;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) wtot += __shfl_xor(wtot, o);
     if (lane == 0) wsum[wave] = wtot;
     if (tid == 0) { s_bin = 65535u; s_run = 0xFFFFFFFFu; }
     __syncthreads();
-    unsigned total = 0, wpre = 0;
-    for (int i = 0; i < 16; ++i) { if (i == wave) wpre = total; total += wsum[i]; }
+    const unsigned gtot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) {
+        const unsigned g = __hip_atomic_load(state + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wg == 0) __hip_atomic_store(state + 5 + ((g + 1) & 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the previous launch's counter: all of its workgroups are gone
+        __hip_atomic_store(state + 16 + wg, gtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(state + 5 + (g & 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            if (__hip_atomic_load(state + 5 + (g & 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)kThWG) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        s_ok = ok; s_gen = g;
+    }
+    __syncthreads();
+    if (!s_ok) { if (wg == 0 && tid == 0 && frameTH_new) *frameTH_new = NAN; return; }          // a workgroup never arrived: make it visible downstream
+    if (tid < kThWG) tot[tid] = __hip_atomic_load(state + 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    unsigned total = 0, gpre = 0;
+    for (int i = 0; i < kThWG; ++i) { if (i == wg) gpre = total; total += tot[i]; }
     const unsigned k = (level == 0) ? (unsigned)(int)(0.7f * (float)total) : state[1];
-    if (wpre <= k && k < wpre + wtot) {                         // exactly one wave (none if k >= total: empty histogram)
-        unsigned run = wpre;
-        bool done = false;
+    const bool owner = gpre <= k && k < gpre + gtot;                   // exactly one workgroup (none if k >= total: empty histogram -> the last one reports)
+    if (!owner && !(k >= total && wg == kThWG - 1)) return;
+    if (owner) {
+        unsigned wpre = gpre;
+        for (int i = 0; i < wave; ++i) wpre += wsum[i];
+        if (wpre <= k && k < wpre + wtot) {                            // exactly one wave
+            unsigned run = wpre;
+            bool done = false;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            unsigned isum = ls[i];
+            for (int i = 0; i < 4; ++i) {
+                unsigned isum = ls[i];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) isum += __shfl_xor(isum, o);
-            if (!done && k < run + isum) {                      // wave-uniform: this round holds the bin
-                unsigned incl = ls[i];
+                for (int o = 32; o > 0; o >>= 1) isum += __shfl_xor(isum, o);
+                if (!done && k < run + isum) {                          // wave-uniform: this round holds the bin
+                    unsigned incl = ls[i];
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-                const unsigned lexcl = run + incl - ls[i];
-                if (lexcl <= k && k < lexcl + ls[i]) {
-                    unsigned r2 = lexcl; int bsel = 3;
-                    if (r2 + q[i].x > k) bsel = 0; else { r2 += q[i].x; if (r2 + q[i].y > k) bsel = 1; else { r2 += q[i].y; if (r2 + q[i].z > k) bsel = 2; else r2 += q[i].z; } }
-                    s_bin = (unsigned)(wave * 4096 + i * 256 + 4 * lane + bsel); s_run = r2;
+                    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+                    const unsigned lexcl = run + incl - ls[i];
+                    if (lexcl <= k && k < lexcl + ls[i]) {
+                        unsigned r2 = lexcl; int bsel = 3;
+                        if (r2 + q[i].x > k) bsel = 0; else { r2 += q[i].x; if (r2 + q[i].y > k) bsel = 1; else { r2 += q[i].y; if (r2 + q[i].z > k) bsel = 2; else r2 += q[i].z; } }
+                        s_bin = (unsigned)(wg * 4096 + wave * 1024 + i * 256 + 4 * lane + bsel); s_run = r2;
+                    }
+                    done = true;
                 }
-                done = true;
+                if (!done) run += isum;
             }
-            if (!done) run += isum;
         }
     }
     __syncthreads();
@@ -859,6 +887,7 @@ __global__ __launch_bounds__(1024) void ba_th_find_kernel(unsigned* __restrict__
             }
             *frameTH_new = th;
         }
+        __hip_atomic_store(state + 4, s_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // next launch: the other counter
     }
 }
 __global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo, const int* __restrict__ stop) {
@@ -927,9 +956,9 @@ __global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restri
 void ba_launch_energy_th(hipStream_t s, const BADev& B) {
     static const bool big = std::getenv("NALO_TH_HIST") != nullptr;        // force the two-histogram path
     if (B.Ppad <= 16384 && !big) { ba_th_small_kernel<<<1, 1024, 0, s>>>(B.en_new, B.Ppad, B.th_hist_hi, B.frameTH + (B.W - 1), B.stop); return; }
-    ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr, B.stop);
+    ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr, B.stop);
     ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo, B.stop);
-    ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1), B.stop);
+    ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1), B.stop);
 }
 // Sharded window: the order statistic is taken over ALL ranks' residuals, so each of the two histograms is summed across ranks before its search
 // (the all-reduce hook sums doubles: counts go through fp64, exact below 2^53). step 0: hi histogram -> buf; 1: buf -> hi histogram, search, fill the
@@ -944,12 +973,12 @@ void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int
     if (step == 0) ba_th_cvt_kernel<<<NHI / 256, 256, 0, s>>>(B.th_hist_hi, buf, NHI, 0);
     else if (step == 1) {
         ba_th_cvt_kernel<<<NHI / 256, 256, 0, s>>>(B.th_hist_hi, buf, NHI, 1);
-        ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr, B.stop);
+        ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr, B.stop);
         ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo, B.stop);
         ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 0);
     } else {
         ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 1);
-        ba_th_find_kernel<<<1, 1024, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1), B.stop);
+        ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1), B.stop);
     }
 }
 
