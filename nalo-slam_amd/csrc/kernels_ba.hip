@@ -536,6 +536,10 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
 #endif
 }
 
+#ifndef NALO_STITCH_SC_SPLIT
+#define NALO_STITCH_SC_SPLIT 2
+#endif
+constexpr int kScSplit = NALO_STITCH_SC_SPLIT;       // workgroups per frame for the Schur-complement rows (8 / kScSplit rows each)
 __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, int ad_in_lds, double* mapped, int ntail, double seq) {
     extern __shared__ double lds[];
     __shared__ int is_last;
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, 
     // workgroups: [0, W] the top system (W frame rows + the corner), then 2 W for the Schur-complement system - TWO per frame, four of its eight rows each (phase 2
     // is bound by LDS bandwidth: 2 x 112 fp64 operands per output; two workgroups on two CUs halve it: 18 -> 11 us at W = 8) - then its corner
     const int sys = blockIdx.x > W ? 1 : 0;
-    const int gb = blockIdx.x - (W + 1), g = sys ? (gb < 2 * W ? gb >> 1 : W) : (int)blockIdx.x, r0 = sys ? (gb & 1) * 4 : 0;
+    const int gb = blockIdx.x - (W + 1), g = sys ? (gb < kScSplit * W ? gb / kScSplit : W) : (int)blockIdx.x, r0 = sys ? (gb % kScSplit) * (8 / kScSplit) : 0;
     const double* __restrict__ adH = D.AD;
     const double* __restrict__ adT = D.AD + (size_t)W * W * 64;
     double* Hs = D.H + (size_t)sys * n1 * n1;
@@ -612,8 +616,8 @@ __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, 
                 put(ri < 4 ? ri : n, ci < 4 ? ci : n, s);
             }
         } else if (g < W) {
-            if (ad_in_lds) { if (D.W == 8) stitch_sc_rows<true, 8>(D, lds, g, r0, 4, put); else stitch_sc_rows<true, 0>(D, lds, g, r0, 4, put); }
-            else stitch_sc_rows<false, 0>(D, lds, g, r0, 4, put);
+            if (ad_in_lds) { if (D.W == 8) stitch_sc_rows<true, 8>(D, lds, g, r0, 8 / kScSplit, put); else stitch_sc_rows<true, 0>(D, lds, g, r0, 8 / kScSplit, put); }
+            else stitch_sc_rows<false, 0>(D, lds, g, r0, 8 / kScSplit, put);
         } else {
             const int cb = 8 * (W - 1);
             for (int e = tid; e < W * 25; e += NT) {
@@ -660,7 +664,7 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
         if (hipFuncSetAttribute((const void*)ba_stitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         lds_allowed = lds;
     }
-    ba_stitch_kernel<<<3 * D.W + 2, 1024, lds, s>>>(D, mask, ad_in_lds, mapped, ntail, seq);
+    ba_stitch_kernel<<<(kScSplit + 1) * D.W + 2, 1024, lds, s>>>(D, mask, ad_in_lds, mapped, ntail, seq);
     return 0;
 }
 
