@@ -482,7 +482,10 @@ def main():
             out["shard1m"] = res
             if world == 1:
                 leg_state["leg"] = "stress250k"
-                out["stress250k"] = stress_leg()
+                try:
+                    out["stress250k"] = stress_leg()
+                except Exception as e:              # never lose the main line to an extra leg
+                    out["stress250k"] = {"error": repr(e)}
                 log("stress250k leg done")
                 leg_state["leg"] = "frontend"
                 try:
