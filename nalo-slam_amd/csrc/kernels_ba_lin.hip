@@ -8,8 +8,9 @@
 //
 // The arithmetic of a residual is ONE set of __device__ functions (lin_setup / lin_pixel / lin_commit / lin_stream); the kernel around them fetches the
 // 32 bilinear taps of a residual COOPERATIVELY: in round r lane q of a quad loads tap q (0,1 = the two texels of row iy, 2,3 = row iy+1) of residual
-// r's pixel, so neighbouring lanes read neighbouring 16-byte {I,dx,dy,0} texels (half the cache-line accesses of one-residual-per-lane gathers), and the
-// texels return to their owner through a per-wave LDS exchange. Points are Hilbert-ordered per host (host_ba.hip), so a wave's residuals project into a
+// r's pixel, so neighbouring lanes read neighbouring texels (half the cache-line accesses of one-residual-per-lane gathers), and the texels return to their
+// owner through a per-wave LDS exchange. The texels come from a second copy of level 0: 12-byte {I,dx,dy} texels in 5x2 tiles of one 128-byte cache line
+// (frame_tile_level0, kernels_pyramid.hip): ~7.0 lines per residual footprint instead of ~9.8 with row-major 16-byte texels. Points are Hilbert-ordered per host (host_ba.hip), so a wave's residuals project into a
 // compact patch of the target image.
 //
 // Grid = (target, point block [, quarter]), TARGET-MAJOR and XCD-aware: all CUs gather from the same target image at a time. The FrameFramePrecalc

@@ -2,13 +2,13 @@
 //
 // The reference's LM loop does up to ~180 calcRes/calcGSSSE evaluations per frame with an 8x8 solve and an SE3::exp in between. Driven from the host every
 // evaluation costs a launch + a completion round trip (~19 us) although the kernels themselves run a few microseconds on a KITTI-sized point cloud: the loop
-// is latency bound. Here ONE persistent launch of up to NALO_LM_MAX_BLOCKS (64) workgroups of 256 lanes runs the whole pyramid descent, ALL levels:
+// is latency bound. Here ONE persistent launch of up to NALO_LM_MAX_BLOCKS (64) workgroups of NALO_LM_THREADS (512) lanes runs the whole pyramid descent, ALL levels:
 // every workgroup evaluates its share of the level's points (fused calcRes + calcGS), reduces it (DPP quad adds -> LDS rows -> fp64 column sums) and
 // publishes the partial as 8-byte {fp32 value, tag} words (agent-scope atomics: the data is the arrival flag, double-buffered by evaluation parity, bounded
 // poll); then EVERY workgroup sums the partials in a fixed order and replays the control flow on its wave 0: 8x8 LDL^T with one matrix row per lane and
 // v_readlane broadcasts, SE3::exp, accept / reject, lambda schedule, cutoff repeat, level descent - exactly the control flow of the host mirror in
 // host_api.hip (NALO_TRK_HOST_LM=1 selects that one, and so do the fixed-affine settings). The workgroups must be co-resident (no cooperative launch is
-// used: 64 workgroups of 256 lanes fit 256 CUs by a wide margin; a violation - the CUs held by another context's long kernel - ends in the bounded poll, not in
+// used: 64 workgroups of 512 lanes fit 256 CUs by a wide margin; a violation - the CUs held by another context's long kernel - ends in the bounded poll, not in
 // a hang: the launch returns NALO_LM_LOST_BLOCK and nalo_trk_track redoes the frame with the host-driven loop and keeps to it for this context).
 #include "nalo_internal.h"
 #include "reduce.h"
