@@ -229,6 +229,31 @@ def test_window_sizes(W, P):
     c.close()
 
 
+@pytest.mark.parametrize("w,h", [(643, 481), (1226, 371)])
+def test_linearize_on_image_sizes_off_the_tile_grid(w, h):
+    """ba_linearize gathers from a copy of level 0 laid out in tiles of 5x2 texels (frame_tile_level0): widths that are no multiple of 5 and odd heights leave
+    the last tile column / row partly unused - same residual states, energies and Jacobian products as the oracle there too (points reach the image border)."""
+    win = synth.make_window(w=w, h=h, W=3, P=600, seed=23)
+    st6 = synth.perturbed_poses(win, sigma_t=0.003, sigma_r=0.0003)
+    orc.lib().orc_set_sum_mode(0)
+    ba = orc.ba_from_window(win, "f32", state6=st6)
+    c = make_ctx(win, st6)
+    E_o = ba.linearize_all(False)
+    ba.apply_res()
+    E = c.ba_linearize(False)
+    st_o, ac_o, jp_o, en_o = ba.slots()
+    st, ac, jp, en, _ = c.ba_get_residuals()
+    assert np.array_equal(st, st_o) and np.array_equal(ac, ac_o)
+    assert abs(E - E_o) < 1e-5 * E_o
+    m = ac_o > 0
+    assert m.sum() > 500
+    assert rel_err(jp[m], jp_o[m]) < 4e-5
+    nw = win.W - 1
+    mm = (en_o[:, nw] >= 0) & (win.exists[:, nw] > 0)
+    assert np.array_equal(mm, en[:, nw] >= 0) and rel_err(en[mm, nw], en_o[mm, nw]) < 2e-5
+    c.close()
+
+
 def test_profile_select_brackets_one_scope(small_window):
     """nalo_profile_select: only the named scope is timed (what bench.py's timed region relies on); NULL = every scope again"""
     c = make_ctx(small_window)
