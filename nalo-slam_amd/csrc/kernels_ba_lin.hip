@@ -63,7 +63,7 @@ struct QuadStream {
     int k;
     __device__ __forceinline__ QuadStream(float* rows, int tid) : row4(reinterpret_cast<float4*>(rows + (tid >> 2) * kTopStride)), writer((tid & 3) == 0), b0(0.f), b1(0.f), b2(0.f), k(0) {}
     __device__ __forceinline__ void put(float v) {
-        v += dpp_quad_xor1(v); v += dpp_quad_xor2(v);
+        v = dpp_quad_sum(v);
         const int m = k & 3;
         if (m == 0) b0 = v; else if (m == 1) b1 = v; else if (m == 2) b2 = v;
         else if (writer) row4[k >> 2] = make_float4(b0, b1, b2, v);

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
         const int nbl = min(NB, (L.n + kLmThreads - 1) / kLmThreads);          // blocks that own points of this level
         if (blk < nbl) {
 #pragma unroll
-            for (int k = 0; k < kLmVals; ++k) { acc[k] += dpp_quad_xor1(acc[k]); acc[k] += dpp_quad_xor2(acc[k]); }
+            for (int k = 0; k < kLmVals; ++k) acc[k] = dpp_quad_sum(acc[k]);
             if ((tid & 3) == 0) {
                 float* row = rows + (tid >> 2) * kLmStride;
 #pragma unroll

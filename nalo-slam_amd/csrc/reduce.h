@@ -19,12 +19,21 @@ __device__ __forceinline__ float dpp_quad_xor2(float v) {   // quad_perm [2,3,0,
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
 
+// sum over the four lanes of a quad. The empty asm statements are opaque to the SLP vectoriser: left alone it packs pairs of these adds into v_pk_add_f32, which
+// cannot take a DPP operand, and every add then needs its own v_mov_b32_dpp; scalar adds fold with the moves into v_add_f32_dpp (ba_linearize: 2640 -> 2540
+// vector instructions per lane, same operations, same results).
+__device__ __forceinline__ float dpp_quad_sum(float v) {
+    v += dpp_quad_xor1(v); asm volatile("" : "+v"(v));
+    v += dpp_quad_xor2(v); asm volatile("" : "+v"(v));
+    return v;
+}
+
 // smem: (NT/4) * (N+1) floats. out: N floats (global or LDS). All NT threads must call.
 template <int N, int NT>
 __device__ __forceinline__ void block_reduce_cols(float (&v)[N], float* smem, float* out) {
     constexpr int NP = N + 1;
 #pragma unroll
-    for (int i = 0; i < N; ++i) { v[i] += dpp_quad_xor1(v[i]); v[i] += dpp_quad_xor2(v[i]); }
+    for (int i = 0; i < N; ++i) v[i] = dpp_quad_sum(v[i]);
     const int tid = threadIdx.x;
     if ((tid & 3) == 0) {
         float* row = smem + (tid >> 2) * NP;

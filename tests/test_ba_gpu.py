@@ -111,8 +111,8 @@ def test_solve_resubstitute_step(pair):
 def test_solve_and_step_on_the_well_conditioned_window():
     """Round-1 review (weak #4): the solver-level bounds of the toy window (x 1e-2, step 5e-3) are what its gauge-weak 68-unknown system allows; the
     W = 8 / P = 3000 window allows a tight check of the SAME quantities - the solved increment x of solveSystemF and the back-substituted point steps -
-    and here it is, tied to the fp64 oracle: the GPU must be as close to the all-fp64 x as the strict fp32 oracle is (x 1.5), and within 2e-4 of the fp32
-    oracle in any case; the point steps within 1e-4 of their largest."""
+    and here it is, tied to the fp64 oracle: the GPU must be as close to the all-fp64 x as the strict fp32 oracle is (x 1.5; measured 0.4-1.4e-4 against the
+    oracle's own 2.8e-4) and within twice that floor of the fp32 oracle; the point steps within 1e-4 of their largest."""
     win = synth.make_window(w=640, h=480, W=8, P=3000, seed=7)
     st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
     orc.lib().orc_set_sum_mode(0)
@@ -132,7 +132,7 @@ def test_solve_and_step_on_the_well_conditioned_window():
     floor_x, mine_x = rel_err(x32, x64), rel_err(x, x64)
     print("x: GPU vs fp64 %.2e, fp32 oracle vs fp64 %.2e, GPU vs fp32 oracle %.2e; steps: GPU vs fp32 oracle %.2e of max" % (mine_x, floor_x, rel_err(x, x32), np.abs(step - s32).max() / np.abs(s32).max()))
     assert mine_x < 1.5 * floor_x + 1e-6, (mine_x, floor_x)
-    assert rel_err(x, x32) < 2e-4
+    assert rel_err(x, x32) < max(2e-4, 2.0 * floor_x)              # two fp32 evaluations may sit on opposite sides of the fp64 truth
     scale = np.abs(s32).max()
     assert np.abs(step - s32).max() < max(1e-4, 1.5 * np.abs(s64 - s32).max() / scale) * scale
     c.close()
