@@ -332,6 +332,10 @@ def main():
     # measured in a separate, untimed pass right after.
     mode = os.environ.get("NALO_BENCH_PROFILE", "dominant")      # dominant | all | none
     job.ctx.profile_select("ba_linearize" if mode == "dominant" else None)
+    # one launch in three is bracketed (co-prime with the 8 linearisations of a keyframe, so every position of the loop is sampled): all eight cost 4-6 % of a
+    # step on this latency-bound window (NALO_BENCH_PROFILE=none vs dominant: 760-768 vs 715-740 keyframes/s on one box); the stress250k leg brackets every launch
+    lin_every = int(os.environ.get("NALO_BENCH_PROFILE_EVERY", "3")) if (mode == "dominant" and not sharded) else 1
+    job.ctx.profile_sample(lin_every)
     job.ctx.profile_enable(mode != "none")
     job.ctx.profile_reset()
     job.evals = 0
@@ -353,6 +357,7 @@ def main():
     value = units / dt
 
     prof = {"ba_linearize": job.ctx.profile_get("ba_linearize")}
+    job.ctx.profile_sample(1)
     # the roofline's denominator measured on this device in the same run: streaming copy / triad over 1 GiB buffers
     try:
         hbm_copy, hbm_triad = job.ctx.hbm_calibrate(1 << 30, 10)
@@ -394,7 +399,7 @@ def main():
                        "multi_gpu": ("points sharded, all-reduce of stitched H,b" if sharded else "replicas (window too small to shard)")},
             "roofline": roof,
             "kernel_ms": {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
-            "kernel_ms_note": "ba_linearize: HIP events over the timed region (%d steps); the other scopes: %d untimed steps right after it" % (args.steps, nprof),
+            "kernel_ms_note": "ba_linearize: HIP events over the timed region (%d steps%s); the other scopes: %d untimed steps right after it" % (args.steps, ", one launch in %d bracketed" % lin_every if lin_every > 1 else "", nprof),
             "tracker_evals_per_step": job.evals / max(args.steps, 1),
             "fine_track_rmse": round(float(rm), 4),
         }

@@ -427,6 +427,10 @@ int nalo_init_get_points(nalo_ctx* ctx, int lvl, int cap, int* n, float* u, floa
 int nalo_profile_enable(nalo_ctx* ctx, int on);
 int nalo_profile_select(nalo_ctx* ctx, const char* kernel);
 int nalo_profile_reset(nalo_ctx* ctx);
+/* bracket only one launch in `every` of the selected scopes (default 1 = all). The event pairs cost a few microseconds of pipeline each: on the KITTI-sized
+ * window 8 bracketed launches per keyframe are 4-6 % of a step; a sampled average (every = 3: co-prime with the 8 launches of a keyframe) measures the same kernel
+ * with a third of the perturbation. nalo_profile_get reports the bracketed launches only. */
+int nalo_profile_sample(nalo_ctx* ctx, int every);
 int nalo_profile_get(nalo_ctx* ctx, const char* kernel, double* total_ms, int* launches);
 
 /* Calibration of the roofline's denominator on THIS device ("fraction of the box's measured device-copy / triad bandwidth from a calibration

@@ -34,7 +34,7 @@ EXPORTS = [
     "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
-    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get", "nalo_hbm_calibrate",
+    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get", "nalo_profile_sample", "nalo_hbm_calibrate",
 ]
 
 
@@ -149,6 +149,7 @@ def load():
     L.nalo_profile_reset.argtypes = [vp]
     L.nalo_profile_select.argtypes = [vp, C.c_char_p]
     L.nalo_profile_get.argtypes = [vp, C.c_char_p, c_dp, c_ip]
+    L.nalo_profile_sample.argtypes = [vp, C.c_int]
     L.nalo_hbm_calibrate.argtypes = [vp, C.c_size_t, C.c_int, c_dp, c_dp]
     _LIB = L
     return L
@@ -720,6 +721,9 @@ class Context:
     def profile_select(self, name=None):
         """bracket only the scope `name` (None = all scopes)"""
         self._ck(self.L.nalo_profile_select(self.h_, None if name is None else name.encode()))
+
+    def profile_sample(self, every=1):
+        self._ck(self.L.nalo_profile_sample(self.h_, int(every)))
 
     def profile_reset(self):
         self._ck(self.L.nalo_profile_reset(self.h_))

@@ -731,6 +731,7 @@ int nalo_profile_enable(nalo_ctx* c, int on) {
     return NALO_OK;
 }
 int nalo_profile_select(nalo_ctx* c, const char* kernel) { if (!c) return NALO_ERR_ARG; c->prof_only = kernel ? kernel : ""; return NALO_OK; }
+int nalo_profile_sample(nalo_ctx* c, int every) { if (!c || every < 1) return NALO_ERR_ARG; c->prof_every = every; c->prof_tick = 0; return NALO_OK; }
 int nalo_profile_reset(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; prof_drain(c); c->prof.clear(); return NALO_OK; }
 int nalo_profile_get(nalo_ctx* c, const char* kernel, double* total_ms, int* launches) {
     if (!c || !kernel) return NALO_ERR_ARG;

@@ -107,6 +107,7 @@ struct nalo_ctx {
     // ---- profiling
     bool prof_on = false;
     std::string prof_only;                   // empty = every scope; else only the scope of that name is bracketed
+    int prof_every = 1; unsigned prof_tick = 0;   // nalo_profile_sample: bracket one launch in prof_every (the brackets perturb a latency-bound pipeline)
     std::vector<hipEvent_t> prof_pool;       // idle events
     std::map<std::string, nalo::ProfEntry> prof;
 };
@@ -153,7 +154,7 @@ struct ProfScope {               // HIP-event bracket on the ctx stream (only wh
     // packets around the kernel (an event pair recorded on the stream costs ~10 us of bubbles per bracket on a latency-bound pipeline)
     nalo_ctx* c; const char* name; hipEvent_t a = nullptr, b = nullptr; bool external;
     ProfScope(nalo_ctx* ctx, const char* n, bool ext = false) : c(ctx), name(n), external(ext) {
-        if (c->prof_on && (c->prof_only.empty() || c->prof_only == n)) {
+        if (c->prof_on && (c->prof_only.empty() || c->prof_only == n) && (c->prof_every <= 1 || (c->prof_tick++ % (unsigned)c->prof_every) == 0)) {
             // events come from a pool (filled by nalo_profile_enable, refilled as brackets are drained): no hipEventCreate on the measured path
             for (hipEvent_t* e : {&a, &b}) { if (c->prof_pool.empty()) (void)hipEventCreate(e); else { *e = c->prof_pool.back(); c->prof_pool.pop_back(); } }
             if (!external) (void)hipEventRecord(a, c->stream);
