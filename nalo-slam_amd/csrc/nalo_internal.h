@@ -143,10 +143,11 @@ inline bool poll_flag(nalo_ctx* c, volatile double* flag, double seq) {
     }
 }
 
-struct HostTimer {                // wall-clock scope, accumulated per name
-    nalo_ctx* c; const char* name; std::chrono::steady_clock::time_point t0;
-    HostTimer(nalo_ctx* ctx, const char* n) : c(ctx), name(n), t0(std::chrono::steady_clock::now()) {}
-    ~HostTimer() { auto& e = c->host_t[name]; e.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); e.second++; }
+struct HostTimer {                // wall-clock scope, accumulated per name; a no-op unless NALO_HOST_TIMING is set (two clock reads, a std::string and a map
+    nalo_ctx* c; const char* name; std::chrono::steady_clock::time_point t0;      // lookup per scope, ~50 scopes per keyframe, are not free on a 1.3 ms step)
+    static bool on() { static const bool v = std::getenv("NALO_HOST_TIMING") != nullptr; return v; }
+    HostTimer(nalo_ctx* ctx, const char* n) : c(ctx), name(n) { if (on()) t0 = std::chrono::steady_clock::now(); }
+    ~HostTimer() { if (!on()) return; auto& e = c->host_t[name]; e.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); e.second++; }
 };
 
 struct ProfScope {               // HIP-event bracket on the ctx stream (only when profiling is enabled, and selected: nalo_profile_select)
