@@ -60,13 +60,20 @@ void* nalo_stream(nalo_ctx* ctx);                 /* hipStream_t every kernel of
  * the reference's CLI (main_dso_pangolin.cpp:400-460 changes exactly these: mode=1 sets the affine modes to 0, mode=2 to -1).
  *   forceAcceptStep   setting_forceAceptStep (:71, default 1). 0: FullSystem::optimize linearises WITHOUT applyRes, compares
  *                     E + calcLEnergy + calcMEnergy against the last accepted values and either applies the step or restores the backup
- *                     (FullSystemOptimize.cpp:511-541). Host-driven loop only (not with the sharded hooks / NALO_BA_DEVICE_GN: NALO_ERR_UNSUPPORTED).
+ *                     (FullSystemOptimize.cpp:511-541). Not offered on a sharded window (NALO_ERR_UNSUPPORTED).
  *   affineOptModeA/B  setting_affineOptModeA / B (:128-129, defaults 1e12 / 1e8): >= 0 = prior on a / b of every frame but the first
  *                     (FrameHessian::getPrior, HessianBlocks.h:286-312), < 0 = fixed: the prior becomes setting_initialAffAPrior / BPrior, JabF[0] / JabF[1]
  *                     are zeroed (Residuals.cpp:241-242), the tracker solves the reduced 6x6 / 7x7 system (CoarseTracker.cpp:1140-1162, host LM loop) and
  *                     zeroes the fixed output (:1255-1256); == 0 switches the tracker's plausibility test to relAff (:1249-1250).
  *   minOptIterations  setting_minOptIterations (:74, default 1).
  * ------------------------------------------------------------------------------------------------ */
+/* The reference constants the library was compiled with (util/settings.cpp:56-160,297, util/settings.h:52,232-234, FullSystem/HessianBlocks.h:61-68,268,
+ * util/NumType.h:41-53), under the reference's own names ("setting_huberTH", "SCALE_XI_TRANS", "patternP[3].x", ...). They come from the one table the host and
+ * device code take their constexpr values from (csrc/ref_constants.h). Float settings carry the value the reference's `float` holds (setting_initialRotPrior =
+ * 1e11 is 99999997952). Returns the number of entries; the first min(cap, n) names (static strings) / values are written; either array may be NULL. No device needed. */
+int nalo_constants(int cap, const char** names, double* values);
+/* the same table as the DEVICE code evaluates it (a one-lane kernel writes every entry): values[i] belongs to names[i] of nalo_constants. Returns the number of entries. */
+int nalo_constants_device(nalo_ctx* ctx, int cap, double* values);
 typedef struct nalo_settings {
     int forceAcceptStep;
     double affineOptModeA, affineOptModeB;
@@ -243,10 +250,15 @@ int nalo_ba_marginalize_points(nalo_ctx* ctx, const uint8_t* flags, double* M, d
  * (the reference asserts it: marginalise or drop them with nalo_ba_marginalize_points / by not re-submitting them). The frame leaves the window:
  * W decreases by one, nalo_ba_get_frames / nalo_ba_get_prior return the remaining frames, and the device window must be re-issued with
  * nalo_ba_set_window (+ set_points, set_residuals) before the next linearisation — FullSystem::marginalizeFrame likewise drops every residual
- * that targets the frame and recomputes the precalc values and adjoints (:161-212). When that next nalo_ba_set_window has exactly ONE frame more
- * than the prior covers, HM/bM are extended by a zero block for it, as EnergyFunctional::insertFrame does (:437-442); any other size mismatch
- * resets the prior to zero. */
+ * that targets the frame and recomputes the precalc values and adjoints (:161-212). The shrunk HM/bM are handed to exactly that NEXT nalo_ba_set_window:
+ * kept if it names the remaining frames, extended by a zero block if it appends one keyframe (EnergyFunctional::insertFrame, :437-442); any other size
+ * resets the prior to zero.
+ * Prior ownership in general: nalo_ba_set_window starts from a ZERO prior unless (a) it directly follows nalo_ba_marginalize_frame (above) or (b) the context
+ * was declared one continuing EnergyFunctional with nalo_ba_set_prior_carry(ctx, 1): then every nalo_ba_set_window keeps HM/bM (same frames) or extends them
+ * (one frame appended), as the reference's single EnergyFunctional does over a session. A caller that keeps HM/bM itself needs neither:
+ * it calls nalo_ba_set_prior after every nalo_ba_set_window. */
 int nalo_ba_marginalize_frame(nalo_ctx* ctx, int idx);
+int nalo_ba_set_prior_carry(nalo_ctx* ctx, int on);
 
 /* read-back of window state (host pointers, any may be NULL) */
 int nalo_ba_get_frames(nalo_ctx* ctx, nalo_frame_state* frames /* W */, double* worldToCam /* W x 12 PRE_worldToCam */,

@@ -51,8 +51,10 @@ int nalo_io_read_times(const char* path, int n_images, int cap, double* stamps, 
  * K_out = {fx, fy, cx, cy} and the per-pixel lookup remapX / remapY [w*h] (position in the original image, -1 = outside) that Undistort::undistort and
  * nalo_undist_set consume. rect_mode crop: the largest axis-aligned normalised rectangle whose border stays inside the original image (the reference's
  * 0.995 shrink iteration, <= 500 rounds); explicit: K = out_calib scaled by w, h (-0.5 on the centre); none: K = parsOrg, *passthrough = 1 (no table is needed;
- * remap is still filled). full (makeOptimalK_full) is an assert(false) in the reference: NALO_IO_ERR_FORMAT. The reference's two slips in the border
- * clean-up are kept (`if(iy == hOrg-1) ix = hOrg-1.001` and the `iy < wOrg-1` test, :981-984). */
+ * remap is still filled). full (makeOptimalK_full) is an assert(false) in the reference: NALO_IO_ERR_FORMAT. Of the reference's two slips in the border
+ * clean-up (:979-982) `if(iy == hOrg-1) ix = hOrg-1.001` is kept; the `iy < wOrg-1` test is kept AND completed by `iy < hOrg-1`: on a landscape sensor the reference
+ * leaves entries with hOrg-1 <= iy < wOrg-1 "valid" and Undistort::undistort reads behind the image for them (undefined there); here they are -1 (pixel value 0),
+ * so that the table is always one nalo_undist_set accepts. */
 int nalo_io_make_rectification(const nalo_camera_file* cam, double K_out[4], float* remapX, float* remapY, int* passthrough);
 
 /* PNG images -- the reference reads them through cv::imread (IOWrapper/OpenCV/ImageRW_OpenCV.cpp:33-53, 88-175): a self-contained decoder on zlib's

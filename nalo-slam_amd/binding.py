@@ -30,7 +30,7 @@ EXPORTS = [
     "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_append_plane_points", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
-    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_plane_scale_fix", "nalo_ba_sw_gray_optimize", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_ba_get_frames", "nalo_ba_get_points",
+    "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_set_prior_carry", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_plane_scale_fix", "nalo_ba_sw_gray_optimize", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_constants", "nalo_constants_device", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
@@ -45,6 +45,16 @@ class Settings(C.Structure):
 
 def lib_path():
     return os.path.join(_HERE, "libnalo_gpu.so")
+
+
+def constants():
+    """{reference name: value} of the constants the library was compiled with (nalo_constants; needs no device)"""
+    L = C.CDLL(lib_path())
+    L.nalo_constants.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double)]
+    n = L.nalo_constants(0, None, None)
+    names, vals = (C.c_char_p * n)(), (C.c_double * n)()
+    assert L.nalo_constants(n, names, vals) == n
+    return {names[i].decode(): vals[i] for i in range(n)}
 
 
 def load():
@@ -376,6 +386,10 @@ class Context:
         self._ck(self.L.nalo_ba_marginalize_frame(self.h_, int(idx)))
         self.W -= 1
 
+    def ba_set_prior_carry(self, on):
+        """declare the context one continuing EnergyFunctional: every ba_set_window keeps (same frames) or extends (one frame appended) HM / bM"""
+        self._ck(self.L.nalo_ba_set_prior_carry(self.h_, int(bool(on))))
+
     def ba_set_residuals(self, exists):
         self._ck(self.L.nalo_ba_set_residuals(self.h_, _u8(np.ascontiguousarray(exists, np.uint8))))
 
@@ -513,6 +527,11 @@ class Context:
         """raw: a contiguous uint8 / uint16 array that stays alive and untouched until frame_wait(slot) (pinned: pinned_array(..., dtype))"""
         assert raw.flags.c_contiguous and raw.dtype in (np.uint8, np.uint16)
         self._ck(self.L.nalo_frame_upload_raw_async(self.h_, slot, raw.ctypes.data_as(C.c_void_p), raw.dtype.itemsize, C.c_float(exposure), C.c_float(factor), None))
+
+    def get_settings(self):
+        st = Settings()
+        self._ck(self.L.nalo_get_settings(self.h_, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in Settings._fields_}
 
     def set_settings(self, force_accept_step=None, affine_opt_mode_a=None, affine_opt_mode_b=None, min_opt_iterations=None):
         st = Settings()

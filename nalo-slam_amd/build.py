@@ -5,7 +5,7 @@ import sys
 import zlib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["host_api.hip", "host_ba.hip", "kernels_pyramid.hip", "kernels_tracker.hip", "kernels_trk_lm.hip", "kernels_ba.hip", "kernels_ba_lin.hip", "kernels_ba_gn.hip", "kernels_dense.hip", "kernels_imm.hip", "kernels_init.hip", "kernels_pixsel.hip", "host_io.cpp", "host_rccl.hip", "host_init.hip"]
+SRC = ["host_api.hip", "host_ba.hip", "kernels_pyramid.hip", "kernels_tracker.hip", "kernels_trk_lm.hip", "kernels_ba.hip", "kernels_ba_lin.hip", "kernels_dense.hip", "kernels_imm.hip", "kernels_init.hip", "kernels_pixsel.hip", "host_io.cpp", "host_rccl.hip", "host_init.hip"]
 OUT = os.path.join(HERE, "libnalo_gpu.so")
 NO_CONTRACT = {"kernels_pyramid.hip", "kernels_imm.hip", "kernels_init.hip", "kernels_pixsel.hip", "host_init.hip"}   # a1 is bit-exact vs the reference's scalar fp32 code: no FMA contraction
 

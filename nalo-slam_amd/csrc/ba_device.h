@@ -25,7 +25,6 @@ enum : uint8_t { PT_VALID = 1, PT_MARG = 2, PT_HAS_PRIOR = 4 };
 struct BADev {
     int W, P, Ppad, nblocks, w, h;
     const float* calib;                         // [10] {fxl, fyl, cxl, cyl, fxli, fyli (CalibHessian::value_scaledf / value_scaledi), cDeltaF[4] (EnergyFunctional)}
-    const int* stop;                            // device-side GN loop: 1 = the loop has terminated, every kernel returns at once
     const float4* img[16];                      // level-0 {I,dx,dy,0} of every window frame (row major)
     const float* img_t[16];                     // the same texels, 12 bytes each, in 5x2 tiles of 128 bytes (frame_tile_level0): what ba_linearize gathers from
     int wt;                                     // tiles per tile row = ceil(w / 5)
@@ -67,21 +66,6 @@ struct BADev {
     double* noapply_E;                          // [nblocks*lin_sub][W] energy partials of a linearisation that is NOT applied (FIX = 2)
 };
 
-// Device-side Gauss-Newton iteration (kernels_ba_gn.hip): constants of one optimize() call, the mutable frame / calibration states and the outputs it
-// writes for the next pass. All pointers are device memory; doubles unless noted.
-struct GNDev {
-    int W, n;
-    const double *HM, *bM, *Sproj;              // marginalisation prior (n x n, n), nullspace projector columns (n x 7; zero columns = dropped)
-    const double *state_zero, *evalPT, *prior, *c_zero;   // [W][10], [W][12], [W][8], [4]
-    const float *ab_exposure, *adHostF, *adTargetF;       // [W], [W*W][64] x 2 (index h + t*W)
-    const double* stitched;                     // [H~_A | H~_sc | misc | step sums ...] of the last reduce/stitch (after the cross-rank sum when sharded)
-    double *state, *backup, *step, *c_value, *c_backup, *w2c, *c2w, *x;   // [W][10] x 3, [4] x 2, [W][12] x 2, [n]
-    float* sums;                                // {sumA, sumB, sumT, sumR} / W of the last step
-    float* pre;                                 // FrameFramePrecalc records [W*W][kPreStride] + calib floats [16]
-    float* xad;                                 // [xc (64) | xAd (W*W*8)] for ba_resub_kernel
-    int *stop, *iters_done;
-};
-
 // {xc (4) | xAd [W*W][8]} of resubstituteFPt for windows of up to 8 frames, passed by value as kernel arguments (ba_resub_kernel)
 struct XadArg { float v[4 + 8 * 64]; };
 
@@ -91,7 +75,6 @@ struct StitchDev {
     const double *M_top, *M_sc;                 // acc13 [W*W][169], G [W][NPL*NPL]
     double* H;                                  // [H~_A (n1*n1) | H~_sc (n1*n1) | tail]
     unsigned* ticket;
-    const int* stop;
     int W, n1, NPL;
 };
 

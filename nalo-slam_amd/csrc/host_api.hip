@@ -89,6 +89,48 @@ void nalo_destroy(nalo_ctx* c) {
     delete c;
 }
 
+// The reference constants this library was compiled with (ref_constants.h: the table the constexpr values of host and device code are generated from),
+// the pattern offsets and the defaults of nalo_settings. Needs no device.
+int nalo_constants(int cap, const char** names, double* values) {
+    static const struct { const char* name; double value; } table[] = {
+#define NALO_REF_ROW(type, name, refname, value) {refname, (double)(nalo::name)},
+        NALO_REF_CONSTANTS(NALO_REF_ROW)
+#undef NALO_REF_ROW
+        {"patternP[0].x", (double)nalo::kPatternDx[0]}, {"patternP[0].y", (double)nalo::kPatternDy[0]}, {"patternP[1].x", (double)nalo::kPatternDx[1]}, {"patternP[1].y", (double)nalo::kPatternDy[1]},
+        {"patternP[2].x", (double)nalo::kPatternDx[2]}, {"patternP[2].y", (double)nalo::kPatternDy[2]}, {"patternP[3].x", (double)nalo::kPatternDx[3]}, {"patternP[3].y", (double)nalo::kPatternDy[3]},
+        {"patternP[4].x", (double)nalo::kPatternDx[4]}, {"patternP[4].y", (double)nalo::kPatternDy[4]}, {"patternP[5].x", (double)nalo::kPatternDx[5]}, {"patternP[5].y", (double)nalo::kPatternDy[5]},
+        {"patternP[6].x", (double)nalo::kPatternDx[6]}, {"patternP[6].y", (double)nalo::kPatternDy[6]}, {"patternP[7].x", (double)nalo::kPatternDx[7]}, {"patternP[7].y", (double)nalo::kPatternDy[7]},
+    };
+    const int n = (int)(sizeof(table) / sizeof(table[0]));
+    for (int i = 0; i < n && i < cap; ++i) { if (names) names[i] = table[i].name; if (values) values[i] = table[i].value; }
+    return n;
+}
+
+// the same table as DEVICE code evaluates it: one lane writes every constant (+ the pattern the kernels index) from inside a kernel
+__global__ void nalo_constants_kernel(double* out) {
+    int i = 0;
+#define NALO_REF_ROW(type, name, refname, value) out[i++] = (double)(nalo::name);
+    NALO_REF_CONSTANTS(NALO_REF_ROW)
+#undef NALO_REF_ROW
+    constexpr int dx[8] = NALO_PATTERN_DX, dy[8] = NALO_PATTERN_DY;
+    for (int k = 0; k < 8; ++k) { out[i++] = (double)dx[k]; out[i++] = (double)dy[k]; }
+}
+int nalo_constants_device(nalo_ctx* c, int cap, double* values) {
+    if (!c || !values) return fail(c, NALO_ERR_ARG, "nalo_constants_device: bad argument");
+    const int n = nalo_constants(0, nullptr, nullptr);
+    NALO_HIP(c, hipSetDevice(c->device));
+    double* d = nullptr;
+    NALO_HIP(c, hipMalloc((void**)&d, (size_t)n * 8));
+    nalo_constants_kernel<<<1, 1, 0, c->stream>>>(d);
+    std::vector<double> h(n);
+    hipError_t e = hipMemcpyAsync(h.data(), d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    NALO_HIP(c, e);
+    for (int i = 0; i < n && i < cap; ++i) values[i] = h[i];
+    return n;
+}
+
 const char* nalo_last_error(nalo_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 int nalo_levels(nalo_ctx* c) { return c ? c->levels : NALO_ERR_ARG; }
 int nalo_sync(nalo_ctx* c) { if (!c) return NALO_ERR_ARG; if (c->copy) NALO_HIP(c, hipStreamSynchronize(c->copy)); NALO_HIP(c, hipStreamSynchronize(c->stream)); NALO_HIP(c, hipStreamSynchronize(c->side)); return NALO_OK; }
@@ -117,6 +159,19 @@ int nalo_frame_upload(nalo_ctx* c, int slot, const float* irradiance, const floa
 // on the context's copy stream, under whatever the main stream is executing (the previous frame's tracking), the pyramid kernels are queued on the main
 // stream behind an event. Returns at once: the host buffers must stay untouched until nalo_frame_wait(ctx, slot) (or nalo_sync) returns. Truly
 // asynchronous only from pinned host memory (nalo_host_alloc / hipHostMalloc); pageable buffers work but are staged by the HIP runtime.
+// The gamma table is shared by all slots of the context: another slot's pyramid kernel (main stream) may still be reading it when the next frame arrives. A running
+// system passes the same CalibHessian::B every frame, so the table is sent once; a DIFFERENT table is copied only after the copy stream has waited for everything
+// queued on the main stream so far.
+static int gamma_upload_async(nalo_ctx* c, const float* gammaB) {
+    if (!gammaB) return NALO_OK;
+    if (c->gamma_have && std::memcmp(c->gamma_last, gammaB, sizeof(c->gamma_last)) == 0) return NALO_OK;
+    NALO_HIP(c, hipEventRecord(c->ev_main, c->stream));
+    NALO_HIP(c, hipStreamWaitEvent(c->copy, c->ev_main, 0));
+    std::memcpy(c->gamma_last, gammaB, sizeof(c->gamma_last));
+    NALO_HIP(c, hipMemcpyAsync(c->gamma_dev, c->gamma_last, 256 * 4, hipMemcpyHostToDevice, c->copy));   // from the context's copy: the caller's table may change after the call
+    c->gamma_have = true;
+    return NALO_OK;
+}
 int nalo_frame_upload_async(nalo_ctx* c, int slot, const float* irradiance, const float* mask, const uint8_t* bgr, const float* gammaB) {
     if (!c || !irradiance || slot < 0 || slot >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_frame_upload_async: bad argument");
     NALO_HIP(c, hipSetDevice(c->device));
@@ -134,7 +189,7 @@ int nalo_frame_upload_async(nalo_ctx* c, int slot, const float* irradiance, cons
     NALO_HIP(c, hipMemcpyAsync(s.I[0], irradiance, n0 * 4, hipMemcpyHostToDevice, c->copy));
     if (mask) NALO_HIP(c, hipMemcpyAsync(s.mask, mask, n0 * 4, hipMemcpyHostToDevice, c->copy));
     if (bgr) NALO_HIP(c, hipMemcpyAsync(s.bgr, bgr, n0 * 3, hipMemcpyHostToDevice, c->copy));
-    if (gammaB) NALO_HIP(c, hipMemcpyAsync(c->gamma_dev, gammaB, 256 * 4, hipMemcpyHostToDevice, c->copy));
+    { int rg = gamma_upload_async(c, gammaB); if (rg) return rg; }
     NALO_HIP(c, hipEventRecord(s.ev_up, c->copy));
     NALO_HIP(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
     int rc = pyramid_build(c, s, gammaB ? c->gamma_dev : nullptr);
@@ -215,7 +270,7 @@ int nalo_frame_upload_raw_async(nalo_ctx* c, int slot, const void* raw, int byte
         NALO_HIP(c, hipStreamWaitEvent(c->copy, c->ev_main, 0));
     }
     NALO_HIP(c, hipMemcpyAsync(s.raw, raw, no * bytes_per_px, hipMemcpyHostToDevice, c->copy));
-    if (gammaB) NALO_HIP(c, hipMemcpyAsync(c->gamma_dev, gammaB, 256 * 4, hipMemcpyHostToDevice, c->copy));
+    { int rg = gamma_upload_async(c, gammaB); if (rg) return rg; }
     NALO_HIP(c, hipEventRecord(s.ev_up, c->copy));
     NALO_HIP(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
     int rc = ingest_launch(c, c->stream, s.raw, bytes_per_px, c->und_wOrg, c->und_hOrg, c->und_G.p, c->und_vig ? c->und_vinv.p : nullptr, c->und_remap ? c->und_rx.p : nullptr,
@@ -406,10 +461,8 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
         // a fixed affine parameter changes the system the LM solves (:1140-1162): those variants live in the host loop below
         static const bool env_host = std::getenv("NALO_TRK_HOST_LM") != nullptr;
         const bool force_host = env_host || c->lm_host_only || c->set.affineOptModeA < 0 || c->set.affineOptModeB < 0;
-        static const int dev_max_n = [] { const char* e = std::getenv("NALO_TRK_DEV_MAXN"); return e ? std::atoi(e) : (1 << 30); }();
-        int stop = coarsestLvl + 1;
-        while (stop > 0 && c->pc_n[stop - 1] <= dev_max_n) --stop;      // levels coarsestLvl..stop on the device
-        if (!force_host && stop <= coarsestLvl) {
+        const int stop = 0;                                            // levels coarsestLvl..0 on the device
+        if (!force_host) {
             if (c->slot_ref < 0 || slot_new < 0 || slot_new >= (int)c->slots.size() || !c->slots[slot_new].valid)
                 return fail(c, NALO_ERR_STATE, "nalo_trk_track: no reference / empty frame slot");
             double o[32];

@@ -18,7 +18,6 @@ void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const floa
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
 void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
-int ba_launch_gn(hipStream_t s, const GNDev& G, int iteration, int never_break, double lambda);
 void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
 void ba_launch_set_th(hipStream_t s, float* dst, const float* th, int W);
@@ -63,10 +62,6 @@ struct BAWindow {
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
     DevBuf<int> blk_host, host_blk, blk_order, sc_grp;
     DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 64 (state, arrival counters, workgroup totals)
-    // device-side Gauss-Newton loop (kernels_ba_gn.hip): constants + states of one optimize() call
-    DevBuf<double> gn_d; DevBuf<float> gn_f; DevBuf<int> gn_i; GNDev gn{};
-    double* gn_host = nullptr; size_t gn_host_cap = 0;              // pinned staging (doubles; the float part follows)
-    bool th_on_side = false;                                        // run the quantile kernels on the side stream (device loop / sharded windows)
     bool step_fused = false, step_sums_deferred = false;            // optimize(): resubstitute + point step in one kernel, its sums finished by the reduce launch
     bool th_pending = false;                                        // a linearize pass whose frameEnergyTH quantile has not been launched yet
     DevBuf<double> acc13, G, AD, stitched;                      // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | misc (2 W^2) | step sums (3) | TH sum, ranks]
@@ -98,6 +93,8 @@ struct BAWindow {
     bool never_break = false;
     DevBuf<double> noapply_E; std::vector<double> noapply_h;          // energy partials of a linearisation that is not applied (forceAcceptStep = false)
     int opt_iterations = 0, opt_rejected = 0;
+    bool prior_next = false;                                        // nalo_ba_marginalize_frame has left HM / bM for the NEXT nalo_ba_set_window (kept or extended there)
+    bool prior_carry = false;                                       // nalo_ba_set_prior_carry: the context is ONE continuing EnergyFunctional, every set_window keeps / extends
 };
 
 void ba_destroy(nalo_ctx* c) {
@@ -117,8 +114,6 @@ void ba_destroy(nalo_ctx* c) {
     if (w->up_host2) (void)hipHostFree(w->up_host2);
     for (float* p : w->pre_map) if (p) (void)hipHostFree(p);
     for (hipEvent_t e : w->ev_up) if (e) (void)hipEventDestroy(e);
-    if (w->gn_host) (void)hipHostFree(w->gn_host);
-    w->gn_d.release(); w->gn_f.release(); w->gn_i.release();
     if (w->ad_host) (void)hipHostFree(w->ad_host);
     if (w->ev_ad) (void)hipEventDestroy(w->ev_ad);
     delete w;
@@ -203,8 +198,6 @@ static int set_adjoints(nalo_ctx* c) {
     NALO_HIP(c, hipEventRecord(w.ev_ad, c->stream));
     w.sd.AD = w.AD.p;
     if (!w.st_ticket.p) { NALO_HIP(c, w.st_ticket.reserve(4)); NALO_HIP(c, hipMemset(w.st_ticket.p, 0, 16)); }
-    if (!w.gn_i.p) { NALO_HIP(c, w.gn_i.reserve(4)); NALO_HIP(c, hipMemset(w.gn_i.p, 0, 16)); }
-    w.dev.stop = nullptr; w.sd.stop = nullptr;                        // only the device-side GN loop arms the early-exit flag
     w.sd.ticket = w.st_ticket.p; w.sd.W = W; w.sd.n1 = n1; w.sd.NPL = w.NPL;
     w.proj_valid = false;
     return NALO_OK;
@@ -240,8 +233,7 @@ static int set_precalc(nalo_ctx* c) {
     // Small windows (the KITTI-sized ones, latency bound): no copy. The H2D blit of these 8 KB sat between the back-substitution and the next linearisation
     // with ~10 us of pipeline gaps around it plus ~5 us of runtime calls on the host; the kernels read the records from mapped host memory instead (scalar
     // loads, a few hundred bytes per workgroup over PCIe: +2 us inside ba_linearize). Large windows keep the device copy (thousands of workgroups).
-    static const bool force_blit = std::getenv("NALO_BA_PRE_BLIT") != nullptr;
-    const bool direct = !force_blit && w.points_set && w.Ppad <= 32768;
+    const bool direct = w.points_set && w.Ppad <= 32768;
     float* rec;
     if (direct) {
         if (w.pre_map_cap < nfl + 16) {
@@ -286,7 +278,7 @@ static int set_precalc(nalo_ctx* c) {
     float* cal = rec + nfl;                                               // CalibHessian::value_scaledf / value_scaledi + cDeltaF travel with the records
     cal[0] = fx; cal[1] = fy; cal[2] = cx; cal[3] = cy; cal[4] = w.c_scaledi[0]; cal[5] = w.c_scaledi[1];
     for (int i = 0; i < 4; ++i) cal[6 + i] = w.cDeltaF[i];
-    NALO_HIP(c, w.pre.reserve(nfl + 16));                                  // (the device-resident GN loop, NALO_BA_DEVICE_GN, writes its records here either way)
+    NALO_HIP(c, w.pre.reserve(nfl + 16));
     if (direct) { w.dev.pre = w.pre_map_dev[w.pre_pos & 3]; w.dev.calib = w.dev.pre + nfl; return NALO_OK; }
     NALO_HIP(c, hipMemcpyAsync(w.pre.p, rec, (nfl + 16) * 4, hipMemcpyHostToDevice, c->stream));
     NALO_HIP(c, hipEventRecord(w.ev_up[w.up_idx], c->stream));
@@ -295,6 +287,12 @@ static int set_precalc(nalo_ctx* c) {
     return NALO_OK;
 }
 
+// every cross-rank sum goes through here: a failed collective (host_rccl.hip latches it) must not be followed by a solve on rank-local sums
+static int call_hook(nalo_ctx* c, nalo_allreduce_fn fn, void* user, double* buf, int n) {
+    fn(user, buf, n);
+    if (c->xchg_failed) return NALO_ERR_HIP;                          // message already in c->err
+    return NALO_OK;
+}
 static int flush_th(nalo_ctx* c);
 static int upload_frame_th(nalo_ctx* c) {
     BAWindow& w = *c->ba;
@@ -350,10 +348,10 @@ static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false)
         ProfScope ps(c, "ba_linearize", true);
         ba_launch_linearize(c->stream, w.dev, mode, fix, ps.a, ps.b);
     }
-    if (mode == 0 && (w.hook || w.th_on_side)) {
+    if (mode == 0 && w.hook) {
         // sharded window: the threshold is part of the all-reduced tail, i.e. on the critical path: run its kernels on the side stream under SC
         if (!w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming)); }
-        if (w.hook && !(w.hook_stream_ordered && !w.hook_side)) {
+        if (!(w.hook_stream_ordered && !w.hook_side)) {
             // the EXACT order statistic over all ranks' residuals (what one GPU holding the whole window computes): both radix histograms are summed
             // across ranks before their search. On the side stream, under SC / reduce / stitch; a blocking hook is called with that stream drained.
             nalo_allreduce_fn fn = w.hook_side ? w.hook_side : w.hook;
@@ -363,27 +361,21 @@ static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false)
             NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
             ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 0);
             if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->side));
-            fn(user, w.th_buf.p, 32768);
+            { int rh = call_hook(c, fn, user, w.th_buf.p, 32768); if (rh) return rh; }
             ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 1);
             if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->side));
-            fn(user, w.th_buf.p, 65536);
+            { int rh = call_hook(c, fn, user, w.th_buf.p, 65536); if (rh) return rh; }
             ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 2);
             NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
             w.th_side_inflight = true;
-        } else if (w.hook) {
+        } else {
             // stream-ordered main hook without a side hook: the same exact search, in line on the main stream
             NALO_HIP(c, w.th_buf.reserve(65536));
             ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 0);
-            w.hook(w.hook_user, w.th_buf.p, 32768);
+            { int rh = call_hook(c, w.hook, w.hook_user, w.th_buf.p, 32768); if (rh) return rh; }
             ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 1);
-            w.hook(w.hook_user, w.th_buf.p, 65536);
+            { int rh = call_hook(c, w.hook, w.hook_user, w.th_buf.p, 65536); if (rh) return rh; }
             ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 2);
-        } else {
-            NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
-            NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
-            ba_launch_energy_th(c->side, w.dev);
-            NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
-            w.th_side_inflight = true;
         }
     } else if (mode == 0) w.th_pending = true;
     if (fix != 2) { w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false; }
@@ -454,7 +446,6 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
     const int n1 = w.n1, NPL = w.NPL, W = w.W;
     const size_t blk = (size_t)n1 * n1;
     bool did = false;
-    static const bool sep_publish = std::getenv("NALO_BA_SEPARATE_PUBLISH") != nullptr;
     const int npub = (int)(2 * blk + 2 * W * W + 5);                 // [H~_A | H~_sc | misc (2 W^2) | step sums (3) | TH sum, rank count]
     const double seq = (double)(w.pub_seq + 1);
     double* dmap = nullptr;
@@ -474,7 +465,7 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
             w.step_sums_deferred = false;
             if (misc_only) { if (!w.hook) ba_launch_publish(c->stream, w.stitched.p + 2 * blk, dmap + 2 * blk, npub - (int)(2 * blk), seq, w.st_ticket.p + 1); }
             else {
-                if (ba_launch_stitch(c->stream, w.sd, top, sc, (w.hook || sep_publish) ? nullptr : dmap, npub - (int)(2 * blk), seq)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
+                if (ba_launch_stitch(c->stream, w.sd, top, sc, w.hook ? nullptr : dmap, npub - (int)(2 * blk), seq)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
                 if (top) w.stitched_top = true;
                 if (sc) w.stitched_sc = true;
             }
@@ -489,11 +480,11 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
             // statistic over all ranks' residuals, linearize_async), so sum / count below re-installs that value; the tail keeps its layout.
             const size_t off = misc_only ? 2 * blk : 0;               // misc_only: only the tail is summed and published
             if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
-            w.hook(w.hook_user, w.stitched.p + off, npub - (int)off);
+            { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + off, npub - (int)off); if (rh) return rh; }
             ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // more than one rank: the common threshold
             ba_launch_publish(c->stream, w.stitched.p + off, dmap + off, npub - (int)off, seq, w.st_ticket.p + 1);
             NALO_HIP(c, hipGetLastError());
-        } else if (sep_publish && !misc_only) ba_launch_publish(c->stream, w.stitched.p, dmap, npub, seq, w.st_ticket.p + 1);
+        }
         { int rc = flush_th(c); if (rc) return rc; }                  // behind the publish: overlaps the host's solve
         if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
         w.pre_synced = w.pre_pos;                               // everything launched on the main stream so far has run (the side stream reads no precalc record)
@@ -501,7 +492,7 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
             const double* s3 = w.stitched_host + 2 * blk + 2 * W * W;
             const float numID = (float)s3[2];
             const float sumNID = numID > 0 ? (float)(s3[1] / numID) : 0.f;
-            const float th = 1.2f;                              // setting_thOptIterations
+            const float th = kThOptIterations;
             w.last_canbreak = std::sqrt(w.st_sumA) < 0.0005 * th && std::sqrt(w.st_sumB) < 0.00005 * th && std::sqrt(w.st_sumR) < 0.00005 * th &&
                               std::sqrt(w.st_sumT) * sumNID < 0.00005 * th;
             w.step_pending = false;
@@ -520,6 +511,11 @@ static int stitch_and_fetch_for_break(nalo_ctx* c) {
 static float tail_th(const BAWindow& w) {
     const double* tl = w.stitched_host + 2 * (size_t)w.n1 * w.n1 + 2 * w.W * w.W + 3;
     return (float)(tl[0] / tl[1]);
+}
+// a threshold search that lost a workgroup at its arrival counter reports NaN from then on (ba_th_find_kernel, sticky): fail instead of installing it
+static int check_th(nalo_ctx* c, float th) {
+    if (std::isfinite(th)) return NALO_OK;
+    return fail(c, NALO_ERR_HIP, "setNewFrameEnergyTH: the device search timed out (a workgroup never arrived); re-issue the window with nalo_ba_set_window");
 }
 static void unpack_system(const BAWindow& w, const double* Ht, double* H, double* b) {
     const int n = w.n, n1 = w.n1;
@@ -645,8 +641,7 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     }
     NALO_HIP(c, w.xad.reserve((size_t)W * W * 8 + 64));
     XadArg karg; const XadArg* kp = nullptr;
-    static const bool no_karg = std::getenv("NALO_RESUB_COPY") != nullptr;
-    if (W <= 8 && !no_karg) {                                              // small window: {xc, xAd} travel as kernel arguments, no copy
+    if (W <= 8) {                                              // small window: {xc, xAd} travel as kernel arguments, no copy
         std::memcpy(karg.v, xc, 16); std::memcpy(karg.v + 4, xAd, (size_t)W * W * 8 * 4);
         kp = &karg;
     } else NALO_HIP(c, hipMemcpyAsync(w.xad.p, xc, ((size_t)W * W * 8 + 64) * 4, hipMemcpyHostToDevice, c->stream));
@@ -697,7 +692,7 @@ static int do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float fD
         NALO_HIP(c, hipStreamSynchronize(c->stream));
         const float numID = (float)s3[2];
         const float sumNID = numID > 0 ? (float)(s3[1] / numID) : 0.f;
-        const float th = 1.2f;                                              // setting_thOptIterations
+        const float th = kThOptIterations;
         *canbreak = std::sqrt(sumA) < 0.0005 * th && std::sqrt(sumB) < 0.00005 * th && std::sqrt(sumR) < 0.00005 * th && std::sqrt(sumT) * sumNID < 0.00005 * th;
     } else w.step_pending = true;                                           // optimize(): the sums ride along with the next fetch (no extra sync)
     return NALO_OK;
@@ -744,7 +739,12 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     w.dev.fix_a = c->set.affineOptModeA < 0; w.dev.fix_b = c->set.affineOptModeB < 0; w.dev.no_th = 0;
     NALO_HIP(c, w.th_hist.reserve(2 * 65536 + 64)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, (2 * 65536 + 64) * 4));
     w.dev.th_hist_hi = w.th_hist.p; w.dev.th_hist_lo = w.th_hist.p + 65536; w.dev.th_state = w.th_hist.p + 2 * 65536;
-    if (w.HM.size() == (size_t)(w.n - 8) * (w.n - 8) && w.n > 12) {
+    // HM / bM survive a nalo_ba_set_window only when that is asked for: right after nalo_ba_marginalize_frame (whose result is meant for this very call) or on a
+    // context declared continuing (nalo_ba_set_prior_carry). Any other window starts from a zero prior, whatever an earlier, unrelated window left behind.
+    const bool keep_prior = w.prior_next || w.prior_carry;
+    w.prior_next = false;
+    if (!keep_prior) { w.HM.assign((size_t)w.n * w.n, 0.0); w.bM.assign(w.n, 0.0); }
+    else if (w.HM.size() == (size_t)(w.n - 8) * (w.n - 8) && w.n > 12) {
         // one frame appended to a window that carries a prior = EnergyFunctional::insertFrame (EnergyFunctional.cpp:437-442): conservativeResize, the new
         // frame's rows / columns zero
         const int no = w.n - 8;
@@ -832,12 +832,8 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     w.dev.lin_sub = w.nblocks >= 128 ? 1 : 4;             // small windows: one workgroup per wave fills more CUs (kernels_ba_lin.hip)
     NALO_HIP(c, w.top_partial.reserve((size_t)w.nblocks * w.dev.lin_sub * W * kTopStride)); {   // ba_sc work distribution: ~1000+ workgroups whatever the window size. Small windows split a point block over 4 (2) workgroups; large
         // ones put up to 8 blocks of a host through one workgroup so that the NPL^2 fp64 partial is written once per group.
-        static const int force_split = [] { const char* e = std::getenv("NALO_SC_SPLIT"); return e ? std::atoi(e) : 0; }();
-        static const int force_bpw = [] { const char* e = std::getenv("NALO_SC_BPW"); return e ? std::atoi(e) : 0; }();
         w.dev.sc_split = w.nblocks <= 256 ? 4 : 1;          // measured (scripts/tune_sc.sh): beyond ~256 blocks more workgroups only add partial traffic
-        if (force_split == 1 || force_split == 2 || force_split == 4) w.dev.sc_split = force_split;
         w.dev.sc_bpw = w.dev.sc_split > 1 ? 1 : (w.nblocks >= 2048 ? 8 : (w.nblocks >= 1024 ? 4 : 2));
-        if (force_bpw > 0 && w.dev.sc_split == 1) w.dev.sc_bpw = force_bpw;
         std::vector<int> grp(W + 1, 0);
         for (int h = 0; h < W; ++h) grp[h + 1] = grp[h] + (w.host_blk_h[h + 1] - w.host_blk_h[h] + w.dev.sc_bpw - 1) / w.dev.sc_bpw;
         w.dev.sc_groups = std::max(grp[W], 1);
@@ -916,6 +912,7 @@ int nalo_ba_get_prior(nalo_ctx* c, double* HM, double* bM) {
 
 #define NALO_BA_READY(name)                                                                                       \
     if (!c || !c->ba || !c->ba->points_set || !c->ba->res_set) return fail(c, NALO_ERR_STATE, name ": window/points/residuals not set"); \
+    if (c->xchg_failed) return fail(c, NALO_ERR_HIP, name ": a cross-rank sum of this context failed earlier; rebuild the window on a new context"); \
     NALO_HIP(c, hipSetDevice(c->device));                                                                         \
     BAWindow& w = *c->ba;
 
@@ -924,7 +921,7 @@ int nalo_ba_linearize(nalo_ctx* c, int fix, double* energy) {
     int rc = linearize_async(c, 0, fix); if (rc) return rc;
     w.pt_acc_on_read = true;
     rc = stitch_and_fetch(c, true, false, true); if (rc) return rc;
-    w.frames[w.W - 1].frameEnergyTH = tail_th(w);
+    { const float th = tail_th(w); rc = check_th(c, th); if (rc) return rc; w.frames[w.W - 1].frameEnergyTH = th; }
     double e = 0; misc_totals(w, &e, &w.resInA);
     if (energy) *energy = e;
     return NALO_OK;
@@ -975,95 +972,10 @@ static int optimize_epilogue(nalo_ctx* c, double* rmse) {
     rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
     w.pt_acc_on_read = false;                                               // the per-point sums stay those of the last solve
     rc = stitch_and_fetch(c, true, false, true, true); if (rc) return rc;  // energy, residual count and the threshold: no stitch
-    nf.frameEnergyTH = tail_th(w);
+    { const float th = tail_th(w); rc = check_th(c, th); if (rc) return rc; nf.frameEnergyTH = th; }
     double e = 0; int nres = 0; misc_totals(w, &e, &nres);
     // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)
     if (rmse) *rmse = std::sqrt((float)(e / (kPatternNum * (double)w.resInA)));
-    return NALO_OK;
-}
-
-// The GN loop with the frame-side work on the device (kernels_ba_gn.hip): every iteration is queued without waiting; ONE synchronisation at the end
-// brings the states back. Used when nothing forces the host into the loop: no hook, or a stream-ordered hook (nalo_ba_set_allreduce_mode).
-static int optimize_device_loop(nalo_ctx* c, int mnumOptIts, int never_break) {
-    BAWindow& w = *c->ba;
-    const int W = w.W, n = w.n, n1 = w.n1, NPL = w.NPL;
-    const size_t blk = (size_t)n1 * n1, PW = (size_t)W * W;
-    if (!w.proj_valid) build_projector(w);
-    // doubles: [HM n*n | bM n | Sproj 7n | state_zero 10W | evalPT 12W | prior 8W | c_zero 4 || state 10W | c_value 4 | backup 10W | step 10W | c_backup 4 | w2c 12W | c2w 12W | x n]
-    const size_t o_HM = 0, o_bM = o_HM + (size_t)n * n, o_S = o_bM + n, o_sz = o_S + 7 * (size_t)n, o_ev = o_sz + 10 * W, o_pr = o_ev + 12 * W, o_cz = o_pr + 8 * W,
-                 o_st = o_cz + 4, o_cv = o_st + 10 * W, n_up = o_cv + 4, o_bk = n_up, o_sp = o_bk + 10 * W, o_cb = o_sp + 10 * W, o_w2c = o_cb + 4, o_c2w = o_w2c + 12 * W,
-                 o_x = o_c2w + 12 * W, n_d = o_x + n;
-    // floats: [ab_exposure W | adHostF 64 W^2 | adTargetF 64 W^2 | sums 4]
-    const size_t f_ab = 0, f_ah = f_ab + 16, f_at = f_ah + 64 * PW, n_fup = f_at + 64 * PW, f_sum = n_fup, n_f = f_sum + 4;
-    const size_t host_words = n_up + (n_fup + 1) / 2 + 16;
-    if (w.gn_host_cap < host_words) { if (w.gn_host) (void)hipHostFree(w.gn_host); w.gn_host = nullptr; NALO_HIP(c, hipHostMalloc((void**)&w.gn_host, host_words * 8)); w.gn_host_cap = host_words; }
-    NALO_HIP(c, w.gn_d.reserve(n_d)); NALO_HIP(c, w.gn_f.reserve(n_f));
-    double* hd = w.gn_host; float* hf = (float*)(w.gn_host + n_up);
-    std::memcpy(hd + o_HM, w.HM.data(), (size_t)n * n * 8); std::memcpy(hd + o_bM, w.bM.data(), (size_t)n * 8); std::memcpy(hd + o_S, w.Sproj.data(), (size_t)n * 7 * 8);
-    for (int f = 0; f < W; ++f) {
-        const HostFrame& fr = w.frames[f];
-        std::memcpy(hd + o_sz + 10 * f, fr.state_zero, 80); std::memcpy(hd + o_ev + 12 * f, fr.evalPT.m, 96); std::memcpy(hd + o_pr + 8 * f, fr.prior, 64);
-        std::memcpy(hd + o_st + 10 * f, fr.state, 80);
-        hf[f_ab + f] = fr.ab_exposure;
-    }
-    for (int i = 0; i < 4; ++i) { hd[o_cz + i] = w.c_value_zero[i]; hd[o_cv + i] = w.c_value[i]; }
-    std::memcpy(hf + f_ah, w.adHostF.data(), 64 * PW * 4); std::memcpy(hf + f_at, w.adTargetF.data(), 64 * PW * 4);
-    NALO_HIP(c, hipMemcpyAsync(w.gn_d.p, hd, n_up * 8, hipMemcpyHostToDevice, c->stream));
-    NALO_HIP(c, hipMemcpyAsync(w.gn_f.p, hf, n_fup * 4, hipMemcpyHostToDevice, c->stream));
-    NALO_HIP(c, hipMemsetAsync(w.gn_i.p, 0, 16, c->stream));
-    NALO_HIP(c, w.xad.reserve(PW * 8 + 64));
-    GNDev& G = w.gn;
-    G.W = W; G.n = n;
-    G.HM = w.gn_d.p + o_HM; G.bM = w.gn_d.p + o_bM; G.Sproj = w.gn_d.p + o_S; G.state_zero = w.gn_d.p + o_sz; G.evalPT = w.gn_d.p + o_ev; G.prior = w.gn_d.p + o_pr; G.c_zero = w.gn_d.p + o_cz;
-    G.state = w.gn_d.p + o_st; G.c_value = w.gn_d.p + o_cv; G.backup = w.gn_d.p + o_bk; G.step = w.gn_d.p + o_sp; G.c_backup = w.gn_d.p + o_cb; G.w2c = w.gn_d.p + o_w2c; G.c2w = w.gn_d.p + o_c2w;
-    G.x = w.gn_d.p + o_x;
-    G.ab_exposure = w.gn_f.p + f_ab; G.adHostF = w.gn_f.p + f_ah; G.adTargetF = w.gn_f.p + f_at; G.sums = w.gn_f.p + f_sum;
-    G.stitched = w.stitched.p; G.pre = w.pre.p; G.xad = w.xad.p; G.stop = w.gn_i.p; G.iters_done = w.gn_i.p + 1;
-    w.th_on_side = true;
-    w.dev.stop = w.gn_i.p; w.sd.stop = w.gn_i.p;
-    ba_launch_reset_oob(c->stream, w.dev);                                  // :412-429
-    int rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :436 (+ applyRes :459-462)
-    for (int it = 0; it < mnumOptIts; ++it) {
-        rc = sc_async(c, 1, 1.f, 0); if (rc) return rc;
-        {
-            ProfScope ps(c, "ba_reduce");
-            if (w.hook) {                                                   // the threshold rides in the all-reduced tail
-                rc = flush_th(c); if (rc) return rc;
-                ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
-            }
-            ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.stitched.p + 2 * blk, w.G.p, true, true,
-                             w.step_sums_deferred ? w.step_partial.p : nullptr, (w.Ppad + 255) / 256, w.stitched.p + 2 * blk + 2 * W * W);
-            w.step_sums_deferred = false;
-            if (ba_launch_stitch(c->stream, w.sd, true, true, nullptr, 0, 0.0)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
-            w.stitched_top = w.stitched_sc = true;
-        }
-        if (w.hook) {
-            w.hook(w.hook_user, w.stitched.p, (int)(2 * blk + 2 * W * W + 5));  // stream-ordered: enqueued behind the stitch
-            ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));
-        }
-        if (ba_launch_gn(c->stream, G, it, never_break, 1e-5)) return fail(c, NALO_ERR_HIP, "ba_gn_kernel: LDS size rejected");   // SOLVER_FIX_LAMBDA (EnergyFunctional.cpp:779)
-        NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
-        {
-            ProfScope ps(c, "ba_resub");
-            ba_launch_resub_step(c->stream, w.dev, w.xad.p + 64, w.xad.p, 1.f, w.step_partial.p);
-        }
-        w.step_sums_deferred = true;
-        w.dev.pre = w.pre.p; w.dev.calib = w.pre.p + PW * kPreStride;
-        rc = linearize_async(c, 0, 0); if (rc) return rc;                   // :511
-    }
-    // the only synchronisation of the loop: states, calibration, last x, misc of the last solve
-    double* back = w.gn_host;                                               // [state 10W | c_value 4 | x n | misc 2W^2]
-    NALO_HIP(c, hipMemcpyAsync(back, w.gn_d.p + o_st, (10 * (size_t)W + 4) * 8, hipMemcpyDeviceToHost, c->stream));
-    NALO_HIP(c, hipMemcpyAsync(back + 10 * W + 4, w.gn_d.p + o_x, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
-    NALO_HIP(c, hipMemcpyAsync(back + 10 * W + 4 + n, w.stitched.p + 2 * blk, 2 * PW * 8, hipMemcpyDeviceToHost, c->stream));
-    NALO_HIP(c, hipStreamSynchronize(c->stream));
-    w.th_on_side = false;
-    w.dev.stop = nullptr; w.sd.stop = nullptr;
-    calib_set_value(w, back + 10 * W);
-    for (int f = 0; f < W; ++f) frame_set_state(w.frames[f], back + 10 * f);
-    w.lastX.assign(back + 10 * W + 4, back + 10 * W + 4 + n);
-    { const double* m = back + 10 * W + 4 + n; double cnt = 0; for (size_t i = 0; i < PW; ++i) cnt += m[2 * i]; w.resInA = (int)(cnt + 0.5); }
-    w.step_pending = false; w.step_fused = false;
     return NALO_OK;
 }
 
@@ -1073,20 +985,11 @@ int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse)
     const int W = w.W;
     if (W < 3) mnumOptIts = 20;                                             // FullSystemOptimize.cpp:401-403
     if (W < 4) mnumOptIts = 15;
-    // NALO_BA_DEVICE_GN=1: the frame-side work of every iteration runs on the device and the loop is queued without waiting (kernels_ba_gn.hip).
-    // Correct (same tests) but measured SLOWER on MI355X: the pivoted (8W+4)^2 LDL^T, SE3::exp and the substitutions are latency-bound serial fp64 work
-    // (190 us per iteration in one workgroup against ~60 us for the host round trip incl. PCIe publish, poll, 17 us AVX2 LDL^T and launches). Kept as an
-    // option; the default is the host-driven loop below.
-    static const bool dev_loop = std::getenv("NALO_BA_DEVICE_GN") != nullptr;
-    if (dev_loop && c->set.forceAcceptStep && (!w.hook || w.hook_stream_ordered)) {
-        int rc = optimize_device_loop(c, mnumOptIts, never_break); if (rc) return rc;
-        return optimize_epilogue(c, rmse);
-    }
     w.opt_iterations = 0; w.opt_rejected = 0;
     if (!c->set.forceAcceptStep) {
         // setting_forceAceptStep = false: every linearisation is an energy evaluation first (FIX = 2: nothing but state_NewEnergy and the threshold input
         // changes) and is applied only if E + E_L + E_M decreased; a rejected step restores the backup (:511-541). Host-driven, one sync per evaluation.
-        if (w.hook || w.th_on_side) return fail(c, NALO_ERR_UNSUPPORTED, "nalo_ba_optimize: forceAcceptStep = 0 is not offered on a sharded window");
+        if (w.hook) return fail(c, NALO_ERR_UNSUPPORTED, "nalo_ba_optimize: forceAcceptStep = 0 is not offered on a sharded window");
         ba_launch_reset_oob(c->stream, w.dev);
         double lastE, lastL, lastM;
         int rc = linearize_noapply(c, &lastE); if (rc) return rc;            // :436-438
@@ -1307,6 +1210,14 @@ int nalo_ba_marginalize_frame(nalo_ctx* c, int idx) {
     w.W -= 1; w.n = 8 * w.W + 4; w.n1 = w.n + 1;
     w.points_set = false; w.res_set = false; w.have_lin = w.have_sc = false; w.proj_valid = false; w.have_snap = false;
     w.lastX.assign(w.n, 0.0);
+    w.prior_next = true;
+    return NALO_OK;
+}
+
+int nalo_ba_set_prior_carry(nalo_ctx* c, int on) {
+    if (!c) return NALO_ERR_ARG;
+    if (!c->ba) c->ba = new BAWindow();
+    c->ba->prior_carry = on != 0;
     return NALO_OK;
 }
 

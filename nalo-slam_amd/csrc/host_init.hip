@@ -406,7 +406,7 @@ int nalo_init_set_first(nalo_ctx* c, int slot_first, int* sparsityFactor, int nu
                 if (!take) continue;
                 P.u[nl] = x + 0.1; P.v[nl] = y + 0.1; P.idepth[nl] = 1; P.iR[nl] = 1; P.isGood[nl] = 1;
                 P.my_type[nl] = lvl ? 1.f : status0[x + (size_t)y * wl];
-                P.outlierTH[nl] = kPatternNum * (12.f * 12.f);                                   // patternNum * setting_outlierTH (util/settings.cpp:99)
+                P.outlierTH[nl] = kPatternNum * kOutlierTH;                                   // patternNum * setting_outlierTH (util/settings.cpp:99)
                 ++nl;
             }
         if (numPoints) numPoints[lvl] = nl;

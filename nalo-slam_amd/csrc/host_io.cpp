@@ -400,13 +400,16 @@ int nalo_io_make_rectification(const nalo_camera_file* cam, double K_out[4], flo
     }
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) { remapX[x + y * w] = x; remapY[x + y * w] = y; }
     R.distort(remapX, remapY, remapX, remapY, h * w);
-    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {                                     // "make rounding resistant" (:972-996), slips included
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {                                     // "make rounding resistant" (:972-996), the `ix = hOrg-1.001` slip included
         float ix = remapX[x + y * w], iy = remapY[x + y * w];
         if (ix == 0) ix = 0.001;
         if (iy == 0) iy = 0.001;
         if (ix == wOrg - 1) ix = wOrg - 1.001;
         if (iy == hOrg - 1) ix = hOrg - 1.001;
-        if (ix > 0 && iy > 0 && ix < wOrg - 1 && iy < wOrg - 1) { remapX[x + y * w] = ix; remapY[x + y * w] = iy; }
+        // DEVIATION from the reference: its test is `iy < wOrg-1` (util/Undistort.cpp:980). On a landscape sensor an entry with hOrg-1 <= iy < wOrg-1 stays
+        // "valid" there and Undistort::undistort then reads rows behind the image (:497-512: an out-of-bounds read). Such entries are outside here (-1 -> pixel 0),
+        // which is also what nalo_undist_set demands of a table; everything the reference defines is unchanged (tests/test_io_cpu.py, tests/test_ingest_gpu.py).
+        if (ix > 0 && iy > 0 && ix < wOrg - 1 && iy < wOrg - 1 && iy < hOrg - 1) { remapX[x + y * w] = ix; remapY[x + y * w] = iy; }
         else { remapX[x + y * w] = -1; remapY[x + y * w] = -1; }
     }
     for (int i = 0; i < 4; ++i) K_out[i] = R.K[i];

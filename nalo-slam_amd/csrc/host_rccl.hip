@@ -44,12 +44,14 @@ static RcclApi& rccl() {
     return api;
 }
 
-struct RcclState { ncclComm_t main = nullptr, side = nullptr; bool owned = false; nalo_ctx* ctx = nullptr; bool failed = false; };
+struct RcclState { ncclComm_t main = nullptr, side = nullptr; bool owned = false; nalo_ctx* ctx = nullptr; };
 
 static void rccl_sum(RcclState* st, ncclComm_t comm, hipStream_t stream, double* buf, int n) {
     const ncclResult_t r = rccl().AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, comm, stream);       // in place, stream ordered
-    if (r != ncclSuccess && !st->failed) {
-        st->failed = true;
+    if (r != ncclSuccess && !st->ctx->xchg_failed) {
+        // the hook itself returns nothing (nalo_allreduce_fn): the latch is read by host_ba.hip right after every hook call, which then returns
+        // NALO_ERR_HIP instead of solving with sums that were never reduced (the ranks would diverge silently)
+        st->ctx->xchg_failed = true;
         st->ctx->err = std::string("ncclAllReduce: ") + (rccl().GetErrorString ? rccl().GetErrorString(r) : "error");
     }
 }

@@ -44,7 +44,6 @@ __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__
 // loop keeps the register count (and so the occupancy) where the memory system wants it.
 template <bool SMALL>
 __global__ __launch_bounds__(kBlk) void ba_pt_acc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
-    if (B.stop && B.stop[0]) return;
     const int b = blockIdx.x, h = B.blk_host[b], W = B.W, d = b * kBlk + threadIdx.x;
     const uint8_t pf = B.pt_flags[d];
     if (!((pf & PT_VALID) && (!margOnly || (pf & PT_MARG)))) return;
@@ -164,7 +163,6 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly, int s
     constexpr bool FUSE = KS == 4;
     __shared__ __attribute__((aligned(16))) float4 Hc4[FUSE ? SUB : 1];
     __shared__ float Bd[FUSE ? SUB : 1];
-    if (B.stop && B.stop[0]) return;
     const int grp = blockIdx.x / KS, ks = blockIdx.x - grp * KS, tid = threadIdx.x, W = B.W;
     int h = 0;
     while (h + 1 < W && grp >= B.sc_grp[h + 1]) ++h;
@@ -328,9 +326,8 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
                                                          const int* __restrict__ host_blk /* [W+1] */, const int* __restrict__ sc_grp /* [W+1] */, int W, int NPL, int sc_tiles, int mask, int KS, int lin_sub,
                                                          double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G,
-                                                         const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out, const int* __restrict__ stop) {
+                                                         const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out) {
     __shared__ double part[16][64];
-    if (stop && stop[0]) return;
     __shared__ double sums[128];
     if ((int)blockIdx.x < W * W) {
         if (!(mask & 1)) return;
@@ -404,7 +401,7 @@ void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NP
                       const float* step_partial, int step_blocks, double* step_out) {
     const int T = NPL / 16, tiles = T * (T + 1) / 2 * 4;
     ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.sc_grp, B.W, NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
-                                                                                       B.sc_split, B.lin_sub, acc13, misc, G, step_partial, step_blocks, step_out, B.stop);
+                                                                                       B.sc_split, B.lin_sub, acc13, misc, G, step_partial, step_blocks, step_out);
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)
@@ -543,7 +540,6 @@ constexpr int kScSplit = NALO_STITCH_SC_SPLIT;       // workgroups per frame for
 __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, int ad_in_lds, double* mapped, int ntail, double seq) {
     extern __shared__ double lds[];
     __shared__ int is_last;
-    if (D.stop && D.stop[0]) return;
     const int W = D.W, n1 = D.n1, n = n1 - 1, NPL = D.NPL, tid = threadIdx.x, NT = blockDim.x;
     // workgroups: [0, W] the top system (W frame rows + the corner), then 2 W for the Schur-complement system - TWO per frame, four of its eight rows each (phase 2
     // is bound by LDS bandwidth: 2 x 112 fp64 operands per output; two workgroups on two CUs halve it: 18 -> 11 us at W = 8) - then its corner
@@ -677,7 +673,6 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
 template <bool STEP, bool KARG>
 __global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __restrict__ xAd_p, const float* __restrict__ xc_p, XadArg X, float stepfacD, float* __restrict__ partial) {
     __shared__ float smem[64 * 4];
-    if (B.stop && B.stop[0]) return;
     const float* xc = KARG ? X.v : xc_p;
     const float* xAd = KARG ? X.v + 4 : xAd_p;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -806,14 +801,17 @@ void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partia
 // loads), publishes its total, and after a 16-party arrival counter (the workgroups are co-resident: 16 x 256 lanes; the spin is bounded) the ONE workgroup whose
 // range holds the k-th entry locates the bin wave -> round -> lane -> bin with shuffles only. (Was: one workgroup of 1024 lanes pulling all 256 KB through one CU,
 // 13 us per search, two searches per pass: on the critical path of every sharded iteration.) state[4] = generation (selects the counter), state[5..6] = the two
-// arrival counters (the idle one is cleared by workgroup 0), state[16..31] = the totals.
+// arrival counters (the idle one is cleared by workgroup 0), state[7] = sticky timeout word, state[16..31] = the totals.
 constexpr int kThWG = 16;
-__global__ __launch_bounds__(256) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new, const int* __restrict__ stop) {
-    if (stop && stop[0]) return;
+__global__ __launch_bounds__(256) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new) {
     __shared__ unsigned wsum[4], tot[kThWG];
     __shared__ unsigned s_bin, s_run, s_gen;
     __shared__ int s_ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    // state[7] = sticky failure word: an earlier search of this window timed out at the arrival counter (its counters may be partly filled, its totals stale).
+    // Every later search then reports NaN instead of a threshold computed from them; the host sees it with the next threshold it fetches and fails the call
+    // (host_ba.hip check_th). nalo_ba_set_window clears the whole state.
+    if (state[7]) { if (wg == 0 && tid == 0 && frameTH_new) *frameTH_new = NAN; return; }
     uint4* h4 = reinterpret_cast<uint4*>(hist + wg * 4096 + wave * 1024) + lane;
     uint4 q[4];
     unsigned ls[4], sum = 0;
@@ -841,12 +839,16 @@ __global__ __launch_bounds__(256) void ba_th_find_kernel(unsigned* __restrict__ 
         s_ok = ok; s_gen = g;
     }
     __syncthreads();
-    if (!s_ok) { if (wg == 0 && tid == 0 && frameTH_new) *frameTH_new = NAN; return; }          // a workgroup never arrived: make it visible downstream
+    if (!s_ok) {                                                                               // a workgroup never arrived: make it visible downstream, for good
+        if (tid == 0) __hip_atomic_store(state + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wg == 0 && tid == 0 && frameTH_new) *frameTH_new = NAN;
+        return;
+    }
     if (tid < kThWG) tot[tid] = __hip_atomic_load(state + 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     unsigned total = 0, gpre = 0;
     for (int i = 0; i < kThWG; ++i) { if (i == wg) gpre = total; total += tot[i]; }
-    const unsigned k = (level == 0) ? (unsigned)(int)(0.7f * (float)total) : state[1];
+    const unsigned k = (level == 0) ? (unsigned)(int)(kFrameEnergyTHN * (float)total) : state[1];
     const bool owner = gpre <= k && k < gpre + gtot;                   // exactly one workgroup (none if k >= total: empty histogram -> the last one reports)
     if (!owner && !(k >= total && wg == kThWG - 1)) return;
     if (owner) {
@@ -885,17 +887,16 @@ __global__ __launch_bounds__(256) void ba_th_find_kernel(unsigned* __restrict__ 
             if (state[3]) th = 12.f * 12.f * (float)kPatternNum;                        // no residual on the newest frame (:110-114)
             else {
                 const float nthElement = sqrtf(__uint_as_float((state[2] << 16) | bin));
-                th = nthElement * 1.5f;                                                 // setting_frameEnergyTHFacMedian
-                th = 26.0f * 0.5f + th * (1.f - 0.5f);                                  // setting_frameEnergyTHConstWeight
-                th = th * th;                                                           // setting_overallEnergyTHWeight = 1
+                th = nthElement * kFrameEnergyTHFacMedian;                              // FullSystemOptimize.cpp:130-133
+                th = 26.0f * kFrameEnergyTHConstWeight + th * (1.f - kFrameEnergyTHConstWeight);
+                th = th * th; th *= kOverallEnergyTHWeight * kOverallEnergyTHWeight;
             }
             *frameTH_new = th;
         }
         __hip_atomic_store(state + 4, s_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // next launch: the other counter
     }
 }
-__global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo, const int* __restrict__ stop) {
-    if (stop && stop[0]) return;
+__global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float f = en[i];
@@ -906,8 +907,7 @@ __global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__
 // Small windows (<= 16384 point slots, a KITTI-sized window has 2048): the same order statistic in ONE launch. The workgroup keeps the energies in
 // registers and runs a most-significant-first radix select with four 256-bin LDS histograms (5 us instead of the 40 us of the two 65536-bin
 // searches above, which sat between the publish and the next back-substitution). It also clears the bins ba_linearize_kernel counted into.
-__global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restrict__ en, int n, unsigned* __restrict__ hist_hi, float* __restrict__ frameTH_new, const int* __restrict__ stop) {
-    if (stop && stop[0]) return;
+__global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restrict__ en, int n, unsigned* __restrict__ hist_hi, float* __restrict__ frameTH_new) {
     __shared__ unsigned hist[256], wtot[16];
     __shared__ unsigned s_bin, s_before;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restri
     unsigned total = 0;
     for (int i = 0; i < 16; ++i) total += wtot[i];
     if (total == 0) { if (tid == 0) *frameTH_new = 12.f * 12.f * (float)kPatternNum; return; }       // no residual on the newest frame (:110-114)
-    unsigned k = (unsigned)(int)(0.7f * (float)total), prefix = 0, mask = 0;
+    unsigned k = (unsigned)(int)(kFrameEnergyTHN * (float)total), prefix = 0, mask = 0;
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
@@ -952,17 +952,16 @@ __global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restri
     }
     if (tid == 0) {
         const float nthElement = sqrtf(__uint_as_float(prefix));
-        float th = nthElement * 1.5f;                           // setting_frameEnergyTHFacMedian
-        th = 26.0f * 0.5f + th * (1.f - 0.5f);                  // setting_frameEnergyTHConstWeight
-        *frameTH_new = th * th;                                 // setting_overallEnergyTHWeight = 1
+        float th = nthElement * kFrameEnergyTHFacMedian;        // FullSystemOptimize.cpp:130-133
+        th = 26.0f * kFrameEnergyTHConstWeight + th * (1.f - kFrameEnergyTHConstWeight);
+        th = th * th; th *= kOverallEnergyTHWeight * kOverallEnergyTHWeight; *frameTH_new = th;
     }
 }
 void ba_launch_energy_th(hipStream_t s, const BADev& B) {
-    static const bool big = std::getenv("NALO_TH_HIST") != nullptr;        // force the two-histogram path
-    if (B.Ppad <= 16384 && !big) { ba_th_small_kernel<<<1, 1024, 0, s>>>(B.en_new, B.Ppad, B.th_hist_hi, B.frameTH + (B.W - 1), B.stop); return; }
-    ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr, B.stop);
-    ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo, B.stop);
-    ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1), B.stop);
+    if (B.Ppad <= 16384) { ba_th_small_kernel<<<1, 1024, 0, s>>>(B.en_new, B.Ppad, B.th_hist_hi, B.frameTH + (B.W - 1)); return; }
+    ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr);
+    ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo);
+    ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1));
 }
 // Sharded window: the order statistic is taken over ALL ranks' residuals, so each of the two histograms is summed across ranks before its search
 // (the all-reduce hook sums doubles: counts go through fp64, exact below 2^53). step 0: hi histogram -> buf; 1: buf -> hi histogram, search, fill the
@@ -977,12 +976,12 @@ void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int
     if (step == 0) ba_th_cvt_kernel<<<NHI / 256, 256, 0, s>>>(B.th_hist_hi, buf, NHI, 0);
     else if (step == 1) {
         ba_th_cvt_kernel<<<NHI / 256, 256, 0, s>>>(B.th_hist_hi, buf, NHI, 1);
-        ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr, B.stop);
-        ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo, B.stop);
+        ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr);
+        ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo);
         ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 0);
     } else {
         ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 1);
-        ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1), B.stop);
+        ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1));
     }
 }
 

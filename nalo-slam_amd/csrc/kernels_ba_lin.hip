@@ -207,7 +207,7 @@ __device__ __forceinline__ void lin_setup(const BADev& B, const LinWhere& w, Lin
     const float Ku0 = u * cal_fxl + cal_cxl, Kv0 = vv * cal_fyl + cal_cyl;
     bool ok = (drescale > 0.f) && Ku0 > 1.1f && Kv0 > 1.1f && Ku0 < wM3G && Kv0 < hM3G;
     // ---- the 8 pattern pixels at the current idepth (projectPoint, ResidualProjections.h:47-57)
-    constexpr int pdx[8] = {0, -1, 1, -2, 0, 2, -1, 0}, pdy[8] = {-2, -1, -1, 0, 0, 0, 1, 2};       // util/settings.cpp:297
+    constexpr int pdx[8] = NALO_PATTERN_DX, pdy[8] = NALO_PATTERN_DY;                               // util/settings.cpp:297 (ref_constants.h)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float xx = pu + (float)pdx[k], yy = pv + (float)pdy[k];
@@ -366,7 +366,6 @@ template <int MODE, int FIX, int WG>
 __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(BADev B) {
     __shared__ __attribute__((aligned(16))) float smem[(WG / 4) * kTopStride];
     static_assert(16 * kTopStride * 4 >= 4 * 65 * 16, "a wave's reduction rows must hold its exchange buffer");
-    if (B.stop && B.stop[0]) return;                                                // the queued GN loop has terminated (kernels_ba_gn.hip)
     const int tid = threadIdx.x;
     const LinWhere w = lin_where<WG>(B, tid);
     if (w.skip) return;

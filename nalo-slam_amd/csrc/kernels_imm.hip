@@ -1,7 +1,7 @@
 // Immature-point kernels for gfx950 (reference paths relative to src/):
 //   imm_create_kernel    ImmaturePoint::ImmaturePoint          FullSystem/ImmaturePoint.cpp:32-60
-//   imm_trace8_kernel    ImmaturePoint::traceOn                FullSystem/ImmaturePoint.cpp:76-435   (eight lanes per immature point; imm_trace_kernel = one lane per point)
-//   imm_optimize_kernel  FullSystem::optimizeImmaturePoint     FullSystem/FullSystemOptPoint.cpp:51-206 with
+//   imm_trace8_kernel    ImmaturePoint::traceOn                FullSystem/ImmaturePoint.cpp:76-435   (eight lanes per immature point)
+//   imm_optimize8_kernel FullSystem::optimizeImmaturePoint     FullSystem/FullSystemOptPoint.cpp:51-206 with
 //                        ImmaturePoint::linearizeResidual      FullSystem/ImmaturePoint.cpp:497-564
 // These are branchy per-point searches (up to 99 line steps x 8 taps, then <= 3 GN steps), thousands of independent points per frame:
 // the reference chunks them 50 per CPU thread (FullSystem.cpp:886). Every decision (status, best step, accept/reject) depends on fp32
@@ -12,13 +12,13 @@
 
 namespace nalo {
 
-constexpr int kImmThreads = 128;
-constexpr float kImmMaxPixSearch = 0.027f, kImmStepsize = 1.0f, kImmGNTh = 0.1f, kImmExtraSlack = 1.2f, kImmSlackInterval = 1.5f, kImmMinImprovement = 2.0f;
-constexpr int kImmMinTraceTestRadius = 2, kImmGNIts = 3, kImmGNItsActivation = 3;
-constexpr float kImmOutlierTH = 12.0f * 12.0f, kImmMinIdepthHAct = 100.0f;
+// setting_maxPixSearch, setting_trace_*, setting_minTraceTestRadius, setting_GNItsOnPointActivation, setting_minIdepthH_act, setting_outlierTH: ref_constants.h
+constexpr float kImmOutlierTH = kOutlierTH, kImmMinIdepthHAct = kMinIdepthHAct;
 enum { IPS_GOOD = 0, IPS_OOB, IPS_OUTLIER, IPS_SKIPPED, IPS_BADCONDITION, IPS_UNINITIALIZED };   // ImmaturePoint.h:47-53
 enum { IRS_IN = 0, IRS_OOB = 1, IRS_OUTLIER = 2 };
-__constant__ int kImmPattern[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};   // settings.cpp:297
+#define NALO_PAT(i) {kPatternDx[i], kPatternDy[i]}
+__constant__ int kImmPattern[8][2] = {NALO_PAT(0), NALO_PAT(1), NALO_PAT(2), NALO_PAT(3), NALO_PAT(4), NALO_PAT(5), NALO_PAT(6), NALO_PAT(7)};   // settings.cpp:297 (ref_constants.h)
+#undef NALO_PAT
 
 __device__ __forceinline__ float imm_interp31(const float4* __restrict__ img, float x, float y, int width) {          // globalFuncs.h:126-140
     const int ix = (int)x, iy = (int)y;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void imm_create_kernel(const float4* __restric
     gradH[p * 3] = gxx; gradH[p * 3 + 1] = gxy; gradH[p * 3 + 2] = gyy;
     if (bad) return;
     float eth = 8 * kImmOutlierTH;
-    eth *= 1.0f * 1.0f;                                                        // setting_overallEnergyTHWeight^2
+    eth *= kOverallEnergyTHWeight * kOverallEnergyTHWeight;
     energyTH[p] = eth;
 }
 
@@ -71,159 +71,6 @@ struct ImmTraceParams {
     const float *KRKi, *Kt, *aff;                    // per host: [nh][9], [nh][3], [nh][2]
     float *idmin, *idmax; int* status; float *quality, *lastUV, *lastInterval;
 };
-
-__global__ __launch_bounds__(kImmThreads) void imm_trace_kernel(ImmTraceParams P) {
-    __shared__ float errors[100 * kImmThreads];                                // errors[step][lane]
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
-    if (p >= P.n) return;
-    const int lastStatus = P.status[p];
-    if (lastStatus == IPS_OOB) return;
-    const int w = P.w, h = P.h;
-    const float u = P.u[p], v = P.v[p];
-    const int hi = P.host_idx[p];
-    float KRKi[9], Kt[3];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) KRKi[i] = P.KRKi[hi * 9 + i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) Kt[i] = P.Kt[hi * 3 + i];
-    const float aff0 = P.aff[hi * 2], aff1 = P.aff[hi * 2 + 1];
-    float color[8], weights[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { color[i] = P.color[p * 8 + i]; weights[i] = P.weights[p * 8 + i]; }
-    float idepth_min = P.idmin[p], idepth_max = P.idmax[p];
-    const float energyTH = P.energyTH[p];
-    const float maxPixSearch = (w + h) * kImmMaxPixSearch;
-    float pr[3], ptpMin[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) pr[i] = KRKi[i * 3] * u + KRKi[i * 3 + 1] * v + KRKi[i * 3 + 2] * 1;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ptpMin[i] = pr[i] + Kt[i] * idepth_min;
-    const float uMin = ptpMin[0] / ptpMin[2], vMin = ptpMin[1] / ptpMin[2];
-    auto ret_oob = [&]() { P.lastUV[p * 2] = -1; P.lastUV[p * 2 + 1] = -1; P.lastInterval[p] = 0; P.status[p] = IPS_OOB; };
-    if (!(uMin > 4 && vMin > 4 && uMin < w - 5 && vMin < h - 5)) { ret_oob(); return; }
-    float dist, uMax, vMax, ptpMax[3];
-    if (isfinite(idepth_max)) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ptpMax[i] = pr[i] + Kt[i] * idepth_max;
-        uMax = ptpMax[0] / ptpMax[2]; vMax = ptpMax[1] / ptpMax[2];
-        if (!(uMax > 4 && vMax > 4 && uMax < w - 5 && vMax < h - 5)) { ret_oob(); return; }
-        dist = (uMin - uMax) * (uMin - uMax) + (vMin - vMax) * (vMin - vMax);
-        dist = sqrtf(dist);
-        if (dist < kImmSlackInterval) {                                        // :139-146
-            P.lastUV[p * 2] = (uMax + uMin) * 0.5f; P.lastUV[p * 2 + 1] = (vMax + vMin) * 0.5f; P.lastInterval[p] = dist;
-            P.status[p] = IPS_SKIPPED;
-            return;
-        }
-    } else {
-        dist = maxPixSearch;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) ptpMax[i] = pr[i] + Kt[i] * 0.01f;         // :152-161
-        uMax = ptpMax[0] / ptpMax[2]; vMax = ptpMax[1] / ptpMax[2];
-        const float ddx = uMax - uMin, ddy = vMax - vMin;
-        const float d = 1.0f / sqrtf(ddx * ddx + ddy * ddy);
-        uMax = uMin + dist * ddx * d; vMax = vMin + dist * ddy * d;
-        if (!(uMax > 4 && vMax > 4 && uMax < w - 5 && vMax < h - 5)) { ret_oob(); return; }
-    }
-    if (!(idepth_min < 0 || (ptpMin[2] > 0.75f && ptpMin[2] < 1.5f))) { ret_oob(); return; }      // :178-184
-    float dx = kImmStepsize * (uMax - uMin), dy = kImmStepsize * (vMax - vMin);
-    const float gxx = P.gradH[p * 3], gxy = P.gradH[p * 3 + 1], gyy = P.gradH[p * 3 + 2];
-    const float a = (dx * gxx + dy * gxy) * dx + (dx * gxy + dy * gyy) * dy;                          // (v^T gradH) v, :187-188
-    const float b = (dy * gxx + (-dx) * gxy) * dy + (dy * gxy + (-dx) * gyy) * (-dx);
-    float errorInPixel = 0.2f + 0.2f * (a + b) / a;
-    if (errorInPixel * kImmMinImprovement > dist && isfinite(idepth_max)) {
-        P.lastUV[p * 2] = (uMax + uMin) * 0.5f; P.lastUV[p * 2 + 1] = (vMax + vMin) * 0.5f; P.lastInterval[p] = dist;
-        P.status[p] = IPS_BADCONDITION;
-        return;
-    }
-    if (errorInPixel > 10) errorInPixel = 10;
-    dx /= dist; dy /= dist;
-    if (dist > maxPixSearch) { uMax = uMin + maxPixSearch * dx; vMax = vMin + maxPixSearch * dy; dist = maxPixSearch; }
-    int numSteps = (int)(1.9999f + dist / kImmStepsize);
-    const float randShift = uMin * 1000 - floorf(uMin * 1000);
-    float ptx = uMin - randShift * dx, pty = vMin - randShift * dy;
-    float rot[8][2];
-#pragma unroll
-    for (int idx = 0; idx < 8; ++idx) {
-        rot[idx][0] = KRKi[0] * kImmPattern[idx][0] + KRKi[1] * kImmPattern[idx][1];
-        rot[idx][1] = KRKi[3] * kImmPattern[idx][0] + KRKi[4] * kImmPattern[idx][1];
-    }
-    if (!isfinite(dx) || !isfinite(dy)) { P.lastInterval[p] = 0; P.lastUV[p * 2] = -1; P.lastUV[p * 2 + 1] = -1; P.status[p] = IPS_OOB; return; }
-    float bestU = 0, bestV = 0, bestEnergy = 1e10f;
-    int bestIdx = -1;
-    if (numSteps >= 100) numSteps = 99;
-    for (int i = 0; i < numSteps; ++i) {                                       // discrete search, :275-304
-        float energy = 0, hits[8];
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) hits[idx] = imm_interp31(P.dI, ptx + rot[idx][0], pty + rot[idx][1], w);   // 32 taps in flight
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {                                    // same terms in the same order; the non-finite case is a select, not a branch
-            const float hit = hits[idx];
-            const float residual = hit - (aff0 * color[idx] + aff1);
-            const float ar = fabsf(residual);
-            const float hw = ar < kHuberTH ? 1 : kHuberTH / ar;
-            energy += isfinite(hit) ? hw * residual * residual * (2 - hw) : 1e5f;
-        }
-        errors[i * kImmThreads + tid] = energy;
-        if (energy < bestEnergy) { bestU = ptx; bestV = pty; bestEnergy = energy; bestIdx = i; }
-        ptx += dx; pty += dy;
-    }
-    float secondBest = 1e10f;                                                  // :308-316
-    for (int i = 0; i < numSteps; ++i) {
-        const float e = errors[i * kImmThreads + tid];
-        if ((i < bestIdx - kImmMinTraceTestRadius || i > bestIdx + kImmMinTraceTestRadius) && e < secondBest) secondBest = e;
-    }
-    const float newQuality = secondBest / bestEnergy;
-    const float q0 = P.quality[p];
-    if (newQuality < q0 || numSteps > 10) P.quality[p] = newQuality;
-    float uBak = bestU, vBak = bestV, stepBack = 0;                            // GN refinement along the line, :320-380
-    const float gnstepsize = 1;
-    if (kImmGNIts > 0) bestEnergy = 1e5f;
-    for (int it = 0; it < kImmGNIts; ++it) {
-        float H = 1, bb = 0, energy = 0;
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) {
-            const float3 hit = imm_interp33(P.dI, bestU + rot[idx][0], bestV + rot[idx][1], w);
-            if (!isfinite(hit.x)) { energy += 1e5f; continue; }
-            const float residual = hit.x - (aff0 * color[idx] + aff1);
-            const float dResdDist = dx * hit.y + dy * hit.z;
-            const float ar = fabsf(residual);
-            const float hw = ar < kHuberTH ? 1 : kHuberTH / ar;
-            H += hw * dResdDist * dResdDist;
-            bb += hw * residual * dResdDist;
-            energy += weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
-        }
-        if (energy > bestEnergy) { stepBack *= 0.5f; bestU = uBak + stepBack * dx; bestV = vBak + stepBack * dy; }
-        else {
-            float step = -gnstepsize * bb / H;
-            if (step < -0.5f) step = -0.5f; else if (step > 0.5f) step = 0.5f;
-            if (!isfinite(step)) step = 0;
-            uBak = bestU; vBak = bestV; stepBack = step;
-            bestU += step * dx; bestV += step * dy; bestEnergy = energy;
-        }
-        if (fabsf(stepBack) < kImmGNTh) break;
-    }
-    if (!(bestEnergy < energyTH * kImmExtraSlack)) {                           // :384-394
-        P.lastInterval[p] = 0; P.lastUV[p * 2] = -1; P.lastUV[p * 2 + 1] = -1;
-        P.status[p] = lastStatus == IPS_OUTLIER ? IPS_OOB : IPS_OUTLIER;
-        return;
-    }
-    if (dx * dx > dy * dy) {                                                   // new interval, :398-408
-        idepth_min = (pr[2] * (bestU - errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU - errorInPixel * dx));
-        idepth_max = (pr[2] * (bestU + errorInPixel * dx) - pr[0]) / (Kt[0] - Kt[2] * (bestU + errorInPixel * dx));
-    } else {
-        idepth_min = (pr[2] * (bestV - errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV - errorInPixel * dy));
-        idepth_max = (pr[2] * (bestV + errorInPixel * dy) - pr[1]) / (Kt[1] - Kt[2] * (bestV + errorInPixel * dy));
-    }
-    if (idepth_min > idepth_max) { const float tmp = idepth_min; idepth_min = idepth_max; idepth_max = tmp; }
-    P.idmin[p] = idepth_min; P.idmax[p] = idepth_max;                          // the members are assigned before the validity test
-    if (!isfinite(idepth_min) || !isfinite(idepth_max) || (idepth_max < 0)) {
-        P.lastInterval[p] = 0; P.lastUV[p * 2] = -1; P.lastUV[p * 2 + 1] = -1;
-        P.status[p] = IPS_OUTLIER;
-        return;
-    }
-    P.lastInterval[p] = 2 * errorInPixel; P.lastUV[p * 2] = bestU; P.lastUV[p * 2 + 1] = bestV;
-    P.status[p] = IPS_GOOD;
-}
 
 // ordered sum over the 8 lanes of a point group: init + t_0 + t_1 + ... + t_7, left to right (the rounding sequence of the scalar loop); every lane
 // of the group receives the total. Lane j takes the running sum of lane j-1 through DPP row_shr:1 (groups of 8 never straddle a 16-lane DPP row).
@@ -394,102 +241,6 @@ struct ImmOptParams {
     int* result; float* idepth_out; uint8_t* res_in;
 };
 
-// one residual of ImmaturePoint::linearizeResidual; state/newState packed 2 bits per residual, energies in LDS ([residual][lane], fp64 like the reference's members)
-__device__ __forceinline__ double imm_linearize(const ImmOptParams& P, int hf, int t, float u_pt, float v_pt, const float (&color)[8], const float (&weights)[8],
-                                                float energyTH, float outlierTHSlack, unsigned& st, unsigned& nst, double* en, double* nen, int i, float& Hdd, float& bd, float idepth) {
-    const int sh = 2 * i;
-    if (((st >> sh) & 3u) == IRS_OOB) { nst = (nst & ~(3u << sh)) | ((unsigned)IRS_OOB << sh); return en[i * kImmThreads]; }
-    const float fxl = P.fx, fyl = P.fy, cxl = P.cx, cyl = P.cy, fxli = 1.0f / P.fx, fyli = 1.0f / P.fy;
-    const float wM3G = P.w - 3, hM3G = P.h - 3;
-    const float* Rt = P.Rt + (size_t)(hf * P.W + t) * 12;
-    const float affLL0 = P.aff[(hf * P.W + t) * 2], affLL1 = P.aff[(hf * P.W + t) * 2 + 1];
-    float R[9], tt[3];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = Rt[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tt[k] = Rt[9 + k];
-    const float4* dIl = P.dI[t];
-    float energyLeft = 0;
-    auto oob = [&]() { nst = (nst & ~(3u << sh)) | ((unsigned)IRS_OOB << sh); return en[i * kImmThreads]; };
-    for (int idx = 0; idx < 8; ++idx) {
-        const int dx = kImmPattern[idx][0], dy = kImmPattern[idx][1];
-        const float k0 = (u_pt + dx - cxl) * fxli, k1 = (v_pt + dy - cyl) * fyli;                    // projectPoint, ResidualProjections.h:61-87
-        float ptp[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ptp[k] = R[k * 3] * k0 + R[k * 3 + 1] * k1 + R[k * 3 + 2] * 1 + tt[k] * idepth;
-        const float drescale = 1.0f / ptp[2];
-        if (!(drescale > 0)) return oob();
-        const float uu = ptp[0] * drescale, vv = ptp[1] * drescale, Ku = uu * fxl + cxl, Kv = vv * fyl + cyl;
-        if (!(Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G)) return oob();
-        const float3 hit = imm_interp33(dIl, Ku, Kv, P.w);
-        if (!isfinite(hit.x)) return oob();
-        const float residual = hit.x - (affLL0 * color[idx] + affLL1);
-        const float ar = fabsf(residual);
-        float hw = ar < kHuberTH ? 1 : kHuberTH / ar;
-        energyLeft += weights[idx] * weights[idx] * hw * residual * residual * (2 - hw);
-        const float dxInterp = hit.y * fxl, dyInterp = hit.z * fyl;
-        const float d_idepth = (dxInterp * drescale * (tt[0] - tt[2] * uu) + dyInterp * drescale * (tt[1] - tt[2] * vv)) * kScaleIdepth;   // derive_idepth :36-45
-        hw *= weights[idx] * weights[idx];
-        Hdd += (hw * d_idepth) * d_idepth;
-        bd += (hw * residual) * d_idepth;
-    }
-    unsigned ns;
-    if (energyLeft > energyTH * outlierTHSlack) { energyLeft = energyTH * outlierTHSlack; ns = IRS_OUTLIER; } else ns = IRS_IN;
-    nst = (nst & ~(3u << sh)) | (ns << sh);
-    nen[i * kImmThreads] = (double)energyLeft;
-    return (double)energyLeft;
-}
-
-__global__ __launch_bounds__(kImmThreads) void imm_optimize_kernel(ImmOptParams P) {
-    __shared__ double en_s[(NALO_MAX_WINDOW - 1) * kImmThreads], nen_s[(NALO_MAX_WINDOW - 1) * kImmThreads];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, tid = threadIdx.x;
-    if (p >= P.n) return;
-    double* en = en_s + tid; double* nen = nen_s + tid;
-    const int W = P.W, hf = P.host[p], nres = W - 1;
-    float color[8], weights[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { color[i] = P.color[p * 8 + i]; weights[i] = P.weights[p * 8 + i]; }
-    const float u = P.u[p], v = P.v[p], energyTH = P.energyTH[p];
-    unsigned st = 0, nst = 0;                                                  // state = IN (0) for every residual; newState = OUTLIER
-    for (int i = 0; i < nres; ++i) { en[i * kImmThreads] = 0; nen[i * kImmThreads] = 0; nst |= (unsigned)IRS_OUTLIER << (2 * i); }
-    for (int t = 0; t < W; ++t) P.res_in[(size_t)p * W + t] = 0;
-    P.idepth_out[p] = NAN;
-    auto tgt = [&](int i) { return i < hf ? i : i + 1; };                      // residual i <-> the i-th frame that is not the host
-    float lastEnergy = 0, lastHdd = 0, lastbd = 0;
-    float currentIdepth = (P.idmax[p] + P.idmin[p]) * 0.5f;
-    for (int i = 0; i < nres; ++i) {
-        // `float += double`: formed in double, rounded once (FullSystemOptPoint.cpp:79)
-        lastEnergy = (float)((double)lastEnergy + imm_linearize(P, hf, tgt(i), u, v, color, weights, energyTH, 1000.f, st, nst, en, nen, i, lastHdd, lastbd, currentIdepth));
-        st = (st & ~(3u << (2 * i))) | (((nst >> (2 * i)) & 3u) << (2 * i));
-        en[i * kImmThreads] = nen[i * kImmThreads];
-    }
-    if (!isfinite(lastEnergy) || lastHdd < kImmMinIdepthHAct) { P.result[p] = 0; return; }
-    float lambda = 0.1f;
-    for (int it = 0; it < kImmGNItsActivation; ++it) {
-        float H = lastHdd; H *= 1 + lambda;
-        const float step = (float)((1.0 / (double)H) * (double)lastbd);        // `(1.0/H) * lastbd` is a double expression, :99
-        const float newIdepth = currentIdepth - step;
-        float newHdd = 0, newbd = 0, newEnergy = 0;
-        for (int i = 0; i < nres; ++i)
-            newEnergy = (float)((double)newEnergy + imm_linearize(P, hf, tgt(i), u, v, color, weights, energyTH, 1.f, st, nst, en, nen, i, newHdd, newbd, newIdepth));
-        if (!isfinite(lastEnergy) || newHdd < kImmMinIdepthHAct) { P.result[p] = 0; return; }
-        if (newEnergy < lastEnergy) {
-            currentIdepth = newIdepth; lastHdd = newHdd; lastbd = newbd; lastEnergy = newEnergy;
-            st = nst;
-            for (int i = 0; i < nres; ++i) en[i * kImmThreads] = nen[i * kImmThreads];
-            lambda *= 0.5f;
-        } else lambda *= 5;
-        if ((double)fabsf(step) < 0.0001 * (double)currentIdepth) break;
-    }
-    if (!isfinite(currentIdepth)) { P.result[p] = -1; return; }
-    int numGood = 0;
-    for (int i = 0; i < nres; ++i) if (((st >> (2 * i)) & 3u) == IRS_IN) numGood++;
-    if (numGood < P.minObs) { P.result[p] = -1; return; }
-    if (!isfinite(energyTH)) { P.result[p] = -1; return; }                     // PointHessian inherits energyTH, :158
-    for (int i = 0; i < nres; ++i) if (((st >> (2 * i)) & 3u) == IRS_IN) P.res_in[(size_t)p * W + tgt(i)] = 1;
-    P.idepth_out[p] = currentIdepth;
-    P.result[p] = 1;
-}
 
 // ---- eight lanes per point (lane l = pattern pixel l), like imm_trace8_kernel. ImmaturePoint::linearizeResidual returns at the FIRST pattern pixel that
 // fails (behind the camera / out of bounds / non-finite), keeping the Hdd / bd contributions of the pixels before it: the group finds that pixel with a
@@ -679,9 +430,9 @@ __global__ __launch_bounds__(256) void pixsel_hist_kernel(const float* __restric
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int th = (int)(hist[0] * 0.5f + 0.5f), q = 90;                              // computeHistQuantil (:67-76); bins above 49 are empty
+        int th = (int)(hist[0] * kMinGradHistCut + 0.5f), q = 90;                              // computeHistQuantil (:67-76); bins above 49 are empty
         for (int i = 0; i < 90; ++i) { th -= (i + 1 < 50 ? hist[i + 1] : 0); if (th < 0) { q = i; break; } }
-        ths[blockIdx.x] = q + 7.0f;
+        ths[blockIdx.x] = q + kMinGradHistAdd;
     }
 }
 __global__ __launch_bounds__(256) void pixsel_smooth_kernel(const float* __restrict__ ths, int w32, int h32, float* __restrict__ thsSmoothed) {
@@ -744,9 +495,7 @@ int imm_trace_launch(nalo_ctx* c, const float4* dI, int n, const float* base /* 
     P.idmin = idmin; P.idmax = idmax; P.status = status; P.quality = quality; P.lastUV = lastUV; P.lastInterval = lastInterval;
     if (n > 0) {
         ProfScope ps(c, "imm_trace");
-        static const bool scalar = std::getenv("NALO_IMM_SCALAR") != nullptr;       // one lane per point (the first version), for comparison
-        if (scalar) imm_trace_kernel<<<(n + kImmThreads - 1) / kImmThreads, kImmThreads, 0, c->stream>>>(P);
-        else imm_trace8_kernel<<<(n + 31) / 32, 256, 0, c->stream>>>(P);
+        imm_trace8_kernel<<<(n + 31) / 32, 256, 0, c->stream>>>(P);
     }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
@@ -763,9 +512,7 @@ int imm_optimize_launch(nalo_ctx* c, const float4* const* dI, int W, const float
     P.result = result; P.idepth_out = idepth_out; P.res_in = res_in;
     if (n > 0) {
         ProfScope ps(c, "imm_optimize");
-        static const bool scalar = std::getenv("NALO_IMM_SCALAR") != nullptr;
-        if (scalar) imm_optimize_kernel<<<(n + kImmThreads - 1) / kImmThreads, kImmThreads, 0, c->stream>>>(P);
-        else imm_optimize8_kernel<<<(n + kImmGroups - 1) / kImmGroups, 256, 0, c->stream>>>(P);
+        imm_optimize8_kernel<<<(n + kImmGroups - 1) / kImmGroups, 256, 0, c->stream>>>(P);
     }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;

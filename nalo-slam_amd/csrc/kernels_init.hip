@@ -9,7 +9,9 @@
 namespace nalo {
 
 constexpr int kInitVals = 91, kInitStride = 96;
-__constant__ int kInitPattern[8][2] = {{0, -2}, {-1, -1}, {1, -1}, {-2, 0}, {0, 0}, {2, 0}, {-1, 1}, {0, 2}};   // settings.cpp:297
+#define NALO_PAT(i) {kPatternDx[i], kPatternDy[i]}
+__constant__ int kInitPattern[8][2] = {NALO_PAT(0), NALO_PAT(1), NALO_PAT(2), NALO_PAT(3), NALO_PAT(4), NALO_PAT(5), NALO_PAT(6), NALO_PAT(7)};   // settings.cpp:297 (ref_constants.h)
+#undef NALO_PAT
 
 struct InitParams {
     const float4 *colorRef, *colorNew; int wl, hl, n;

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void pixsel_cells_kernel(PixSelArgs P, uint8_t
     const int mx = cell ? min(pot, w - x0) : 0, my = cell ? min(pot, h - y0) : 0, tot = mx * my, per = (tot + L - 1) / L;
     const int p0 = min(sub * per, tot), p1 = min(p0 + per, tot);                         // this lane's raster run of the cell
     const int w1 = w / 2, w2 = w / 4, thsStep = w / 32;
-    const float dw1 = 0.75f, dw2 = dw1 * dw1;                   // setting_gradDownweightPerLevel (settings.cpp:156)
+    const float dw1 = kGradDownweightPerLevel, dw2 = dw1 * dw1;  // settings.cpp:156
     constexpr unsigned long long kCellMask = L >= 64 ? ~0ull : ((1ull << L) - 1);
     if constexpr (!SELECT) {
         bool any = false;

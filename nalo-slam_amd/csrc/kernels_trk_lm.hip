@@ -494,9 +494,8 @@ int trk_lm_launch(nalo_ctx* c, int slot_new, const double T0[12], const double a
     int maxn = 1;
     for (int l = stop_lvl; l <= coarsest; ++l) maxn = std::max(maxn, c->pc_n[l]);
     // workgroups: 64 at most on KITTI-sized clouds (the exchange between them is the cost that grows), 128 once the largest level has 8+ rounds of 64 x 256 points
-    // (1920x1072, 250 k points: 513 us per frame with 64, 469 with 128, 499 with 192, 544 with 256); NALO_LM_BLOCKS overrides
-    static const int env_blocks = [] { const char* e = std::getenv("NALO_LM_BLOCKS"); return e ? std::min(std::max(std::atoi(e), 1), 256) : 0; }();
-    const int max_blocks = env_blocks ? env_blocks : (maxn >= 8 * NALO_LM_MAX_BLOCKS * kLmThreads ? 2 * NALO_LM_MAX_BLOCKS : NALO_LM_MAX_BLOCKS);
+    // (1920x1072, 250 k points: 513 us per frame with 64, 469 with 128, 499 with 192, 544 with 256)
+    const int max_blocks = (maxn >= 8 * NALO_LM_MAX_BLOCKS * kLmThreads ? 2 * NALO_LM_MAX_BLOCKS : NALO_LM_MAX_BLOCKS);
     const int NB = std::min(max_blocks, (maxn + kLmThreads - 1) / kLmThreads);
     if (!c->lm_partial.p || (c->lm_launches & 0xFFFFFu) == 0) {      // first use / tag wrap-around: no stale word may carry a live tag
         NALO_HIP(c, c->lm_partial.reserve((size_t)2 * 256 * 64));

@@ -12,17 +12,9 @@
 
 #include "../../include/nalo_gpu.h"
 #include "host_math.h"
+#include "ref_constants.h"
 
 namespace nalo {
-
-// reference constants (util/settings.cpp, FullSystem/HessianBlocks.h:61-68)
-constexpr float kScaleIdepth = 1.0f, kScaleXiRot = 1.0f, kScaleXiTrans = 0.5f, kScaleF = 50.0f, kScaleC = 50.0f,
-                kScaleA = 10.0f, kScaleB = 1000.0f;
-constexpr float kHuberTH = 9.0f, kCoarseCutoffTH = 20.0f, kOutlierTHSumComponent = 2500.0f;
-constexpr float kIdepthFixPrior = 2500.0f, kIdepthFixPriorMargFac = 360000.0f;
-constexpr double kInitialRotPrior = 1e11, kInitialTransPrior = 1e10, kInitialAffPrior = 1e14, kInitialCalibHessian = 5e9;
-constexpr double kAffineOptModeA = 1e12, kAffineOptModeB = 1e8, kSolverModeDelta = 1e-5, kMargWeightFac = 0.25;
-constexpr int kPatternNum = 8;
 
 template <typename T>
 struct DevBuf {                  // owning device buffer, grows on demand
@@ -69,6 +61,7 @@ struct nalo_ctx {
     hipStream_t stream = nullptr, side = nullptr, copy = nullptr;   // copy: H2D frame uploads of nalo_frame_upload_async (overlap the kernels of `stream`)
     hipEvent_t ev_main = nullptr;            // main-stream marker the copy stream waits on before it overwrites a slot that has been used
     float* gamma_dev = nullptr;              // 256-entry gamma table of the asynchronous upload path
+    float gamma_last[256]; bool gamma_have = false;   // what gamma_dev holds: the table is re-sent only when the caller's differs (and then behind every kernel that may read it)
     // raw-frame ingest (nalo_undist_set / nalo_frame_upload_raw): photometric + geometric undistortion tables, raw staging
     int und_wOrg = 0, und_hOrg = 0, und_photometric = 0, und_GDepth = 0; bool und_set = false, und_remap = false, und_vig = false;
     nalo::DevBuf<float> und_G, und_vinv, und_rx, und_ry; nalo::DevBuf<uint8_t> und_raw, und_mask, und_bgr;
@@ -98,6 +91,7 @@ struct nalo_ctx {
     nalo::BAWindow* ba = nullptr;
     nalo::PixSel* pixsel = nullptr;          // pixel selector state (kernels_pixsel.hip)
     void* rccl = nullptr;                    // RCCL communicators of the sharded BA (host_rccl.hip)
+    bool xchg_failed = false;                // a cross-rank sum failed (host_rccl.hip): the ranks' systems may differ, every later BA call of this context fails
     nalo::Initializer* init = nullptr;       // two-frame initialiser state (host_init.hip)
     nalo_settings set = {1, nalo::kAffineOptModeA, nalo::kAffineOptModeB, 1};   // util/settings.cpp:71,128-129,74
 

@@ -712,7 +712,7 @@ int orc_ba_do_step(OrcBA* ba, float stepfacC, float stepfacT, float stepfacR, fl
     sumA/=ba->W; sumB/=ba->W; sumR/=ba->W; sumT/=ba->W; sumID/=numID; sumNID/=numID;
     orc_ba_set_precalc(ba);
     ba->t_other += now_s()-t0;
-    const float th=1.2f;                                   /* setting_thOptIterations */
+    const float th=SETTING_TH_OPT_ITERATIONS;
     return sqrtf(sumA)<0.0005*th && sqrtf(sumB)<0.00005*th && sqrtf(sumR)<0.00005*th && sqrtf(sumT)*sumNID<0.00005*th;
 }
 

@@ -174,3 +174,36 @@ double orc_tier_get(const OrcTier* t, int i) {
     return orc_sum_mode ? (double)t->A1m[i] : t->D[i];
 #endif
 }
+
+/* the constants of orc_common.h under the reference's own names (tests/test_constants_cpu.py compares them with tests/golden/constants_ref.json) */
+int orc_constants(int cap, const char** names, double* values) {
+    static const struct { const char* name; double value; } t[] = {
+        {"SCALE_IDEPTH", SCALE_IDEPTH}, {"SCALE_XI_ROT", SCALE_XI_ROT}, {"SCALE_XI_TRANS", SCALE_XI_TRANS}, {"SCALE_F", SCALE_F}, {"SCALE_C", SCALE_C},
+        {"SCALE_A", SCALE_A}, {"SCALE_B", SCALE_B}, {"PYR_LEVELS", ORC_PYR_MAX}, {"patternNum", ORC_PATTERN_NUM}, {"patternPadding", ORC_PATTERN_PADDING},
+        {"MAX_RES_PER_POINT", ORC_MAX_RES_PER_POINT}, {"NUM_THREADS", ORC_NUM_THREADS}, {"CPARS", ORC_CPARS},
+        {"setting_huberTH", SETTING_HUBER_TH}, {"setting_coarseCutoffTH", SETTING_COARSE_CUTOFF_TH}, {"setting_outlierTH", SETTING_OUTLIER_TH},
+        {"setting_outlierTHSumComponent", SETTING_OUTLIER_TH_SUMCOMP}, {"setting_idepthFixPrior", SETTING_IDEPTH_FIX_PRIOR},
+        {"setting_idepthFixPriorMargFac", SETTING_IDEPTH_FIX_PRIOR_MARGFAC}, {"setting_initialRotPrior", SETTING_INITIAL_ROT_PRIOR},
+        {"setting_initialTransPrior", SETTING_INITIAL_TRANS_PRIOR}, {"setting_initialAffBPrior", SETTING_INITIAL_AFFB_PRIOR},
+        {"setting_initialAffAPrior", SETTING_INITIAL_AFFA_PRIOR}, {"setting_initialCalibHessian", SETTING_INITIAL_CALIB_HESSIAN},
+        {"setting_solverModeDelta", SETTING_SOLVER_MODE_DELTA}, {"setting_affineOptModeA", SETTING_AFFINE_OPT_MODE_A}, {"setting_affineOptModeB", SETTING_AFFINE_OPT_MODE_B},
+        {"setting_margWeightFac", SETTING_MARG_WEIGHT_FAC}, {"setting_frameEnergyTHConstWeight", SETTING_FRAME_ENERGY_TH_CONST_WEIGHT},
+        {"setting_frameEnergyTHN", SETTING_FRAME_ENERGY_TH_N}, {"setting_frameEnergyTHFacMedian", SETTING_FRAME_ENERGY_TH_FAC_MEDIAN},
+        {"setting_overallEnergyTHWeight", SETTING_OVERALL_ENERGY_TH_WEIGHT}, {"setting_thOptIterations", SETTING_TH_OPT_ITERATIONS},
+        {"setting_minIdepthH_act", SETTING_MIN_IDEPTH_H_ACT}, {"setting_minGradHistCut", SETTING_MIN_GRAD_HIST_CUT}, {"setting_minGradHistAdd", SETTING_MIN_GRAD_HIST_ADD},
+        {"setting_gradDownweightPerLevel", SETTING_GRAD_DOWNWEIGHT_PER_LEVEL}, {"setting_maxPixSearch", SETTING_MAX_PIX_SEARCH},
+        {"setting_minTraceTestRadius", SETTING_MIN_TRACE_TEST_RADIUS}, {"setting_GNItsOnPointActivation", SETTING_GN_ITS_ON_POINT_ACTIVATION},
+        {"setting_trace_stepsize", SETTING_TRACE_STEPSIZE}, {"setting_trace_GNIterations", SETTING_TRACE_GN_ITERATIONS},
+        {"setting_trace_GNThreshold", SETTING_TRACE_GN_THRESHOLD}, {"setting_trace_extraSlackOnTH", SETTING_TRACE_EXTRA_SLACK_ON_TH},
+        {"setting_trace_slackInterval", SETTING_TRACE_SLACK_INTERVAL}, {"setting_trace_minImprovementFactor", SETTING_TRACE_MIN_IMPROVEMENT_FACTOR},
+        {"frameEnergyTH_init", FRAME_ENERGY_TH_INIT},
+        {"patternP[0].x", 0}, {"patternP[0].y", 0}, {"patternP[1].x", 0}, {"patternP[1].y", 0}, {"patternP[2].x", 0}, {"patternP[2].y", 0}, {"patternP[3].x", 0}, {"patternP[3].y", 0},
+        {"patternP[4].x", 0}, {"patternP[4].y", 0}, {"patternP[5].x", 0}, {"patternP[5].y", 0}, {"patternP[6].x", 0}, {"patternP[6].y", 0}, {"patternP[7].x", 0}, {"patternP[7].y", 0},
+    };
+    const int n = (int)(sizeof(t) / sizeof(t[0]));
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = t[i].name;
+        if (values) values[i] = i >= n - 16 ? (double)orc_patternP[(i - (n - 16)) / 2][(i - (n - 16)) % 2] : t[i].value;
+    }
+    return n;
+}

@@ -13,17 +13,17 @@
  */
 #include "orc_common.h"
 
-#define IMM_MAX_PIX_SEARCH 0.027f        /* setting_maxPixSearch */
-#define IMM_MIN_TRACE_TEST_RADIUS 2      /* setting_minTraceTestRadius */
-#define IMM_GN_ITS_ACTIVATION 3          /* setting_GNItsOnPointActivation */
-#define IMM_TRACE_STEPSIZE 1.0f
-#define IMM_TRACE_GN_ITS 3
-#define IMM_TRACE_GN_TH 0.1f
-#define IMM_TRACE_EXTRA_SLACK 1.2f
-#define IMM_TRACE_SLACK_INTERVAL 1.5f
-#define IMM_TRACE_MIN_IMPROVEMENT 2.0f
-#define IMM_OUTLIER_TH (12.0f * 12.0f)   /* setting_outlierTH */
-#define IMM_MIN_IDEPTH_H_ACT 100.0f      /* setting_minIdepthH_act */
+#define IMM_MAX_PIX_SEARCH SETTING_MAX_PIX_SEARCH
+#define IMM_MIN_TRACE_TEST_RADIUS SETTING_MIN_TRACE_TEST_RADIUS
+#define IMM_GN_ITS_ACTIVATION SETTING_GN_ITS_ON_POINT_ACTIVATION
+#define IMM_TRACE_STEPSIZE SETTING_TRACE_STEPSIZE
+#define IMM_TRACE_GN_ITS SETTING_TRACE_GN_ITERATIONS
+#define IMM_TRACE_GN_TH SETTING_TRACE_GN_THRESHOLD
+#define IMM_TRACE_EXTRA_SLACK SETTING_TRACE_EXTRA_SLACK_ON_TH
+#define IMM_TRACE_SLACK_INTERVAL SETTING_TRACE_SLACK_INTERVAL
+#define IMM_TRACE_MIN_IMPROVEMENT SETTING_TRACE_MIN_IMPROVEMENT_FACTOR
+#define IMM_OUTLIER_TH SETTING_OUTLIER_TH
+#define IMM_MIN_IDEPTH_H_ACT SETTING_MIN_IDEPTH_H_ACT
 
 enum { IPS_GOOD = 0, IPS_OOB, IPS_OUTLIER, IPS_SKIPPED, IPS_BADCONDITION, IPS_UNINITIALIZED };   /* ImmaturePoint.h:47-53 */
 enum { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };                                                  /* Residuals.h ResState */
@@ -335,9 +335,9 @@ void orc_pixsel_make_hists(const float* absg0, int w, int h, float* ths, float* 
             if (g > 48) g = 48;
             hist[g + 1]++; hist[0]++;
         }
-        int th = (int)(hist[0] * 0.5f + 0.5f), q = 90;
+        int th = (int)(hist[0] * SETTING_MIN_GRAD_HIST_CUT + 0.5f), q = 90;
         for (int i = 0; i < 90; i++) { th -= (i + 1 < 50 ? hist[i + 1] : 0); if (th < 0) { q = i; break; } }
-        ths[x + y * w32] = q + 7.0f;
+        ths[x + y * w32] = q + SETTING_MIN_GRAD_HIST_ADD;
     }
     for (int y = 0; y < h32; y++) for (int x = 0; x < w32; x++) {
         float sum = 0, num = 0;

@@ -338,7 +338,7 @@ void orc_initf_set_first(void* p, const float* const* dI, const float* statusMap
                             P->u[nl] = x + 0.1; P->v[nl] = y + 0.1; P->idepth[nl] = 1; P->iR[nl] = 1; P->isGood[nl] = 1;
                             P->energy[2 * nl] = P->energy[2 * nl + 1] = 0; P->lastHessian[nl] = 0; P->lastHessian_new[nl] = 0;
                             P->my_type[nl] = (lvl != 0) ? 1 : statusMap0[x + y * wl];
-                            P->outlierTH[nl] = 8 * (12.0f * 12.0f);                                  /* patternNum*setting_outlierTH, settings.cpp:99 */
+                            P->outlierTH[nl] = ORC_PATTERN_NUM * SETTING_OUTLIER_TH;                                  /* patternNum*setting_outlierTH, settings.cpp:99 */
                         }
                         nl++;
                     }

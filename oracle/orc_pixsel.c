@@ -33,7 +33,7 @@ void orc_pixsel_libc_tables(int n, unsigned char* randomPattern, int* draws) {
 void orc_pixsel_select(const float* dI, const float* absg0, const float* absg1, const float* absg2, int w, int h, const float* thsSmoothed,
                        const unsigned char* randomPattern, int pot, float thFactor, float* map_out, int* n_out) {
     const int w1 = w / 2, w2 = w / 4, thsStep = w / 32;
-    const float dw1 = 0.75f, dw2 = dw1 * dw1;                 /* setting_gradDownweightPerLevel, settings.cpp:156 */
+    const float dw1 = SETTING_GRAD_DOWNWEIGHT_PER_LEVEL, dw2 = dw1 * dw1;   /* settings.cpp:156 */
     memset(map_out, 0, sizeof(float) * (size_t)w * h);
     int n2 = 0, n3 = 0, n4 = 0;
     for (int y4 = 0; y4 < h; y4 += 4 * pot) for (int x4 = 0; x4 < w; x4 += 4 * pot) {

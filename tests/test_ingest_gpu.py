@@ -127,3 +127,30 @@ def test_raw_ingest_async_equals_sync():
             for l in range(c.levels):
                 assert np.array_equal(c.frame_download(k, l)[0], ref[k][l]), (rep, k, l)
     c.close()
+
+
+def test_camera_file_to_ingest_end_to_end(tmp_path):
+    """camera.txt -> nalo_io_make_rectification -> nalo_undist_set -> nalo_frame_upload_raw, on a landscape sensor with an explicit output K whose rectified
+    view reaches below the original image (the reference's `iy < wOrg-1` slip, util/Undistort.cpp:980, used to produce a table the product's own
+    ingest rejected). The product's table must be accepted as it is, pixels outside the original image are 0, the rest is bit-exact against the oracle."""
+    import ctypes as C
+    from test_io_cpu import CameraFile, _rectify
+    lib = C.CDLL(binding.lib_path())
+    (tmp_path / "below.txt").write_text("Pinhole 400 400 319.5 239.5 0\n640 480\n0.5 0.5 0.5 0.1 0\n640 480\n")
+    cf = CameraFile(); assert lib.nalo_io_read_camera(str(tmp_path / "below.txt").encode(), C.byref(cf)) == 0
+    rc, K, rx, ry, pt = _rectify(lib, cf)
+    assert rc == 0 and pt == 0
+    w, h, wo, ho = cf.w, cf.h, cf.w_org, cf.h_org
+    rng = np.random.RandomState(3)
+    raw = rng.randint(0, 256, (ho, wo)).astype(np.uint8)
+    G = np.linspace(0, 255, 256).astype(np.float32)
+    c = binding.Context(w, h, tuple(K), n_slots=1)
+    c.undist_set(wo, ho, G, None, 1, rx, ry)                                  # raised "remap entry outside the original image" before the fix
+    c.frame_upload_raw(0, raw, exposure=1.0, factor=1.0)
+    img = orc.undistort(raw, G, None, 1, 1.0, rx, ry, w, h)
+    dI_o, _ = orc.make_images(img, c.levels)
+    dI_g, _ = c.frame_download(0, 0)
+    assert np.array_equal(dI_g, dI_o[:w * h])
+    outside = (rx < 0).reshape(-1)
+    assert outside.sum() > 1000 and (dI_g[outside, 0] == 0).all() and (dI_g[~outside, 0] != 0).mean() > 0.98
+    c.close()

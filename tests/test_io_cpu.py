@@ -280,7 +280,10 @@ def test_rectification_tables_all_models(lib, tmp_path):
         rc, K, rx, ry, pt = _rectify(lib, cf)
         rc_o, K_o, rx_o, ry_o, pt_o = _rectify_oracle(cf)
         assert rc == 0 and rc_o == 0 and pt == pt_o == (1 if name == "kb" else 0), name
-        assert np.array_equal(K, K_o) and np.array_equal(rx, rx_o) and np.array_equal(ry, ry_o), name
+        # equal entry for entry, except where the reference's `iy < wOrg-1` slip (util/Undistort.cpp:980) keeps taps behind a landscape image: outside here
+        slip = ry_o >= cf.h_org - 1
+        assert np.array_equal(K, K_o) and np.array_equal(rx[~slip], rx_o[~slip]) and np.array_equal(ry[~slip], ry_o[~slip]), name
+        assert (rx[slip] == -1).all() and (ry[slip] == -1).all() and (slip.any() == (name == "fov")), name
         inside = rx >= 0
         assert inside.mean() > 0.9, name                  # (the explicit FOV calibration leaves its corners outside the original image)
         assert (rx[inside] < cf.w_org - 1).all() and (ry[inside] > 0).all()
@@ -292,6 +295,19 @@ def test_rectification_tables_all_models(lib, tmp_path):
         else:                                     # the rectified principal point looks along the optical axis: it maps to the original principal point
             x0, y0 = int(round(K[2])), int(round(K[3]))
             assert abs(rx[y0, x0] - cf.pars[2]) < 1.5 * abs(cf.pars[0] / K[0]) + 1e-3 and abs(ry[y0, x0] - cf.pars[3]) < 1.5 * abs(cf.pars[1] / K[1]) + 1e-3
+    # an explicit output K on a landscape sensor whose rectified view reaches below the original image: the reference's `iy < wOrg-1` slip (util/Undistort.cpp:980)
+    # leaves rows hOrg-1 <= iy < wOrg-1 "valid" (it then reads behind the image); the product marks exactly those entries outside and changes nothing else
+    (tmp_path / "below.txt").write_text("Pinhole 400 400 319.5 239.5 0\n640 480\n0.5 0.5 0.5 0.1 0\n640 480\n")
+    cf = CameraFile(); assert lib.nalo_io_read_camera(str(tmp_path / "below.txt").encode(), C.byref(cf)) == 0
+    rc, K, rx, ry, pt = _rectify(lib, cf)
+    rc_o, K_o, rx_o, ry_o, pt_o = _rectify_oracle(cf)
+    assert rc == 0 and rc_o == 0 and np.array_equal(K, K_o)
+    slip = (ry_o >= cf.h_org - 1)                                   # what the reference keeps although the taps leave the image
+    assert slip.sum() > 1000 and (ry_o[slip] < cf.w_org - 1).all()
+    assert (rx[slip] == -1).all() and (ry[slip] == -1).all()
+    assert np.array_equal(rx[~slip], rx_o[~slip]) and np.array_equal(ry[~slip], ry_o[~slip])
+    ok = rx >= 0
+    assert ok.mean() > 0.3 and (rx[ok].astype(int) + 1 < cf.w_org).all() and (ry[ok].astype(int) + 1 < cf.h_org).all()
     # the modes the reference refuses
     (tmp_path / "full.txt").write_text("EquiDistant 190.9 190.9 254.9 256.8 0.003 0.0007 -0.002 0.0002\n512 512\nfull\n512 512\n")
     cf = CameraFile(); lib.nalo_io_read_camera(str(tmp_path / "full.txt").encode(), C.byref(cf))

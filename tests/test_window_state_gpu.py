@@ -220,6 +220,52 @@ def test_marginalize_frame_matches_oracle(carried):
         c2.close()
 
 
+def test_prior_ownership_across_set_window(carried):
+    """Who owns HM / bM across nalo_ba_set_window (ADVICE r2): kept / extended only right after nalo_ba_marginalize_frame (EnergyFunctional::insertFrame's
+    conservativeResize, EnergyFunctional.cpp:437-442) or on a context declared continuing; any other window starts from a zero prior."""
+    win, ba, c, x = carried
+    HM, bM = ba.get_prior()
+    fr_o = [ba.frame(f) for f in range(win.W)]
+    kw = lambda idxs: dict(states=[fr_o[i]["state"] for i in idxs], states_zero=[fr_o[i]["state_zero"] for i in idxs], frame_ids=list(idxs))
+    c2 = binding.Context(win.w, win.h, win.K, n_slots=win.W)
+    for i in range(win.W):
+        c2.frame_upload(i, win.images[i])
+    full = list(range(win.W))
+    c2.ba_set_window(full, [fr_o[i]["evalPT"] for i in full], **kw(full))
+    c2.ba_set_prior(HM, bM)
+    c2.ba_marginalize_frame(1)
+    Hs, bs = c2.ba_get_prior()
+    rest = [i for i in full if i != 1]
+    # (a) the remaining frames + one appended keyframe: the shrunk prior, extended by a zero block
+    grown = rest + [1]
+    c2.ba_set_window(grown, [fr_o[i]["evalPT"] for i in grown], **kw(grown))
+    Hg, bg = c2.ba_get_prior()
+    n = Hs.shape[0]
+    assert Hg.shape == (n + 8, n + 8) and np.array_equal(Hg[:n, :n], Hs) and np.array_equal(bg[:n], bs)
+    assert not Hg[n:, :].any() and not Hg[:, n:].any() and not bg[n:].any()
+    # (b) the carry-over is consumed: an unrelated window of the SAME size on the same context starts from zero
+    c2.ba_set_window(full, [fr_o[i]["evalPT"] for i in full], **kw(full))
+    Hz, bz = c2.ba_get_prior()
+    assert not Hz.any() and not bz.any()
+    # (c) a context declared continuing keeps the prior over the same frames and extends it for an appended one
+    c2.ba_set_prior_carry(True)
+    sub = full[:-1]
+    c2.ba_set_window(sub, [fr_o[i]["evalPT"] for i in sub], **kw(sub))
+    m = 8 * len(sub) + 4
+    Hsub = np.ascontiguousarray(HM[:m, :m]); bsub = np.ascontiguousarray(bM[:m])
+    c2.ba_set_prior(Hsub, bsub)
+    c2.ba_set_window(sub, [fr_o[i]["evalPT"] for i in sub], **kw(sub))
+    Hk, bk = c2.ba_get_prior()
+    assert np.array_equal(Hk, Hsub) and np.array_equal(bk, bsub)
+    c2.ba_set_window(full, [fr_o[i]["evalPT"] for i in full], **kw(full))
+    He, be = c2.ba_get_prior()
+    assert np.array_equal(He[:m, :m], Hsub) and not He[m:, :].any() and not He[:, m:].any() and np.array_equal(be[:m], bsub) and not be[m:].any()
+    c2.ba_set_prior_carry(False)
+    c2.ba_set_window(full, [fr_o[i]["evalPT"] for i in full], **kw(full))
+    assert not c2.ba_get_prior()[0].any()
+    c2.close()
+
+
 def test_gamma_table_in_make_images(small_window):
     """makeImages with CalibHessian::B (HessianBlocks.cpp:181-187): absSquaredGrad *= (B[c+1]-B[c])^2, bit-exact like the rest of a1"""
     win = small_window
