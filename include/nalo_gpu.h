@@ -427,6 +427,12 @@ int nalo_init_do_step(nalo_ctx* ctx, int n, const uint8_t* isGood, const float* 
 int nalo_init_set_first(nalo_ctx* ctx, int slot_first, int* sparsityFactor, int numPoints[NALO_MAX_LEVELS]);
 int nalo_init_track_frame(nalo_ctx* ctx, int slot_new, float exposure_first, float exposure_new, int* ok);
 int nalo_init_get_state(nalo_ctx* ctx, double thisToNext[12], double aff[2], int* snapped, int* frameID, int* snappedAt, int* n_evals);
+/* nalo_init_set_state / nalo_init_set_points: write back what trackFrame carries from frame to frame (thisToNext, thisToNext_aff, snapped, frameID, snappedAt; per
+ *     level the Pnt members idepth, idepth_new, iR, isGood, lastHessian, energy, maxstep and the *_new / iRSumNum members stale entries of which survive a frame; NULL = leave as is): resume of a checkpointed initialisation, and what
+ *     the teacher-forced parity test uses to start every frame from the oracle's state. n must equal the level's point count. */
+int nalo_init_set_state(nalo_ctx* ctx, const double thisToNext[12], const double aff[2], int snapped, int frameID, int snappedAt);
+int nalo_init_set_points(nalo_ctx* ctx, int lvl, int n, const float* idepth, const float* idepth_new, const float* iR, const uint8_t* isGood, const float* lastHessian,
+                         const float* energy2, const float* maxstep, const float* lastHessian_new, const float* energy_new2, const uint8_t* isGood_new, const float* iRSumNum);
 int nalo_init_get_points(nalo_ctx* ctx, int lvl, int cap, int* n, float* u, float* v, float* idepth, float* iR, uint8_t* isGood, float* lastHessian, float* energy2,
                          float* my_type, float* outlierTH, int* parent, float* parentDist, int* neighbours, float* neighboursDist);
 

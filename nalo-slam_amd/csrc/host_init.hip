@@ -536,6 +536,26 @@ int nalo_init_get_state(nalo_ctx* c, double thisToNext[12], double aff[2], int* 
     return NALO_OK;
 }
 
+// restore of the carried state (what trackFrame reads from the previous frame): checkpoint / resume of an initialisation, and the teacher-forced parity runs
+int nalo_init_set_state(nalo_ctx* c, const double thisToNext[12], const double aff[2], int snapped, int frameID, int snappedAt) {
+    if (!c || !c->init || c->init->slot_first < 0) return fail(c, c ? NALO_ERR_STATE : NALO_ERR_ARG, "nalo_init_set_state: nalo_init_set_first has not run");
+    if (!thisToNext || !aff) return fail(c, NALO_ERR_ARG, "nalo_init_set_state: bad argument");
+    Initializer& I = *c->init;
+    I.thisToNext = SE3::from(thisToNext); I.aff[0] = aff[0]; I.aff[1] = aff[1];
+    I.snapped = snapped != 0; I.frameID = frameID; I.snappedAt = snappedAt;
+    return NALO_OK;
+}
+int nalo_init_set_points(nalo_ctx* c, int lvl, int n, const float* idepth, const float* idepth_new, const float* iR, const uint8_t* isGood, const float* lastHessian,
+                         const float* energy2, const float* maxstep, const float* lastHessian_new, const float* energy_new2, const uint8_t* isGood_new, const float* iRSumNum) {
+    if (!c || !c->init || c->init->slot_first < 0) return fail(c, c ? NALO_ERR_STATE : NALO_ERR_ARG, "nalo_init_set_points: nalo_init_set_first has not run");
+    if (lvl < 0 || lvl >= c->init->levels || n != c->init->L[lvl].n) return fail(c, NALO_ERR_ARG, "nalo_init_set_points: level / point count do not match the initialiser's");
+    InitLevel& P = c->init->L[lvl];
+    auto take = [&](auto& dst, const auto* src, size_t mult) { if (src && n) std::memcpy(dst.data(), src, (size_t)n * mult * sizeof(*src)); };
+    take(P.idepth, idepth, 1); take(P.idepth_new, idepth_new, 1); take(P.iR, iR, 1); take(P.isGood, isGood, 1); take(P.lastHessian, lastHessian, 1); take(P.energy, energy2, 2);
+    take(P.maxstep, maxstep, 1); take(P.lastHessian_new, lastHessian_new, 1); take(P.energy_new, energy_new2, 2); take(P.isGood_new, isGood_new, 1); take(P.iRSumNum, iRSumNum, 1);
+    return NALO_OK;
+}
+
 int nalo_init_get_points(nalo_ctx* c, int lvl, int cap, int* n, float* u, float* v, float* idepth, float* iR, uint8_t* isGood, float* lastHessian, float* energy2, float* my_type,
                          float* outlierTH, int* parent, float* parentDist, int* neighbours, float* neighboursDist) {
     if (!c || !c->init) return fail(c, c ? NALO_ERR_STATE : NALO_ERR_ARG, "nalo_init_get_points: no initialiser");

@@ -662,7 +662,8 @@ class Initializer:
     """CoarseInitializer (setFirst + trackFrame and everything they call) on the CPU."""
     FIELDS = {"u": (np.float32, 1), "v": (np.float32, 1), "idepth": (np.float32, 1), "idepth_new": (np.float32, 1), "iR": (np.float32, 1), "lastHessian": (np.float32, 1),
               "energy": (np.float32, 2), "outlierTH": (np.float32, 1), "my_type": (np.float32, 1), "neighboursDist": (np.float32, 10), "parentDist": (np.float32, 1),
-              "isGood": (np.uint8, 1), "parent": (np.int32, 1), "neighbours": (np.int32, 10), "maxstep": (np.float32, 1)}
+              "isGood": (np.uint8, 1), "parent": (np.int32, 1), "neighbours": (np.int32, 10), "maxstep": (np.float32, 1),
+              "lastHessian_new": (np.float32, 1), "energy_new": (np.float32, 2), "isGood_new": (np.uint8, 1), "iRSumNum": (np.float32, 1)}
 
     def __init__(self, w, h, levels, K, kind="f32"):
         self.L = lib(kind)
@@ -720,6 +721,28 @@ class Initializer:
         out = np.zeros((n, m) if m > 1 else n, dt)
         assert self.L.orc_initf_get(self.h_, lvl, field.encode(), out.ctypes.data_as(C.c_void_p)) == 0
         return out
+
+    CARRIED = ("idepth", "idepth_new", "iR", "lastHessian", "energy", "isGood", "maxstep", "lastHessian_new", "energy_new", "isGood_new", "iRSumNum")
+
+    def set(self, lvl, field, value):
+        dt, m = self.FIELDS[field]
+        a = np.ascontiguousarray(value, dt)
+        assert a.size == self.num(lvl) * m
+        self.L.orc_initf_set.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p]
+        assert self.L.orc_initf_set(self.h_, lvl, field.encode(), a.ctypes.data_as(C.c_void_p)) == 0
+
+    def carried(self):
+        """everything trackFrame reads from the previous frame: the pose / affine / snap state and, per level, the CARRIED Pnt members"""
+        return dict(state=self.state(), points=[{k: self.get(l, k) for k in self.CARRIED} for l in range(self.levels)])
+
+    def set_carried(self, car):
+        s = car["state"]
+        self.L.orc_initf_set_state.argtypes = [C.c_void_p, c_dp, c_dp, c_ip]
+        self.L.orc_initf_set_state(self.h_, dp(np.ascontiguousarray(s["thisToNext"], np.float64).reshape(-1)), dp(np.ascontiguousarray(s["aff"], np.float64)),
+                                   ip(np.array([int(s["snapped"]), s["frameID"], s["snappedAt"]], np.int32)))
+        for l in range(self.levels):
+            for k in self.CARRIED:
+                self.set(l, k, car["points"][l][k])
 
     def state(self):
         T, aff, st = np.zeros(12), np.zeros(2), np.zeros(4, np.int32)

@@ -572,8 +572,23 @@ int orc_initf_get(void* p, int lvl, const char* field, void* out) {
     G("u", P->u, 1, 4) G("v", P->v, 1, 4) G("idepth", P->idepth, 1, 4) G("idepth_new", P->idepth_new, 1, 4) G("iR", P->iR, 1, 4) G("lastHessian", P->lastHessian, 1, 4)
     G("energy", P->energy, 2, 4) G("outlierTH", P->outlierTH, 1, 4) G("my_type", P->my_type, 1, 4) G("neighboursDist", P->neighboursDist, 10, 4) G("parentDist", P->parentDist, 1, 4)
     G("isGood", P->isGood, 1, 1) G("parent", P->parent, 1, 4) G("neighbours", P->neighbours, 10, 4) G("maxstep", P->maxstep, 1, 4)
+    G("lastHessian_new", P->lastHessian_new, 1, 4) G("energy_new", P->energy_new, 2, 4) G("isGood_new", P->isGood_new, 1, 1) G("iRSumNum", P->iRSumNum, 1, 4)
 #undef G
     return -1;
+}
+/* the carried state of a Pnt array, written from outside (teacher-forced parity runs: every back-end starts a frame from the same state) */
+int orc_initf_set(void* p, int lvl, const char* field, const void* in) {
+    OrcInitLvl* P = &((OrcInit*)p)->L[lvl]; const size_t n = P->n;
+#define S(name, ptr, mult, sz) if (!strcmp(field, name)) { memcpy(ptr, in, n * (mult) * (sz)); return 0; }
+    S("idepth", P->idepth, 1, 4) S("idepth_new", P->idepth_new, 1, 4) S("iR", P->iR, 1, 4) S("lastHessian", P->lastHessian, 1, 4) S("energy", P->energy, 2, 4)
+    S("isGood", P->isGood, 1, 1) S("maxstep", P->maxstep, 1, 4)
+    S("lastHessian_new", P->lastHessian_new, 1, 4) S("energy_new", P->energy_new, 2, 4) S("isGood_new", P->isGood_new, 1, 1) S("iRSumNum", P->iRSumNum, 1, 4)
+#undef S
+    return -1;
+}
+void orc_initf_set_state(void* p, const double T[12], const double aff[2], const int st[3]) {
+    OrcInit* I = (OrcInit*)p; memcpy(I->thisToNext, T, sizeof(I->thisToNext)); I->aff[0] = aff[0]; I->aff[1] = aff[1];
+    I->snapped = st[0]; I->frameID = st[1]; I->snappedAt = st[2];
 }
 void orc_initf_get_state(void* p, double T[12], double aff[2], int st[4]) {
     OrcInit* I = (OrcInit*)p; memcpy(T, I->thisToNext, sizeof(I->thisToNext)); aff[0] = I->aff[0]; aff[1] = I->aff[1];

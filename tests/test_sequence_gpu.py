@@ -12,7 +12,8 @@ Two runs per image size:
   closed loop     each back-end consumes its OWN numbers for the whole sequence. Two fp32 evaluations drift apart in a chaotic estimator: the strict
                   fp32 oracle against the all-fp64 oracle reaches 2e-5 .. 5e-5 over these sequences (measured, tests/seq_helpers.py dry run), which is
                   the noise floor of the reference's own arithmetic. Bar: 5e-5 per keyframe (2e-4 after a flipped decision) on the window trajectory
-                  after Sim(3) alignment (the monocular gauge is held by priors only; see check()), 2e-3 on the raw poses.
+                  after Sim(3) alignment (the monocular gauge is held by priors only; see check()); the raw poses within max(2e-4, 3x the raw
+                  distance between the two oracles at that keyframe).
 The tracker's affine parameters are compared at 1e-3 (a) / 0.05 grey levels (b): b is scaled by SCALE_B = 1000 inside the LM, whose stopping
 rule is |inc| < 1e-3 in scaled units."""
 import numpy as np
@@ -43,7 +44,11 @@ def check(rec, drv, tol_state, tol_clean, tol_flipped):
         # its far end, while its shape agrees to 1e-5), so the estimate itself is compared after the best Sim(3) alignment; the raw distance keeps a loose bound.
         A, Bg, B64 = [f.w2c for f in fo], [f.w2c for f in fg], [f.w2c for f in f64]
         floor, worst = sim3_aligned_dist(A, B64), sim3_aligned_dist(A, Bg)
-        assert raw < 2e-3, "keyframe %d: raw pose delta %.2e" % (rec["k"], raw)
+        # the raw (gauge-included) distance is tied to what the reference's own arithmetic does in the same closed loop (VERDICT r2 #1c): 3x the raw distance
+        # between the strict fp32 and the all-fp64 oracle at this keyframe, never tighter than 2e-4
+        raw_floor = max(pose_dist(a.w2c, b.w2c) for a, b in zip(fo, f64))
+        tol_state.setdefault("raw", []).append((raw, raw_floor))
+        assert raw < max(2e-4, 3 * raw_floor), "keyframe %d: raw pose delta %.2e, raw fp64-oracle floor %.2e" % (rec["k"], raw, raw_floor)
     tol = max(tol, 1.5 * floor)
     if len(fo) < 5:                      # the first windows (2-4 frames, a few hundred points) are weakly constrained, like the toy window of test_ba_gpu.py
         tol = max(tol, 3e-5)
@@ -98,6 +103,8 @@ def test_keyframe_sequence(w, h, n_kf, teacher):
     assert np.abs(drv.log[-1]["prior"][1][0]).max() > 0
     print("%dx%d %s: pose delta per keyframe:" % (w, h, "teacher-forced" if teacher else "closed loop"), ["%.1e" % x for x in worst], "flips", tol_state["flips"],
           "fp64-oracle floor:", ["%.1e" % x for x in tol_state["floor"]])
+    if not teacher:
+        print("  raw (gpu-vs-fp32, fp64-vs-fp32):", ["%.1e/%.1e" % x for x in tol_state["raw"]])
     if teacher:                                   # most keyframes sit at the fixed bar, whatever the floor allows on the weak ones
         assert np.median(worst) < 1e-5
     B[1].close()
