@@ -83,7 +83,9 @@ struct BAWindow {
     int sc_shift = -1;
     // snapshot of the mutable window state (bench/test utility: replay the same synthetic keyframe)
     DevBuf<float4> snap_geo; DevBuf<uint8_t> snap_state, snap_flags; DevBuf<float> snap_prior;
-    std::vector<HostFrame> snap_frames; std::vector<double> snap_HM, snap_bM; std::vector<uint8_t> snap_flags_h; double snap_calib[4] = {}; bool have_snap = false;
+    std::vector<HostFrame> snap_frames; std::vector<double> snap_HM, snap_bM; std::vector<uint8_t> snap_flags_h; bool have_snap = false;
+    double snap_calib[4] = {}, snap_calib_scaled[4] = {}; float snap_scaledf[4] = {}, snap_scaledi[4] = {};   // CalibHessian as it is: a fresh window holds value_scaled = K exactly,
+                                                                    // setValue(value) would round it through SCALE_F * (SCALE_F_INVERSE * K)
     nalo_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
     bool hook_stream_ordered = false;                               // the hook enqueues its collective on nalo_stream(ctx): no host synchronisation around it
@@ -1393,7 +1395,8 @@ int nalo_ba_snapshot(nalo_ctx* c) {
     NALO_HIP(c, hipMemcpyAsync(w.snap_prior.p, w.pt_prior.p, N * 4, hipMemcpyDeviceToDevice, c->stream));
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     w.snap_frames = w.frames; w.snap_HM = w.HM; w.snap_bM = w.bM; w.snap_flags_h = w.flags_h;
-    std::memcpy(w.snap_calib, w.c_value, sizeof(w.snap_calib));
+    std::memcpy(w.snap_calib, w.c_value, sizeof(w.snap_calib)); std::memcpy(w.snap_calib_scaled, w.c_value_scaled, sizeof(w.snap_calib_scaled));
+    std::memcpy(w.snap_scaledf, w.c_scaledf, sizeof(w.snap_scaledf)); std::memcpy(w.snap_scaledi, w.c_scaledi, sizeof(w.snap_scaledi));
     w.have_snap = true;
     return NALO_OK;
 }
@@ -1408,7 +1411,8 @@ int nalo_ba_restore(nalo_ctx* c) {
     NALO_HIP(c, hipMemcpyAsync(w.pt_prior.p, w.snap_prior.p, N * 4, hipMemcpyDeviceToDevice, c->stream));
     NALO_HIP(c, hipMemsetAsync(w.rs_energy.p, 0, NS * 8, c->stream));
     w.frames = w.snap_frames; w.HM = w.snap_HM; w.bM = w.snap_bM; w.flags_h = w.snap_flags_h;
-    calib_set_value(w, w.snap_calib);
+    std::memcpy(w.c_value, w.snap_calib, sizeof(w.snap_calib)); std::memcpy(w.c_value_scaled, w.snap_calib_scaled, sizeof(w.snap_calib_scaled));
+    std::memcpy(w.c_scaledf, w.snap_scaledf, sizeof(w.snap_scaledf)); std::memcpy(w.c_scaledi, w.snap_scaledi, sizeof(w.snap_scaledi));
     int rc = upload_frame_th(c); if (rc) return rc;
     rc = set_adjoints(c); if (rc) return rc;
     rc = set_precalc(c); if (rc) return rc;
