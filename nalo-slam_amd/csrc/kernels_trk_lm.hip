@@ -24,6 +24,9 @@ namespace nalo {
 #ifndef NALO_LM_G
 #define NALO_LM_G 1
 #endif
+#ifndef NALO_LM_CACHE_PT
+#define NALO_LM_CACHE_PT 1
+#endif
 #ifndef NALO_LM_MAX_BLOCKS
 #define NALO_LM_MAX_BLOCKS 64
 #endif
@@ -54,16 +57,54 @@ struct LmState {                             // lives in LDS; written by lane 0 
 };
 
 // ---- fp64 helpers for lane 0 -------------------------------------------------------------------------------------------
+// The LM increments of the tracker are small rotations (|omega| of a few 1e-2 at most): below 0.5 rad every trigonometric factor of the exponential is an
+// even power series in theta (theta^2 = |omega|^2), evaluated by Horner in fp64 with truncation error < 1e-20 - no sqrt, no sincos, no division on
+// the serial path wave 0 walks between two evaluations (the general branch keeps the closed forms).
 __device__ __forceinline__ void lm_se3_exp(const double (&xi)[8], double (&T)[12]) {   // Sophus SE3::exp (se3.hpp:407-428), quaternion form
     const double wx = xi[3], wy = xi[4], wz = xi[5];
-    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
-    double qi, qr, sh = 0, ch = 1;
-    if (th < 1e-10) { const double t4 = th2 * th2; qi = 0.5 - th2 / 48.0 + t4 / 3840.0; qr = 1.0 - 0.5 * th2 + t4 / 384.0; }
-    else { sincos(0.5 * th, &sh, &ch); qi = sh / th; qr = ch; }
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    double qi, qr, a, bq;                      // qi = sin(th/2)/th, qr = cos(th/2), a = (1 - cos th)/th^2, bq = (th - sin th)/th^3
+    if (th2 < 0.25) {
+        const double u = 0.25 * th2;           // (th/2)^2
+        // sin(x)/x and cos(x) in u = x^2, x = th/2 <= 0.25: 9 terms each (next term < 1e-25)
+        double sc = -1.0 / 121645100408832000.0, cc = 1.0 / 6402373705728000.0;
+        sc = sc * u + 1.0 / 355687428096000.0; cc = cc * u - 1.0 / 20922789888000.0;
+        sc = sc * u - 1.0 / 1307674368000.0;   cc = cc * u + 1.0 / 87178291200.0;
+        sc = sc * u + 1.0 / 6227020800.0;      cc = cc * u - 1.0 / 479001600.0;
+        sc = sc * u - 1.0 / 39916800.0;        cc = cc * u + 1.0 / 3628800.0;
+        sc = sc * u + 1.0 / 362880.0;          cc = cc * u - 1.0 / 40320.0;
+        sc = sc * u - 1.0 / 5040.0;            cc = cc * u + 1.0 / 720.0;
+        sc = sc * u + 1.0 / 120.0;             cc = cc * u - 1.0 / 24.0;
+        sc = sc * u - 1.0 / 6.0;               cc = cc * u + 0.5;
+        sc = sc * u + 1.0;                     cc = 1.0 - cc * u;
+        qi = 0.5 * sc; qr = cc;
+        // (1 - cos th)/th^2 and (th - sin th)/th^3 in v = th^2 <= 0.25: 10 terms each (next term < 1e-21)
+        const double v = th2;
+        double pa = -1.0 / 51090942171709440000.0, pb = 1.0 / 1124000727777607680000.0;
+        pa = pa * v + 1.0 / 121645100408832000.0; pb = pb * v - 1.0 / 2432902008176640000.0;
+        pa = pa * v - 1.0 / 355687428096000.0;    pb = pb * v + 1.0 / 6402373705728000.0;
+        pa = pa * v + 1.0 / 1307674368000.0;      pb = pb * v - 1.0 / 20922789888000.0;
+        pa = pa * v - 1.0 / 6227020800.0;         pb = pb * v + 1.0 / 87178291200.0;
+        pa = pa * v + 1.0 / 39916800.0;           pb = pb * v - 1.0 / 479001600.0;
+        pa = pa * v - 1.0 / 362880.0;             pb = pb * v + 1.0 / 3628800.0;
+        pa = pa * v + 1.0 / 5040.0;               pb = pb * v - 1.0 / 40320.0;
+        pa = pa * v - 1.0 / 120.0;                pb = pb * v + 1.0 / 720.0;
+        pa = pa * v + 1.0 / 6.0;                  pb = pb * v - 1.0 / 24.0;
+        bq = pa; a = pb * v + 0.5;
+    } else {
+        const double th = sqrt(th2);
+        double sh, ch;
+        sincos(0.5 * th, &sh, &ch);
+        qi = sh / th; qr = ch;
+        // 1 - cos(th) = 2 sin^2(th/2), sin(th) = 2 sin(th/2) cos(th/2): one sincos for the whole exponential
+        a = (2.0 * sh * sh) / th2; bq = (th - 2.0 * sh * ch) / (th2 * th);
+    }
     double q[4] = {qr, qi * wx, qi * wy, qi * wz};
-    const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    // SO3's constructor normalises the quaternion: |q|^2 = 1 + e with |e| ~ 1e-16, so 1/|q| is one Newton step of the reciprocal square root at 1
+    const double qn2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    const double qs = 1.5 - 0.5 * qn2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) q[i] /= qn;
+    for (int i = 0; i < 4; ++i) q[i] *= qs;
     const double w = q[0], x = q[1], y = q[2], z = q[3];
     const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                          2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
@@ -73,15 +114,8 @@ __device__ __forceinline__ void lm_se3_exp(const double (&xi)[8], double (&T)[12
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
-    if (th < 1e-10) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) V[i] = R[i];
-    } else {
-        // 1 - cos(th) = 2 sin^2(th/2), sin(th) = 2 sin(th/2) cos(th/2): one sincos for the whole exponential
-        const double a = (2.0 * sh * sh) / th2, bq = (th - 2.0 * sh * ch) / (th2 * th);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + bq * O2[i];
-    }
+    for (int i = 0; i < 9; ++i) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + a * O[i] + bq * O2[i];      // theta -> 0: a -> 1/2, bq -> 1/6 (Sophus switches to V = R below 1e-10: a 1e-20 difference)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -107,39 +141,45 @@ __device__ __forceinline__ void lm_wave_sync() {                                
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// 8x8 symmetric solve, one matrix row per lane (lanes 0..7; a[] = row `lane`, rhs = b[lane]); returns x[lane]. LDL^T without pivoting:
-// the LM system H + lambda diag(H) is positive definite, and a zero/non-finite pivot zeroes its column and its unknown exactly like the
-// host's pivoted variant does for an empty system. Row k / the solved unknowns travel through v_readlane: no LDS, no dependent memory.
-__device__ __forceinline__ double lm_ldlt8_wave(double (&a)[8], double rhs, int lane) {
-    double dd = 0;
+// 8x8 symmetric solve, computed REDUNDANTLY by every lane of wave 0 on registers: U = upper triangle of H with the damped diagonal (row-major, 36 entries,
+// wave-uniform values), x = solution of U x = rhs. LDL^T without pivoting: the LM system H + lambda diag(H) is positive definite, and a zero / non-finite
+// pivot zeroes its column and its unknown exactly like the host's pivoted variant does for an empty system. No cross-lane traffic at all: the first version
+// kept one matrix row per lane and moved pivot rows and unknowns through v_readlane (72 + 60 of them, each a VALU -> SGPR round trip on the one wave
+// that everybody waits for: ~2500 of the ~6000 clocks between two evaluations); here the same n^3/6 multiply-adds are plain fp64 FMAs with their
+// natural instruction-level parallelism. 1/d by v_rcp_f64 + two Newton steps (full fp64 accuracy; half the length of the IEEE division sequence).
+__device__ __forceinline__ constexpr int lm_ut(int r, int c) { return r * 8 - r * (r - 1) / 2 + (c - r); }      // index of (r, c), r <= c, in the packed upper triangle
+__device__ __forceinline__ void lm_ldlt8_uniform(double (&U)[36], const double (&rhs)[8], double (&x)[8]) {
+    double dinv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        double rk[8];
-#pragma unroll
-        for (int j = k; j < 8; ++j) rk[j] = lm_bcast(a[j], k);
-        const double d = rk[k];
+        const double d = U[lm_ut(k, k)];
         const bool ok = d != 0.0 && isfinite(d);
-        if (lane == k) dd = d;
-        const double l = ok ? a[k] / d : 0.0;
-        if (lane > k) {
+        double rd = __builtin_amdgcn_rcp(d);
+        rd = rd * (2.0 - d * rd); rd = rd * (2.0 - d * rd);
+        dinv[k] = ok ? rd : 0.0;
 #pragma unroll
-            for (int j = k + 1; j < 8; ++j) a[j] -= l * rk[j];
-            a[k] = l;
+        for (int i = k + 1; i < 8; ++i) {
+            const double l = U[lm_ut(k, i)] * dinv[k];           // L[i][k]
+#pragma unroll
+            for (int j = i; j < 8; ++j) U[lm_ut(i, j)] -= l * U[lm_ut(k, j)];
+            U[lm_ut(k, i)] = l;                                  // L^T overwrites the strict upper triangle
         }
     }
-    double y = rhs;                                                               // L y = rhs, column oriented
+    double y[8];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) { const double yj = lm_bcast(y, j); if (lane > j) y -= a[j] * yj; }
-    double x = (dd != 0.0 && isfinite(dd)) ? y / dd : 0.0;
+    for (int i = 0; i < 8; ++i) {                                // L y = rhs
+        double sacc = rhs[i];
 #pragma unroll
-    for (int i = 6; i >= 0; --i) {                                                // L^T x = z: row i gathers L[j][i] x_j from the lanes j > i
-        const double t = (lane > i && lane < 8) ? a[i] * x : 0.0;
-        double sacc = 0;
-#pragma unroll
-        for (int j = i + 1; j < 8; ++j) sacc += lm_bcast(t, j);
-        if (lane == i) x -= sacc;
+        for (int j = 0; j < i; ++j) sacc -= U[lm_ut(j, i)] * y[j];
+        y[i] = sacc;
     }
-    return x;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {                               // D z = y, L^T x = z
+        double sacc = y[i] * dinv[i];
+#pragma unroll
+        for (int j = i + 1; j < 8; ++j) sacc -= U[lm_ut(i, j)] * x[j];
+        x[i] = sacc;
+    }
 }
 
 // prepare the float parameters of an evaluation at (T, aff) for level lvl (CoarseTracker.cpp:907-916); the caller's lane 0 passes write = true
@@ -197,6 +237,8 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
     const float lambdaExtrapolationLimit = 0.001f;
     int timed_out = 0;
     if (tid == 0) bar_ok = 1;
+    float c_id = 0.f, c_x = 0.f, c_y = 0.f, c_rc = 0.f;   // this lane's point of level cached_lvl (levels that fit one round of the grid)
+    int cached_lvl = -1;
 
     // every block keeps its own copy of the LM state and advances it with the same inputs (the summed partials): the control flow is
     // replicated, not broadcast, which saves a second grid barrier per evaluation
@@ -235,6 +277,15 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
             // G points per lane per round in flight (point loads, then the texel gathers, then the arithmetic); the rounds stride over the grid
             constexpr int G = NALO_LM_G;
             const int gthreads = NB * kLmThreads;
+            // A level whose points fit ONE round of the grid (every level of a KITTI-sized cloud: <= 64 x 512 points) gives each lane one point for all the
+            // ~5 evaluations of the level: it is loaded once and stays in four registers, which takes one of the two dependent memory round trips (point ->
+            // texels) out of every later evaluation.
+            const bool one_round = NALO_LM_CACHE_PT && G == 1 && L.n <= gthreads;
+            if (one_round && cached_lvl != lvl) {
+                const int i = blk * kLmThreads + tid, ii = i < L.n ? i : 0;
+                c_id = L.id[ii]; c_x = L.u[ii]; c_y = L.v[ii]; c_rc = L.col[ii];
+                cached_lvl = lvl;
+            }
             for (int base = blk * kLmThreads + tid; base < L.n; base += G * gthreads) {
                 float id[G], x[G], y[G], rc[G], Ku[G], Kv[G], uu[G], vv[G], nid[G];
                 bool inb[G], ok[G];
@@ -243,7 +294,8 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
                     const int i = base + g * gthreads;
                     inb[g] = i < L.n;
                     const int ii = inb[g] ? i : 0;
-                    id[g] = L.id[ii]; x[g] = L.u[ii]; y[g] = L.v[ii]; rc[g] = L.col[ii];
+                    if (one_round) { id[g] = c_id; x[g] = c_x; y[g] = c_y; rc[g] = c_rc; }
+                    else { id[g] = L.id[ii]; x[g] = L.u[ii]; y[g] = L.v[ii]; rc[g] = L.col[ii]; }
                 }
                 float4 p00[G], p10[G], p01[G], p11[G];
 #pragma unroll
@@ -399,20 +451,21 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
             const double aff0 = S.aff[0], aff1 = S.aff[1];
             if (next_action == 1) {
                 if (it < lm_max_iterations(lvl)) {                                               // :1133-1184
-                    double a[8];
+                    double U[36], rhs[8], iv[8], is[8];
                     const float opl = 1 + lambda;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { a[j] = lane < 8 ? S.H[lane * 8 + j] : 0.0; if (j == lane) a[j] *= opl; }
-                    const double rhs = lane < 8 ? -S.b[lane] : 0.0;
-                    double inc = lm_ldlt8_wave(a, rhs, lane);
+                    for (int r = 0; r < 8; ++r) {                // wave-uniform LDS reads (broadcast): every lane holds the whole system
+#pragma unroll
+                        for (int cc = r; cc < 8; ++cc) U[lm_ut(r, cc)] = S.H[r * 8 + cc];
+                        U[lm_ut(r, r)] *= opl;
+                        rhs[r] = -S.b[r];
+                    }
+                    lm_ldlt8_uniform(U, rhs, iv);
                     float extrapFac = 1;
                     if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf(sqrtf(lambdaExtrapolationLimit / lambda));
-                    inc *= extrapFac;
                     // labels swapped vs tangent order in the reference (:1172-1173): entries 0-2 scale with SCALE_XI_ROT, 3-5 with SCALE_XI_TRANS
-                    const double incSl = inc * (lane < 3 ? (double)kScaleXiRot : lane < 6 ? (double)kScaleXiTrans : lane == 6 ? (double)kScaleA : (double)kScaleB);
-                    double iv[8], is[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { iv[i] = lm_bcast(inc, i); is[i] = lm_bcast(incSl, i); }
+                    for (int i = 0; i < 8; ++i) { iv[i] *= extrapFac; is[i] = iv[i] * (i < 3 ? (double)kScaleXiRot : i < 6 ? (double)kScaleXiTrans : i == 6 ? (double)kScaleA : (double)kScaleB); }
                     double ssum = 0, nrm = 0;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { ssum += is[i]; nrm += iv[i] * iv[i]; }

@@ -118,10 +118,10 @@ inline int fail(nalo_ctx* c, int code, const std::string& msg) { if (c) c->err =
 
 // Wait for a kernel to publish `seq` into host-mapped memory (system-scope release on the device side). Spinning on the
 // flag costs a few microseconds; hipStreamSynchronize costs tens. Every 2^20 spins the stream is queried for a fault and the wall clock is
-// checked: after NALO_POLL_TIMEOUT_S (default 10 s) without the flag the call fails with NALO_ERR_HIP (a faulted kernel or a collective
+// checked: after 10 s without the flag the call fails with NALO_ERR_HIP (a faulted kernel or a collective
 // that never completes must not stall the caller for minutes).
 inline bool poll_flag(nalo_ctx* c, volatile double* flag, double seq) {
-    static const double timeout_s = [] { const char* e = std::getenv("NALO_POLL_TIMEOUT_S"); const double v = e ? std::atof(e) : 10.0; return v > 0 ? v : 10.0; }();
+    constexpr double timeout_s = 10.0;
     std::chrono::steady_clock::time_point t0;
     bool timing = false;
     for (unsigned long long spins = 0;; ++spins) {

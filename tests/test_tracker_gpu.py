@@ -199,7 +199,7 @@ def test_lost_workgroup_degrades_to_the_host_driven_loop(ctx, small_window, tmp_
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "lost_block.py"
     script.write_text(_LOST_BLOCK_SCRIPT)
-    env = dict(os.environ, NALO_LM_TEST_TIMEOUT="1")
+    env = dict(os.environ, NALO_LM_TEST_TIMEOUT="1", NALO_HOST_TIMING="1")      # the second switch: the host-side wall-clock accounting printed at nalo_destroy
     p = subprocess.run([sys.executable, str(script), root, json.dumps(np.asarray(T0).tolist())], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "drives the tracker's LM loop from the host" in p.stderr
@@ -208,3 +208,5 @@ def test_lost_workgroup_degrades_to_the_host_driven_loop(ctx, small_window, tmp_
         assert r["ok"] == ok == 1
         assert pose_dist(np.asarray(r["T"]), T) < 1e-5 and np.abs(np.asarray(r["aff"]) - aff).max() < 1e-3
     assert p.stderr.count("drives the tracker's LM loop from the host") == 1          # latched: the second frame did not try the persistent kernel again
+    acct = [l for l in p.stderr.splitlines() if l.startswith("[nalo host]")]
+    assert any("trk_track" in l and "calls=     2" in l for l in acct) and any("trk_set_ref" in l for l in acct), p.stderr[-1500:]
