@@ -10,6 +10,7 @@ namespace nalo {
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly);
 void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 void ba_launch_reset_oob(hipStream_t s, const BADev& B);
+void ba_launch_restore(hipStream_t s, const BADev& B, const float4* geo, const uint8_t* state, const uint8_t* flags, const float* prior, const float* th);
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
                       const float* step_partial, int step_blocks, double* step_out);
 void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial, const XadArg* karg = nullptr);
@@ -1405,16 +1406,21 @@ int nalo_ba_restore(nalo_ctx* c) {
     HostTimer ht(c, "ba_restore");
     if (!w.have_snap) return fail(c, NALO_ERR_STATE, "nalo_ba_restore: no snapshot");
     const size_t N = w.Ppad, NS = (size_t)w.W * N;
-    NALO_HIP(c, hipMemcpyAsync(w.pt_geo.p, w.snap_geo.p, N * 16, hipMemcpyDeviceToDevice, c->stream));
-    NALO_HIP(c, hipMemcpyAsync(w.rs_state.p, w.snap_state.p, NS, hipMemcpyDeviceToDevice, c->stream));
-    NALO_HIP(c, hipMemcpyAsync(w.pt_flags.p, w.snap_flags.p, N, hipMemcpyDeviceToDevice, c->stream));
-    NALO_HIP(c, hipMemcpyAsync(w.pt_prior.p, w.snap_prior.p, N * 4, hipMemcpyDeviceToDevice, c->stream));
-    NALO_HIP(c, hipMemsetAsync(w.rs_energy.p, 0, NS * 8, c->stream));
+    (void)N; (void)NS;
     w.frames = w.snap_frames; w.HM = w.snap_HM; w.bM = w.snap_bM; w.flags_h = w.snap_flags_h;
+    {   // one launch: device state from the snapshot, energies zeroed, thresholds installed (a pending quantile pass is flushed first: it clears its histogram)
+        int rf = flush_th(c); if (rf) return rf;
+        float th[16] = {};
+        for (int i = 0; i < w.W; ++i) th[i] = w.frames[i].frameEnergyTH;
+        NALO_HIP(c, w.frameTH.reserve(16));
+        w.dev.frameTH = w.frameTH.p;
+        ba_launch_restore(c->stream, w.dev, w.snap_geo.p, w.snap_state.p, w.snap_flags.p, w.snap_prior.p, th);
+        w.th_pending = false;
+        NALO_HIP(c, hipGetLastError());
+    }
     std::memcpy(w.c_value, w.snap_calib, sizeof(w.snap_calib)); std::memcpy(w.c_value_scaled, w.snap_calib_scaled, sizeof(w.snap_calib_scaled));
     std::memcpy(w.c_scaledf, w.snap_scaledf, sizeof(w.snap_scaledf)); std::memcpy(w.c_scaledi, w.snap_scaledi, sizeof(w.snap_scaledi));
-    int rc = upload_frame_th(c); if (rc) return rc;
-    rc = set_adjoints(c); if (rc) return rc;
+    int rc = set_adjoints(c); if (rc) return rc;
     rc = set_precalc(c); if (rc) return rc;
     w.have_lin = w.have_sc = false;
     return NALO_OK;

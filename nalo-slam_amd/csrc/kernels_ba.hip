@@ -313,6 +313,24 @@ void ba_launch_set_th(hipStream_t s, float* dst, const float* th, int W) {
     for (int i = 0; i < 16; ++i) a.v[i] = i < W ? th[i] : 0.f;
     ba_set_th_kernel<<<1, 16, 0, s>>>(dst, a, W);
 }
+// nalo_ba_restore (bench / test utility) in ONE launch: the mutable device state of the window back from its snapshot, the residual energies zeroed, the frames'
+// energy thresholds installed (was four device-to-device copies, a fill and a 16-lane kernel: ~60 us of launches and gaps per replayed keyframe)
+__global__ __launch_bounds__(256) void ba_restore_kernel(BADev B, const float4* __restrict__ geo, const uint8_t* __restrict__ state, const uint8_t* __restrict__ flags,
+                                                         const float* __restrict__ prior, ThArg th) {
+    const size_t N = (size_t)B.Ppad, NS = (size_t)B.W * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < NS; i += (size_t)gridDim.x * blockDim.x) {
+        B.rs_state[i] = state[i];
+        B.rs_energy[i] = make_float2(0.f, 0.f);
+        if (i < N) { B.pt_geo[i] = geo[i]; B.pt_flags[i] = flags[i]; B.pt_prior[i] = prior[i]; }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < B.W) B.frameTH[threadIdx.x] = th.v[threadIdx.x];
+}
+void ba_launch_restore(hipStream_t s, const BADev& B, const float4* geo, const uint8_t* state, const uint8_t* flags, const float* prior, const float* th) {
+    ThArg a;
+    for (int i = 0; i < 16; ++i) a.v[i] = i < B.W ? th[i] : 0.f;
+    const size_t NS = (size_t)B.W * B.Ppad;
+    ba_restore_kernel<<<(unsigned)std::min<size_t>((NS + 255) / 256, 16384), 256, 0, s>>>(B, geo, state, flags, prior, a);
+}
 void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
     const size_t n = (size_t)B.W * B.Ppad;
     ba_reset_oob_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(B.rs_state, B.rs_energy, n);

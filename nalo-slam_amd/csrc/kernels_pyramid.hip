@@ -43,43 +43,11 @@ __global__ __launch_bounds__(256) void pyr_grad_kernel(const float* __restrict__
     }
 }
 
-// All levels in TWO launches (the per-level version was 2L-1 dependent launches of a few microseconds each: 56 us per KITTI frame, now ~12).
+// All levels' gradients in one launch (the level-by-level path of pyramids with an odd parent level; round 3: even pyramids take pyr_one_pass_kernel below).
 struct PyrLevels {
     float* I[NALO_MAX_LEVELS]; float4* dI[NALO_MAX_LEVELS]; float* absg[NALO_MAX_LEVELS];
     int wl[NALO_MAX_LEVELS], hl[NALO_MAX_LEVELS], blk0[NALO_MAX_LEVELS + 1], L;
 };
-// Box pyramid of every level from one pass over level 0: a block owns a 32x32 level-0 tile = 16x16 level-1 pixels and walks up through LDS
-// (8x8, 4x4, 2x2, 1). Each parent is 0.25f * (((p00 + p10) + p01) + p11) of its children: the values of the level-by-level loop bit for bit.
-__global__ __launch_bounds__(256) void pyr_down_all_kernel(PyrLevels P) {
-    __shared__ float sI[2][16 * 16];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int tiles_x = (P.wl[1] + 15) / 16;
-    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
-    {
-        const int x = bx * 16 + tx, y = by * 16 + ty, w0 = P.wl[0];
-        float v = 0.f;
-        if (x < P.wl[1] && y < P.hl[1]) {
-            const float2 a = *reinterpret_cast<const float2*>(P.I[0] + 2 * x + 2 * y * w0);
-            const float2 b = *reinterpret_cast<const float2*>(P.I[0] + 2 * x + 2 * y * w0 + w0);
-            v = 0.25f * (((a.x + a.y) + b.x) + b.y);
-            P.I[1][x + y * P.wl[1]] = v;
-        }
-        sI[0][ty * 16 + tx] = v;
-    }
-    int side = 16, cur = 0;
-    for (int l = 2; l < P.L; ++l) {
-        __syncthreads();
-        const int ps = side; side >>= 1;
-        if (side == 0) break;
-        if (tx < side && ty < side) {
-            const int x = bx * side + tx, y = by * side + ty, o = 2 * tx + 2 * ty * ps;
-            const float v = 0.25f * (((sI[cur][o] + sI[cur][o + 1]) + sI[cur][o + ps]) + sI[cur][o + ps + 1]);
-            if (x < P.wl[l] && y < P.hl[l]) P.I[l][x + y * P.wl[l]] = v;
-            sI[cur ^ 1][ty * side + tx] = v;
-        }
-        cur ^= 1;
-    }
-}
 __global__ __launch_bounds__(256) void pyr_grad_all_kernel(PyrLevels P, const float* __restrict__ gammaB) {
     int l = 0;
     while (l + 1 < P.L && (int)blockIdx.x >= P.blk0[l + 1]) ++l;
@@ -96,6 +64,199 @@ __global__ __launch_bounds__(256) void pyr_grad_all_kernel(PyrLevels P, const fl
         if (!isfinite(dy)) dy = 0.f;
         ab = dx * dx + dy * dy;   // this file is built with -ffp-contract=off: rounds as the reference's scalar code
         if (gammaB) {                                   // HessianBlocks.h:400-406 getBGradOnly
+            int ci = (int)(c + 0.5f);
+            ci = ci < 5 ? 5 : (ci > 250 ? 250 : ci);
+            const float gw = gammaB[ci + 1] - gammaB[ci];
+            ab *= gw * gw;
+        }
+    }
+    P.dI[l][idx] = make_float4(c, dx, dy, 0.f);
+    P.absg[l][idx] = ab;
+}
+
+// ---- round 3: ONE pass over level 0 for the whole pyramid. pyr_down_all + pyr_grad_all read level 0 twice and every upper level twice more
+// (37 B of traffic per level-0 pixel against 25.3 algorithmic: 0.30 of the HBM roofline at 1920x1072). Here a workgroup owns a 64x32 tile of level 0 and
+// stages it in LDS WITH a halo of H = 2^(NL-1) pixels, walks the box pyramid up inside LDS (the same 0.25f * (((p00 + p10) + p01) + p11) nesting: the values
+// of the level-by-level loop bit for bit) and writes {I, dx, dy} + absSquaredGrad of the levels 0 .. NL-1 from there; the halo is what the central differences of
+// level l need of the neighbouring tiles (one pixel at level l = 2^l at level 0). The levels >= NL only get their planar box values here (a 64x32 tile still
+// holds whole pixels of level 5) and their gradients in one small second launch (pyr_grad_all over those levels: 1/64 of the pixels). NL = all levels for
+// pyramids of <= 4 levels (a KITTI frame: ONE launch), 3 otherwise (read amplification (72 x 40) / (64 x 32) = 1.4 on 4 of ~30 bytes per pixel).
+// The reference's gradient runs over the FLAT index (HessianBlocks.cpp:168-181): column 0 differences against the last pixel of the row above, column w-1
+// against the first pixel of the row below. Those two neighbours lie in no tile halo: the edge lanes rebuild them from level 0 (pyr_box_at, same nesting).
+template <int L>
+__device__ __forceinline__ float pyr_box_at(const float* __restrict__ I0, int w0, int x, int y) {
+    if constexpr (L == 0) return I0[x + y * w0];
+    else {
+        const float a = pyr_box_at<L - 1>(I0, w0, 2 * x, 2 * y), b = pyr_box_at<L - 1>(I0, w0, 2 * x + 1, 2 * y);
+        const float c = pyr_box_at<L - 1>(I0, w0, 2 * x, 2 * y + 1), d = pyr_box_at<L - 1>(I0, w0, 2 * x + 1, 2 * y + 1);
+        return 0.25f * (((a + b) + c) + d);
+    }
+}
+#ifndef NALO_PYR_TW
+#define NALO_PYR_TW 64
+#define NALO_PYR_TH 32
+#endif
+#ifndef NALO_PYR_NT
+#define NALO_PYR_NT 1      // nontemporal stores of the texels: 14.6 -> 12.9 us at 1920x1072 (the pyramid is written once, read by later kernels)
+#endif
+constexpr int kPyrTW = NALO_PYR_TW, kPyrTH = NALO_PYR_TH;
+typedef float pyr_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pyr_store(float4* p, float c, float dx, float dy) {
+#if NALO_PYR_NT
+    pyr_f4 t; t.x = c; t.y = dx; t.z = dy; t.w = 0.f; __builtin_nontemporal_store(t, reinterpret_cast<pyr_f4*>(p));
+#else
+    *p = make_float4(c, dx, dy, 0.f);
+#endif
+}
+__device__ __forceinline__ void pyr_store(float* p, float v) {
+#if NALO_PYR_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <int NL> struct PyrLds {                              // LDS layout of the staged levels 0 .. NL-1 (with halo) and of the halo-free levels above
+    static constexpr int H = 1 << (NL - 1);
+    static constexpr int rw(int l) { return (kPyrTW >> l) + 2 * (H >> l); }
+    static constexpr int rh(int l) { return (kPyrTH >> l) + 2 * (H >> l); }
+    static constexpr int off(int l) { int o = 0; for (int k = 0; k < l; ++k) o += k < NL ? rw(k) * rh(k) : (kPyrTW >> k) * (kPyrTH >> k); return o; }
+    static constexpr int total = off(NALO_MAX_LEVELS);
+};
+// flat-index neighbours of the image's first / last column, per staged level and tile row: edge[2 * off(l) + ty] = I_l(w_l - 1, y - 1) (left neighbour of
+// x = 0), edge[2 * off(l) + (TH >> l) + ty] = I_l(0, y + 1) (right neighbour of x = w_l - 1); rebuilt from level 0 by a few lanes DURING the tile load (their
+// dependent global loads - 4^l per value - would otherwise sit on the critical path of every border tile, i.e. of the whole launch)
+__device__ constexpr int kPyrEdgeOff[5] = {0, kPyrTH, kPyrTH + (kPyrTH >> 1), kPyrTH + (kPyrTH >> 1) + (kPyrTH >> 2), kPyrTH + (kPyrTH >> 1) + (kPyrTH >> 2) + (kPyrTH >> 3)};
+template <int LV>
+__device__ __forceinline__ void pyr_edge_level(const PyrLevels& P, float* __restrict__ edge, int x0, int y0, int k) {     // k = lane of the wave that owns level LV
+    constexpr int TH = kPyrTH >> LV, TW = kPyrTW >> LV;
+    if (LV >= P.L || k >= 2 * TH) return;
+    const int e = 2 * kPyrEdgeOff[LV] + k, right = k >= TH, ty = right ? k - TH : k;
+    const int wl = P.wl[LV], hl = P.hl[LV], bx = x0 >> LV, y = (y0 >> LV) + ty;
+    float v = 0.f;
+    if (y >= 1 && y <= hl - 2) {
+        if (!right && bx == 0) v = pyr_box_at<LV>(P.I[0], P.wl[0], wl - 1, y - 1);
+        if (right && bx <= wl - 1 && wl - 1 < bx + TW) v = pyr_box_at<LV>(P.I[0], P.wl[0], 0, y + 1);
+    }
+    edge[e] = v;
+}
+template <int NL, int LV>
+__device__ __forceinline__ void pyr_emit_level(const PyrLevels& P, const float* __restrict__ lds, const float* __restrict__ edge, const float* __restrict__ gammaB, int x0, int y0, int tid) {
+    using Lay = PyrLds<NL>;
+    if (LV >= P.L) return;
+    constexpr int RW = Lay::rw(LV), HL = Lay::H >> LV, TW = kPyrTW >> LV, TH = kPyrTH >> LV;
+    const float* __restrict__ S = lds + Lay::off(LV);
+    const int wl = P.wl[LV], hl = P.hl[LV], bx = x0 >> LV, by = y0 >> LV;
+    for (int i = tid; i < TW * TH; i += 256) {
+        const int tx = i % TW, ty = i / TW, x = bx + tx, y = by + ty;
+        if (x >= wl || y >= hl) continue;
+        const float* sp = S + (ty + HL) * RW + tx + HL;
+        const float c = sp[0];
+        float dx = 0.f, dy = 0.f, ab = 0.f;
+        if (y >= 1 && y <= hl - 2) {                            // idx >= w && idx < w (h - 1)
+            const float left = x > 0 ? sp[-1] : edge[2 * kPyrEdgeOff[LV] + ty];
+            const float right = x < wl - 1 ? sp[1] : edge[2 * kPyrEdgeOff[LV] + TH + ty];
+            dx = 0.5f * (right - left);
+            dy = 0.5f * (sp[RW] - sp[-RW]);
+            if (!isfinite(dx)) dx = 0.f;
+            if (!isfinite(dy)) dy = 0.f;
+            ab = dx * dx + dy * dy;                             // -ffp-contract=off: rounds as the reference's scalar code
+            if (gammaB) {                                       // HessianBlocks.h:400-406 getBGradOnly
+                int ci = (int)(c + 0.5f);
+                ci = ci < 5 ? 5 : (ci > 250 ? 250 : ci);
+                const float gw = gammaB[ci + 1] - gammaB[ci];
+                ab *= gw * gw;
+            }
+        }
+        const int idx = x + y * wl;
+        pyr_store(&P.dI[LV][idx], c, dx, dy);
+        pyr_store(&P.absg[LV][idx], ab);
+    }
+}
+template <int NL>
+__global__ __launch_bounds__(256) void pyr_one_pass_kernel(PyrLevels P, const float* __restrict__ gammaB) {
+    using Lay = PyrLds<NL>;
+    __shared__ float lds[Lay::total];
+    __shared__ float edge[4 * kPyrTH];                          // 2 x (TH + TH/2 + TH/4 + TH/8) <= 4 TH
+    constexpr int H = Lay::H;
+    const int tid = threadIdx.x, tiles_x = (P.wl[0] + kPyrTW - 1) / kPyrTW;
+    const int x0 = (blockIdx.x % tiles_x) * kPyrTW, y0 = (blockIdx.x / tiles_x) * kPyrTH;
+    {                                                           // level 0 with its halo; outside the image: 0 (never used by a pixel that is written)
+        constexpr int RW = Lay::rw(0), RH = Lay::rh(0);
+        const int w0 = P.wl[0], h0 = P.hl[0];
+        const float* __restrict__ I0 = P.I[0];
+        // all loads of the tile first (registers), then the LDS stores: a rolled loop waits for every load before its own LDS store, i.e. a dozen
+        // dependent HBM round trips per tile (measured: 8 us for ONE tile of a KITTI frame)
+        constexpr int NLD = (RW * RH + 255) / 256;
+        float v[NLD];
+        bool inb[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {                         // branch-free: an out-of-image lane loads pixel 0 and discards it (a load under a divergent
+            const int i = tid + 256 * k, rx = i % RW, ry = i / RW, gx = x0 - H + rx, gy = y0 - H + ry;   // branch is waited for at the join: one round trip each)
+            inb[k] = i < RW * RH && gx >= 0 && gx < w0 && gy >= 0 && gy < h0;
+            v[k] = I0[inb[k] ? gx + gy * w0 : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) v[k] = inb[k] ? v[k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) { const int i = tid + 256 * k; if (i < RW * RH) lds[i] = v[k]; }
+        // the flat-index neighbours of the border columns (only border tiles load anything): wave l owns level l, so the four levels' dependent loads run
+        // side by side instead of as four masked branches of one wave
+        static_assert(2 * kPyrTH <= 64, "one wave holds a level's edge values");
+        switch (tid >> 6) {
+            case 0: pyr_edge_level<0>(P, edge, x0, y0, tid & 63); break;
+            case 1: if constexpr (NL > 1) pyr_edge_level<1>(P, edge, x0, y0, tid & 63); break;
+            case 2: if constexpr (NL > 2) pyr_edge_level<2>(P, edge, x0, y0, tid & 63); break;
+            default: if constexpr (NL > 3) pyr_edge_level<3>(P, edge, x0, y0, tid & 63); break;
+        }
+
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 1; l < NALO_MAX_LEVELS; ++l) {                 // the box pyramid inside LDS: levels < NL over the haloed region, the ones above over the tile only
+        if (l < P.L) {
+            const bool halo = l < NL, phalo = l - 1 < NL;
+            const int RW = halo ? Lay::rw(l) : (kPyrTW >> l), RH = halo ? Lay::rh(l) : (kPyrTH >> l);
+            const int PW = phalo ? Lay::rw(l - 1) : (kPyrTW >> (l - 1));
+            // a halo-free level above a haloed parent (l == NL) starts at the parent's interior
+            const int po = (!halo && phalo) ? (H >> (l - 1)) * PW + (H >> (l - 1)) : 0;
+            const float* __restrict__ src = lds + Lay::off(l - 1) + po;
+            float* __restrict__ dst = lds + Lay::off(l);
+            for (int i = tid; i < RW * RH; i += 256) {
+                const int rx = i % RW, ry = i / RW;
+                const float* q = src + 2 * ry * PW + 2 * rx;
+                const float v = 0.25f * (((q[0] + q[1]) + q[PW]) + q[PW + 1]);
+                dst[i] = v;
+                if (!halo) {                                    // planar box value of an upper level: input of the second launch
+                    const int x = (x0 >> l) + rx, y = (y0 >> l) + ry;
+                    if (x < P.wl[l] && y < P.hl[l]) P.I[l][x + y * P.wl[l]] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    pyr_emit_level<NL, 0>(P, lds, edge, gammaB, x0, y0, tid);
+    if constexpr (NL > 1) pyr_emit_level<NL, 1>(P, lds, edge, gammaB, x0, y0, tid);
+    if constexpr (NL > 2) pyr_emit_level<NL, 2>(P, lds, edge, gammaB, x0, y0, tid);
+    if constexpr (NL > 3) pyr_emit_level<NL, 3>(P, lds, edge, gammaB, x0, y0, tid);
+}
+// gradients of the levels >= l0 from their planar box values (the second launch of a pyramid with more than four levels)
+__global__ __launch_bounds__(256) void pyr_grad_tail_kernel(PyrLevels P, const float* __restrict__ gammaB, int l0) {
+    int l = l0;
+    const int b = blockIdx.x + P.blk0[l0];
+    while (l + 1 < P.L && b >= P.blk0[l + 1]) ++l;
+    const int wl = P.wl[l], hl = P.hl[l], n = wl * hl;
+    const int idx = (b - P.blk0[l]) * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float* __restrict__ I = P.I[l];
+    const float c = I[idx];
+    float dx = 0.f, dy = 0.f, ab = 0.f;
+    if (idx >= wl && idx < wl * (hl - 1)) {
+        dx = 0.5f * (I[idx + 1] - I[idx - 1]);
+        dy = 0.5f * (I[idx + wl] - I[idx - wl]);
+        if (!isfinite(dx)) dx = 0.f;
+        if (!isfinite(dy)) dy = 0.f;
+        ab = dx * dx + dy * dy;
+        if (gammaB) {
             int ci = (int)(c + 0.5f);
             ci = ci < 5 ? 5 : (ci > 250 ? 250 : ci);
             const float gw = gammaB[ci + 1] - gammaB[ci];
@@ -226,8 +387,21 @@ int pyramid_build(nalo_ctx* c, FrameSlot& s, const float* gammaB_dev) {
     // the hierarchical pass needs even parents all the way up (true for DSO pyramids: a level is only added while w and h are even) and <= 6 levels
     bool fused = c->levels >= 2 && c->levels <= 6;
     for (int l = 1; l < c->levels && fused; ++l) fused = (c->wl[l - 1] % 2 == 0) && (c->hl[l - 1] % 2 == 0);
-    if (fused) pyr_down_all_kernel<<<((c->wl[1] + 15) / 16) * ((c->hl[1] + 15) / 16), 256, 0, c->stream>>>(P);
-    else for (int l = 1; l < c->levels; ++l) {
+    if (fused) {
+        // one pass over level 0 (pyr_one_pass_kernel): every level of a pyramid of <= 4 levels, the three finest + the planar values of the rest otherwise
+        const int tiles = ((c->wl[0] + kPyrTW - 1) / kPyrTW) * ((c->hl[0] + kPyrTH - 1) / kPyrTH);
+        switch (c->levels) {
+            case 2: pyr_one_pass_kernel<2><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev); break;
+            case 3: pyr_one_pass_kernel<3><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev); break;
+            case 4: pyr_one_pass_kernel<4><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev); break;
+            default:
+                pyr_one_pass_kernel<3><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev);
+                pyr_grad_tail_kernel<<<nb - P.blk0[3], 256, 0, c->stream>>>(P, gammaB_dev, 3);
+        }
+        NALO_HIP(c, hipGetLastError());
+        return NALO_OK;
+    }
+    for (int l = 1; l < c->levels; ++l) {                     // a pyramid with an odd parent level (explicit `levels`): level by level
         const int n = c->wl[l] * c->hl[l];
         pyr_down_kernel<<<std::min((n + 255) / 256, 2048), 256, 0, c->stream>>>(s.I[l - 1], s.I[l], c->wl[l], c->hl[l], c->wl[l - 1]);
     }
