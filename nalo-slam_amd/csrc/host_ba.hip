@@ -584,36 +584,46 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     { HostTimer h2(c, "ba.solve.fetch_wait"); rc = stitch_and_fetch(c, true, true); }
     if (rc) return rc;
     HostTimer h3(c, "ba.solve.host_math");
-    // H = (HL + HM + HA) with the diagonal * (1+lambda), minus Hsc/(1+lambda); b = bL + (bM + HM delta) + bA - bsc   (:795-868), one pass
-    // over the published systems; then the Jacobi-scaled LDL^T (:872-885). Scratch lives in the window: no allocation per iteration.
-    w.solve_scratch.resize((size_t)n * n + 5 * (size_t)n); w.solve_perm.resize(n);
-    double* HF = w.solve_scratch.data(); double* bF = HF + (size_t)n * n; double* sv = bF + n; double* yv = sv + n; double* delta = yv + 2 * n;
+    // H = (HL + HM + HA) with the diagonal * (1+lambda), minus Hsc/(1+lambda); b = bL + (bM + HM delta) + bA - bsc   (:795-868), then the Jacobi scaling
+    // (:872-885): TWO passes over the published systems (the diagonal first: the scaling needs it), written straight into the padded, scaled matrix the
+    // factorisation works on. Eigen's LDLT (the reference, :880) reads the LOWER triangle only; H_sc carries fp32-rounding asymmetry (w*a_j*a_k vs
+    // w*a_k*a_j), so the upper triangle the factorisation reads is filled from the lower one: entry (r, c >= r) is computed from the sources' (c, r).
+    // Scratch lives in the window: no allocation per iteration.
+    const int lda = (n + 7) & ~7;
+    w.solve_scratch.resize((size_t)lda * lda + 8 * (size_t)lda + n); w.solve_perm.resize(n);
+    double* HF = w.solve_scratch.data(); double* bF = HF + (size_t)lda * lda; double* sv = bF + lda; double* delta = sv + lda; double* yv = delta + lda;   // yv: 3 lda
+    float* xF = reinterpret_cast<float*>(yv + 3 * (size_t)lda);
     std::vector<double>& x = w.lastX; x.resize(n);
     const double* HAp = w.stitched_host; const double* HSp = w.stitched_host + (size_t)n1 * n1;
     misc_totals(w, nullptr, &w.resInA);
     for (int i = 0; i < 4; ++i) delta[i] = (double)w.cDeltaF[i];
     for (int h = 0; h < W; ++h) for (int i = 0; i < 8; ++i) delta[4 + 8 * h + i] = w.frames[h].delta[i];
     const double fsc = 1.0 / (1 + lambda);
-    for (int r = 0; r < n; ++r) {
-        double HLd, bLr;                                                    // accumulateLF with usePrior (AccumulatedTopHessian.cpp:292-302): diagonal only
+    { HostTimer hl(c, "ba.solve.math.assemble");
+    for (int r = 0; r < n; ++r) {                                           // diagonal + right-hand side; accumulateLF with usePrior (AccumulatedTopHessian.cpp:292-302): diagonal only
+        double HLd, bLr;
         if (r < 4) { HLd = kInitialCalibHessian; bLr = kInitialCalibHessian * (double)w.cDeltaF[r]; }
         else { const HostFrame& f = w.frames[(r - 4) >> 3]; const int i = (r - 4) & 7; HLd = f.prior[i]; bLr = f.prior[i] * f.delta_prior[i]; }
         const double* hm = &w.HM[(size_t)r * n]; const double* ha = HAp + (size_t)r * n1; const double* hs = HSp + (size_t)r * n1;
-        double* hf = HF + (size_t)r * n;
         double sdot = 0;
-        for (int cc = 0; cc < n; ++cc) { hf[cc] = (0.0 + hm[cc]) + ha[cc]; sdot += hm[cc] * delta[cc]; }
-        hf[r] = (HLd + hm[r]) + ha[r];
-        hf[r] *= (1 + lambda);
-        for (int cc = 0; cc < n; ++cc) hf[cc] -= hs[cc] * fsc;
-        bF[r] = bLr + (w.bM[r] + sdot) + ha[n] - hs[n];
+        for (int cc = 0; cc < n; ++cc) sdot += hm[cc] * delta[cc];
+        double dg = (HLd + hm[r]) + ha[r];
+        dg *= (1 + lambda);
+        dg -= hs[r] * fsc;
+        sv[r] = 1.0 / std::sqrt(dg + 10);
+        HF[(size_t)r * lda + r] = dg;
+        bF[r] = (bLr + (w.bM[r] + sdot) + ha[n] - hs[n]) * sv[r];
+    }
+    for (int r = 0; r < n; ++r) {                                           // lower-triangle entries (r, cc < r), stored mirrored at (cc, r) and scaled
+        const double* hm = &w.HM[(size_t)r * n]; const double* ha = HAp + (size_t)r * n1; const double* hs = HSp + (size_t)r * n1;
+        const double si = sv[r];
+        for (int cc = 0; cc < r; ++cc) HF[(size_t)cc * lda + r] = si * (((0.0 + hm[cc]) + ha[cc]) - hs[cc] * fsc) * sv[cc];
+        HF[(size_t)r * lda + r] = si * HF[(size_t)r * lda + r] * si;
+        for (int cc = n; cc < lda; ++cc) HF[(size_t)r * lda + cc] = 0.0;   // the padding columns the blocked factorisation sweeps over
+    }
     }
     { HostTimer hl(c, "ba.solve.math.ldlt");
-    for (int i = 0; i < n; ++i) sv[i] = 1.0 / std::sqrt(HF[(size_t)i * n + i] + 10);
-    for (int i = 0; i < n; ++i) { double* hf = HF + (size_t)i * n; const double si = sv[i]; for (int j = 0; j < n; ++j) hf[j] = si * hf[j] * sv[j]; bF[i] *= si; }
-    // Eigen's LDLT (the reference, :880) reads the lower triangle only; H_sc carries fp32-rounding asymmetry (w*a_j*a_k vs w*a_k*a_j), so the lower
-    // triangle is mirrored into the upper one the factorisation works on
-    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) HF[(size_t)i * n + j] = HF[(size_t)j * n + i];
-    ldlt_solve_inplace(n, HF, bF, x.data(), yv, w.solve_perm.data());
+    ldlt_solve_blocked(n, lda, HF, bF, x.data(), yv, w.solve_perm.data());
     for (int i = 0; i < n; ++i) x[i] *= sv[i];
     }
     if (iteration >= 2) {                                                   // SOLVER_ORTHOGONALIZE_X_LATER (:898-902)
@@ -627,7 +637,6 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     for (int i = 0; i < 4; ++i) w.c_step[i] = -x[i];
     float* xAd = w.up_host + (size_t)W * W * kPreStride + 16 + 64;
     float* xc = w.up_host + (size_t)W * W * kPreStride + 16;
-    std::vector<float> xF(n);
     for (int i = 0; i < n; ++i) xF[i] = (float)x[i];
     for (int i = 0; i < 4; ++i) xc[i] = xF[i];
     for (int h = 0; h < W; ++h) {
