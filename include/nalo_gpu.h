@@ -163,6 +163,10 @@ int nalo_trk_track(nalo_ctx* ctx, int slot_new, double T_io[12], double aff_io[2
                    const float exposures[2], int coarsestLvl, const double minResForAbort[5],
                    double lastResiduals[5], double lastFlowIndicators[3], int* ok, int* n_evals);
 
+/* measurement aid: LM evaluations per pyramid level (evals[l]) and point-cloud sizes (n[l]) of the last nalo_trk_track; the algorithmic bytes of that frame are
+ * sum_l evals[l] * n[l] * 64 B. Either array may be NULL. */
+int nalo_trk_last_evals(nalo_ctx* ctx, int evals[5], int n[5]);
+
 /* ------------------------------------------------------------------------------------------------
  * Back-end: sliding-window photometric bundle adjustment.
  * ------------------------------------------------------------------------------------------------ */

@@ -442,6 +442,13 @@ int nalo_trk_eval(nalo_ctx* c, int slot_new, int lvl, const double R[9], const d
     return NALO_OK;
 }
 
+// evaluations per pyramid level and point-cloud sizes of the last nalo_trk_track that ran in the persistent kernel: the algorithmic bytes of that launch are
+// sum_l evals[l] * n[l] * 64 (16 B point + four 12-B taps per point and evaluation)
+int nalo_trk_last_evals(nalo_ctx* c, int evals[5], int n[5]) {
+    if (!c) return NALO_ERR_ARG;
+    for (int i = 0; i < 5; ++i) { if (evals) evals[i] = c->lm_evals_lvl[i]; if (n) n[i] = i < c->levels ? c->pc_n[i] : 0; }
+    return NALO_OK;
+}
 int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2], const double ref_aff[2], const float exposures[2],
                    int coarsestLvl, const double minResForAbort[5], double lastResiduals[5], double lastFlow[3], int* ok, int* n_evals) {
     if (!c || !T_io || !aff_io || !ref_aff || !exposures || !ok) return fail(c, NALO_ERR_ARG, "nalo_trk_track: bad argument");

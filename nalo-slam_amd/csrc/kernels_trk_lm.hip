@@ -11,6 +11,7 @@
 // used: 64 workgroups of 512 lanes fit 256 CUs by a wide margin; a violation - the CUs held by another context's long kernel - ends in the bounded poll, not in
 // a hang: the launch returns NALO_LM_LOST_BLOCK and nalo_trk_track redoes the frame with the host-driven loop and keeps to it for this context).
 #include "nalo_internal.h"
+#include <hip/hip_ext.h>
 #include "reduce.h"
 
 namespace nalo {
@@ -54,6 +55,7 @@ struct LmState {                             // lives in LDS; written by lane 0 
     float RKi[9], t[3], Ki[9], affa, affb, b0, cutoff, maxEnergy;
     float lambda, levelCutoffRepeat;
     int lvl, it, phase, haveRepeated, good, evals, done, break_pending, next_lvl;
+    int evals_lvl[NALO_MAX_LEVELS];          // evaluations per pyramid level (the algorithmic bytes of the launch: sum_l evals_l n_l 64 B)
 };
 
 // ---- fp64 helpers for lane 0 -------------------------------------------------------------------------------------------
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
         S.flow[0] = S.flow[1] = S.flow[2] = 1000;
         S.lvl = P.coarsest; S.it = 0; S.phase = 0; S.next_lvl = -1; S.haveRepeated = P.have_repeated_in; S.good = 1; S.evals = 0; S.done = 0; S.break_pending = 0;
         S.levelCutoffRepeat = 1; S.lambda = 0.01f;
+        for (int i = 0; i < NALO_MAX_LEVELS; ++i) S.evals_lvl[i] = 0;
         double T0[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) T0[i] = P.T0[i];
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
             int phase = S.phase, it = S.it, lvl = S.lvl, brk = S.break_pending, haveRep = S.haveRepeated, good = S.good, done = 0, next_lvl = S.next_lvl;
             float lambda = S.lambda, lcr = S.levelCutoffRepeat;
             const int evals = S.evals + 1;
+            if (lane == 0) S.evals_lvl[S.lvl] += 1;
             // sums (52 doubles) -> stats6 and this lane's entry of the scaled H / b (CoarseTracker.cpp:1040-1046, 869-884)
             const double E = sums[45], nE = sums[46], nSat = sums[47], nW = sums[48], sT = sums[49], sRT = sums[50], sN = sums[51];
             const double st[6] = {E, nE, sT / (sN + 0.1), 0, sRT / (sN + 0.1), (double)((float)nSat / (float)nE)};
@@ -520,6 +524,8 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
         if (timed_out) ok = -1;
 #ifdef NALO_LM_TICKS
         for (int i = 0; i < 5; ++i) o[26 + i] = (double)tick_sum[i];
+#else
+        for (int i = 0; i < 5; ++i) o[26 + i] = (double)S.evals_lvl[i];
 #endif
         o[22] = (double)ok; o[23] = (double)S.evals; o[24] = (double)S.next_lvl; o[25] = (double)S.haveRepeated;
         __threadfence_system();
@@ -557,12 +563,14 @@ int trk_lm_launch(nalo_ctx* c, int slot_new, const double T0[12], const double a
     P.partial = c->lm_partial.p;
     P.tag0 = (unsigned)((++c->lm_launches & 0xFFFFFu) << 12);
     {
-        ProfScope ps(c, "trk_lm");
-        trk_lm_kernel<<<NB, kLmThreads, 0, c->stream>>>(P);
+        ProfScope ps(c, "trk_lm", true);                  // dispatch-attached timestamps: no barrier packets around the one launch of a tracked frame
+        if (ps.a) hipExtLaunchKernelGGL(trk_lm_kernel, dim3(NB), dim3(kLmThreads), 0, c->stream, ps.a, ps.b, 0, P);
+        else trk_lm_kernel<<<NB, kLmThreads, 0, c->stream>>>(P);
     }
     NALO_HIP(c, hipGetLastError());
     if (!poll_flag(c, &c->trk_out_host[64 + 31], P.seq)) return NALO_ERR_HIP;
     std::memcpy(out24, c->trk_out_host + 64, sizeof(double) * 26);
+    for (int i = 0; i < 5; ++i) c->lm_evals_lvl[i] = (int)c->trk_out_host[64 + 26 + i];
 #ifdef NALO_LM_TICKS
     { const double* t = c->trk_out_host + 64 + 26; fprintf(stderr, "[lm ticks] evals=%d eval=%.0f blockred=%.0f gridsum=%.0f lane0=%.0f (shader clocks per eval)\n", (int)out24[23], t[0] / out24[23], t[1] / out24[23], t[2] / out24[23], t[3] / out24[23]); }
 #endif

@@ -79,6 +79,7 @@ struct nalo_ctx {
     unsigned long long trk_seq = 0;
     nalo::DevBuf<unsigned long long> lm_partial;   // persistent LM kernel: [2][blocks][64] block partials {fp32, tag}
     unsigned long long lm_launches = 0;
+    int lm_evals_lvl[5] = {};                // LM evaluations per pyramid level of the last persistent-kernel launch (nalo_trk_last_evals)
     bool lm_host_only = false;                 // latched when a trk_lm launch lost a workgroup (CUs taken by another context): the host-driven LM loop from then on
     nalo::DevBuf<int> scan_tmp;              // compaction counts
     nalo::DevBuf<int> trk_cnt;               // hits per level-0 pixel of the reference scatter (ordered redo of pixels with >= 3 hits)
