@@ -863,7 +863,7 @@ def frontend_legs(rounds=30):
     L = c.levels
     alg_pyr = 4.0 * w * h + 16.0 * w * h * sum(0.25 ** l for l in range(L))
     res["pyramid"] = timed("pyramid", lambda: c.frame_rebuild(1), alg_pyr)
-    res["pyramid"]["note"] = "two launches (box pyramid of all levels, gradients of all levels); 4wh in + 16 B per pixel of every level out"
+    res["pyramid"]["note"] = "one pass over level 0 for the levels 0-2 (LDS tiles with halo) + one small launch for the gradients of the levels >= 3; 4wh in + 16 B per pixel of every level out"
     # ---- dense map
     import ctypes as C
     cap = w * h
@@ -880,10 +880,9 @@ def frontend_legs(rounds=30):
     dm()
     bbox_px = int((rect[1] - rect[0]) * (rect[3] - rect[2]))
     res["dense_map"] = timed("dense_map", dm, 11.0 * bbox_px + 24.0 * n.value, n_rounds=10)
-    res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="count + scan + write launches of makeMap; the D2H copy of the point list is not in avg_us")
+    res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="ONE launch since round 3: ordered compaction by decoupled look-back with the accept test of MapPoint.cpp:403 "
+                            "(the reference's order-dependent maxy / maxz) riding along; the D2H copy of the point list is not in avg_us")
     res["dense_bbox"] = timed("dense_bbox", dm, 4.0 * (w - 4) * (h - 4), n_rounds=10)
-    res["dense_extent"] = timed("dense_extent", dm, 2 * 24.0 * n.value, n_rounds=10)
-    res["dense_extent"]["note"] = "the accept test of MapPoint.cpp:403 with the reference's order-dependent maxy / maxz: two passes over the world points (24 B each)"
     # ---- raw-frame ingest (photometric undistortion + remap fused in front of makeImages): an 8-bit sensor frame slightly larger than the rectified image
     wo, ho = w + 64, h + 48
     raw = rng.randint(0, 256, (ho, wo)).astype(np.uint8)

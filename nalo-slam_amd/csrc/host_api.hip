@@ -73,12 +73,12 @@ void nalo_destroy(nalo_ctx* c) {
         c->trk_idepth[l].release(); c->trk_wsum[l].release(); c->trk_wbak[l].release();
         c->pc_u[l].release(); c->pc_v[l].release(); c->pc_id[l].release(); c->pc_col[l].release();
     }
-    c->trk_partial.release(); c->trk_out.release(); c->lm_partial.release(); c->scan_tmp.release(); c->trk_cnt.release(); c->upload_tmp.release();
+    c->dense_lb.release(); c->trk_partial.release(); c->trk_out.release(); c->lm_partial.release(); c->scan_tmp.release(); c->trk_cnt.release(); c->upload_tmp.release();
     if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
     if (c->pinned_f) (void)hipHostFree(c->pinned_f);
     if (c->imm_host) (void)hipHostFree(c->imm_host);
     c->imm_dev.release(); c->imm_res.release();
-    c->und_G.release(); c->und_vinv.release(); c->und_rx.release(); c->und_ry.release(); c->und_raw.release(); c->und_mask.release(); c->und_bgr.release();
+    c->und_G.release(); c->und_vinv.release(); c->und_rxy.release(); c->und_raw.release(); c->und_mask.release(); c->und_bgr.release();
     for (auto& kv : c->prof) for (auto& ev : kv.second.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (hipEvent_t e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
@@ -213,8 +213,10 @@ int nalo_undist_set(nalo_ctx* c, int wOrg, int hOrg, const float* G, int GDepth,
         // out-of-image entries are -1, Undistort.cpp:998-1010); checked here because a violated table is an out-of-bounds device read
         for (size_t i = 0; i < n; ++i) if (!(remapX[i] < 0) && !(remapX[i] >= 0 && remapY[i] >= 0 && (int)remapX[i] + 1 < wOrg && (int)remapY[i] + 1 < hOrg))
             return fail(c, NALO_ERR_ARG, "nalo_undist_set: remap entry outside the original image");
-        NALO_HIP(c, c->und_rx.reserve(n)); NALO_HIP(c, c->und_ry.reserve(n));
-        NALO_HIP(c, hipMemcpy(c->und_rx.p, remapX, n * 4, hipMemcpyHostToDevice)); NALO_HIP(c, hipMemcpy(c->und_ry.p, remapY, n * 4, hipMemcpyHostToDevice));
+        std::vector<float> xy(2 * n);
+        for (size_t i = 0; i < n; ++i) { xy[2 * i] = remapX[i]; xy[2 * i + 1] = remapY[i]; }
+        NALO_HIP(c, c->und_rxy.reserve(2 * n));
+        NALO_HIP(c, hipMemcpy(c->und_rxy.p, xy.data(), 2 * n * 4, hipMemcpyHostToDevice));
     }
     c->und_wOrg = wOrg; c->und_hOrg = hOrg; c->und_photometric = photometricCalibration; c->und_GDepth = GDepth; c->und_remap = remapX != nullptr; c->und_vig = vignetteMapInv != nullptr;
     c->und_set = true;
@@ -238,8 +240,8 @@ int nalo_frame_upload_raw(nalo_ctx* c, int slot, const void* raw, int bytes_per_
     if (bgr_org) { NALO_HIP(c, c->und_bgr.reserve(no * 3)); NALO_HIP(c, hipMemcpyAsync(c->und_bgr.p, bgr_org, no * 3, hipMemcpyHostToDevice, c->stream)); if (!s.bgr) NALO_HIP(c, hipMalloc((void**)&s.bgr, n0 * 3)); }
     const float* gdev = nullptr;
     if (gammaB) { NALO_HIP(c, c->upload_tmp.reserve(256)); NALO_HIP(c, hipMemcpyAsync(c->upload_tmp.p, gammaB, 256 * 4, hipMemcpyHostToDevice, c->stream)); gdev = c->upload_tmp.p; }
-    int rc = ingest_launch(c, c->stream, c->und_raw.p, bytes_per_px, c->und_wOrg, c->und_hOrg, c->und_G.p, c->und_vig ? c->und_vinv.p : nullptr, c->und_remap ? c->und_rx.p : nullptr,
-                           c->und_remap ? c->und_ry.p : nullptr, photometric, factor, mask_org ? c->und_mask.p : nullptr, bgr_org ? c->und_bgr.p : nullptr, s.I[0], s.mask, s.bgr);
+    int rc = ingest_launch(c, c->stream, c->und_raw.p, bytes_per_px, c->und_wOrg, c->und_hOrg, c->und_G.p, c->und_vig ? c->und_vinv.p : nullptr, c->und_remap ? reinterpret_cast<const float2*>(c->und_rxy.p) : nullptr,
+                           photometric, factor, mask_org ? c->und_mask.p : nullptr, bgr_org ? c->und_bgr.p : nullptr, s.I[0], s.mask, s.bgr);
     if (rc) return rc;
     rc = pyramid_build(c, s, gdev);
     if (rc) return rc;
@@ -273,8 +275,8 @@ int nalo_frame_upload_raw_async(nalo_ctx* c, int slot, const void* raw, int byte
     { int rg = gamma_upload_async(c, gammaB); if (rg) return rg; }
     NALO_HIP(c, hipEventRecord(s.ev_up, c->copy));
     NALO_HIP(c, hipStreamWaitEvent(c->stream, s.ev_up, 0));
-    int rc = ingest_launch(c, c->stream, s.raw, bytes_per_px, c->und_wOrg, c->und_hOrg, c->und_G.p, c->und_vig ? c->und_vinv.p : nullptr, c->und_remap ? c->und_rx.p : nullptr,
-                           c->und_remap ? c->und_ry.p : nullptr, photometric, factor, nullptr, nullptr, s.I[0], nullptr, nullptr);
+    int rc = ingest_launch(c, c->stream, s.raw, bytes_per_px, c->und_wOrg, c->und_hOrg, c->und_G.p, c->und_vig ? c->und_vinv.p : nullptr, c->und_remap ? reinterpret_cast<const float2*>(c->und_rxy.p) : nullptr,
+                           photometric, factor, nullptr, nullptr, s.I[0], nullptr, nullptr);
     if (rc) return rc;
     rc = pyramid_build(c, s, gammaB ? c->gamma_dev : nullptr);
     if (rc) return rc;

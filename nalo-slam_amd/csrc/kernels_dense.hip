@@ -9,155 +9,219 @@
 #include <cfloat>
 #include <climits>
 #include "nalo_internal.h"
+#include <hip/hip_ext.h>
 
 namespace nalo {
 
-__global__ __launch_bounds__(256) void dense_bbox_kernel(const float* __restrict__ mask, int w, int h, float value, int* __restrict__ rect /* minx,maxx,miny,maxy */) {
-    int minx = INT_MAX, maxx = INT_MIN, miny = INT_MAX, maxy = INT_MIN;
-    for (int y = 2 + blockIdx.x; y < h - 2; y += gridDim.x) {              // a workgroup walks whole rows: no division per pixel, coalesced row segments
-        const float* row = mask + (size_t)y * w;
-        for (int x = 2 + threadIdx.x; x < w - 2; x += blockDim.x) {
-            if (row[x] != value) continue;
-            minx = min(minx, x); maxx = max(maxx, x); miny = min(miny, y); maxy = max(maxy, y);
-        }
-    }
-    // wave, then workgroup reduction: ONE lane per workgroup touches the four global words, and the grid has at most 512 workgroups. Every lane (then every
-    // wave) doing so serialised 10^4..10^5 atomics on four addresses: 374 / 365 us at 1920x1072 against a 8 MB read of the mask.
-    __shared__ int sm[4][4];
+// Three launches, no host round trip between them (round 3; was seven launches and two synchronisations, ~105 us at 1920x1072):
+//   dense_rows_kernel   one workgroup per image row: {min x, max x} of the pixels with mask == value, eight loads in flight per lane, NO atomics (thousands of
+//                       atomicMin/Max on four words were what the first versions spent their time on)
+//   dense_count_kernel  every workgroup folds the row table into the box (block 0 stores it), then the aggregate of its 2048-pixel chunk of the box:
+//                       {kept points, min x, min y, min z, max x of their world coordinates}
+//   dense_write_kernel  exclusive prefix of the aggregates in front of the chunk (a block-wide fold of <= nb entries: cheaper than a spinning look-back, whose
+//                       agent-scope polling of 380 workgroups cost 100 us here), the points written in raster order, and the accept test of MapPoint.cpp:403:
+// the reference's loop keeps float extrema but compares the double coordinate against them, and its maxy / maxz are "the last point whose y (z) is strictly
+// above the running minimum" (SURVEY App. C.6). The running minimum after point k is min_{i<=k} (float) y_i (rounding is monotone), so point k qualifies iff
+// y_k > (double) min(prefix, (float) y_k), prefix = the chunks in front + an in-order scan inside the workgroup; the largest qualifying index wins (one 64-bit
+// atomicMax on {index + 1, float bits} per workgroup; the host decodes the two words).
+__global__ __launch_bounds__(256) void dense_rows_kernel(const float* __restrict__ mask, int w, int h, float value, int2* __restrict__ rows /* [h]: min x, max x */) {
+    const int y = 2 + blockIdx.x;
+    int minx = INT_MAX, maxx = INT_MIN;
+    const float* row = mask + (size_t)y * w;
+    for (int x0 = 2; x0 < w - 2; x0 += 8 * 256) {
+        float v[8];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        minx = min(minx, __shfl_down(minx, o)); maxx = max(maxx, __shfl_down(maxx, o)); miny = min(miny, __shfl_down(miny, o)); maxy = max(maxy, __shfl_down(maxy, o));
+        for (int k = 0; k < 8; ++k) { const int x = x0 + k * 256 + threadIdx.x; v[k] = row[x < w - 2 ? x : 2]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int x = x0 + k * 256 + threadIdx.x; if (x < w - 2 && v[k] == value) { minx = min(minx, x); maxx = max(maxx, x); } }
     }
-    if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; sm[wv][0] = minx; sm[wv][1] = maxx; sm[wv][2] = miny; sm[wv][3] = maxy; }
+    __shared__ int sm[4][2];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { minx = min(minx, __shfl_down(minx, o)); maxx = max(maxx, __shfl_down(maxx, o)); }
+    if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; sm[wv][0] = minx; sm[wv][1] = maxx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) { minx = min(minx, sm[k][0]); maxx = max(maxx, sm[k][1]); miny = min(miny, sm[k][2]); maxy = max(maxy, sm[k][3]); }
-        if (minx != INT_MAX) { atomicMin(&rect[0], minx); atomicMax(&rect[1], maxx); atomicMin(&rect[2], miny); atomicMax(&rect[3], maxy); }
+        for (int k = 1; k < 4; ++k) { minx = min(minx, sm[k][0]); maxx = max(maxx, sm[k][1]); }
+        rows[y] = make_int2(minx, maxx);
     }
 }
 
 struct DenseParams {
     const float* mask; const float4* dI; const uint8_t* bgr;
-    int w, rx0, ry0, rw, rh;
+    int w, h;
+    const int2* rows;                            // dense_rows_kernel
+    int* rect;                                   // {minx, maxx, miny, maxy}: written by block 0 of dense_count_kernel, read by dense_write_kernel and the host
     float p0, p1, p2, p3, pcolor, fxi, fyi, cx, cy;
     double c2w[12];
+    float* agg;                                  // [nblocks][8]: {count (int bits), min x, min y, min z, max x} of a chunk's kept points
+    unsigned long long* last;                    // [2]: packed (index + 1, float bits) of the last point that qualifies for maxy / maxz (decoded by the host)
+    float* out6;                                 // {minx, maxx, miny, maxy, minz, maxz} of the serial loop
+    int* n_out;
 };
 constexpr int kDenseChunk = 2048;
 
-template <int WRITE>
-__global__ __launch_bounds__(256) void dense_map_kernel(DenseParams P, int* __restrict__ counts, const int* __restrict__ offsets, int cap,
-                                                        int* __restrict__ ou, int* __restrict__ ov, float* __restrict__ oid, float* __restrict__ ocol,
-                                                        uint8_t* __restrict__ obgr, double* __restrict__ world /* [cap][3] */) {
-    __shared__ int wave_cnt[4];
-    __shared__ int running;
-    const int total = P.rw * P.rh, base = blockIdx.x * kDenseChunk;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) running = WRITE ? offsets[blockIdx.x] : 0;
-    __syncthreads();
-    for (int r = 0; r < kDenseChunk / 256; ++r) {
-        const int e = base + r * 256 + threadIdx.x;
-        bool keep = false; int i = 0, j = 0; float idepth = 0.f;
+__device__ __forceinline__ void dn_world(const DenseParams& P, int i, int j, float idepth, double (&m)[3]) {
+    float c0 = P.fxi * j + (-P.cx * P.fxi), c1 = P.fyi * i + (-P.cy * P.fyi), c2 = 1.f;       // cP = Ki * (j,i,1) / idepth (float), mP = camToWorld * cP (double)  (:390-394)
+    c0 /= idepth; c1 /= idepth; c2 /= idepth;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) m[q] = P.c2w[q * 4] * (double)c0 + P.c2w[q * 4 + 1] * (double)c1 + P.c2w[q * 4 + 2] * (double)c2 + P.c2w[q * 4 + 3];
+}
+// which pixels of this lane's R rounds are kept (MapPoint.cpp:366-380); the mask loads are issued together, an out-of-range lane reads pixel (rx0, ry0) and drops it
+template <int R>
+__device__ __forceinline__ void dn_keep(const DenseParams& P, int b, int tid, int rx0, int ry0, int rw, int total, bool (&keep)[R], float (&idp)[R]) {
+    float mv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = b * kDenseChunk + r * 256 + tid, ee = e < total ? e : 0;
+        mv[r] = P.mask[(rx0 + ee % rw) + (ry0 + ee / rw) * P.w];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = b * kDenseChunk + r * 256 + tid;
+        keep[r] = false; idp[r] = 0.f;
         if (e < total) {
-            i = P.ry0 + e / P.rw; j = P.rx0 + e % P.rw;
-            if (P.mask[j + i * P.w] == P.pcolor && (i % 3 == 0 || j % 3 == 0)) {
+            const int i = ry0 + e / rw, j = rx0 + e % rw;
+            if (mv[r] == P.pcolor && (i % 3 == 0 || j % 3 == 0)) {
                 const float ddepth = P.p0 * (j * P.fxi - P.cx * P.fxi) + P.p1 * (i * P.fyi - P.cy * P.fyi) + P.p2;   // MapPoint.cpp:377
-                if (ddepth != 0.f) { const float depth = -P.p3 / ddepth; if (depth != 0.f) { idepth = 1.f / depth; keep = true; } }
+                if (ddepth != 0.f) { const float depth = -P.p3 / ddepth; if (depth != 0.f) { idp[r] = 1.f / depth; keep[r] = true; } }
             }
         }
-        const unsigned long long m = __ballot(keep);
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = __popcll(m);
-        __syncthreads();
-        int off = running;
-        for (int k = 0; k < wave; ++k) off += wave_cnt[k];
-        if (WRITE && keep && off + rank < cap) {
-            const int o = off + rank, px = j + i * P.w;
-            ou[o] = j; ov[o] = i; oid[o] = idepth; ocol[o] = P.dI[px].x;
-            if (P.bgr) { obgr[3 * o] = P.bgr[3 * px]; obgr[3 * o + 1] = P.bgr[3 * px + 1]; obgr[3 * o + 2] = P.bgr[3 * px + 2]; }
-            // cP = Ki * (j,i,1) / idepth (float), mP = camToWorld * cP (double)  (:390-394)
-            float c0 = P.fxi * j + (-P.cx * P.fxi), c1 = P.fyi * i + (-P.cy * P.fyi), c2 = 1.f;
-            c0 /= idepth; c1 /= idepth; c2 /= idepth;
-            for (int q = 0; q < 3; ++q) world[3 * (size_t)o + q] = P.c2w[q * 4] * (double)c0 + P.c2w[q * 4 + 1] * (double)c1 + P.c2w[q * 4 + 2] * (double)c2 + P.c2w[q * 4 + 3];
+    }
+}
+__global__ __launch_bounds__(256) void dense_count_kernel(DenseParams P) {
+    constexpr int R = kDenseChunk / 256;
+    __shared__ int sr[4][4];
+    __shared__ float red[4][5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    // ---- the box from the row table (every workgroup on its own: a few hundred entries from L2, all loads in flight; block 0 publishes it and re-arms `last`).
+    // No "last workgroup folds it" scheme: an agent-scope fence per workgroup (__threadfence = L2 write-back) cost 20 us in the row kernel and 80 us here.
+    int minx = INT_MAX, maxx = INT_MIN, miny = INT_MAX, maxy = INT_MIN;
+    {
+        int2 rr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int y = 2 + tid + 256 * k; rr[k] = P.rows[y < P.h - 2 ? y : 2]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int y = 2 + tid + 256 * k; if (y < P.h - 2 && rr[k].x != INT_MAX) { minx = min(minx, rr[k].x); maxx = max(maxx, rr[k].y); miny = min(miny, y); maxy = max(maxy, y); } }
+        for (int y = 2 + tid + 2048; y < P.h - 2; y += 256) { const int2 r = P.rows[y]; if (r.x != INT_MAX) { minx = min(minx, r.x); maxx = max(maxx, r.y); miny = min(miny, y); maxy = max(maxy, y); } }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { minx = min(minx, __shfl_xor(minx, o)); maxx = max(maxx, __shfl_xor(maxx, o)); miny = min(miny, __shfl_xor(miny, o)); maxy = max(maxy, __shfl_xor(maxy, o)); }
+    if (lane == 0) { sr[wave][0] = minx; sr[wave][1] = maxx; sr[wave][2] = miny; sr[wave][3] = maxy; }
+    __syncthreads();
+    const int rx0 = min(min(sr[0][0], sr[1][0]), min(sr[2][0], sr[3][0])), rx1 = max(max(sr[0][1], sr[1][1]), max(sr[2][1], sr[3][1]));
+    const int ry0 = min(min(sr[0][2], sr[1][2]), min(sr[2][2], sr[3][2])), ry1 = max(max(sr[0][3], sr[1][3]), max(sr[2][3], sr[3][3]));
+    if (b == 0 && tid == 0) { P.rect[0] = rx0; P.rect[1] = rx1; P.rect[2] = ry0; P.rect[3] = ry1; P.last[0] = 0ull; P.last[1] = 0ull; P.n_out[0] = 0; }
+    const bool any = rx0 != INT_MAX && rx1 > rx0 && ry1 > ry0;
+    const int rw = any ? rx1 - rx0 : 1, total = any ? rw * (ry1 - ry0) : 0, nb = (total + kDenseChunk - 1) / kDenseChunk;
+    if (b >= nb) return;
+    bool keep[R]; float idp[R];
+    dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp);
+    int cnt = 0;
+    float mnx = FLT_MAX, mny = FLT_MAX, mnz = FLT_MAX, mxx = FLT_MIN;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!keep[r]) continue;
+        const int e = b * kDenseChunk + r * 256 + tid;
+        double m[3]; dn_world(P, ry0 + e / rw, rx0 + e % rw, idp[r], m);
+        const float fx = (float)m[0];
+        mnx = fminf(mnx, fx); mxx = fmaxf(mxx, fx); mny = fminf(mny, (float)m[1]); mnz = fminf(mnz, (float)m[2]);
+        ++cnt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o)); }
+    if (lane == 0) { red[wave][0] = __int_as_float(cnt); red[wave][1] = mnx; red[wave][2] = mny; red[wave][3] = mnz; red[wave][4] = mxx; }
+    __syncthreads();
+    if (tid == 0) {
+        float* o = P.agg + (size_t)b * 8;
+        o[0] = __int_as_float(__float_as_int(red[0][0]) + __float_as_int(red[1][0]) + __float_as_int(red[2][0]) + __float_as_int(red[3][0]));
+        o[1] = fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1])); o[2] = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
+        o[3] = fminf(fminf(red[0][3], red[1][3]), fminf(red[2][3], red[3][3])); o[4] = fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4]));
+    }
+}
+__global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap, int* __restrict__ ou, int* __restrict__ ov, float* __restrict__ oid, float* __restrict__ ocol,
+                                                          uint8_t* __restrict__ obgr) {
+    constexpr int R = kDenseChunk / 256;
+    __shared__ int cnt[R][4];
+    __shared__ float gmin[R][4][2];              // min of (float) y, (float) z per (round, wave) group of kept points
+    __shared__ float red[4][5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int rx0 = P.rect[0], rx1 = P.rect[1], ry0 = P.rect[2], ry1 = P.rect[3];
+    const bool any = rx0 != INT_MAX && rx1 > rx0 && ry1 > ry0;
+    const int rw = any ? rx1 - rx0 : 1, total = any ? rw * (ry1 - ry0) : 0, nb = (total + kDenseChunk - 1) / kDenseChunk;
+    if (b < nb) {
+        // ---- exclusive prefix of the chunks in front: count, min x / y / z, max x (order-free folds; the in-order part happens inside the workgroup)
+        int ecnt = 0; float e1 = FLT_MAX, e2 = FLT_MAX, e3 = FLT_MAX, e4 = FLT_MIN;
+        for (int p = tid; p < b; p += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(P.agg + (size_t)p * 8); const float a4 = P.agg[(size_t)p * 8 + 4];
+            ecnt += __float_as_int(a.x); e1 = fminf(e1, a.y); e2 = fminf(e2, a.z); e3 = fminf(e3, a.w); e4 = fmaxf(e4, a4);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ecnt += __shfl_xor(ecnt, o); e1 = fminf(e1, __shfl_xor(e1, o)); e2 = fminf(e2, __shfl_xor(e2, o)); e3 = fminf(e3, __shfl_xor(e3, o)); e4 = fmaxf(e4, __shfl_xor(e4, o)); }
+        if (lane == 0) { red[wave][0] = __int_as_float(ecnt); red[wave][1] = e1; red[wave][2] = e2; red[wave][3] = e3; red[wave][4] = e4; }
+        bool keep[R]; float idp[R]; int rank[R];
+        dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp);
+        double wy[R], wz[R];                     // world y, z of the kept points (compared as doubles against the float running minima)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = b * kDenseChunk + r * 256 + tid;
+            float fy = FLT_MAX, fz = FLT_MAX; wy[r] = 0; wz[r] = 0;
+            if (keep[r]) { double m[3]; dn_world(P, ry0 + e / rw, rx0 + e % rw, idp[r], m); wy[r] = m[1]; wz[r] = m[2]; fy = (float)m[1]; fz = (float)m[2]; }
+            const unsigned long long mk = __ballot(keep[r]);
+            rank[r] = __popcll(mk & ((1ull << lane) - 1ull));
+            float gy = fy, gz = fz;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { gy = fminf(gy, __shfl_xor(gy, o)); gz = fminf(gz, __shfl_xor(gz, o)); }
+            if (lane == 0) { cnt[r][wave] = __popcll(mk); gmin[r][wave][0] = gy; gmin[r][wave][1] = gz; }
         }
         __syncthreads();
-        if (threadIdx.x == 0) running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        ecnt = __float_as_int(red[0][0]) + __float_as_int(red[1][0]) + __float_as_int(red[2][0]) + __float_as_int(red[3][0]);
+        e1 = fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1])); e2 = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
+        e3 = fminf(fminf(red[0][3], red[1][3]), fminf(red[2][3], red[3][3])); e4 = fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4]));
+        if (b == nb - 1 && tid == 0) {           // the last chunk: prefix + its own aggregate = the totals of the serial loop (maxy / maxz follow from the last workgroup)
+            const float* a = P.agg + (size_t)b * 8;
+            P.n_out[0] = ecnt + __float_as_int(a[0]);
+            P.out6[0] = fminf(e1, a[1]); P.out6[1] = fmaxf(e4, a[4]); P.out6[2] = fminf(e2, a[2]); P.out6[4] = fminf(e3, a[3]);
+        }
+        // ---- the points in raster order; the in-order prefix minima decide who may be "the last point above the running minimum"
+        int off = ecnt;
+        float runy = e2, runz = e3;
+        int l1 = -1, l2 = -1; float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int goff = off; float gy = runy, gz = runz;                     // offset / running minima in front of this (round, wave) group
+            for (int k = 0; k < wave; ++k) { goff += cnt[r][k]; gy = fminf(gy, gmin[r][k][0]); gz = fminf(gz, gmin[r][k][1]); }
+            const float fy = keep[r] ? (float)wy[r] : FLT_MAX, fz = keep[r] ? (float)wz[r] : FLT_MAX;
+            float py = fy, pz = fz;                                         // inclusive prefix minimum over the wave in lane order (lanes without a point carry FLT_MAX)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const float ty = __shfl_up(py, o), tz = __shfl_up(pz, o); if (lane >= o) { py = fminf(py, ty); pz = fminf(pz, tz); } }
+            if (keep[r]) {
+                const int e = b * kDenseChunk + r * 256 + tid, i = ry0 + e / rw, j = rx0 + e % rw;
+                const int o = goff + rank[r];
+                if (o < cap) {
+                    const int px = j + i * P.w;
+                    ou[o] = j; ov[o] = i; oid[o] = idp[r]; ocol[o] = P.dI[px].x;
+                    if (P.bgr) { obgr[3 * o] = P.bgr[3 * px]; obgr[3 * o + 1] = P.bgr[3 * px + 1]; obgr[3 * o + 2] = P.bgr[3 * px + 2]; }
+                }
+                const float ry_ = fminf(gy, py), rz_ = fminf(gz, pz);       // the running minima AFTER this point's own update
+                if (wy[r] > (double)ry_) { l1 = o; v1 = fy; }
+                if (wz[r] > (double)rz_) { l2 = o; v2 = fz; }
+            }
+            for (int k = 0; k < 4; ++k) { off += cnt[r][k]; runy = fminf(runy, gmin[r][k][0]); runz = fminf(runz, gmin[r][k][1]); }   // this round is behind us
+        }
+        // the largest qualifying index of the workgroup (nearly every point qualifies: one atomic per LANE was 380 k serialised updates of two words, 88 us)
+        unsigned long long q1 = l1 >= 0 ? ((unsigned long long)(unsigned)(l1 + 1) << 32) | __float_as_uint(v1) : 0ull;
+        unsigned long long q2 = l2 >= 0 ? ((unsigned long long)(unsigned)(l2 + 1) << 32) | __float_as_uint(v2) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t1 = __shfl_xor(q1, o), t2 = __shfl_xor(q2, o); q1 = t1 > q1 ? t1 : q1; q2 = t2 > q2 ? t2 : q2; }
+        __shared__ unsigned long long sq[4][2];
+        if (lane == 0) { sq[wave][0] = q1; sq[wave][1] = q2; }
         __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < 4; ++k) { q1 = sq[k][0] > q1 ? sq[k][0] : q1; q2 = sq[k][1] > q2 ? sq[k][1] : q2; }
+            if (q1) atomicMax(&P.last[0], q1);
+            if (q2) atomicMax(&P.last[1], q2);
+        }
     }
-    if (!WRITE && threadIdx.x == 0) counts[blockIdx.x] = running;
-}
-
-__global__ __launch_bounds__(1024) void dense_scan_kernel(const int* __restrict__ counts, int* __restrict__ offsets, int nb) {
-    __shared__ int part[1024];
-    const int per = (nb + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, nb);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += counts[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; } offsets[nb] = run; }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
-}
-
-// out6 = {minx, maxx, miny, maxy, minz, maxz} exactly as the serial loop of MapPoint.cpp:362-397 leaves them: minima and maxx are plain extrema; maxy (maxz) is
-// the y (z) of the LAST point whose coordinate is strictly above the running minimum after that point's own minimum update (the reference compares against
-// miny / minz where it means maxy / maxz). Three small launches over chunks of kExtChunk points instead of one workgroup striding the whole list (1.19 ms for
-// 433 k points at 1920x1072): A per-chunk extrema (coalesced), B exclusive prefix minima over the chunks (serial over ~100 values), C per chunk an in-order
-// prefix-min scan (thread-local runs + an LDS scan over the 256 threads) and the largest qualifying index, combined with integer atomicMax.
-constexpr int kExtChunk = 4096;
-__global__ __launch_bounds__(256) void dense_extent_a_kernel(const double* __restrict__ world, int n, float* __restrict__ cmin /* [nb][4]: min x,y,z, max x */) {
-    __shared__ float sm[4][4];
-    const int lo = blockIdx.x * kExtChunk, hi = min(lo + kExtChunk, n);
-    // the reference keeps float extrema and compares the double coordinate against them; min / max over a set do not depend on the order
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx0 = FLT_MIN;
-    for (int k = lo + threadIdx.x; k < hi; k += 256)
-        for (int q = 0; q < 3; ++q) { const double v = world[3 * (size_t)k + q]; if (v < (double)mn[q]) mn[q] = (float)v; if (q == 0 && v > (double)mx0) mx0 = (float)v; }
-    for (int o = 32; o > 0; o >>= 1) { for (int q = 0; q < 3; ++q) mn[q] = fminf(mn[q], __shfl_down(mn[q], o)); mx0 = fmaxf(mx0, __shfl_down(mx0, o)); }
-    if ((threadIdx.x & 63) == 0) { const int wv = threadIdx.x >> 6; sm[wv][0] = mn[0]; sm[wv][1] = mn[1]; sm[wv][2] = mn[2]; sm[wv][3] = mx0; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) { mn[0] = fminf(mn[0], sm[k][0]); mn[1] = fminf(mn[1], sm[k][1]); mn[2] = fminf(mn[2], sm[k][2]); mx0 = fmaxf(mx0, sm[k][3]); }
-        float* o = cmin + 4 * (size_t)blockIdx.x; o[0] = mn[0]; o[1] = mn[1]; o[2] = mn[2]; o[3] = mx0;
-    }
-}
-__global__ __launch_bounds__(64) void dense_extent_b_kernel(float* __restrict__ cmin, int nb, float* __restrict__ out6, int* __restrict__ last2) {
-    if (threadIdx.x != 0) return;
-    float run[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, rmx = FLT_MIN;
-    for (int i = 0; i < nb; ++i) {
-        float* c = cmin + 4 * (size_t)i;
-        for (int q = 0; q < 3; ++q) { const float v = c[q]; c[q] = run[q]; run[q] = fminf(run[q], v); }      // exclusive prefix minimum
-        rmx = fmaxf(rmx, c[3]);
-    }
-    out6[0] = run[0]; out6[1] = rmx; out6[2] = run[1]; out6[4] = run[2];
-    last2[0] = -1; last2[1] = -1;
-}
-__global__ __launch_bounds__(256) void dense_extent_c_kernel(const double* __restrict__ world, int n, const float* __restrict__ cmin, int* __restrict__ last2) {
-    __shared__ float s1[256], s2[256];
-    constexpr int PT = kExtChunk / 256;                                   // consecutive points per thread
-    const int t = threadIdx.x, lo = blockIdx.x * kExtChunk + t * PT, hi = min(lo + PT, n);
-    float m1 = FLT_MAX, m2 = FLT_MAX;
-    for (int k = lo; k < hi; ++k) { const double y = world[3 * (size_t)k + 1], z = world[3 * (size_t)k + 2]; if (y < (double)m1) m1 = (float)y; if (z < (double)m2) m2 = (float)z; }
-    s1[t] = m1; s2[t] = m2;
-    __syncthreads();
-    // running minima before this thread's first point: the chunk's exclusive prefix, then the threads before it (256 values: a serial walk per thread is
-    // ~128 LDS reads on average; the launch is dominated by the two passes over the points)
-    float run1 = cmin[4 * (size_t)blockIdx.x + 1], run2 = cmin[4 * (size_t)blockIdx.x + 2];
-    for (int i = 0; i < t; ++i) { run1 = fminf(run1, s1[i]); run2 = fminf(run2, s2[i]); }
-    int l1 = -1, l2 = -1;
-    for (int k = lo; k < hi; ++k) {
-        const double y = world[3 * (size_t)k + 1], z = world[3 * (size_t)k + 2];
-        if (y < (double)run1) run1 = (float)y;
-        if (y > (double)run1) l1 = k;
-        if (z < (double)run2) run2 = (float)z;
-        if (z > (double)run2) l2 = k;
-    }
-    for (int o = 32; o > 0; o >>= 1) { l1 = max(l1, __shfl_down(l1, o)); l2 = max(l2, __shfl_down(l2, o)); }
-    if ((t & 63) == 0) { if (l1 >= 0) atomicMax(&last2[0], l1); if (l2 >= 0) atomicMax(&last2[1], l2); }
-}
-__global__ __launch_bounds__(64) void dense_extent_d_kernel(const double* __restrict__ world, const int* __restrict__ last2, float* __restrict__ out6) {
-    if (threadIdx.x != 0) return;
-    out6[3] = last2[0] >= 0 ? (float)world[3 * (size_t)last2[0] + 1] : FLT_MIN;
-    out6[5] = last2[1] >= 0 ? (float)world[3 * (size_t)last2[1] + 2] : FLT_MIN;
 }
 
 }  // namespace nalo
@@ -172,65 +236,78 @@ extern "C" int nalo_dense_make_map(nalo_ctx* c, int slot, const float plane[4], 
     if (!s.valid || !s.mask) return fail(c, NALO_ERR_STATE, "nalo_dense_make_map: slot has no pyramid / mask (nalo_frame_upload with mask)");
     NALO_HIP(c, hipSetDevice(c->device));
     *n_out = 0; *accept = 0;
-    // ---- bbox scan (MapPoint.cpp:287-310)
+    // ---- bbox scan (MapPoint.cpp:287-310), makeMap and the accept test: three launches back to back, the box never leaves the device in between
+    const int nblk = std::max(1, ((c->w - 4) * (c->h - 4) + kDenseChunk - 1) / kDenseChunk);
+    const size_t hrows = ((size_t)c->h + 1) & ~(size_t)1;                  // the aggregates behind the row table stay 16-byte aligned
+    const size_t lbw = hrows + (size_t)nblk * 4 + 8;                       // int2 rows[h] | float agg[nblk][8] | last[2] | ticket  (in 8-byte words)
+    if (c->dense_lb.cap < lbw) {
+        NALO_HIP(c, hipStreamSynchronize(c->stream));
+        NALO_HIP(c, c->dense_lb.reserve(lbw));
+        NALO_HIP(c, hipMemsetAsync(c->dense_lb.p, 0, lbw * 8, c->stream));   // `last` and the ticket start at zero and are re-armed by the kernel
+    }
+    int2* rows = reinterpret_cast<int2*>(c->dense_lb.p);
     NALO_HIP(c, c->scan_tmp.reserve(8));
-    const int init[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
-    NALO_HIP(c, hipMemcpyAsync(c->scan_tmp.p, init, 16, hipMemcpyHostToDevice, c->stream));
-    { ProfScope ps(c, "dense_bbox"); dense_bbox_kernel<<<std::max(1, std::min(c->h - 4, 512)), 256, 0, c->stream>>>(s.mask, c->w, c->h, mask_value, c->scan_tmp.p); }
+    {   // dispatch-attached timestamps (no barrier packets around the launch: an event pair recorded on the stream adds several microseconds to a 5 us kernel)
+        ProfScope ps(c, "dense_bbox", true);
+        if (ps.a) hipExtLaunchKernelGGL(dense_rows_kernel, dim3(std::max(1, c->h - 4)), dim3(256), 0, c->stream, ps.a, ps.b, 0, s.mask, c->w, c->h, mask_value, rows);
+        else dense_rows_kernel<<<std::max(1, c->h - 4), 256, 0, c->stream>>>(s.mask, c->w, c->h, mask_value, rows);
+    }
     int rect[4];
-    NALO_HIP(c, hipMemcpyAsync(rect, c->scan_tmp.p, 16, hipMemcpyDeviceToHost, c->stream));
-    NALO_HIP(c, hipStreamSynchronize(c->stream));
-    if (rect_out) std::memcpy(rect_out, rect, 16);
-    if (mask_value == 0.f) return NALO_OK;                                   // `if(pcolor==0) return;` (:355-357)
-    const int rw = rect[1] - rect[0], rh = rect[3] - rect[2];
     float ext[6] = {FLT_MAX, FLT_MIN, FLT_MAX, FLT_MIN, FLT_MAX, FLT_MIN};
     int n = 0;
-    if (rect[0] != INT_MAX && rw > 0 && rh > 0) {
-        DenseParams P;
-        P.mask = s.mask; P.dI = s.dI[0]; P.bgr = s.bgr; P.w = c->w; P.rx0 = rect[0]; P.ry0 = rect[2]; P.rw = rw; P.rh = rh;
-        P.p0 = plane[0]; P.p1 = plane[1]; P.p2 = plane[2]; P.p3 = plane[3]; P.pcolor = mask_value;
-        P.fxi = 1.0f / c->fx[0]; P.fyi = 1.0f / c->fy[0]; P.cx = c->cx[0]; P.cy = c->cy[0];            // DenseMapping::makeK level 0
-        std::memcpy(P.c2w, camToWorld, sizeof(P.c2w));
-        const int total = rw * rh, nb = (total + kDenseChunk - 1) / kDenseChunk;
-        NALO_HIP(c, c->scan_tmp.reserve((size_t)2 * nb + 2));
-        int *counts = c->scan_tmp.p, *offsets = counts + nb;
-        const size_t capz = (size_t)std::max(cap, 1);
-        // scratch: u,v (int), idepth,color (float), bgr, world(double) carved from upload_tmp
-        const size_t words = capz * (4 + 1 + 6) + 64;
-        NALO_HIP(c, c->upload_tmp.reserve(words));
-        int* du = (int*)c->upload_tmp.p; int* dv = du + capz; float* did = (float*)(dv + capz); float* dcol = did + capz;
-        uint8_t* dbgr = (uint8_t*)(dcol + capz);
-        double* dworld = (double*)(c->upload_tmp.p + capz * 5 + (capz * 5 % 2));
-        {
-            ProfScope ps(c, "dense_map");
-            dense_map_kernel<0><<<nb, 256, 0, c->stream>>>(P, counts, nullptr, cap, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-            dense_scan_kernel<<<1, 1024, 0, c->stream>>>(counts, offsets, nb);
-            dense_map_kernel<1><<<nb, 256, 0, c->stream>>>(P, nullptr, offsets, cap, du, dv, did, dcol, dbgr, dworld);
-        }
-        NALO_HIP(c, hipMemcpyAsync(&n, offsets + nb, 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t capz = (size_t)std::max(cap, 1);
+    const size_t words = capz * 5 + 64;                                      // scratch: u, v (int), idepth, colour (float), bgr carved from upload_tmp
+    NALO_HIP(c, c->upload_tmp.reserve(words));
+    int* du = (int*)c->upload_tmp.p; int* dv = du + capz; float* did = (float*)(dv + capz); float* dcol = did + capz;
+    uint8_t* dbgr = (uint8_t*)(dcol + capz);
+    NALO_HIP(c, c->trk_partial.reserve(16));
+    DenseParams P;
+    P.mask = s.mask; P.dI = s.dI[0]; P.bgr = s.bgr; P.w = c->w; P.h = c->h; P.rows = rows; P.rect = c->scan_tmp.p;
+    P.p0 = plane[0]; P.p1 = plane[1]; P.p2 = plane[2]; P.p3 = plane[3]; P.pcolor = mask_value;
+    P.fxi = 1.0f / c->fx[0]; P.fyi = 1.0f / c->fy[0]; P.cx = c->cx[0]; P.cy = c->cy[0];            // DenseMapping::makeK level 0
+    std::memcpy(P.c2w, camToWorld, sizeof(P.c2w));
+    P.agg = reinterpret_cast<float*>(c->dense_lb.p + hrows);
+    P.last = c->dense_lb.p + hrows + (size_t)nblk * 4;
+    P.out6 = c->trk_partial.p; P.n_out = reinterpret_cast<int*>(c->trk_partial.p + 8);
+    if (mask_value == 0.f) {                                                 // `if(pcolor==0) return;` (:355-357): only the box is wanted
+        dense_count_kernel<<<1, 256, 0, c->stream>>>(P);
+        NALO_HIP(c, hipMemcpyAsync(rect, c->scan_tmp.p, 16, hipMemcpyDeviceToHost, c->stream));
         NALO_HIP(c, hipStreamSynchronize(c->stream));
-        if (n > cap) return fail(c, NALO_ERR_ARG, "nalo_dense_make_map: cap too small");
-        if (n > 0) {
-            float* d6 = (float*)(dworld + 3 * capz);
-            const int nbe = (n + kExtChunk - 1) / kExtChunk;
-            NALO_HIP(c, c->trk_partial.reserve(16 + 4 * (size_t)nbe));
-            float* cmin = c->trk_partial.p + 16; int* last2 = (int*)(c->trk_partial.p + 8);
-            {
-                ProfScope pse(c, "dense_extent");
-                dense_extent_a_kernel<<<nbe, 256, 0, c->stream>>>(dworld, n, cmin);
-                dense_extent_b_kernel<<<1, 64, 0, c->stream>>>(cmin, nbe, c->trk_partial.p, last2);
-                dense_extent_c_kernel<<<nbe, 256, 0, c->stream>>>(dworld, n, cmin, last2);
-                dense_extent_d_kernel<<<1, 64, 0, c->stream>>>(dworld, last2, c->trk_partial.p);
-            }
-            (void)d6;
-            NALO_HIP(c, hipMemcpyAsync(ext, c->trk_partial.p, 24, hipMemcpyDeviceToHost, c->stream));
-            if (out_u) NALO_HIP(c, hipMemcpyAsync(out_u, du, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-            if (out_v) NALO_HIP(c, hipMemcpyAsync(out_v, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-            if (out_idepth) NALO_HIP(c, hipMemcpyAsync(out_idepth, did, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-            if (out_color) NALO_HIP(c, hipMemcpyAsync(out_color, dcol, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-            if (out_bgr && s.bgr) NALO_HIP(c, hipMemcpyAsync(out_bgr, dbgr, (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
-            NALO_HIP(c, hipStreamSynchronize(c->stream));
+        if (rect_out) std::memcpy(rect_out, rect, 16);
+        return NALO_OK;
+    }
+    {
+        ProfScope ps(c, "dense_map", true);                    // start of the first dispatch .. end of the second
+        if (ps.a) {
+            hipExtLaunchKernelGGL(dense_count_kernel, dim3(nblk), dim3(256), 0, c->stream, ps.a, nullptr, 0, P);
+            hipExtLaunchKernelGGL(dense_write_kernel, dim3(nblk), dim3(256), 0, c->stream, nullptr, ps.b, 0, P, cap, du, dv, did, dcol, dbgr);
+        } else {
+            dense_count_kernel<<<nblk, 256, 0, c->stream>>>(P);
+            dense_write_kernel<<<nblk, 256, 0, c->stream>>>(P, cap, du, dv, did, dcol, dbgr);
         }
+    }
+    float res[9];
+    unsigned long long lastq[2] = {0, 0};
+    NALO_HIP(c, hipMemcpyAsync(rect, c->scan_tmp.p, 16, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(res, c->trk_partial.p, sizeof(res), hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipMemcpyAsync(lastq, P.last, 16, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k) {                                            // maxy / maxz: the coordinate of the last qualifying point, FLT_MIN if none (the reference's seed)
+        const unsigned bits = (unsigned)lastq[k]; float v = FLT_MIN;
+        if (lastq[k] >> 32) std::memcpy(&v, &bits, 4);
+        res[k == 0 ? 3 : 5] = v;
+    }
+    if (rect_out) std::memcpy(rect_out, rect, 16);
+    std::memcpy(&n, &res[8], 4);
+    if (n > cap) return fail(c, NALO_ERR_ARG, "nalo_dense_make_map: cap too small");
+    if (n > 0) {
+        std::memcpy(ext, res, 24);
+        if (out_u) NALO_HIP(c, hipMemcpyAsync(out_u, du, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (out_v) NALO_HIP(c, hipMemcpyAsync(out_v, dv, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (out_idepth) NALO_HIP(c, hipMemcpyAsync(out_idepth, did, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (out_color) NALO_HIP(c, hipMemcpyAsync(out_color, dcol, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        if (out_bgr && s.bgr) NALO_HIP(c, hipMemcpyAsync(out_bgr, dbgr, (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
+        NALO_HIP(c, hipStreamSynchronize(c->stream));
     }
     NALO_HIP(c, hipGetLastError());
     *n_out = n;

@@ -5,6 +5,7 @@
 // Output texel = float4 {I, dx, dy, 0}: one aligned 16-byte load per bilinear tap in the gather kernels.
 // Bandwidth-bound streaming kernels: 16 B/lane stores, 256-thread blocks, grid-stride.
 #include "nalo_internal.h"
+#include <hip/hip_ext.h>
 
 namespace nalo {
 
@@ -276,56 +277,79 @@ __global__ __launch_bounds__(256) void pyr_grad_tail_kernel(PyrLevels P, const f
 struct IngestParams {
     const void* raw; int bpp;                       // 1 or 2 bytes per pixel
     int wOrg, hOrg, w, h;
-    const float *G, *vinv, *remapX, *remapY;        // G [GDepth]; vinv [wOrg*hOrg] or null; remap [w*h] or null (passthrough)
+    const float *G, *vinv; const float2* remapXY;   // G [GDepth]; vinv [wOrg*hOrg] or null; remap [w*h] {x, y} interleaved, or null (passthrough)
     int photometric;                                // 0: data = factor * raw, 1: G only, 2: G * vignetteMapInv
     float factor;
     const uint8_t *mask_org, *bgr_org;              // [wOrg*hOrg], [wOrg*hOrg*3] or null
     float* out_I; float* out_mask; uint8_t* out_bgr;
     double ifx, ify;                                // cv::resize: 1 / ((double)w / wOrg)
 };
-__device__ __forceinline__ float ingest_tap(const IngestParams& P, int p) {
-    const unsigned v = P.bpp == 1 ? (unsigned)reinterpret_cast<const uint8_t*>(P.raw)[p] : (unsigned)reinterpret_cast<const uint16_t*>(P.raw)[p];
-    if (P.photometric == 0) return P.factor * (float)v;
-    float d = P.G[v];
-    if (P.photometric == 2) d *= P.vinv[p];
-    return d;
+// Round 3: the pass is bound by the NUMBER of memory instructions per pixel (15 in the first version: two remap loads, four byte taps, four vignette
+// taps, four response look-ups, one store - 0.19 of the HBM roofline), not by bytes. Now 6: the remap table is interleaved {x, y} (one 8-byte load, built by
+// nalo_undist_set), the two taps of a row come with ONE load (2 or 4 raw bytes; 8 bytes of the vignette map), the 8-bit response lives in LDS, and nothing sits
+// under a divergent branch (an outside pixel computes on pixel 0 and is zeroed at the end). The arithmetic is the reference's, operation for operation.
+template <int BPP>
+__device__ __forceinline__ void ingest_pair(const void* __restrict__ raw, int p, unsigned& a, unsigned& b) {      // raw[p], raw[p + 1]
+    if constexpr (BPP == 1) { uint16_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(raw) + p, 2); a = v & 0xFFu; b = v >> 8; }
+    else { uint32_t v; __builtin_memcpy(&v, reinterpret_cast<const uint16_t*>(raw) + p, 4); a = v & 0xFFFFu; b = v >> 16; }
 }
+template <int BPP, int PHOTO>
 __global__ __launch_bounds__(256) void ingest_kernel(IngestParams P) {
-    const int n = P.w * P.h;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-        float o;
-        if (!P.remapX) o = ingest_tap(P, idx);
-        else {
-            float xx = P.remapX[idx], yy = P.remapY[idx];
-            if (xx < 0) o = 0.f;
-            else {
-                const int xxi = (int)xx, yyi = (int)yy;
-                xx -= xxi; yy -= yyi;
-                const float xxyy = xx * yy;
-                const int p = xxi + yyi * P.wOrg;
-                o = xxyy * ingest_tap(P, p + 1 + P.wOrg) + (yy - xxyy) * ingest_tap(P, p + P.wOrg) + (xx - xxyy) * ingest_tap(P, p + 1) + (1 - xx - yy + xxyy) * ingest_tap(P, p);
-            }
-        }
-        P.out_I[idx] = o;
-        if (P.mask_org || P.bgr_org) {                     // cv::resize(.., INTER_NEAREST): sx = min(floor(x * ifx), wOrg - 1)
-            const int y = idx / P.w, x = idx - y * P.w;
-            int sx = (int)floor(x * P.ifx), sy = (int)floor(y * P.ify);
-            sx = sx < P.wOrg - 1 ? sx : P.wOrg - 1; sy = sy < P.hOrg - 1 ? sy : P.hOrg - 1;
-            const int sp = sx + sy * P.wOrg;
-            if (P.mask_org) P.out_mask[idx] = (float)P.mask_org[sp] * 1.0f;
-            if (P.bgr_org) { P.out_bgr[3 * idx] = P.bgr_org[3 * sp]; P.out_bgr[3 * idx + 1] = P.bgr_org[3 * sp + 1]; P.out_bgr[3 * idx + 2] = P.bgr_org[3 * sp + 2]; }
-        }
+    __shared__ float sG[BPP == 1 && PHOTO > 0 ? 256 : 1];
+    if constexpr (BPP == 1 && PHOTO > 0) { sG[threadIdx.x] = P.G[threadIdx.x]; __syncthreads(); }
+    const float* __restrict__ Gt = (BPP == 1 && PHOTO > 0) ? sG : P.G;
+    const int n = P.w * P.h, idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    auto data = [&](unsigned v, float vi) -> float {                       // PhotometricUndistorter::processFrame (Undistort.cpp:224-251) at one original pixel
+        if constexpr (PHOTO == 0) return P.factor * (float)v;
+        float d = Gt[v];
+        if constexpr (PHOTO == 2) d *= vi;
+        return d;
+    };
+    float o;
+    if (!P.remapXY) {
+        unsigned v;
+        if constexpr (BPP == 1) v = reinterpret_cast<const uint8_t*>(P.raw)[idx]; else v = reinterpret_cast<const uint16_t*>(P.raw)[idx];
+        o = data(v, PHOTO == 2 ? P.vinv[idx] : 1.f);
+    } else {
+        const float2 r = P.remapXY[idx];
+        float xx = r.x, yy = r.y;
+        const bool outside = xx < 0;
+        if (outside) { xx = 0.f; yy = 0.f; }
+        const int xxi = (int)xx, yyi = (int)yy;
+        xx -= xxi; yy -= yyi;
+        const float xxyy = xx * yy;
+        const int p = xxi + yyi * P.wOrg;
+        unsigned v00, v10, v01, v11;
+        ingest_pair<BPP>(P.raw, p, v00, v10);
+        ingest_pair<BPP>(P.raw, p + P.wOrg, v01, v11);
+        float2 i0 = make_float2(1.f, 1.f), i1 = i0;
+        if constexpr (PHOTO == 2) { __builtin_memcpy(&i0, P.vinv + p, 8); __builtin_memcpy(&i1, P.vinv + p + P.wOrg, 8); }
+        o = xxyy * data(v11, i1.y) + (yy - xxyy) * data(v01, i1.x) + (xx - xxyy) * data(v10, i0.y) + (1 - xx - yy + xxyy) * data(v00, i0.x);
+        if (outside) o = 0.f;
+    }
+    P.out_I[idx] = o;
+    if (P.mask_org || P.bgr_org) {                     // cv::resize(.., INTER_NEAREST): sx = min(floor(x * ifx), wOrg - 1)
+        const int y = idx / P.w, x = idx - y * P.w;
+        int sx = (int)floor(x * P.ifx), sy = (int)floor(y * P.ify);
+        sx = sx < P.wOrg - 1 ? sx : P.wOrg - 1; sy = sy < P.hOrg - 1 ? sy : P.hOrg - 1;
+        const int sp = sx + sy * P.wOrg;
+        if (P.mask_org) P.out_mask[idx] = (float)P.mask_org[sp] * 1.0f;
+        if (P.bgr_org) { P.out_bgr[3 * idx] = P.bgr_org[3 * sp]; P.out_bgr[3 * idx + 1] = P.bgr_org[3 * sp + 1]; P.out_bgr[3 * idx + 2] = P.bgr_org[3 * sp + 2]; }
     }
 }
-int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float* remapX, const float* remapY, int photometric,
+int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float2* remapXY, int photometric,
                   float factor, const uint8_t* mask_org, const uint8_t* bgr_org, float* out_I, float* out_mask, uint8_t* out_bgr) {
     IngestParams P;
-    P.raw = raw; P.bpp = bpp; P.wOrg = wOrg; P.hOrg = hOrg; P.w = c->w; P.h = c->h; P.G = G; P.vinv = vinv; P.remapX = remapX; P.remapY = remapY; P.photometric = photometric;
+    P.raw = raw; P.bpp = bpp; P.wOrg = wOrg; P.hOrg = hOrg; P.w = c->w; P.h = c->h; P.G = G; P.vinv = vinv; P.remapXY = remapXY; P.photometric = photometric;
     P.factor = factor; P.mask_org = mask_org; P.bgr_org = bgr_org; P.out_I = out_I; P.out_mask = out_mask; P.out_bgr = out_bgr;
     P.ifx = 1.0 / ((double)c->w / wOrg); P.ify = 1.0 / ((double)c->h / hOrg);
-    const int n = c->w * c->h;
-    ProfScope ps(c, "ingest");
-    ingest_kernel<<<(n + 255) / 256, 256, 0, st>>>(P);                  // one pixel per lane, consecutive workgroups on consecutive memory (scripts/ubench/copy.hip)
+    const int n = c->w * c->h, grid = (n + 255) / 256;                   // one pixel per lane, consecutive workgroups on consecutive memory (scripts/ubench/copy.hip)
+    ProfScope ps(c, "ingest", true);                                       // dispatch-attached timestamps
+#define NALO_INGEST(B_, P_) do { if (ps.a) hipExtLaunchKernelGGL((ingest_kernel<B_, P_>), dim3(grid), dim3(256), 0, st, ps.a, ps.b, 0, P); else ingest_kernel<B_, P_><<<grid, 256, 0, st>>>(P); } while (0)
+    if (bpp == 1) { if (photometric == 0) NALO_INGEST(1, 0); else if (photometric == 1) NALO_INGEST(1, 1); else NALO_INGEST(1, 2); }
+    else { if (photometric == 0) NALO_INGEST(2, 0); else if (photometric == 1) NALO_INGEST(2, 1); else NALO_INGEST(2, 2); }
+#undef NALO_INGEST
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }
@@ -375,7 +399,7 @@ void hbm_stream_launch(hipStream_t st, const float4* a, const float4* b, float4*
 
 int pyramid_build(nalo_ctx* c, FrameSlot& s, const float* gammaB_dev) {
     s.tiled_valid = false;
-    ProfScope ps(c, "pyramid");
+    ProfScope ps(c, "pyramid", true);                                      // dispatch-attached timestamps: start of the first launch .. end of the last
     PyrLevels P;
     P.L = c->levels;
     int nb = 0;
@@ -390,22 +414,28 @@ int pyramid_build(nalo_ctx* c, FrameSlot& s, const float* gammaB_dev) {
     if (fused) {
         // one pass over level 0 (pyr_one_pass_kernel): every level of a pyramid of <= 4 levels, the three finest + the planar values of the rest otherwise
         const int tiles = ((c->wl[0] + kPyrTW - 1) / kPyrTW) * ((c->hl[0] + kPyrTH - 1) / kPyrTH);
+#define NALO_PYR1(NL_, E0_, E1_) do { if (ps.a) hipExtLaunchKernelGGL((pyr_one_pass_kernel<NL_>), dim3(tiles), dim3(256), 0, c->stream, E0_, E1_, 0, P, gammaB_dev); \
+                                      else pyr_one_pass_kernel<NL_><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev); } while (0)
         switch (c->levels) {
-            case 2: pyr_one_pass_kernel<2><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev); break;
-            case 3: pyr_one_pass_kernel<3><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev); break;
-            case 4: pyr_one_pass_kernel<4><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev); break;
+            case 2: NALO_PYR1(2, ps.a, ps.b); break;
+            case 3: NALO_PYR1(3, ps.a, ps.b); break;
+            case 4: NALO_PYR1(4, ps.a, ps.b); break;
             default:
-                pyr_one_pass_kernel<3><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev);
-                pyr_grad_tail_kernel<<<nb - P.blk0[3], 256, 0, c->stream>>>(P, gammaB_dev, 3);
+                NALO_PYR1(3, ps.a, nullptr);
+                if (ps.a) hipExtLaunchKernelGGL(pyr_grad_tail_kernel, dim3(nb - P.blk0[3]), dim3(256), 0, c->stream, nullptr, ps.b, 0, P, gammaB_dev, 3);
+                else pyr_grad_tail_kernel<<<nb - P.blk0[3], 256, 0, c->stream>>>(P, gammaB_dev, 3);
         }
+#undef NALO_PYR1
         NALO_HIP(c, hipGetLastError());
         return NALO_OK;
     }
+    if (ps.a) (void)hipEventRecord(ps.a, c->stream);
     for (int l = 1; l < c->levels; ++l) {                     // a pyramid with an odd parent level (explicit `levels`): level by level
         const int n = c->wl[l] * c->hl[l];
         pyr_down_kernel<<<std::min((n + 255) / 256, 2048), 256, 0, c->stream>>>(s.I[l - 1], s.I[l], c->wl[l], c->hl[l], c->wl[l - 1]);
     }
     pyr_grad_all_kernel<<<nb, 256, 0, c->stream>>>(P, gammaB_dev);
+    if (ps.b) (void)hipEventRecord(ps.b, c->stream);
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }

@@ -64,7 +64,7 @@ struct nalo_ctx {
     float gamma_last[256]; bool gamma_have = false;   // what gamma_dev holds: the table is re-sent only when the caller's differs (and then behind every kernel that may read it)
     // raw-frame ingest (nalo_undist_set / nalo_frame_upload_raw): photometric + geometric undistortion tables, raw staging
     int und_wOrg = 0, und_hOrg = 0, und_photometric = 0, und_GDepth = 0; bool und_set = false, und_remap = false, und_vig = false;
-    nalo::DevBuf<float> und_G, und_vinv, und_rx, und_ry; nalo::DevBuf<uint8_t> und_raw, und_mask, und_bgr;
+    nalo::DevBuf<float> und_G, und_vinv, und_rxy; nalo::DevBuf<uint8_t> und_raw, und_mask, und_bgr;   // und_rxy: the remap table interleaved {x, y} (one 8-byte load per pixel in the ingest pass)
     std::string err;
     std::vector<nalo::FrameSlot> slots;
 
@@ -82,6 +82,7 @@ struct nalo_ctx {
     int lm_evals_lvl[5] = {};                // LM evaluations per pyramid level of the last persistent-kernel launch (nalo_trk_last_evals)
     bool lm_host_only = false;                 // latched when a trk_lm launch lost a workgroup (CUs taken by another context): the host-driven LM loop from then on
     nalo::DevBuf<int> scan_tmp;              // compaction counts
+    nalo::DevBuf<unsigned long long> dense_lb;   // nalo_dense_make_map scratch: row table | chunk aggregates | last[2] | ticket
     nalo::DevBuf<int> trk_cnt;               // hits per level-0 pixel of the reference scatter (ordered redo of pixels with >= 3 hits)
     nalo::DevBuf<float> upload_tmp;
     float* pinned_f = nullptr; size_t pinned_f_cap = 0;
@@ -188,7 +189,7 @@ constexpr int NALO_LM_LOST_BLOCK = 1000;     // trk_lm_launch only (never crosse
 int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
 int frame_tile_level0(nalo_ctx* c, nalo::FrameSlot& s);
 void hbm_stream_launch(hipStream_t st, const float4* a, const float4* b, float4* d, size_t n, int triad);
-int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float* remapX, const float* remapY, int photometric,
+int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float2* remapXY, int photometric,
                   float factor, const uint8_t* mask_org, const uint8_t* bgr_org, float* out_I, float* out_mask, uint8_t* out_bgr);
 // kernels_tracker.hip
 int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const float* dId, const float* dHdi);
