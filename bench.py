@@ -292,7 +292,9 @@ def cpu_baseline(win, st6, trk, budget_s=20.0, track=True, nthreads=6, linearize
             "(FullSystemOptimize.cpp:154-164)" % nthreads) if not linearize_mt else \
            ("all usable cores: %d workers for accumulate, resubstitute AND linearizeAll (chunks of 50 points, as upstream DSO); the tracker stays "
             "single-threaded as in the reference" % nthreads)
-    return dict(value=kfs, unit="keyframes/s", cores=nthreads, kind="port", sample=sample, threading=note)
+    return dict(value=kfs, unit="keyframes/s", cores=nthreads, kind="port", sample=sample, threading=note,
+                build="liboracle_fast.so: -O3 -march=native (the reference's flags, CMakeLists.txt:48), scalar calcRes, SSE (_mm_*) calcGSSSE / Accumulator9 as "
+                      "MatrixAccumulators.h:1091-1166 writes them, a persistent worker pool handing out chunks of 50 points (IndexThreadReduce.h:76-137)")
 
 
 def main():

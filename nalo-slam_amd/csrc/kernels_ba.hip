@@ -721,14 +721,29 @@ __global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __r
                         if (t < W && t != h && (rs[i] & RS_ACTIVE)) bsum -= term;
                     }
                 }
-            } else {                                            // large window: bandwidth bound, inactive slots are not fetched
-                for (int t = 0; t < W; ++t) {
-                    if (t == h) continue;
-                    const size_t si = (size_t)t * B.Ppad + d;
-                    if (!(B.rs_state[si] & RS_ACTIVE)) continue;
-                    const float4 j0 = B.rs_jp0[si], j1 = B.rs_jp1[si];
-                    const float* xa = xAd + (size_t)(h * W + t) * 8;
-                    bsum -= xa[0] * j0.x + xa[1] * j0.y + xa[2] * j0.z + xa[3] * j0.w + xa[4] * j1.x + xa[5] * j1.y + xa[6] * j1.z + xa[7] * j1.w;
+            } else {
+                // large window: every state byte first, then the JpJdF pairs of the ACTIVE slots with all loads in flight (an inactive slot re-reads the
+                // point's first slot instead of branching: a load under a lane-divergent branch is waited for at the join, which made this loop a chain of
+                // 2 (W - 1) dependent round trips: 16.7 us for 62 MB at 1.75 M residuals)
+                for (int t0 = 0; t0 < W; t0 += 8) {
+                    uint8_t rs[8]; float4 j0[8], j1[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const int t = t0 + i; rs[i] = (t < W && t != h) ? B.rs_state[(size_t)t * B.Ppad + d] : 0; }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int t = t0 + i;
+                        const bool on = t < W && (rs[i] & RS_ACTIVE);
+                        const size_t si = (size_t)(on ? t : 0) * B.Ppad + d;
+                        j0[i] = B.rs_jp0[si]; j1[i] = B.rs_jp1[si];
+                        if (!on) rs[i] = 0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int t = t0 + i;
+                        const float* xa = xAd + (size_t)(h * W + min(t, W - 1)) * 8;
+                        const float term = xa[0] * j0[i].x + xa[1] * j0[i].y + xa[2] * j0[i].z + xa[3] * j0[i].w + xa[4] * j1[i].x + xa[5] * j1[i].y + xa[6] * j1[i].z + xa[7] * j1[i].w;
+                        if (rs[i] & RS_ACTIVE) bsum -= term;
+                    }
                 }
             }
             stp = -bsum * pa.z;

@@ -381,6 +381,44 @@ static double linearize_points(OrcBA* ba, int fix, int lo, int hi) {
         } }
     return E;
 }
+#ifdef ORC_FAST
+/* Persistent worker pool of the timed baseline (the reference keeps its IndexThreadReduce workers alive and hands them chunk ranges, util/IndexThreadReduce.h:76-137;
+ * rounds 1-2 created and joined the threads per call, which made the all-cores line SLOWER than the 6-thread one). One pool per process, grown on demand;
+ * workers sleep on a condition variable between jobs. */
+typedef struct { pthread_t th[ORC_MAXTHREADS]; int n; pthread_mutex_t mu; pthread_cond_t cv_go, cv_done; unsigned gen; int pending; void* (*fn)(void*); void* arg[ORC_MAXTHREADS]; int nrun; } OrcPool;
+static OrcPool g_pool = { .n = 0, .mu = PTHREAD_MUTEX_INITIALIZER, .cv_go = PTHREAD_COND_INITIALIZER, .cv_done = PTHREAD_COND_INITIALIZER };
+static void* pool_worker(void* a) {
+    const int id = (int)(size_t)a; unsigned seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.cv_go, &g_pool.mu);
+        seen = g_pool.gen;
+        if (id < g_pool.nrun) {
+            void* (*fn)(void*) = g_pool.fn; void* arg = g_pool.arg[id];
+            pthread_mutex_unlock(&g_pool.mu);
+            fn(arg);
+            pthread_mutex_lock(&g_pool.mu);
+            if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.cv_done);
+        }
+    }
+    return 0;
+}
+/* runs fn(args[t]) for t = 0 .. nt-1: t = 0 on the caller, the rest on the pool */
+static void pool_run(int nt, void* (*fn)(void*), void** args) {
+    if (nt > ORC_MAXTHREADS) nt = ORC_MAXTHREADS;
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.n < nt - 1) { pthread_create(&g_pool.th[g_pool.n], 0, pool_worker, (void*)(size_t)g_pool.n); g_pool.n++; }
+    g_pool.fn = fn; g_pool.nrun = nt - 1; g_pool.pending = nt - 1;
+    for (int t = 1; t < nt; t++) g_pool.arg[t - 1] = args[t];
+    g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.cv_go);
+    pthread_mutex_unlock(&g_pool.mu);
+    fn(args[0]);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.pending > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+}
+#endif
 typedef struct { OrcBA* ba; int fix, tid, nt; double E; } LinJob;
 static void* lin_job_run(void* arg) {
     LinJob* j=(LinJob*)arg; OrcBA* ba=j->ba; j->E=0;
@@ -391,11 +429,9 @@ double orc_ba_linearize_all(OrcBA* ba, int fix) {
     double t0=now_s(), E=0; int W=ba->W;
 #ifdef ORC_FAST
     if (ba->linearize_mt && ba->nthreads_used>1) {     /* upstream DSO's linearizeAll_Reductor over chunks of points; residuals are independent */
-        LinJob jobs[ORC_MAXTHREADS]; pthread_t th[ORC_MAXTHREADS]; int nt=ba->nthreads_used;
-        for (int t=0;t<nt;t++) { jobs[t].ba=ba; jobs[t].fix=fix; jobs[t].tid=t; jobs[t].nt=nt; }
-        for (int t=1;t<nt;t++) pthread_create(&th[t],0,lin_job_run,&jobs[t]);
-        lin_job_run(&jobs[0]);
-        for (int t=1;t<nt;t++) pthread_join(th[t],0);
+        LinJob jobs[ORC_MAXTHREADS]; void* args[ORC_MAXTHREADS]; int nt=ba->nthreads_used;
+        for (int t=0;t<nt;t++) { jobs[t].ba=ba; jobs[t].fix=fix; jobs[t].tid=t; jobs[t].nt=nt; args[t]=&jobs[t]; }
+        pool_run(nt, lin_job_run, args);
         for (int t=0;t<nt;t++) E+=jobs[t].E;
     } else
 #endif
@@ -583,10 +619,9 @@ static void run_jobs(OrcBA* ba, int kind, int mode, int shift, const float* xc, 
     Job jobs[ORC_MAXTHREADS]; int nt=ba->nthreads_used;
     for (int t=0;t<nt;t++) { jobs[t].ba=ba; jobs[t].tid=t; jobs[t].kind=kind; jobs[t].mode=mode; jobs[t].shift=shift; jobs[t].xc=xc; jobs[t].xAd=xAd; }
 #ifdef ORC_FAST
-    pthread_t th[ORC_MAXTHREADS];
-    for (int t=1;t<nt;t++) pthread_create(&th[t],0,job_run,&jobs[t]);
-    job_run(&jobs[0]);
-    for (int t=1;t<nt;t++) pthread_join(th[t],0);
+    void* args[ORC_MAXTHREADS];
+    for (int t=0;t<nt;t++) args[t]=&jobs[t];
+    pool_run(nt, job_run, args);
 #else
     for (int t=0;t<nt;t++) job_run(&jobs[t]);     /* serial emulation of the static chunk split: deterministic */
 #endif

@@ -281,13 +281,54 @@ void orc_trk_calc_res(OrcTracker* T, const float* dI_new, int lvl, const double 
  * Accumulator9::updateSSE_eighted (MatrixAccumulators.h:1091-1166): 45 upper-tri entries x 4 SSE lanes,
  * shiftUp every >1000 updates (:1325-1344), finish adds the 4 lanes of tier 1m (:1001-1017).
  * H,b divided by the PADDED count, then scaled (:873-884). */
+#ifdef ORC_FAST
+#include <xmmintrin.h>
+/* The timed baseline's calcGSSSE as the reference writes it: four points per step in __m128 lanes, the nine J rows as in CoarseTracker.cpp:846-867,
+ * Accumulator9::updateSSE_eighted (MatrixAccumulators.h:1091-1166: 45 x {load, mul, add, store} on SSEData) and the three-tier shiftUp. Same lane arithmetic as
+ * the portable loop below (which the strict builds run). */
+static void calc_gs_sse(OrcTracker* T, int lvl, float aff_a, float b0, float* S /* 45*4, aligned */, float* S1k, float* S1m) {
+    const __m128 fxl = _mm_set1_ps(T->fx[lvl]), fyl = _mm_set1_ps(T->fy[lvl]), b0v = _mm_set1_ps(b0), a = _mm_set1_ps(aff_a);
+    const __m128 one = _mm_set1_ps(1.f), minusOne = _mm_set1_ps(-1.f), zero = _mm_set1_ps(0.f);
+    float numIn1 = 0, numIn1k = 0;
+    const int n = T->bw_n;
+    for (int i = 0; i < n; i += 4) {
+        const __m128 dx = _mm_mul_ps(_mm_loadu_ps(T->bw_dx + i), fxl), dy = _mm_mul_ps(_mm_loadu_ps(T->bw_dy + i), fyl);
+        const __m128 u = _mm_loadu_ps(T->bw_u + i), v = _mm_loadu_ps(T->bw_v + i), id = _mm_loadu_ps(T->bw_idepth + i);
+        __m128 J[9];
+        J[0] = _mm_mul_ps(id, dx);
+        J[1] = _mm_mul_ps(id, dy);
+        J[2] = _mm_sub_ps(zero, _mm_mul_ps(id, _mm_add_ps(_mm_mul_ps(u, dx), _mm_mul_ps(v, dy))));
+        J[3] = _mm_sub_ps(zero, _mm_add_ps(_mm_mul_ps(_mm_mul_ps(u, v), dx), _mm_mul_ps(dy, _mm_add_ps(one, _mm_mul_ps(v, v)))));
+        J[4] = _mm_add_ps(_mm_mul_ps(_mm_mul_ps(u, v), dy), _mm_mul_ps(dx, _mm_add_ps(one, _mm_mul_ps(u, u))));
+        J[5] = _mm_sub_ps(_mm_mul_ps(u, dy), _mm_mul_ps(v, dx));
+        J[6] = _mm_mul_ps(a, _mm_sub_ps(b0v, _mm_loadu_ps(T->bw_ref + i)));
+        J[7] = minusOne;
+        J[8] = _mm_loadu_ps(T->bw_res + i);
+        const __m128 w = _mm_loadu_ps(T->bw_w + i);
+        float* pt = S;
+        for (int r = 0; r < 9; r++) {
+            const __m128 Jw = _mm_mul_ps(J[r], w);
+            for (int c = r; c < 9; c++) { _mm_store_ps(pt, _mm_add_ps(_mm_load_ps(pt), _mm_mul_ps(Jw, J[c]))); pt += 4; }
+        }
+        numIn1++;
+        if (numIn1 > 1000) { for (int k = 0; k < 180; k += 4) { _mm_store_ps(S1k + k, _mm_add_ps(_mm_load_ps(S1k + k), _mm_load_ps(S + k))); _mm_store_ps(S + k, zero); } numIn1k += numIn1; numIn1 = 0; }
+        if (numIn1k > 1000) { for (int k = 0; k < 180; k += 4) { _mm_store_ps(S1m + k, _mm_add_ps(_mm_load_ps(S1m + k), _mm_load_ps(S1k + k))); _mm_store_ps(S1k + k, zero); } numIn1k = 0; }
+    }
+    for (int k = 0; k < 180; k++) { S1k[k] += S[k]; S[k] = 0; }
+    for (int k = 0; k < 180; k++) { S1m[k] += S1k[k]; S1k[k] = 0; }
+}
+#endif
 void orc_trk_calc_gs(OrcTracker* T, int lvl, float aff_a /* (float)affLL[0] */, float b0, double H_out[64], double b_out[8]) {
     T->n_calcgs++;
-    static float S[45*4], S1k[45*4], S1m[45*4]; static double D[45];
+    static float S[45*4] __attribute__((aligned(16))), S1k[45*4] __attribute__((aligned(16))), S1m[45*4] __attribute__((aligned(16))); static double D[45];
     memset(S,0,sizeof(S)); memset(S1k,0,sizeof(S1k)); memset(S1m,0,sizeof(S1m)); memset(D,0,sizeof(D));
     float numIn1=0, numIn1k=0;
     real fxl=T->fx[lvl], fyl=T->fy[lvl];
     int n=T->bw_n;
+#ifdef ORC_FAST
+    calc_gs_sse(T, lvl, aff_a, b0, S, S1k, S1m);
+    n = 0;                                                       /* the portable loop below is the strict builds' */
+#endif
     for (int i=0;i<n;i+=4) {
         real J[9][4], w[4];
         for (int l=0;l<4;l++) {
@@ -325,6 +366,7 @@ void orc_trk_calc_gs(OrcTracker* T, int lvl, float aff_a /* (float)affLL[0] */, 
         double d = ref ? (double)(float)(S1m[idx*4]+S1m[idx*4+1]+S1m[idx*4+2]+S1m[idx*4+3]) : D[idx];
         Hf[r*9+c]=Hf[c*9+r]=d; idx++;
     }
+    n = T->bw_n;
     double inv = ref ? (double)(1.0f/n) : 1.0/(double)n;
     static const double sc[8] = {SCALE_XI_ROT,SCALE_XI_ROT,SCALE_XI_ROT,SCALE_XI_TRANS,SCALE_XI_TRANS,SCALE_XI_TRANS,SCALE_A,SCALE_B};
     for (int r=0;r<8;r++) { for (int c=0;c<8;c++) H_out[r*8+c] = Hf[r*9+c]*inv*sc[r]*sc[c]; b_out[r] = Hf[r*9+8]*inv*sc[r]; }
