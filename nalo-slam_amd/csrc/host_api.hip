@@ -707,17 +707,8 @@ int nalo_init_calc_res_and_gs(nalo_ctx* c, int slot_first, int slot_new, int lvl
     for (int s : {slot_first, slot_new}) if (s < 0 || s >= (int)c->slots.size() || !c->slots[s].valid) return fail(c, NALO_ERR_STATE, "nalo_init_calc_res_and_gs: frame slot has no pyramid");
     NALO_HIP(c, hipSetDevice(c->device));
     const SE3 T = SE3::from(refToNew);
-    // RKi = (R * K^-1).cast<float>(), t.cast<float>(), r2new_aff = (exp(a), b) as floats (:347-349)
-    const double fxd = c->fx[lvl], fyd = c->fy[lvl], cxd = c->cx[lvl], cyd = c->cy[lvl];
-    const double Ki[9] = {1.0 / fxd, 0, -cxd / fxd, 0, 1.0 / fyd, -cyd / fyd, 0, 0, 1};
-    float RKi[9], tf[3];
-    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) RKi[i * 3 + j] = (float)(T.R(i, 0) * Ki[j] + T.R(i, 1) * Ki[3 + j] + T.R(i, 2) * Ki[6 + j]); tf[i] = (float)T.t(i); }
-    const float r2new0 = (float)std::exp(aff[0]), r2new1 = (float)aff[1];
-    const float K4[4] = {(float)fxd, (float)fyd, (float)cxd, (float)cyd};
-    const double tsq = T.t(0) * T.t(0) + T.t(1) * T.t(1) + T.t(2) * T.t(2);
-    float alphaEnergy = (float)((double)alphaW * (0.0 + tsq * n));                     // EAlpha.A is always 0 in the reference (:560-575)
-    float alphaOpt;
-    if (alphaEnergy > alphaK * n) { alphaOpt = 0; alphaEnergy = alphaK * n; } else alphaOpt = alphaW;
+    InitParams P; InitPose X;
+    init_pose_setup(c, lvl, n, T, aff, alphaW, alphaK, couplingWeight, P, X);
     double sums[96] = {};
     if (n > 0) {
         // words in: [u | v | idepth_new | iR | energy(2n) | outlierTH | isGood bytes]; out: [energy_new(2n) | maxstep | lastHessian_new | Jb(10n) | isGood_new bytes]; then 96 doubles
@@ -731,7 +722,11 @@ int nalo_init_calc_res_and_gs(nalo_ctx* c, int slot_first, int slot_new, int lvl
         float* d = c->imm_dev.p;
         const size_t sums_off = (in_w + out_w + 1) & ~(size_t)1;                                                      // 8-byte aligned
         NALO_HIP(c, hipMemcpyAsync(d, hst, (in_w + out_w) * 4, hipMemcpyHostToDevice, c->stream));
-        rc = init_calc_launch(c, c->slots[slot_first].dI[lvl], c->slots[slot_new].dI[lvl], lvl, n, K4, RKi, tf, r2new0, r2new1, alphaOpt, couplingWeight, d, d + in_w, (double*)(d + sums_off));
+        P.colorRef = c->slots[slot_first].dI[lvl]; P.colorNew = c->slots[slot_new].dI[lvl];
+        P.u = d; P.v = d + N; P.idepth = nullptr; P.idepth_new = d + 2 * N; P.iR = d + 3 * N; P.energy = d + 4 * N; P.outlierTH = d + 6 * N; P.isGood = (const uint8_t*)(d + 7 * N);
+        float* outw = d + in_w;
+        P.energy_new = outw; P.maxstep = outw + 2 * N; P.lastHessian_new = outw + 3 * N; P.Jb = outw + 4 * N; P.isGood_new = (uint8_t*)(outw + 14 * N);
+        rc = init_calc_launch(c, P, lvl, (double*)(d + sums_off));
         if (rc) return rc;
         NALO_HIP(c, hipMemcpyAsync(ho, d + in_w, (sums_off - in_w + 2 * 96) * 4, hipMemcpyDeviceToHost, c->stream));
         NALO_HIP(c, hipStreamSynchronize(c->stream));
@@ -739,19 +734,7 @@ int nalo_init_calc_res_and_gs(nalo_ctx* c, int slot_first, int slot_new, int lvl
         std::memcpy(JbBuffer_new, ho + 4 * N, 10 * N * 4); std::memcpy(isGood_new, ho + 14 * N, N);
         std::memcpy(sums, hst + sums_off, 91 * 8);
     }
-    // Accumulator9::finish -> float matrix, then topLeftCorner<8,8> / topRightCorner<8,1> (:596-599) and the alpha terms (:601-607)
-    int e = 0;
-    for (int a = 0; a < 9; ++a) for (int b = a; b < 9; ++b, ++e) {
-        const double va = (double)(float)sums[e], vs = (double)(float)sums[45 + e];
-        if (b < 8) { H_out[a * 8 + b] = H_out[b * 8 + a] = va; H_out_sc[a * 8 + b] = H_out_sc[b * 8 + a] = vs; }
-        else if (a < 8) { b_out[a] = va; b_out_sc[a] = vs; }
-    }
-    double xi[6]; se3_log(T, xi);
-    for (int k = 0; k < 3; ++k) {
-        H_out[k * 8 + k] = (double)(float)((float)H_out[k * 8 + k] + alphaOpt * n);
-        b_out[k] = (double)(float)((float)b_out[k] + (float)xi[k] * alphaOpt * n);
-    }
-    E3[0] = (double)(float)sums[90]; E3[1] = alphaEnergy; E3[2] = 2.0 * n;
+    init_sums_to_system(sums, T, n, P, X, H_out, b_out, H_out_sc, b_out_sc, E3);
     return NALO_OK;
 }
 
@@ -759,15 +742,15 @@ int nalo_init_do_step(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb
     if (!c || n < 0 || !inc || (n > 0 && (!isGood || !JbBuffer || !maxstep || !idepth || !idepth_new))) return fail(c, NALO_ERR_ARG, "nalo_init_do_step: bad argument");
     if (n == 0) return NALO_OK;
     NALO_HIP(c, hipSetDevice(c->device));
-    // words: [Jb(10n) | maxstep | idepth | idepth_new (in/out) | inc(8) | isGood bytes]
-    const size_t N = (size_t)n, tot = 13 * N + 8 + (N + 3) / 4;
+    // words: [Jb(10n) | maxstep | idepth | idepth_new (in/out) | isGood bytes]
+    const size_t N = (size_t)n, tot = 13 * N + (N + 3) / 4;
     int rc = imm_stage(c, tot); if (rc) return rc;
     float* hst = c->imm_host;
     std::memcpy(hst, JbBuffer, 10 * N * 4); std::memcpy(hst + 10 * N, maxstep, N * 4); std::memcpy(hst + 11 * N, idepth, N * 4); std::memcpy(hst + 12 * N, idepth_new, N * 4);
-    std::memcpy(hst + 13 * N, inc, 32); std::memcpy(hst + 13 * N + 8, isGood, N);
+    std::memcpy(hst + 13 * N, isGood, N);
     float* d = c->imm_dev.p;
     NALO_HIP(c, hipMemcpyAsync(d, hst, tot * 4, hipMemcpyHostToDevice, c->stream));
-    rc = init_do_step_launch(c, n, (const uint8_t*)(d + 13 * N + 8), d, d + 10 * N, d + 11 * N, lambda, d + 13 * N, d + 12 * N);
+    rc = init_do_step_launch(c, n, (const uint8_t*)(d + 13 * N), d, d + 10 * N, d + 11 * N, lambda, inc, d + 12 * N);
     if (rc) return rc;
     NALO_HIP(c, hipMemcpyAsync(hst + 12 * N, d + 12 * N, N * 4, hipMemcpyDeviceToHost, c->stream));
     NALO_HIP(c, hipStreamSynchronize(c->stream));

@@ -11,13 +11,18 @@
 // What runs where: the two per-point passes that touch the images (calcResAndGS, doStep) and both selections are kernels; everything else here is SEQUENTIAL
 // BY CONSTRUCTION in the reference — optReg is a Gauss-Seidel sweep (point i reads the iR its lower-index neighbours were just given), resetPoints likewise,
 // propagateUp adds children into their parent in index order (fp32, order matters), and makeNN's result depends on the traversal order of nanoflann's k-d
-// tree wherever neighbours are equidistant (points sit on the integer grid + 0.1, so most 10-NN sets end in a tie). The host code keeps those orders; the
-// point arrays (SoA) live on the host between the kernel calls and travel through the pinned staging block of the context. The initialiser runs once per
-// sequence on a few tens of thousands of points: ~50 kernel evaluations per frame.
+// tree wherever neighbours are equidistant (points sit on the integer grid + 0.1, so most 10-NN sets end in a tie). The host code keeps those orders.
+//
+// Residency: inside a level's Levenberg-Marquardt loop the Pnt arrays (SoA) and both JbBuffers live on the DEVICE (InitDev below): doStep, calcResAndGS (which also
+// forms calcEC's three sums) and applyStep are kernels on them, and one evaluation moves 94 doubles plus {idepth_new, isGood_new} down (what the host's mirror of
+// applyStep and the next optReg sweep read) and, after an accepted step, the re-regularised iR up. The host mirror is authoritative between levels (propagateDown /
+// resetPoints before a level, propagateUp after the last): one packed upload when a level starts, one packed download when it ends. makeNN's 10-NN / parent
+// queries are independent per point and run on a few host threads against trees built one level per thread.
 #include "nalo_internal.h"
 #include <cfloat>
 #include <cmath>
 #include <numeric>
+#include <thread>
 
 namespace nalo {
 
@@ -205,21 +210,43 @@ struct InitLevel {
     }
 };
 
+constexpr int kInitHostThreads = 8;                      // makeNN's query slices (the reference's own pool has NUM_THREADS = 6, util/NumType.h:42)
+
 struct Initializer {
     int levels = 0, slot_first = -1;
     InitLevel L[NALO_MAX_LEVELS];
-    std::vector<float> Jb, Jb_new;                       // JbBuffer / JbBuffer_new (one buffer for all levels, as in the reference)
     SE3 thisToNext = SE3::identity();
     double aff[2] = {0, 0};                              // thisToNext_aff
     bool snapped = false, fixAffine = true;
     int frameID = -1, snappedAt = 0, n_evals = 0;
     float alphaK = 2.5f * 2.5f, alphaW = 150.f * 150.f, regWeight = 0.8f, couplingWeight = 1.f;
     DevBuf<uint8_t> map_dev; DevBuf<int> cnt_dev;
+    // device residency of the Pnt arrays: one block per level, word offsets from lvl_off(); JbBuffer / JbBuffer_new are one pair for all levels, as in the reference
+    DevBuf<float> lvl_dev[NALO_MAX_LEVELS], jb_dev[2];
+    bool static_on_dev = false;
+    int jb_cur = 0;
+    float* pin = nullptr; size_t pin_half = 0;           // pinned staging: [0, pin_half) host -> device, [pin_half, 2 pin_half) device -> host
 };
+
+// word offsets inside a level's device block: the static members, then the members a level's LM loop changes ("dyn": one packed upload / download per level), the last
+// two of which (idepth_new, isGood_new) come down after every evaluation together with the 94 sums that follow them
+struct LvlOff { size_t u, v, outlierTH, dyn, idepth, iR, lastHessian, lastHessian_new, maxstep, energy, energy_new, isGood, idepth_new, isGood_new, dyn_end, sums, total; };
+static LvlOff lvl_off(size_t n) {
+    const size_t nb = (n + 3) / 4;
+    LvlOff o;
+    o.u = 0; o.v = n; o.outlierTH = 2 * n; o.dyn = (3 * n + 1) & ~(size_t)1;
+    o.idepth = o.dyn; o.iR = o.idepth + n; o.lastHessian = o.iR + n; o.lastHessian_new = o.lastHessian + n; o.maxstep = o.lastHessian_new + n;
+    o.energy = o.maxstep + n; o.energy_new = o.energy + 2 * n; o.isGood = o.energy_new + 2 * n; o.idepth_new = o.isGood + nb; o.isGood_new = o.idepth_new + n;
+    o.dyn_end = o.isGood_new + nb; o.sums = (o.dyn_end + 1) & ~(size_t)1; o.total = o.sums + 2 * 96;
+    return o;
+}
 
 void init_destroy(nalo_ctx* c) {
     if (!c->init) return;
     c->init->map_dev.release(); c->init->cnt_dev.release();
+    for (auto& b : c->init->lvl_dev) b.release();
+    for (auto& b : c->init->jb_dev) b.release();
+    if (c->init->pin) (void)hipHostFree(c->init->pin);
     delete c->init; c->init = nullptr;
 }
 
@@ -298,39 +325,139 @@ static void reset_points(Initializer& I, int lvl) {                             
         }
     }
 }
-static void apply_step(Initializer& I, int lvl) {                                              // applyStep :939-956
+// applyStep (:939-956) on the host mirror, for the members the host sweeps read (the device runs init_apply_step_kernel on all of them; the JbBuffer swap is jb_cur)
+static void apply_step_host(Initializer& I, int lvl) {
     InitLevel& P = I.L[lvl];
     for (int i = 0; i < P.n; ++i) {
         if (!P.isGood[i]) { P.idepth[i] = P.idepth_new[i] = P.iR[i]; continue; }
-        P.energy[2 * (size_t)i] = P.energy_new[2 * (size_t)i]; P.energy[2 * (size_t)i + 1] = P.energy_new[2 * (size_t)i + 1];
         P.isGood[i] = P.isGood_new[i];
         P.idepth[i] = P.idepth_new[i];
-        P.lastHessian[i] = P.lastHessian_new[i];
     }
-    I.Jb.swap(I.Jb_new);
-}
-static void calc_ec(const Initializer& I, int lvl, float out[3]) {                             // calcEC :634-655 (fp32 products, fp64 sums)
-    const InitLevel& P = I.L[lvl];
-    if (!I.snapped) { out[0] = 0; out[1] = 0; out[2] = (float)P.n; return; }
-    double e_old = 0, e_new = 0; int num = 0;
-    for (int i = 0; i < P.n; ++i) {
-        if (!P.isGood_new[i]) continue;
-        const float rOld = (P.idepth[i] - P.iR[i]), rNew = (P.idepth_new[i] - P.iR[i]);
-        e_old += (double)(rOld * rOld); e_new += (double)(rNew * rNew); ++num;
-    }
-    out[0] = I.couplingWeight * (float)e_old; out[1] = I.couplingWeight * (float)e_new; out[2] = (float)num;
 }
 
-static int calc(nalo_ctx* c, Initializer& I, int lvl, int slot_new, const SE3& T, const double aff[2], double H[64], double b[8], double Hsc[64], double bsc[8], float res[3]) {
-    InitLevel& P = I.L[lvl];
+static int dev_prepare(nalo_ctx* c, Initializer& I) {                                          // device blocks + pinned staging for the current point counts
+    size_t maxn = 0, maxtot = 0;
+    for (int l = 0; l < I.levels; ++l) { const LvlOff o = lvl_off((size_t)I.L[l].n); NALO_HIP(c, I.lvl_dev[l].reserve(o.total)); maxn = std::max(maxn, (size_t)I.L[l].n); maxtot = std::max(maxtot, o.total); }
+    for (auto& b : I.jb_dev) NALO_HIP(c, b.reserve(10 * maxn + 16));
+    if (I.pin_half < maxtot) {
+        if (I.pin) (void)hipHostFree(I.pin);
+        I.pin = nullptr; I.pin_half = 0;
+        NALO_HIP(c, hipHostMalloc((void**)&I.pin, 2 * maxtot * sizeof(float)));
+        I.pin_half = maxtot;
+    }
+    if (!I.static_on_dev) {
+        for (int l = 0; l < I.levels; ++l) {
+            const InitLevel& P = I.L[l]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
+            if (!n) continue;
+            std::memcpy(I.pin + o.u, P.u.data(), n * 4); std::memcpy(I.pin + o.v, P.v.data(), n * 4); std::memcpy(I.pin + o.outlierTH, P.outlierTH.data(), n * 4);
+            NALO_HIP(c, hipMemcpyAsync(I.lvl_dev[l].p, I.pin, 3 * n * 4, hipMemcpyHostToDevice, c->stream));
+            NALO_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        I.static_on_dev = true;
+    }
+    return NALO_OK;
+}
+// host mirror -> device, every member a level's loop reads or keeps (the *_new members hold stale entries that survive, as in the reference)
+static int level_upload(nalo_ctx* c, Initializer& I, int lvl) {
+    HostTimer ht(c, "init.level_io");
+    const InitLevel& P = I.L[lvl]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
+    if (!n) return NALO_OK;
+    float* h = I.pin - o.dyn;
+    std::memcpy(h + o.idepth, P.idepth.data(), n * 4); std::memcpy(h + o.iR, P.iR.data(), n * 4); std::memcpy(h + o.lastHessian, P.lastHessian.data(), n * 4);
+    std::memcpy(h + o.lastHessian_new, P.lastHessian_new.data(), n * 4); std::memcpy(h + o.maxstep, P.maxstep.data(), n * 4); std::memcpy(h + o.energy, P.energy.data(), 2 * n * 4);
+    std::memcpy(h + o.energy_new, P.energy_new.data(), 2 * n * 4); std::memcpy(h + o.isGood, P.isGood.data(), n); std::memcpy(h + o.idepth_new, P.idepth_new.data(), n * 4);
+    std::memcpy(h + o.isGood_new, P.isGood_new.data(), n);
+    NALO_HIP(c, hipMemcpyAsync(I.lvl_dev[lvl].p + o.dyn, I.pin, (o.dyn_end - o.dyn) * 4, hipMemcpyHostToDevice, c->stream));
+    return NALO_OK;
+}
+static int level_download(nalo_ctx* c, Initializer& I, int lvl) {
+    HostTimer ht(c, "init.level_io");
+    InitLevel& P = I.L[lvl]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
+    if (!n) return NALO_OK;
+    float* hd = I.pin + I.pin_half;
+    NALO_HIP(c, hipMemcpyAsync(hd, I.lvl_dev[lvl].p + o.dyn, (o.dyn_end - o.dyn) * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    const float* h = hd - o.dyn;
+    std::memcpy(P.idepth.data(), h + o.idepth, n * 4); std::memcpy(P.lastHessian.data(), h + o.lastHessian, n * 4); std::memcpy(P.lastHessian_new.data(), h + o.lastHessian_new, n * 4);
+    std::memcpy(P.maxstep.data(), h + o.maxstep, n * 4); std::memcpy(P.energy.data(), h + o.energy, 2 * n * 4); std::memcpy(P.energy_new.data(), h + o.energy_new, 2 * n * 4);
+    std::memcpy(P.isGood.data(), h + o.isGood, n); std::memcpy(P.idepth_new.data(), h + o.idepth_new, n * 4); std::memcpy(P.isGood_new.data(), h + o.isGood_new, n);
+    return NALO_OK;
+}
+static int iR_upload(nalo_ctx* c, Initializer& I, int lvl) {                                   // after optReg: the only member the host changes inside the loop
+    const InitLevel& P = I.L[lvl]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
+    if (!n) return NALO_OK;
+    std::memcpy(I.pin, P.iR.data(), n * 4);
+    NALO_HIP(c, hipMemcpyAsync(I.lvl_dev[lvl].p + o.iR, I.pin, n * 4, hipMemcpyHostToDevice, c->stream));
+    return NALO_OK;
+}
+
+// calcResAndGS on the resident level (writes JbBuffer_new = jb_dev[1 - jb_cur]); brings back the sums and {idepth_new, isGood_new}. regEnergy = calcEC (:634-655)
+static int calc(nalo_ctx* c, Initializer& I, int lvl, int slot_new, const SE3& T, const double aff[2], double H[64], double b[8], double Hsc[64], double bsc[8], float res[3], float regEnergy[3]) {
+    HostTimer ht(c, "init.calc");
+    InitLevel& L = I.L[lvl]; const size_t n = (size_t)L.n; const LvlOff o = lvl_off(n);
+    InitParams P; InitPose X;
+    init_pose_setup(c, lvl, L.n, T, aff, I.alphaW, I.alphaK, I.couplingWeight, P, X);
+    double sums[96] = {};
+    if (n) {
+        float* d = I.lvl_dev[lvl].p;
+        P.colorRef = c->slots[I.slot_first].dI[lvl]; P.colorNew = c->slots[slot_new].dI[lvl];
+        P.u = d + o.u; P.v = d + o.v; P.outlierTH = d + o.outlierTH; P.idepth = d + o.idepth; P.idepth_new = d + o.idepth_new; P.iR = d + o.iR; P.energy = d + o.energy;
+        P.isGood = (const uint8_t*)(d + o.isGood); P.isGood_new = (uint8_t*)(d + o.isGood_new); P.energy_new = d + o.energy_new; P.maxstep = d + o.maxstep;
+        P.lastHessian_new = d + o.lastHessian_new; P.Jb = I.jb_dev[1 - I.jb_cur].p;
+        int rc = init_calc_launch(c, P, lvl, (double*)(d + o.sums)); if (rc) return rc;
+        float* hd = I.pin + I.pin_half;
+        NALO_HIP(c, hipMemcpyAsync(hd, d + o.idepth_new, (o.sums + 2 * 94 - o.idepth_new) * 4, hipMemcpyDeviceToHost, c->stream));
+        NALO_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(L.idepth_new.data(), hd, n * 4); std::memcpy(L.isGood_new.data(), hd + (o.isGood_new - o.idepth_new), n);
+        std::memcpy(sums, hd + (o.sums - o.idepth_new), 94 * 8);
+    }
     double E3[3];
-    const int rc = nalo_init_calc_res_and_gs(c, I.slot_first, slot_new, lvl, P.n, P.u.data(), P.v.data(), P.idepth_new.data(), P.iR.data(), P.isGood.data(), P.energy.data(),
-                                             P.outlierTH.data(), T.m, aff, I.alphaW, I.alphaK, I.couplingWeight, P.isGood_new.data(), P.energy_new.data(), P.maxstep.data(),
-                                             P.lastHessian_new.data(), I.Jb_new.data(), H, b, Hsc, bsc, E3);
-    if (rc) return rc;
+    init_sums_to_system(sums, T, L.n, P, X, H, b, Hsc, bsc, E3);
     res[0] = (float)E3[0]; res[1] = (float)E3[1]; res[2] = (float)E3[2];
+    if (!I.snapped) { regEnergy[0] = 0; regEnergy[1] = 0; regEnergy[2] = (float)L.n; }
+    else { regEnergy[0] = I.couplingWeight * (float)sums[91]; regEnergy[1] = I.couplingWeight * (float)sums[92]; regEnergy[2] = (float)sums[93]; }
     ++I.n_evals;
     return NALO_OK;
+}
+static int apply_step(nalo_ctx* c, Initializer& I, int lvl) {
+    HostTimer ht(c, "init.apply_step");
+    InitLevel& L = I.L[lvl]; const LvlOff o = lvl_off((size_t)L.n);
+    float* d = I.lvl_dev[lvl].p;
+    const int rc = init_apply_step_launch(c, L.n, (uint8_t*)(d + o.isGood), (const uint8_t*)(d + o.isGood_new), d + o.idepth, d + o.idepth_new, d + o.iR, d + o.energy, d + o.energy_new,
+                                          d + o.lastHessian, d + o.lastHessian_new);
+    if (rc) return rc;
+    apply_step_host(I, lvl);
+    I.jb_cur = 1 - I.jb_cur;
+    return NALO_OK;
+}
+
+void init_pose_setup(const nalo_ctx* c, int lvl, int n, const SE3& T, const double aff[2], float alphaW, float alphaK, float couplingWeight, InitParams& P, InitPose& X) {
+    // RKi = (R * K^-1).cast<float>(), t.cast<float>(), r2new_aff = (exp(a), b) as floats (:347-349)
+    const double fxd = c->fx[lvl], fyd = c->fy[lvl], cxd = c->cx[lvl], cyd = c->cy[lvl];
+    const double Ki[9] = {1.0 / fxd, 0, -cxd / fxd, 0, 1.0 / fyd, -cyd / fyd, 0, 0, 1};
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P.RKi[i * 3 + j] = (float)(T.R(i, 0) * Ki[j] + T.R(i, 1) * Ki[3 + j] + T.R(i, 2) * Ki[6 + j]); P.t[i] = (float)T.t(i); }
+    P.r2new0 = (float)std::exp(aff[0]); P.r2new1 = (float)aff[1];
+    P.fx = (float)fxd; P.fy = (float)fyd; P.cx = (float)cxd; P.cy = (float)cyd;
+    const double tsq = T.t(0) * T.t(0) + T.t(1) * T.t(1) + T.t(2) * T.t(2);
+    float alphaEnergy = (float)((double)alphaW * (0.0 + tsq * n));                     // EAlpha.A is always 0 in the reference (:560-575)
+    if (alphaEnergy > alphaK * n) { P.alphaOpt = 0; alphaEnergy = alphaK * n; } else P.alphaOpt = alphaW;
+    P.couplingWeight = couplingWeight; P.n = n;
+    X.alphaEnergy = alphaEnergy;
+}
+void init_sums_to_system(const double* sums, const SE3& T, int n, const InitParams& P, const InitPose& X, double* H_out, double* b_out, double* H_out_sc, double* b_out_sc, double E3[3]) {
+    // Accumulator9::finish -> float matrix, then topLeftCorner<8,8> / topRightCorner<8,1> (:596-599) and the alpha terms (:601-607)
+    int e = 0;
+    for (int a = 0; a < 9; ++a) for (int b = a; b < 9; ++b, ++e) {
+        const double va = (double)(float)sums[e], vs = (double)(float)sums[45 + e];
+        if (b < 8) { H_out[a * 8 + b] = H_out[b * 8 + a] = va; H_out_sc[a * 8 + b] = H_out_sc[b * 8 + a] = vs; }
+        else if (a < 8) { b_out[a] = va; b_out_sc[a] = vs; }
+    }
+    double xi[6]; se3_log(T, xi);
+    for (int k = 0; k < 3; ++k) {
+        H_out[k * 8 + k] = (double)(float)((float)H_out[k * 8 + k] + P.alphaOpt * n);
+        b_out[k] = (double)(float)((float)b_out[k] + (float)xi[k] * P.alphaOpt * n);
+    }
+    E3[0] = (double)(float)sums[90]; E3[1] = X.alphaEnergy; E3[2] = 2.0 * n;
 }
 
 static int make_pixel_status(nalo_ctx* c, Initializer& I, int slot, int lvl, float desiredDensity, int* sparsityFactor, std::vector<uint8_t>& map_host, int* numGood) {
@@ -378,13 +505,15 @@ int nalo_init_set_first(nalo_ctx* c, int slot_first, int* sparsityFactor, int nu
     if (!c->init) c->init = new Initializer();
     Initializer& I = *c->init;
     I.levels = c->levels; I.slot_first = slot_first;
-    I.Jb.assign((size_t)c->w * c->h * 10, 0.f); I.Jb_new.assign((size_t)c->w * c->h * 10, 0.f);
+    I.static_on_dev = false; I.jb_cur = 0;
+    HostTimer htf(c, "init_set_first");
     const float densities[] = {0.03f, 0.05f, 0.15f, 0.5f, 1.f, 1.f};
     const int pad = 2;                                                                           // patternPadding (util/settings.h:234)
     std::vector<float> status0((size_t)c->w * c->h);
     std::vector<uint8_t> mapB;
     for (int lvl = 0; lvl < I.levels; ++lvl) {
         const int wl = c->wl[lvl], hl = c->hl[lvl];
+        HostTimer hs(c, lvl ? "init.select_upper" : "init.select_l0");
         if (lvl == 0) {
             // PixelSelector sel(w,h); sel.currentPotential = 3; sel.makeMaps(firstFrame, statusMap, densities[0]*w*h, 1, false, 2)   (:806-811)
             int pot = 3, have = 0;
@@ -411,18 +540,24 @@ int nalo_init_set_first(nalo_ctx* c, int slot_first, int* sparsityFactor, int nu
             }
         if (numPoints) numPoints[lvl] = nl;
     }
-    // makeNN (:992-1069): 10 nearest neighbours inside the level, nearest point of (u/2 - 0.25, v/2 - 0.25) one level up
+    // makeNN (:992-1069): 10 nearest neighbours inside the level, nearest point of (u/2 - 0.25, v/2 - 0.25) one level up. The trees are built one level per thread
+    // (each build is sequential, its order decides the ties); the queries only read them and are independent per point, so they are cut into slices for a few threads.
     {
+        HostTimer hn(c, "init.make_nn");
         const float NNDistFactor = 0.05f;
-        std::vector<GridKdTree> trees;
-        trees.reserve(I.levels);
-        for (int l = 0; l < I.levels; ++l) trees.emplace_back(I.L[l].u.data(), I.L[l].v.data(), I.L[l].n);
-        for (int lvl = 0; lvl < I.levels; ++lvl) {
+        std::vector<GridKdTree*> trees(I.levels, nullptr);
+        {
+            std::vector<std::thread> th;
+            for (int l = 1; l < I.levels; ++l) th.emplace_back([&, l] { trees[l] = new GridKdTree(I.L[l].u.data(), I.L[l].v.data(), I.L[l].n); });
+            trees[0] = new GridKdTree(I.L[0].u.data(), I.L[0].v.data(), I.L[0].n);
+            for (auto& t : th) t.join();
+        }
+        auto queries = [&](int lvl, int i0, int i1) {
             InitLevel& P = I.L[lvl];
-            for (int i = 0; i < P.n; ++i) {
+            for (int i = i0; i < i1; ++i) {
                 int ri[10]; float rd[10];
                 float q[2] = {P.u[i], P.v[i]};
-                trees[lvl].knn(q, 10, ri, rd);
+                trees[lvl]->knn(q, 10, ri, rd);
                 float sumDF = 0;
                 for (int k = 0; k < 10; ++k) {
                     P.nn[(size_t)i * 10 + k] = ri[k];
@@ -433,12 +568,20 @@ int nalo_init_set_first(nalo_ctx* c, int slot_first, int* sparsityFactor, int nu
                 for (int k = 0; k < 10; ++k) P.nnDist[(size_t)i * 10 + k] *= 10 / sumDF;
                 if (lvl < I.levels - 1) {
                     q[0] = q[0] * 0.5f - 0.25f; q[1] = q[1] * 0.5f - 0.25f;
-                    trees[lvl + 1].knn(q, 1, ri, rd);
+                    trees[lvl + 1]->knn(q, 1, ri, rd);
                     P.parent[i] = ri[0];
                     P.parentDist[i] = expf(-rd[0] * NNDistFactor);
                 } else { P.parent[i] = -1; P.parentDist[i] = -1; }
             }
-        }
+        };
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int nt = std::max(1, std::min(kInitHostThreads, hw > 0 ? hw : 1));
+        auto slice = [&](int t) { for (int lvl = 0; lvl < I.levels; ++lvl) { const long n = I.L[lvl].n; queries(lvl, (int)(n * t / nt), (int)(n * (t + 1) / nt)); } };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(slice, t);
+        slice(0);
+        for (auto& t : th) t.join();
+        for (auto* t : trees) delete t;
     }
     I.thisToNext = SE3::identity();
     I.snapped = false; I.frameID = I.snappedAt = 0;
@@ -450,6 +593,9 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
     if (!c->init || c->init->slot_first < 0) return fail(c, NALO_ERR_STATE, "nalo_init_track_frame: nalo_init_set_first has not run");
     if (slot_new < 0 || slot_new >= (int)c->slots.size() || !c->slots[slot_new].valid) return fail(c, NALO_ERR_STATE, "nalo_init_track_frame: frame slot has no pyramid");
     Initializer& I = *c->init;
+    HostTimer htf(c, "init_track_frame");
+    NALO_HIP(c, hipSetDevice(c->device));
+    { const int rc = dev_prepare(c, I); if (rc) return rc; }
     const int maxIterations[] = {5, 5, 10, 30, 50, 50};
     I.alphaK = 2.5 * 2.5; I.alphaW = 150 * 150; I.regWeight = 0.8; I.couplingWeight = 1;
     if (!I.snapped) {
@@ -464,11 +610,16 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
     if (exposure_first > 0 && exposure_new > 0) { aff_cur[0] = logf(exposure_new / exposure_first); aff_cur[1] = 0; }      // coarse approximation (:123-124)
     const float wM[8] = {kScaleXiRot, kScaleXiRot, kScaleXiRot, kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleA, kScaleB};   // :64-67, labels as the reference has them
     for (int lvl = I.levels - 1; lvl >= 0; --lvl) {
-        if (lvl < I.levels - 1) propagate_down(I, lvl + 1);
         double H[64], b[8], Hsc[64], bsc[8]; float resOld[3];
-        reset_points(I, lvl);
-        int rc = calc(c, I, lvl, slot_new, T_cur, aff_cur, H, b, Hsc, bsc, resOld); if (rc) return rc;
-        apply_step(I, lvl);
+        {
+            HostTimer hp(c, "init.propagate");
+            if (lvl < I.levels - 1) propagate_down(I, lvl + 1);
+            reset_points(I, lvl);
+        }
+        int rc = level_upload(c, I, lvl); if (rc) return rc;
+        float regEnergy[3];
+        rc = calc(c, I, lvl, slot_new, T_cur, aff_cur, H, b, Hsc, bsc, resOld, regEnergy); if (rc) return rc;
+        rc = apply_step(c, I, lvl); if (rc) return rc;
         float lambda = 0.1f; const float eps = 1e-4f; int fails = 0, iteration = 0;
         InitLevel& P = I.L[lvl];
         for (;;) {
@@ -494,10 +645,12 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
             double xi[6]; for (int i = 0; i < 6; ++i) xi[i] = inc[i];
             const SE3 T_new = se3_exp(xi) * T_cur;
             const double aff_new[2] = {aff_cur[0] + inc[6], aff_cur[1] + inc[7]};
-            rc = nalo_init_do_step(c, P.n, P.isGood.data(), I.Jb.data(), P.maxstep.data(), P.idepth.data(), lambda, inc, P.idepth_new.data()); if (rc) return rc;
-            double Hn[64], bn[8], Hscn[64], bscn[8]; float resNew[3], regEnergy[3];
-            rc = calc(c, I, lvl, slot_new, T_new, aff_new, Hn, bn, Hscn, bscn, resNew); if (rc) return rc;
-            calc_ec(I, lvl, regEnergy);
+            {   // doStep (:910-938) on the resident arrays; idepth_new comes back with the evaluation that follows
+                const LvlOff o = lvl_off((size_t)P.n); float* d = I.lvl_dev[lvl].p;
+                rc = init_do_step_launch(c, P.n, (const uint8_t*)(d + o.isGood), I.jb_dev[I.jb_cur].p, d + o.maxstep, d + o.idepth, lambda, inc, d + o.idepth_new); if (rc) return rc;
+            }
+            double Hn[64], bn[8], Hscn[64], bscn[8]; float resNew[3];
+            rc = calc(c, I, lvl, slot_new, T_new, aff_new, Hn, bn, Hscn, bscn, resNew, regEnergy); if (rc) return rc;
             const float eTotalNew = (resNew[0] + resNew[1] + regEnergy[1]);
             const float eTotalOld = (resOld[0] + resOld[1] + regEnergy[0]);
             if (eTotalOld > eTotalNew) {
@@ -505,8 +658,9 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
                 std::memcpy(H, Hn, sizeof(H)); std::memcpy(b, bn, sizeof(b)); std::memcpy(Hsc, Hscn, sizeof(Hsc)); std::memcpy(bsc, bscn, sizeof(bsc));
                 resOld[0] = resNew[0]; resOld[1] = resNew[1]; resOld[2] = resNew[2];
                 aff_cur[0] = aff_new[0]; aff_cur[1] = aff_new[1]; T_cur = T_new;
-                apply_step(I, lvl);
-                opt_reg(I, lvl);
+                rc = apply_step(c, I, lvl); if (rc) return rc;
+                { HostTimer ho(c, "init.opt_reg"); opt_reg(I, lvl); }
+                rc = iR_upload(c, I, lvl); if (rc) return rc;
                 lambda *= 0.5; fails = 0;
                 if (lambda < 0.0001) lambda = 0.0001;
             } else {
@@ -517,9 +671,10 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
             if (!(nrm > eps) || iteration >= maxIterations[lvl] || fails >= 2) break;
             ++iteration;
         }
+        rc = level_download(c, I, lvl); if (rc) return rc;
     }
     I.thisToNext = T_cur; I.aff[0] = aff_cur[0]; I.aff[1] = aff_cur[1];
-    for (int i = 0; i < I.levels - 1; ++i) propagate_up(I, i);
+    { HostTimer hp(c, "init.propagate"); for (int i = 0; i < I.levels - 1; ++i) propagate_up(I, i); }
     ++I.frameID;
     if (!I.snapped) I.snappedAt = 0;
     if (I.snapped && I.snappedAt == 0) I.snappedAt = I.frameID;

@@ -8,17 +8,10 @@
 
 namespace nalo {
 
-constexpr int kInitVals = 91, kInitStride = 96;
+constexpr int kInitVals = 94, kInitStride = 96;      // 45 (acc9) + 45 (acc9SC) + E + calcEC's {sum rOld^2, sum rNew^2, count}
 #define NALO_PAT(i) {kPatternDx[i], kPatternDy[i]}
 __constant__ int kInitPattern[8][2] = {NALO_PAT(0), NALO_PAT(1), NALO_PAT(2), NALO_PAT(3), NALO_PAT(4), NALO_PAT(5), NALO_PAT(6), NALO_PAT(7)};   // settings.cpp:297 (ref_constants.h)
 #undef NALO_PAT
-
-struct InitParams {
-    const float4 *colorRef, *colorNew; int wl, hl, n;
-    float fx, fy, cx, cy, RKi[9], t[3], r2new0, r2new1, alphaOpt, couplingWeight;
-    const float *u, *v, *idepth_new, *iR, *energy, *outlierTH; const uint8_t* isGood;
-    uint8_t* isGood_new; float *energy_new, *maxstep, *lastHessian_new, *Jb;
-};
 
 __device__ __forceinline__ float3 init_interp33(const float4* __restrict__ img, float x, float y, int width) {
     const int ix = (int)x, iy = (int)y;
@@ -95,6 +88,10 @@ __global__ __launch_bounds__(256) void init_calc_kernel(InitParams P, double* __
             } else {
                 acc[90] += en;
                 P.isGood_new[i] = 1; P.energy_new[i * 2] = en; P.energy_new[i * 2 + 1] = (idn - 1) * (idn - 1);
+                if (P.idepth) {                                               // calcEC (:634-655) reads exactly what this pass has at hand: the regulariser's old / new energy
+                    const float iR = P.iR[i], rOld = P.idepth[i] - iR, rNew = idn - iR;
+                    acc[91] += rOld * rOld; acc[92] += rNew * rNew; acc[93] += 1.f;
+                }
 #pragma unroll
                 for (int idx = 0; idx < 8; ++idx) {                          // acc9: upper triangle of [dp0..dp7, r] outer products (constant indices)
                     float J[9];
@@ -142,13 +139,13 @@ __global__ __launch_bounds__(1024) void init_finish_kernel(const double* __restr
 }
 // CoarseInitializer::doStep (:910-938)
 __global__ __launch_bounds__(256) void init_do_step_kernel(int n, const uint8_t* __restrict__ isGood, const float* __restrict__ Jb, const float* __restrict__ maxstep,
-                                                          const float* __restrict__ idepth, float lambda, const float* __restrict__ inc, float* __restrict__ idepth_new) {
+                                                          const float* __restrict__ idepth, float lambda, InitInc inc, float* __restrict__ idepth_new) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !isGood[i]) return;
     const float* jb = Jb + (size_t)i * 10;
     float dot = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dot += jb[k] * inc[k];
+    for (int k = 0; k < 8; ++k) dot += jb[k] * inc.v[k];
     const float b = jb[8] + dot;
     float step = -b * jb[9] / (1 + lambda);
     float ms = 0.25f * maxstep[i];
@@ -161,28 +158,38 @@ __global__ __launch_bounds__(256) void init_do_step_kernel(int n, const uint8_t*
     idepth_new[i] = nid;
 }
 
-// base: device words [u | v | idepth_new | iR | energy(2n) | outlierTH | isGood (n bytes, padded)], outputs follow (see host_api.hip)
-int init_calc_launch(nalo_ctx* c, const float4* colorRef, const float4* colorNew, int lvl, int n, const float K4[4], const float RKi[9], const float t[3], float r2new0, float r2new1,
-                     float alphaOpt, float couplingWeight, const float* base, float* outw, double* sums91) {
-    InitParams P;
-    P.colorRef = colorRef; P.colorNew = colorNew; P.wl = c->wl[lvl]; P.hl = c->hl[lvl]; P.n = n;
-    P.fx = K4[0]; P.fy = K4[1]; P.cx = K4[2]; P.cy = K4[3];
-    for (int i = 0; i < 9; ++i) P.RKi[i] = RKi[i];
-    for (int i = 0; i < 3; ++i) P.t[i] = t[i];
-    P.r2new0 = r2new0; P.r2new1 = r2new1; P.alphaOpt = alphaOpt; P.couplingWeight = couplingWeight;
-    const size_t N = (size_t)n;
-    P.u = base; P.v = base + N; P.idepth_new = base + 2 * N; P.iR = base + 3 * N; P.energy = base + 4 * N; P.outlierTH = base + 6 * N; P.isGood = (const uint8_t*)(base + 7 * N);
-    P.energy_new = outw; P.maxstep = outw + 2 * N; P.lastHessian_new = outw + 3 * N; P.Jb = outw + 4 * N; P.isGood_new = (uint8_t*)(outw + 14 * N);
-    const int nb = (n + 255) / 256;
+// CoarseInitializer::applyStep (:939-956) on the resident arrays (the JbBuffer swap is a pointer swap on the host)
+__global__ __launch_bounds__(256) void init_apply_step_kernel(int n, uint8_t* __restrict__ isGood, const uint8_t* __restrict__ isGood_new, float* __restrict__ idepth,
+                                                             float* __restrict__ idepth_new, const float* __restrict__ iR, float* __restrict__ energy,
+                                                             const float* __restrict__ energy_new, float* __restrict__ lastHessian, const float* __restrict__ lastHessian_new) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!isGood[i]) { const float r = iR[i]; idepth[i] = r; idepth_new[i] = r; return; }
+    energy[2 * i] = energy_new[2 * i]; energy[2 * i + 1] = energy_new[2 * i + 1];
+    isGood[i] = isGood_new[i];
+    idepth[i] = idepth_new[i];
+    lastHessian[i] = lastHessian_new[i];
+}
+
+int init_calc_launch(nalo_ctx* c, InitParams& P, int lvl, double* sums) {
+    P.wl = c->wl[lvl]; P.hl = c->hl[lvl];
+    const int nb = (P.n + 255) / 256;
     NALO_HIP(c, c->trk_partial.reserve(((size_t)nb * kInitStride + 128) * 2));          // doubles in a float buffer
     double* partial = (double*)c->trk_partial.p;
     init_calc_kernel<<<nb, 256, 0, c->stream>>>(P, partial);
-    init_finish_kernel<<<1, 1024, 0, c->stream>>>(partial, nb, sums91);
+    init_finish_kernel<<<1, 1024, 0, c->stream>>>(partial, nb, sums);
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }
-int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float* inc, float* idepth_new) {
-    if (n > 0) init_do_step_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, isGood, Jb, maxstep, idepth, lambda, inc, idepth_new);
+int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float inc[8], float* idepth_new) {
+    InitInc I; for (int k = 0; k < 8; ++k) I.v[k] = inc[k];
+    if (n > 0) init_do_step_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, isGood, Jb, maxstep, idepth, lambda, I, idepth_new);
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+int init_apply_step_launch(nalo_ctx* c, int n, uint8_t* isGood, const uint8_t* isGood_new, float* idepth, float* idepth_new, const float* iR, float* energy, const float* energy_new,
+                           float* lastHessian, const float* lastHessian_new) {
+    if (n > 0) init_apply_step_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, isGood, isGood_new, idepth, idepth_new, iR, energy, energy_new, lastHessian, lastHessian_new);
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }

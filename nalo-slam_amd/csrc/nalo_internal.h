@@ -180,10 +180,24 @@ void pixsel_invalidate_hists(nalo_ctx* c, int slot);
 // staging for the immature-point entry points: pinned host block + device block of `floats` 4-byte words (grown on demand)
 int imm_stage(nalo_ctx* c, size_t words);
 int imm_put_launch(nalo_ctx* c, float* dst, const float* src, int n);
-// kernels_init.hip
-int init_calc_launch(nalo_ctx* c, const float4* colorRef, const float4* colorNew, int lvl, int n, const float K4[4], const float RKi[9], const float t[3], float r2new0, float r2new1,
-                     float alphaOpt, float couplingWeight, const float* base, float* outw, double* sums91);
-int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float* inc, float* idepth_new);
+// kernels_init.hip: one calcResAndGS pass over one level. Every per-point array is a device pointer; idepth (the current inverse depths) may be NULL, then calcEC's
+// three sums (slots 91..93) stay zero. sums: 94 doubles on the device.
+struct InitParams {
+    const float4 *colorRef, *colorNew; int wl, hl, n;
+    float fx, fy, cx, cy, RKi[9], t[3], r2new0, r2new1, alphaOpt, couplingWeight;
+    const float *u, *v, *idepth, *idepth_new, *iR, *energy, *outlierTH; const uint8_t* isGood;
+    uint8_t* isGood_new; float *energy_new, *maxstep, *lastHessian_new, *Jb;
+};
+struct InitInc { float v[8]; };
+int init_calc_launch(nalo_ctx* c, InitParams& P, int lvl, double* sums);
+int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float inc[8], float* idepth_new);
+int init_apply_step_launch(nalo_ctx* c, int n, uint8_t* isGood, const uint8_t* isGood_new, float* idepth, float* idepth_new, const float* iR, float* energy, const float* energy_new,
+                           float* lastHessian, const float* lastHessian_new);
+// host_init.hip: the host arithmetic either side of that pass (pose / affine / alpha terms in, Accumulator9 sums -> H, b, Hsc, bsc, E out), shared by the staged
+// entry point (nalo_init_calc_res_and_gs) and the resident trackFrame
+struct InitPose { float alphaEnergy; };
+void init_pose_setup(const nalo_ctx* c, int lvl, int n, const nalo::SE3& T, const double aff[2], float alphaW, float alphaK, float couplingWeight, InitParams& P, InitPose& X);
+void init_sums_to_system(const double* sums, const nalo::SE3& T, int n, const InitParams& P, const InitPose& X, double* H, double* b, double* Hsc, double* bsc, double E3[3]);
 // kernels_pyramid.hip
 constexpr int NALO_LM_LOST_BLOCK = 1000;     // trk_lm_launch only (never crosses the C ABI): the persistent kernel's workgroups were not co-resident
 int pyramid_build(nalo_ctx* c, nalo::FrameSlot& s, const float* gammaB_dev);
