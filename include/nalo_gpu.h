@@ -437,6 +437,17 @@ int nalo_init_get_state(nalo_ctx* ctx, double thisToNext[12], double aff[2], int
 int nalo_init_set_state(nalo_ctx* ctx, const double thisToNext[12], const double aff[2], int snapped, int frameID, int snappedAt);
 int nalo_init_set_points(nalo_ctx* ctx, int lvl, int n, const float* idepth, const float* idepth_new, const float* iR, const uint8_t* isGood, const float* lastHessian,
                          const float* energy2, const float* maxstep, const float* lastHessian_new, const float* energy_new2, const uint8_t* isGood_new, const float* iRSumNum);
+/* nalo_init_sweep: one of trackFrame's per-level sweeps on its own, on the initialiser's current state (replaces CoarseInitializer::optReg :656-691, ::propagateUp
+ *     :695-734 (lvl = srcLvl, 0 .. levels-2), ::propagateDown :736-766 (lvl = srcLvl, 1 .. levels-1), ::resetPoints :882-909; optReg reads `snapped` as set by
+ *     nalo_init_set_state / trackFrame). trackFrame calls the same code; the entry point exists so that each sweep can be checked against the reference's alone. */
+/* nalo_init_get_carried: the read side of nalo_init_set_points for the members nalo_init_get_points does not return (iRSumNum is recomputed by propagateUp before
+ *     anything reads it and is not kept); the first min(cap, n) entries, any output may be NULL. */
+int nalo_init_get_carried(nalo_ctx* ctx, int lvl, int cap, float* idepth_new, float* maxstep, float* lastHessian_new, float* energy_new2, uint8_t* isGood_new);
+#define NALO_INIT_SWEEP_OPT_REG 0
+#define NALO_INIT_SWEEP_PROPAGATE_UP 1
+#define NALO_INIT_SWEEP_PROPAGATE_DOWN 2
+#define NALO_INIT_SWEEP_RESET_POINTS 3
+int nalo_init_sweep(nalo_ctx* ctx, int which, int lvl);
 int nalo_init_get_points(nalo_ctx* ctx, int lvl, int cap, int* n, float* u, float* v, float* idepth, float* iR, uint8_t* isGood, float* lastHessian, float* energy2,
                          float* my_type, float* outlierTH, int* parent, float* parentDist, int* neighbours, float* neighboursDist);
 

@@ -32,7 +32,7 @@ EXPORTS = [
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_set_prior_carry", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_plane_scale_fix", "nalo_ba_sw_gray_optimize", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_constants", "nalo_constants_device", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
-    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_init_set_state", "nalo_init_set_points", "nalo_dist_make_map", "nalo_pixsel_make_hists",
+    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_init_set_state", "nalo_init_set_points", "nalo_init_get_carried", "nalo_init_sweep", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get", "nalo_profile_sample", "nalo_hbm_calibrate",
 ]
@@ -143,6 +143,8 @@ def load():
     L.nalo_trk_last_evals.argtypes = [vp, c_ip, c_ip]
     L.nalo_init_set_state.argtypes = [vp, c_dp, c_dp, C.c_int, C.c_int, C.c_int]
     L.nalo_init_set_points.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp]
+    L.nalo_init_get_carried.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p]
+    L.nalo_init_sweep.argtypes = [vp, C.c_int, C.c_int]
     L.nalo_pixsel_make_hists.argtypes = [vp, C.c_int, c_fp, c_fp]
     L.nalo_pixsel_set_random.argtypes = [vp, c_u8p, c_ip]
     L.nalo_pixsel_select.argtypes = [vp, C.c_int, C.c_int, C.c_float, c_fp, c_ip]
@@ -601,6 +603,20 @@ class Context:
             a = {k: np.ascontiguousarray(p[k], np.uint8 if k.startswith("isGood") else np.float32) for k in p}
             self._ck(self.L.nalo_init_set_points(self.h_, l, len(a["idepth"]), _f(a["idepth"]), _f(a["idepth_new"]), _f(a["iR"]), _u8(a["isGood"]), _f(a["lastHessian"]),
                                                  _f(a["energy"]), _f(a["maxstep"]), _f(a["lastHessian_new"]), _f(a["energy_new"]), _u8(a["isGood_new"]), _f(a["iRSumNum"])))
+
+    SWEEPS = dict(opt_reg=0, propagate_up=1, propagate_down=2, reset_points=3)
+
+    def init_sweep(self, which, lvl):
+        """one of trackFrame's sweeps alone: optReg(lvl), propagateUp(srcLvl), propagateDown(srcLvl), resetPoints(lvl)"""
+        self._ck(self.L.nalo_init_sweep(self.h_, self.SWEEPS[which], lvl))
+
+    def init_carried(self, lvl):
+        """the Pnt members nalo_init_set_points writes and init_points() does not return"""
+        n = len(self.init_points(lvl)["u"]); m = max(n, 1)
+        o = dict(idepth_new=np.zeros(m, np.float32), maxstep=np.zeros(m, np.float32), lastHessian_new=np.zeros(m, np.float32), energy_new=np.zeros((m, 2), np.float32),
+                 isGood_new=np.zeros(m, np.uint8))
+        self._ck(self.L.nalo_init_get_carried(self.h_, lvl, n, _f(o["idepth_new"]), _f(o["maxstep"]), _f(o["lastHessian_new"]), _f(o["energy_new"]), _u8(o["isGood_new"])))
+        return {k: v[:n] for k, v in o.items()}
 
     def init_points(self, lvl):
         n = np.zeros(1, np.int32)

@@ -8,16 +8,16 @@
 //                                               applyStep (:939-956), optReg (:656-691); then propagateUp (:695-734) and the snapped / frameID bookkeeping
 //   nalo_init_get_state / nalo_init_get_points   read-back of thisToNext, thisToNext_aff, snapped, frameID, snappedAt and the Pnt arrays
 //
-// What runs where: the two per-point passes that touch the images (calcResAndGS, doStep) and both selections are kernels; everything else here is SEQUENTIAL
-// BY CONSTRUCTION in the reference — optReg is a Gauss-Seidel sweep (point i reads the iR its lower-index neighbours were just given), resetPoints likewise,
-// propagateUp adds children into their parent in index order (fp32, order matters), and makeNN's result depends on the traversal order of nanoflann's k-d
-// tree wherever neighbours are equidistant (points sit on the integer grid + 0.1, so most 10-NN sets end in a tie). The host code keeps those orders.
+// What runs where: everything per point is a kernel. The two passes that touch the images (calcResAndGS, which also forms calcEC's sums, and doStep), applyStep,
+// propagateDown / propagateUp (one lane per point / per parent, children summed in index order as the reference's fp32 += does) and resetPoints are plain
+// parallel kernels; optReg and the top level's resetPoints are Gauss-Seidel sweeps in the reference (point i reads what its lower-index neighbours were just
+// given) and run as dependency-ordered kernels on a schedule this file builds once per setFirst (build_sweep below, kernels_init.hip). makeNN's result depends on
+// the traversal order of nanoflann's k-d tree wherever neighbours are equidistant (points sit on the integer grid + 0.1, so most 10-NN sets end in a tie): the
+// trees are built on the host in the reference's order, one level per thread, and queried from a few host threads.
 //
-// Residency: inside a level's Levenberg-Marquardt loop the Pnt arrays (SoA) and both JbBuffers live on the DEVICE (InitDev below): doStep, calcResAndGS (which also
-// forms calcEC's three sums) and applyStep are kernels on them, and one evaluation moves 94 doubles plus {idepth_new, isGood_new} down (what the host's mirror of
-// applyStep and the next optReg sweep read) and, after an accepted step, the re-regularised iR up. The host mirror is authoritative between levels (propagateDown /
-// resetPoints before a level, propagateUp after the last): one packed upload when a level starts, one packed download when it ends. makeNN's 10-NN / parent
-// queries are independent per point and run on a few host threads against trees built one level per thread.
+// Residency: the Pnt arrays (SoA) and both JbBuffers live on the DEVICE for the whole of trackFrame (InitLevel's device block, lvl_off()); one evaluation moves 94
+// doubles to the host, where the Levenberg-Marquardt bookkeeping (8x8 solve, accept / reject, lambda) runs. The host mirror of the arrays is refreshed lazily
+// (nalo_init_get_points / nalo_init_set_points) and uploaded when it is the newer side (after setFirst or nalo_init_set_points).
 #include "nalo_internal.h"
 #include <cfloat>
 #include <cmath>
@@ -223,7 +223,11 @@ struct Initializer {
     DevBuf<uint8_t> map_dev; DevBuf<int> cnt_dev;
     // device residency of the Pnt arrays: one block per level, word offsets from lvl_off(); JbBuffer / JbBuffer_new are one pair for all levels, as in the reference
     DevBuf<float> lvl_dev[NALO_MAX_LEVELS], jb_dev[2];
-    bool static_on_dev = false;
+    DevBuf<int> tab_dev[NALO_MAX_LEVELS];                // per level: the sweep schedule, parent, the children lists (TabOff)
+    DevBuf<float> sweep_scratch;                         // 2 x max n floats (padded): the sweep's values | the inverse depths in schedule order
+    int nsteps[NALO_MAX_LEVELS] = {};
+    bool static_on_dev = false;                          // u, v, outlierTH and the tables are uploaded
+    bool dev_valid = false, host_valid = true;           // which side holds the current Pnt state
     int jb_cur = 0;
     float* pin = nullptr; size_t pin_half = 0;           // pinned staging: [0, pin_half) host -> device, [pin_half, 2 pin_half) device -> host
 };
@@ -245,6 +249,8 @@ void init_destroy(nalo_ctx* c) {
     if (!c->init) return;
     c->init->map_dev.release(); c->init->cnt_dev.release();
     for (auto& b : c->init->lvl_dev) b.release();
+    for (auto& b : c->init->tab_dev) b.release();
+    c->init->sweep_scratch.release();
     for (auto& b : c->init->jb_dev) b.release();
     if (c->init->pin) (void)hipHostFree(c->init->pin);
     delete c->init; c->init = nullptr;
@@ -275,91 +281,81 @@ static void ldlt_f32(const float* Ain, const float* bin, float* x) {
     for (int i = 0; i < N; ++i) x[perm[i]] = z[i];
 }
 
-static void opt_reg(Initializer& I, int lvl) {                                                 // optReg :656-691
-    InitLevel& P = I.L[lvl];
-    if (!I.snapped) { std::fill(P.iR.begin(), P.iR.end(), 1.f); return; }
-    for (int i = 0; i < P.n; ++i) {
-        if (!P.isGood[i]) continue;
-        float vals[10]; int m = 0;
-        for (int j = 0; j < 10; ++j) { const int o = P.nn[(size_t)i * 10 + j]; if (o != -1 && P.isGood[o]) vals[m++] = P.iR[o]; }
-        if (m > 2) {
-            std::nth_element(vals, vals + m / 2, vals + m);
-            P.iR[i] = (1 - I.regWeight) * P.idepth[i] + I.regWeight * vals[m / 2];
-        }
-    }
+// ---------------------------------------------------------------------------------------------------------------- sweep schedule and tables of one level
+// int words of a level's table block: rec [n][12] = {point, its 10 neighbours (n where there is none), -} in schedule order (16-byte records first), off [nsteps + 1], parent [n],
+// child_off [n + 1] / child_idx [n_below]: the points of the level below grouped by parent, in index order
+struct TabOff { size_t rec, off, parent, child_off, child_idx, total; };
+static TabOff tab_off(size_t n, size_t nsteps, size_t n_below) {
+    TabOff o; o.rec = 0; o.off = 12 * n; o.parent = o.off + nsteps + 1; o.child_off = o.parent + n; o.child_idx = o.child_off + n + 1; o.total = o.child_idx + n_below + 4;
+    return o;
 }
-static void propagate_up(Initializer& I, int src) {                                            // propagateUp :695-734
-    InitLevel &S = I.L[src], &T = I.L[src + 1];
-    std::fill(T.iR.begin(), T.iR.end(), 0.f); std::fill(T.iRSumNum.begin(), T.iRSumNum.end(), 0.f);
-    for (int i = 0; i < S.n; ++i) {
-        if (!S.isGood[i]) continue;
-        const int par = S.parent[i];
-        T.iR[par] += S.iR[i] * S.lastHessian[i];
-        T.iRSumNum[par] += S.lastHessian[i];
+// The order optReg / resetPoints impose: i before j (i < j) whenever one is among the other's neighbours. step[i] = 1 + max step of the points ordered before i;
+// the points of a step are independent. Steps wider than kSweepNT are cut. Returns off (nsteps + 1 entries) and the points in schedule order.
+static void build_sweep(const InitLevel& P, std::vector<int>& off, std::vector<int>& order) {
+    const int n = P.n;
+    std::vector<int> step(n, 0), pending(n, 0);
+    int depth = 0;
+    for (int i = 0; i < n; ++i) {
+        int st = pending[i];
+        for (int k = 0; k < 10; ++k) { const int j = P.nn[(size_t)i * 10 + k]; if (j >= 0 && j < i) st = std::max(st, step[j] + 1); }
+        step[i] = st; depth = std::max(depth, st + 1);
+        for (int k = 0; k < 10; ++k) { const int j = P.nn[(size_t)i * 10 + k]; if (j > i) pending[j] = std::max(pending[j], st + 1); }
     }
-    for (int i = 0; i < T.n; ++i) if (T.iRSumNum[i] > 0) { T.idepth[i] = T.iR[i] = (T.iR[i] / T.iRSumNum[i]); T.isGood[i] = 1; }
-    opt_reg(I, src + 1);
-}
-static void propagate_down(Initializer& I, int src) {                                          // propagateDown :736-766
-    InitLevel &S = I.L[src], &T = I.L[src - 1];
-    for (int i = 0; i < T.n; ++i) {
-        const int par = T.parent[i];
-        if (!S.isGood[par] || S.lastHessian[par] < 0.1) continue;
-        if (!T.isGood[i]) { T.iR[i] = T.idepth[i] = T.idepth_new[i] = S.iR[par]; T.isGood[i] = 1; T.lastHessian[i] = 0; }
-        else {
-            const float fused = (T.iR[i] * T.lastHessian[i] * 2 + S.iR[par] * S.lastHessian[par]) / (T.lastHessian[i] * 2 + S.lastHessian[par]);
-            T.iR[i] = T.idepth[i] = T.idepth_new[i] = fused;
-        }
-    }
-    opt_reg(I, src - 1);
-}
-static void reset_points(Initializer& I, int lvl) {                                            // resetPoints :882-909
-    InitLevel& P = I.L[lvl];
-    for (int i = 0; i < P.n; ++i) {
-        P.energy[2 * (size_t)i] = P.energy[2 * (size_t)i + 1] = 0;
-        P.idepth_new[i] = P.idepth[i];
-        if (lvl == I.levels - 1 && !P.isGood[i]) {
-            float sum = 0, cnt = 0;
-            for (int j = 0; j < 10; ++j) { const int o = P.nn[(size_t)i * 10 + j]; if (o == -1 || !P.isGood[o]) continue; sum += P.iR[o]; cnt += 1; }
-            if (cnt > 0) { P.isGood[i] = 1; P.iR[i] = P.idepth[i] = P.idepth_new[i] = sum / cnt; }
-        }
-    }
-}
-// applyStep (:939-956) on the host mirror, for the members the host sweeps read (the device runs init_apply_step_kernel on all of them; the JbBuffer swap is jb_cur)
-static void apply_step_host(Initializer& I, int lvl) {
-    InitLevel& P = I.L[lvl];
-    for (int i = 0; i < P.n; ++i) {
-        if (!P.isGood[i]) { P.idepth[i] = P.idepth_new[i] = P.iR[i]; continue; }
-        P.isGood[i] = P.isGood_new[i];
-        P.idepth[i] = P.idepth_new[i];
-    }
+    std::vector<int> cnt(depth + 1, 0);
+    for (int i = 0; i < n; ++i) ++cnt[step[i] + 1];
+    for (int d = 0; d < depth; ++d) cnt[d + 1] += cnt[d];
+    order.assign(n, 0);
+    { std::vector<int> at(cnt.begin(), cnt.end() - 1); for (int i = 0; i < n; ++i) order[at[step[i]]++] = i; }
+    off.clear();
+    for (int d = 0; d < depth; ++d) for (int p = cnt[d]; p < cnt[d + 1]; p += kSweepNT) off.push_back(p);
+    off.push_back(n);
 }
 
-static int dev_prepare(nalo_ctx* c, Initializer& I) {                                          // device blocks + pinned staging for the current point counts
+static int dev_prepare(nalo_ctx* c, Initializer& I) {                                          // device blocks, tables, pinned staging for the current point counts
     size_t maxn = 0, maxtot = 0;
     for (int l = 0; l < I.levels; ++l) { const LvlOff o = lvl_off((size_t)I.L[l].n); NALO_HIP(c, I.lvl_dev[l].reserve(o.total)); maxn = std::max(maxn, (size_t)I.L[l].n); maxtot = std::max(maxtot, o.total); }
     for (auto& b : I.jb_dev) NALO_HIP(c, b.reserve(10 * maxn + 16));
+    NALO_HIP(c, I.sweep_scratch.reserve(2 * (maxn + 8) + 32));
     if (I.pin_half < maxtot) {
         if (I.pin) (void)hipHostFree(I.pin);
         I.pin = nullptr; I.pin_half = 0;
         NALO_HIP(c, hipHostMalloc((void**)&I.pin, 2 * maxtot * sizeof(float)));
         I.pin_half = maxtot;
     }
-    if (!I.static_on_dev) {
-        for (int l = 0; l < I.levels; ++l) {
-            const InitLevel& P = I.L[l]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
-            if (!n) continue;
-            std::memcpy(I.pin + o.u, P.u.data(), n * 4); std::memcpy(I.pin + o.v, P.v.data(), n * 4); std::memcpy(I.pin + o.outlierTH, P.outlierTH.data(), n * 4);
-            NALO_HIP(c, hipMemcpyAsync(I.lvl_dev[l].p, I.pin, 3 * n * 4, hipMemcpyHostToDevice, c->stream));
-            NALO_HIP(c, hipStreamSynchronize(c->stream));
+    if (I.static_on_dev) return NALO_OK;
+    HostTimer ht(c, "init.tables");
+    std::vector<int> off, order, tab;
+    for (int l = 0; l < I.levels; ++l) {
+        const InitLevel& P = I.L[l]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
+        I.nsteps[l] = 0;
+        if (!n) continue;
+        std::memcpy(I.pin + o.u, P.u.data(), n * 4); std::memcpy(I.pin + o.v, P.v.data(), n * 4); std::memcpy(I.pin + o.outlierTH, P.outlierTH.data(), n * 4);
+        NALO_HIP(c, hipMemcpyAsync(I.lvl_dev[l].p, I.pin, 3 * n * 4, hipMemcpyHostToDevice, c->stream));
+        build_sweep(P, off, order);
+        const size_t ns = off.size() - 1, n_below = l > 0 ? (size_t)I.L[l - 1].n : 0;
+        I.nsteps[l] = (int)ns;
+        const TabOff t = tab_off(n, ns, n_below);
+        tab.assign(t.total, 0);
+        for (size_t p = 0; p < n; ++p) { int* r = &tab[t.rec + 12 * p]; r[0] = order[p]; for (int k = 0; k < 10; ++k) { const int j = P.nn[(size_t)order[p] * 10 + k]; r[1 + k] = j < 0 ? (int)n : j; } r[11] = 0; }
+        std::memcpy(&tab[t.off], off.data(), (ns + 1) * 4);
+        std::memcpy(&tab[t.parent], P.parent.data(), n * 4);
+        if (l > 0) {                                                                            // counting sort of the level below by parent (stable: index order inside a parent)
+            const InitLevel& B = I.L[l - 1];
+            int* co = &tab[t.child_off];
+            for (int i = 0; i < B.n; ++i) if (B.parent[i] >= 0) ++co[B.parent[i] + 1];
+            for (size_t q = 0; q < n; ++q) co[q + 1] += co[q];
+            std::vector<int> at(co, co + n);
+            for (int i = 0; i < B.n; ++i) if (B.parent[i] >= 0) tab[t.child_idx + at[B.parent[i]]++] = i;
         }
-        I.static_on_dev = true;
+        NALO_HIP(c, I.tab_dev[l].reserve(t.total));
+        NALO_HIP(c, hipMemcpyAsync(I.tab_dev[l].p, tab.data(), t.total * 4, hipMemcpyHostToDevice, c->stream));
+        NALO_HIP(c, hipStreamSynchronize(c->stream));                                           // pin / tab are reused by the next level
     }
+    I.static_on_dev = true; I.dev_valid = false;
     return NALO_OK;
 }
-// host mirror -> device, every member a level's loop reads or keeps (the *_new members hold stale entries that survive, as in the reference)
+// host mirror -> device, every member trackFrame reads or keeps (the *_new members hold stale entries that survive, as in the reference)
 static int level_upload(nalo_ctx* c, Initializer& I, int lvl) {
-    HostTimer ht(c, "init.level_io");
     const InitLevel& P = I.L[lvl]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
     if (!n) return NALO_OK;
     float* h = I.pin - o.dyn;
@@ -368,30 +364,85 @@ static int level_upload(nalo_ctx* c, Initializer& I, int lvl) {
     std::memcpy(h + o.energy_new, P.energy_new.data(), 2 * n * 4); std::memcpy(h + o.isGood, P.isGood.data(), n); std::memcpy(h + o.idepth_new, P.idepth_new.data(), n * 4);
     std::memcpy(h + o.isGood_new, P.isGood_new.data(), n);
     NALO_HIP(c, hipMemcpyAsync(I.lvl_dev[lvl].p + o.dyn, I.pin, (o.dyn_end - o.dyn) * 4, hipMemcpyHostToDevice, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));                                               // the staging block is reused by the next level
     return NALO_OK;
 }
 static int level_download(nalo_ctx* c, Initializer& I, int lvl) {
-    HostTimer ht(c, "init.level_io");
     InitLevel& P = I.L[lvl]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
     if (!n) return NALO_OK;
     float* hd = I.pin + I.pin_half;
     NALO_HIP(c, hipMemcpyAsync(hd, I.lvl_dev[lvl].p + o.dyn, (o.dyn_end - o.dyn) * 4, hipMemcpyDeviceToHost, c->stream));
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     const float* h = hd - o.dyn;
-    std::memcpy(P.idepth.data(), h + o.idepth, n * 4); std::memcpy(P.lastHessian.data(), h + o.lastHessian, n * 4); std::memcpy(P.lastHessian_new.data(), h + o.lastHessian_new, n * 4);
+    std::memcpy(P.idepth.data(), h + o.idepth, n * 4); std::memcpy(P.iR.data(), h + o.iR, n * 4); std::memcpy(P.lastHessian.data(), h + o.lastHessian, n * 4);
+    std::memcpy(P.lastHessian_new.data(), h + o.lastHessian_new, n * 4);
     std::memcpy(P.maxstep.data(), h + o.maxstep, n * 4); std::memcpy(P.energy.data(), h + o.energy, 2 * n * 4); std::memcpy(P.energy_new.data(), h + o.energy_new, 2 * n * 4);
     std::memcpy(P.isGood.data(), h + o.isGood, n); std::memcpy(P.idepth_new.data(), h + o.idepth_new, n * 4); std::memcpy(P.isGood_new.data(), h + o.isGood_new, n);
     return NALO_OK;
 }
-static int iR_upload(nalo_ctx* c, Initializer& I, int lvl) {                                   // after optReg: the only member the host changes inside the loop
-    const InitLevel& P = I.L[lvl]; const size_t n = (size_t)P.n; const LvlOff o = lvl_off(n);
-    if (!n) return NALO_OK;
-    std::memcpy(I.pin, P.iR.data(), n * 4);
-    NALO_HIP(c, hipMemcpyAsync(I.lvl_dev[lvl].p + o.iR, I.pin, n * 4, hipMemcpyHostToDevice, c->stream));
+// make the device the current side (upload the mirror if it is newer) / make the host mirror current
+static int dev_sync(nalo_ctx* c, Initializer& I) {
+    int rc = dev_prepare(c, I); if (rc) return rc;
+    if (!I.dev_valid) {
+        HostTimer ht(c, "init.mirror_io");
+        for (int l = 0; l < I.levels; ++l) { rc = level_upload(c, I, l); if (rc) return rc; }
+        I.dev_valid = true;
+    }
+    return NALO_OK;
+}
+static int host_sync(nalo_ctx* c, Initializer& I) {
+    if (I.host_valid) return NALO_OK;
+    HostTimer ht(c, "init.mirror_io");
+    NALO_HIP(c, hipSetDevice(c->device));
+    for (int l = 0; l < I.levels; ++l) { const int rc = level_download(c, I, l); if (rc) return rc; }
+    I.host_valid = true;
     return NALO_OK;
 }
 
-// calcResAndGS on the resident level (writes JbBuffer_new = jb_dev[1 - jb_cur]); brings back the sums and {idepth_new, isGood_new}. regEnergy = calcEC (:634-655)
+struct LvlPtr { float *idepth, *idepth_new, *iR, *lastHessian, *lastHessian_new, *maxstep, *energy, *energy_new; uint8_t *isGood, *isGood_new; };
+static LvlPtr lvl_ptr(Initializer& I, int lvl) {
+    const LvlOff o = lvl_off((size_t)I.L[lvl].n); float* d = I.lvl_dev[lvl].p;
+    return LvlPtr{d + o.idepth, d + o.idepth_new, d + o.iR, d + o.lastHessian, d + o.lastHessian_new, d + o.maxstep, d + o.energy, d + o.energy_new,
+                  (uint8_t*)(d + o.isGood), (uint8_t*)(d + o.isGood_new)};
+}
+static int sweep(nalo_ctx* c, Initializer& I, int lvl, int mode) {
+    const InitLevel& P = I.L[lvl];
+    if (!P.n) return NALO_OK;
+    const TabOff t = tab_off((size_t)P.n, (size_t)I.nsteps[lvl], lvl > 0 ? (size_t)I.L[lvl - 1].n : 0);
+    const LvlPtr q = lvl_ptr(I, lvl);
+    const int* tab = I.tab_dev[lvl].p;
+    return init_sweep_launch(c, mode, P.n, I.nsteps[lvl], tab + t.off, tab + t.rec, q.iR, q.isGood, q.idepth, q.idepth_new, I.regWeight, I.sweep_scratch.p);
+}
+static int opt_reg(nalo_ctx* c, Initializer& I, int lvl) {                                     // optReg :656-691
+    if (!I.snapped) return init_fill_launch(c, I.L[lvl].n, lvl_ptr(I, lvl).iR, nullptr, nullptr);
+    return sweep(c, I, lvl, 0);
+}
+static int propagate_up(nalo_ctx* c, Initializer& I, int src) {                                // propagateUp :695-734
+    const int nT = I.L[src + 1].n;
+    if (nT) {
+        const TabOff t = tab_off((size_t)nT, (size_t)I.nsteps[src + 1], (size_t)I.L[src].n);
+        const LvlPtr S = lvl_ptr(I, src), T = lvl_ptr(I, src + 1);
+        const int* tab = I.tab_dev[src + 1].p;
+        const int rc = init_propagate_up_launch(c, nT, tab + t.child_off, tab + t.child_idx, S.isGood, S.iR, S.lastHessian, T.isGood, T.iR, T.idepth); if (rc) return rc;
+    }
+    return opt_reg(c, I, src + 1);
+}
+static int propagate_down(nalo_ctx* c, Initializer& I, int src) {                              // propagateDown :736-766
+    const int n = I.L[src - 1].n;
+    if (n && I.L[src].n) {
+        const TabOff t = tab_off((size_t)n, (size_t)I.nsteps[src - 1], src - 1 > 0 ? (size_t)I.L[src - 2].n : 0);
+        const LvlPtr S = lvl_ptr(I, src), T = lvl_ptr(I, src - 1);
+        const int rc = init_propagate_down_launch(c, n, I.tab_dev[src - 1].p + t.parent, S.isGood, S.lastHessian, S.iR, T.isGood, T.iR, T.idepth, T.idepth_new, T.lastHessian); if (rc) return rc;
+    }
+    return opt_reg(c, I, src - 1);
+}
+static int reset_points(nalo_ctx* c, Initializer& I, int lvl) {                                // resetPoints :882-909
+    const LvlPtr q = lvl_ptr(I, lvl);
+    const int rc = init_reset_launch(c, I.L[lvl].n, q.energy, q.idepth_new, q.idepth); if (rc) return rc;
+    return lvl == I.levels - 1 ? sweep(c, I, lvl, 1) : NALO_OK;
+}
+
+// calcResAndGS on the resident level (writes JbBuffer_new = jb_dev[1 - jb_cur]); the 94 sums come back, regEnergy = calcEC (:634-655)
 static int calc(nalo_ctx* c, Initializer& I, int lvl, int slot_new, const SE3& T, const double aff[2], double H[64], double b[8], double Hsc[64], double bsc[8], float res[3], float regEnergy[3]) {
     HostTimer ht(c, "init.calc");
     InitLevel& L = I.L[lvl]; const size_t n = (size_t)L.n; const LvlOff o = lvl_off(n);
@@ -400,16 +451,15 @@ static int calc(nalo_ctx* c, Initializer& I, int lvl, int slot_new, const SE3& T
     double sums[96] = {};
     if (n) {
         float* d = I.lvl_dev[lvl].p;
+        const LvlPtr q = lvl_ptr(I, lvl);
         P.colorRef = c->slots[I.slot_first].dI[lvl]; P.colorNew = c->slots[slot_new].dI[lvl];
-        P.u = d + o.u; P.v = d + o.v; P.outlierTH = d + o.outlierTH; P.idepth = d + o.idepth; P.idepth_new = d + o.idepth_new; P.iR = d + o.iR; P.energy = d + o.energy;
-        P.isGood = (const uint8_t*)(d + o.isGood); P.isGood_new = (uint8_t*)(d + o.isGood_new); P.energy_new = d + o.energy_new; P.maxstep = d + o.maxstep;
-        P.lastHessian_new = d + o.lastHessian_new; P.Jb = I.jb_dev[1 - I.jb_cur].p;
+        P.u = d + o.u; P.v = d + o.v; P.outlierTH = d + o.outlierTH; P.idepth = q.idepth; P.idepth_new = q.idepth_new; P.iR = q.iR; P.energy = q.energy;
+        P.isGood = q.isGood; P.isGood_new = q.isGood_new; P.energy_new = q.energy_new; P.maxstep = q.maxstep; P.lastHessian_new = q.lastHessian_new; P.Jb = I.jb_dev[1 - I.jb_cur].p;
         int rc = init_calc_launch(c, P, lvl, (double*)(d + o.sums)); if (rc) return rc;
         float* hd = I.pin + I.pin_half;
-        NALO_HIP(c, hipMemcpyAsync(hd, d + o.idepth_new, (o.sums + 2 * 94 - o.idepth_new) * 4, hipMemcpyDeviceToHost, c->stream));
+        NALO_HIP(c, hipMemcpyAsync(hd, d + o.sums, 94 * 8, hipMemcpyDeviceToHost, c->stream));
         NALO_HIP(c, hipStreamSynchronize(c->stream));
-        std::memcpy(L.idepth_new.data(), hd, n * 4); std::memcpy(L.isGood_new.data(), hd + (o.isGood_new - o.idepth_new), n);
-        std::memcpy(sums, hd + (o.sums - o.idepth_new), 94 * 8);
+        std::memcpy(sums, hd, 94 * 8);
     }
     double E3[3];
     init_sums_to_system(sums, T, L.n, P, X, H, b, Hsc, bsc, E3);
@@ -419,14 +469,10 @@ static int calc(nalo_ctx* c, Initializer& I, int lvl, int slot_new, const SE3& T
     ++I.n_evals;
     return NALO_OK;
 }
-static int apply_step(nalo_ctx* c, Initializer& I, int lvl) {
-    HostTimer ht(c, "init.apply_step");
-    InitLevel& L = I.L[lvl]; const LvlOff o = lvl_off((size_t)L.n);
-    float* d = I.lvl_dev[lvl].p;
-    const int rc = init_apply_step_launch(c, L.n, (uint8_t*)(d + o.isGood), (const uint8_t*)(d + o.isGood_new), d + o.idepth, d + o.idepth_new, d + o.iR, d + o.energy, d + o.energy_new,
-                                          d + o.lastHessian, d + o.lastHessian_new);
+static int apply_step(nalo_ctx* c, Initializer& I, int lvl) {                                  // applyStep :939-956; the JbBuffer swap is jb_cur
+    const LvlPtr q = lvl_ptr(I, lvl);
+    const int rc = init_apply_step_launch(c, I.L[lvl].n, q.isGood, q.isGood_new, q.idepth, q.idepth_new, q.iR, q.energy, q.energy_new, q.lastHessian, q.lastHessian_new);
     if (rc) return rc;
-    apply_step_host(I, lvl);
     I.jb_cur = 1 - I.jb_cur;
     return NALO_OK;
 }
@@ -505,7 +551,7 @@ int nalo_init_set_first(nalo_ctx* c, int slot_first, int* sparsityFactor, int nu
     if (!c->init) c->init = new Initializer();
     Initializer& I = *c->init;
     I.levels = c->levels; I.slot_first = slot_first;
-    I.static_on_dev = false; I.jb_cur = 0;
+    I.static_on_dev = false; I.dev_valid = false; I.host_valid = true; I.jb_cur = 0;
     HostTimer htf(c, "init_set_first");
     const float densities[] = {0.03f, 0.05f, 0.15f, 0.5f, 1.f, 1.f};
     const int pad = 2;                                                                           // patternPadding (util/settings.h:234)
@@ -595,29 +641,23 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
     Initializer& I = *c->init;
     HostTimer htf(c, "init_track_frame");
     NALO_HIP(c, hipSetDevice(c->device));
-    { const int rc = dev_prepare(c, I); if (rc) return rc; }
+    { const int rc = dev_sync(c, I); if (rc) return rc; }
+    I.host_valid = false;
     const int maxIterations[] = {5, 5, 10, 30, 50, 50};
     I.alphaK = 2.5 * 2.5; I.alphaW = 150 * 150; I.regWeight = 0.8; I.couplingWeight = 1;
     if (!I.snapped) {
         I.thisToNext.m[3] = I.thisToNext.m[7] = I.thisToNext.m[11] = 0;
-        for (int lvl = 0; lvl < I.levels; ++lvl) {
-            InitLevel& P = I.L[lvl];
-            std::fill(P.iR.begin(), P.iR.end(), 1.f); std::fill(P.idepth_new.begin(), P.idepth_new.end(), 1.f); std::fill(P.lastHessian.begin(), P.lastHessian.end(), 0.f);
-        }
+        for (int lvl = 0; lvl < I.levels; ++lvl) { const LvlPtr q = lvl_ptr(I, lvl); const int rc = init_fill_launch(c, I.L[lvl].n, q.iR, q.idepth_new, q.lastHessian); if (rc) return rc; }
     }
     SE3 T_cur = I.thisToNext;
     double aff_cur[2] = {I.aff[0], I.aff[1]};
     if (exposure_first > 0 && exposure_new > 0) { aff_cur[0] = logf(exposure_new / exposure_first); aff_cur[1] = 0; }      // coarse approximation (:123-124)
     const float wM[8] = {kScaleXiRot, kScaleXiRot, kScaleXiRot, kScaleXiTrans, kScaleXiTrans, kScaleXiTrans, kScaleA, kScaleB};   // :64-67, labels as the reference has them
     for (int lvl = I.levels - 1; lvl >= 0; --lvl) {
-        double H[64], b[8], Hsc[64], bsc[8]; float resOld[3];
-        {
-            HostTimer hp(c, "init.propagate");
-            if (lvl < I.levels - 1) propagate_down(I, lvl + 1);
-            reset_points(I, lvl);
-        }
-        int rc = level_upload(c, I, lvl); if (rc) return rc;
-        float regEnergy[3];
+        double H[64], b[8], Hsc[64], bsc[8]; float resOld[3], regEnergy[3];
+        int rc = NALO_OK;
+        if (lvl < I.levels - 1) { rc = propagate_down(c, I, lvl + 1); if (rc) return rc; }
+        rc = reset_points(c, I, lvl); if (rc) return rc;
         rc = calc(c, I, lvl, slot_new, T_cur, aff_cur, H, b, Hsc, bsc, resOld, regEnergy); if (rc) return rc;
         rc = apply_step(c, I, lvl); if (rc) return rc;
         float lambda = 0.1f; const float eps = 1e-4f; int fails = 0, iteration = 0;
@@ -645,9 +685,9 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
             double xi[6]; for (int i = 0; i < 6; ++i) xi[i] = inc[i];
             const SE3 T_new = se3_exp(xi) * T_cur;
             const double aff_new[2] = {aff_cur[0] + inc[6], aff_cur[1] + inc[7]};
-            {   // doStep (:910-938) on the resident arrays; idepth_new comes back with the evaluation that follows
-                const LvlOff o = lvl_off((size_t)P.n); float* d = I.lvl_dev[lvl].p;
-                rc = init_do_step_launch(c, P.n, (const uint8_t*)(d + o.isGood), I.jb_dev[I.jb_cur].p, d + o.maxstep, d + o.idepth, lambda, inc, d + o.idepth_new); if (rc) return rc;
+            {   // doStep (:910-938)
+                const LvlPtr q = lvl_ptr(I, lvl);
+                rc = init_do_step_launch(c, P.n, q.isGood, I.jb_dev[I.jb_cur].p, q.maxstep, q.idepth, lambda, inc, q.idepth_new); if (rc) return rc;
             }
             double Hn[64], bn[8], Hscn[64], bscn[8]; float resNew[3];
             rc = calc(c, I, lvl, slot_new, T_new, aff_new, Hn, bn, Hscn, bscn, resNew, regEnergy); if (rc) return rc;
@@ -659,8 +699,7 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
                 resOld[0] = resNew[0]; resOld[1] = resNew[1]; resOld[2] = resNew[2];
                 aff_cur[0] = aff_new[0]; aff_cur[1] = aff_new[1]; T_cur = T_new;
                 rc = apply_step(c, I, lvl); if (rc) return rc;
-                { HostTimer ho(c, "init.opt_reg"); opt_reg(I, lvl); }
-                rc = iR_upload(c, I, lvl); if (rc) return rc;
+                rc = opt_reg(c, I, lvl); if (rc) return rc;
                 lambda *= 0.5; fails = 0;
                 if (lambda < 0.0001) lambda = 0.0001;
             } else {
@@ -671,10 +710,10 @@ int nalo_init_track_frame(nalo_ctx* c, int slot_new, float exposure_first, float
             if (!(nrm > eps) || iteration >= maxIterations[lvl] || fails >= 2) break;
             ++iteration;
         }
-        rc = level_download(c, I, lvl); if (rc) return rc;
     }
     I.thisToNext = T_cur; I.aff[0] = aff_cur[0]; I.aff[1] = aff_cur[1];
-    { HostTimer hp(c, "init.propagate"); for (int i = 0; i < I.levels - 1; ++i) propagate_up(I, i); }
+    for (int i = 0; i < I.levels - 1; ++i) { const int rc = propagate_up(c, I, i); if (rc) return rc; }
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
     ++I.frameID;
     if (!I.snapped) I.snappedAt = 0;
     if (I.snapped && I.snappedAt == 0) I.snappedAt = I.frameID;
@@ -704,6 +743,8 @@ int nalo_init_set_points(nalo_ctx* c, int lvl, int n, const float* idepth, const
                          const float* energy2, const float* maxstep, const float* lastHessian_new, const float* energy_new2, const uint8_t* isGood_new, const float* iRSumNum) {
     if (!c || !c->init || c->init->slot_first < 0) return fail(c, c ? NALO_ERR_STATE : NALO_ERR_ARG, "nalo_init_set_points: nalo_init_set_first has not run");
     if (lvl < 0 || lvl >= c->init->levels || n != c->init->L[lvl].n) return fail(c, NALO_ERR_ARG, "nalo_init_set_points: level / point count do not match the initialiser's");
+    { const int rc = host_sync(c, *c->init); if (rc) return rc; }
+    c->init->dev_valid = false;
     InitLevel& P = c->init->L[lvl];
     auto take = [&](auto& dst, const auto* src, size_t mult) { if (src && n) std::memcpy(dst.data(), src, (size_t)n * mult * sizeof(*src)); };
     take(P.idepth, idepth, 1); take(P.idepth_new, idepth_new, 1); take(P.iR, iR, 1); take(P.isGood, isGood, 1); take(P.lastHessian, lastHessian, 1); take(P.energy, energy2, 2);
@@ -711,10 +752,44 @@ int nalo_init_set_points(nalo_ctx* c, int lvl, int n, const float* idepth, const
     return NALO_OK;
 }
 
+int nalo_init_get_carried(nalo_ctx* c, int lvl, int cap, float* idepth_new, float* maxstep, float* lastHessian_new, float* energy_new2, uint8_t* isGood_new) {
+    if (!c || !c->init) return fail(c, c ? NALO_ERR_STATE : NALO_ERR_ARG, "nalo_init_get_carried: no initialiser");
+    if (lvl < 0 || lvl >= c->init->levels) return fail(c, NALO_ERR_ARG, "nalo_init_get_carried: bad argument");
+    { const int rc = host_sync(c, *c->init); if (rc) return rc; }
+    const InitLevel& P = c->init->L[lvl];
+    const size_t m = (size_t)std::min(cap, P.n);
+    auto put = [&](auto* dst, const auto& src, size_t mult) { if (dst && m) std::memcpy(dst, src.data(), m * mult * sizeof(*dst)); };
+    put(idepth_new, P.idepth_new, 1); put(maxstep, P.maxstep, 1); put(lastHessian_new, P.lastHessian_new, 1); put(energy_new2, P.energy_new, 2); put(isGood_new, P.isGood_new, 1);
+    return NALO_OK;
+}
+
+// one of trackFrame's sweeps on its own, on the resident arrays (the parity tests compare each with the oracle's on identical state)
+int nalo_init_sweep(nalo_ctx* c, int which, int lvl) {
+    if (!c || !c->init || c->init->slot_first < 0) return fail(c, c ? NALO_ERR_STATE : NALO_ERR_ARG, "nalo_init_sweep: nalo_init_set_first has not run");
+    Initializer& I = *c->init;
+    const bool ok = which == NALO_INIT_SWEEP_PROPAGATE_UP ? (lvl >= 0 && lvl < I.levels - 1) : which == NALO_INIT_SWEEP_PROPAGATE_DOWN ? (lvl >= 1 && lvl < I.levels) : (lvl >= 0 && lvl < I.levels);
+    if (!ok) return fail(c, NALO_ERR_ARG, "nalo_init_sweep: level out of range");
+    NALO_HIP(c, hipSetDevice(c->device));
+    int rc = dev_sync(c, I); if (rc) return rc;
+    I.host_valid = false;
+    I.regWeight = 0.8;
+    switch (which) {
+        case NALO_INIT_SWEEP_OPT_REG: rc = opt_reg(c, I, lvl); break;
+        case NALO_INIT_SWEEP_PROPAGATE_UP: rc = propagate_up(c, I, lvl); break;
+        case NALO_INIT_SWEEP_PROPAGATE_DOWN: rc = propagate_down(c, I, lvl); break;
+        case NALO_INIT_SWEEP_RESET_POINTS: rc = reset_points(c, I, lvl); break;
+        default: return fail(c, NALO_ERR_ARG, "nalo_init_sweep: unknown sweep");
+    }
+    if (rc) return rc;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    return NALO_OK;
+}
+
 int nalo_init_get_points(nalo_ctx* c, int lvl, int cap, int* n, float* u, float* v, float* idepth, float* iR, uint8_t* isGood, float* lastHessian, float* energy2, float* my_type,
                          float* outlierTH, int* parent, float* parentDist, int* neighbours, float* neighboursDist) {
     if (!c || !c->init) return fail(c, c ? NALO_ERR_STATE : NALO_ERR_ARG, "nalo_init_get_points: no initialiser");
     if (lvl < 0 || lvl >= c->init->levels || !n) return fail(c, NALO_ERR_ARG, "nalo_init_get_points: bad argument");
+    { const int rc = host_sync(c, *c->init); if (rc) return rc; }
     const InitLevel& P = c->init->L[lvl];
     *n = P.n;
     const size_t m = (size_t)std::min(cap, P.n);

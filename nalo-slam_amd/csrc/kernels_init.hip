@@ -5,6 +5,7 @@
 // fp64 column sums -> block partial -> fp64 finish. doStep (:910-938) is a thread-per-point kernel.
 #include "nalo_internal.h"
 #include "reduce.h"
+#include <type_traits>
 
 namespace nalo {
 
@@ -169,6 +170,234 @@ __global__ __launch_bounds__(256) void init_apply_step_kernel(int n, uint8_t* __
     isGood[i] = isGood_new[i];
     idepth[i] = idepth_new[i];
     lastHessian[i] = lastHessian_new[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------- the "sequential" sweeps
+// optReg (:656-691) and the top level's resetPoints (:882-909) are Gauss-Seidel sweeps: point i reads the values its lower-index neighbours were just given and the
+// OLD values of its higher-index neighbours. Ordered by dependency instead of by index they are exact and parallel: i and j are ordered (lower index first) whenever one
+// is among the other's 10 neighbours, every point's step is 1 + the largest step among the points it is ordered after, and the points of one step touch nothing of each
+// other. The host builds that schedule once per setFirst (host_init.hip: a few hundred steps of ~40 points on the KITTI frame, cut to <= kSweepNT points). One workgroup
+// walks it with the level's iR in LDS (+inf = not good, which is also how resetPoints' newly good points become visible to later ones; a missing neighbour is the
+// index n, a slot that always holds +inf); the records of the next four
+// steps are in flight while four steps compute. Levels too large for LDS keep the values in a global scratch array, read and written past the L1 (same kernel, LDS = false).
+struct SweepAccessLds { static __device__ __forceinline__ float ld(const float* p) { return *p; } static __device__ __forceinline__ void st(float* p, float x) { *p = x; } };
+struct SweepAccessGlobal {
+    static __device__ __forceinline__ float ld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ void st(float* p, float x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+// compare-exchange of two non-NaN values: the bare instructions (fminf / fmaxf would first quiet every input with a v_max_f32 x, x)
+__device__ __forceinline__ void sweep_ce(float& a, float& b) {
+    float lo, hi;
+    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    a = lo; b = hi;
+}
+// ascending sort of 10 values: 29 compare-exchanges in 8 layers (checked exhaustively on 0/1 inputs, scripts/check_sort10.py)
+__device__ __forceinline__ void sweep_sort10(float (&v)[10]) {
+#define CE(a, b) sweep_ce(v[a], v[b]);
+    CE(0, 8) CE(1, 9) CE(2, 7) CE(3, 5) CE(4, 6)
+    CE(0, 2) CE(1, 4) CE(5, 8) CE(7, 9)
+    CE(0, 3) CE(2, 4) CE(5, 7) CE(6, 9)
+    CE(0, 1) CE(3, 6) CE(8, 9)
+    CE(1, 5) CE(2, 3) CE(4, 8) CE(6, 7)
+    CE(1, 2) CE(3, 5) CE(4, 6) CE(7, 8)
+    CE(2, 3) CE(4, 5) CE(6, 7)
+    CE(3, 4) CE(5, 6)
+#undef CE
+}
+// MODE 0: optReg with snapped == true. MODE 1: the `lvl == top && !isGood` part of resetPoints.   rec: [n][3] int4 = {point, nn0..nn9, -} in schedule order.
+// A grid-wide pass before (init_sweep_pre_kernel) writes the values the walk starts from (iR, NaN where the point is not good) and, for optReg, the points' inverse
+// depths in schedule order, so that the walk's loads depend on nothing; a grid-wide pass after it (init_sweep_post_kernel) writes the results back under the
+// reference's conditions. The single workgroup in between only fills its LDS (float4, eight loads in flight), walks the schedule and stores the values.
+struct SweepRec { int4 a, b, c; float idp; };
+template <int MODE>
+__global__ __launch_bounds__(256) void init_sweep_pre_kernel(int n, int npad, const int4* __restrict__ rec, const float* __restrict__ iR, const uint8_t* __restrict__ isGood,
+                                                            const float* __restrict__ idepth, float* __restrict__ val, float* __restrict__ idp_s) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= n) { val[i] = __builtin_inff(); return; }                              // slot n: what a missing neighbour (index n in rec) reads
+    val[i] = isGood[i] ? iR[i] : __builtin_inff();
+    if (MODE == 0) idp_s[i] = idepth[rec[(size_t)i * 3].x];
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void init_sweep_post_kernel(int n, const float* __restrict__ val, float* __restrict__ iR, uint8_t* __restrict__ isGood, float* __restrict__ idepth,
+                                                             float* __restrict__ idepth_new) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = val[i];
+    if (MODE == 0) { if (isGood[i]) iR[i] = x; }
+    else if (!isGood[i] && x < __builtin_inff()) { isGood[i] = 1; iR[i] = x; idepth[i] = x; idepth_new[i] = x; }
+}
+// gval: the values in global memory (n + 1 floats rounded up to float4s, 16-byte aligned), start values in, results out; idp_s as above
+template <int MODE, bool LDS>
+__global__ __launch_bounds__(kSweepNT) void init_sweep_kernel(int n, int nsteps, const int* __restrict__ off, const int4* __restrict__ rec, float w, float one_minus_w,
+                                                             float* __restrict__ gval, const float* __restrict__ idp_s) {
+    using A = typename std::conditional<LDS, SweepAccessLds, SweepAccessGlobal>::type;
+    extern __shared__ float4 sweep_sm4[];
+    float* sweep_sm = (float*)sweep_sm4;
+    const int n4 = (n + 4) >> 2;
+    float* val = LDS ? sweep_sm : gval;
+    int* soff = (int*)(sweep_sm + (LDS ? 4 * n4 : 0));                               // off[], then n up to entry nsteps4 + 4 (empty steps: the walk is unrolled by four)
+    const int nsteps4 = (nsteps + 3) & ~3;
+    const int tid = threadIdx.x;
+    if (LDS) {
+        const float4* g4 = (const float4*)gval;
+        for (int j0 = 0; j0 < n4; j0 += 8 * kSweepNT) {
+            float4 x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int j = j0 + k * kSweepNT + tid; x[k] = g4[j < n4 ? j : n4 - 1]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int j = j0 + k * kSweepNT + tid; if (j < n4) sweep_sm4[j] = x[k]; }
+        }
+    }
+    for (int s = tid; s <= nsteps4 + 4; s += kSweepNT) soff[s] = off[s < nsteps ? s : nsteps];
+    __syncthreads();
+    auto load = [&](int s) {
+        const int p0 = soff[s] + tid, p = p0 < n ? p0 : n - 1;
+        const int4* r = rec + (size_t)p * 3;
+        SweepRec R; R.a = r[0]; R.b = r[1]; R.c = r[2]; R.idp = MODE == 0 ? idp_s[p] : 0.f;
+        return R;
+    };
+    auto step = [&](int s, const SweepRec& R) {
+        const bool act = soff[s] + tid < soff[s + 1];
+        const int i = R.a.x;
+        const int nn[10] = {R.a.y, R.a.z, R.a.w, R.b.x, R.b.y, R.b.z, R.b.w, R.c.x, R.c.y, R.c.z};
+        const float inf = __builtin_inff();
+        const bool self_good = A::ld(val + i) < inf;
+        if (act && (MODE == 0 ? self_good : !self_good)) {
+            float v[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) v[k] = A::ld(val + nn[k]);
+            if (MODE == 0) {
+                sweep_sort10(v);                                                    // the m good neighbours' values first, +inf behind them
+                if (v[2] < inf) {                                                   // nnn > 2; nth_element(idnn, idnn + nnn/2, idnn + nnn): the nnn/2-th smallest
+                    const float med = v[9] < inf ? v[5] : (v[7] < inf ? v[4] : (v[5] < inf ? v[3] : (v[3] < inf ? v[2] : v[1])));
+                    A::st(val + i, __fadd_rn(__fmul_rn(one_minus_w, R.idp), __fmul_rn(w, med)));
+                }
+            } else {
+                float sum = 0.f, cnt = 0.f;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) if (v[k] < inf) { sum = __fadd_rn(sum, v[k]); cnt += 1.f; }
+                if (cnt > 0) A::st(val + i, sum / cnt);
+            }
+        }
+        // the step's LDS writes before anyone's next reads. __syncthreads() would also drain the records in flight (its fence covers global memory): in LDS mode only
+        // the LDS counter has to reach zero before the barrier
+        if (LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads();
+    };
+    // the records of the next four steps are requested when a group of four starts and land while it computes
+    SweepRec c0 = load(0), c1 = load(1), c2 = load(2), c3 = load(3);
+    for (int s = 0; s < nsteps4; s += 4) {
+        const SweepRec n0 = load(s + 4), n1 = load(s + 5), n2 = load(s + 6), n3 = load(s + 7);
+        step(s, c0); step(s + 1, c1); step(s + 2, c2); step(s + 3, c3);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+    if (LDS) {
+        float4* g4 = (float4*)gval;
+        for (int j = tid; j < n4; j += kSweepNT) g4[j] = sweep_sm4[j];
+    }
+}
+
+// resetPoints' per-point part (:885-888); the unsnapped start of trackFrame (:100-110); optReg with snapped == false (:659-664)
+__global__ __launch_bounds__(256) void init_reset_kernel(int n, float* __restrict__ energy, float* __restrict__ idepth_new, const float* __restrict__ idepth) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    energy[2 * i] = 0.f; energy[2 * i + 1] = 0.f; idepth_new[i] = idepth[i];
+}
+__global__ __launch_bounds__(256) void init_fill_kernel(int n, float* __restrict__ iR, float* __restrict__ idepth_new, float* __restrict__ lastHessian) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    iR[i] = 1.f;
+    if (idepth_new) idepth_new[i] = 1.f;
+    if (lastHessian) lastHessian[i] = 0.f;
+}
+// propagateDown (:736-766) without its optReg: one lane per point of the finer level
+__global__ __launch_bounds__(256) void init_propagate_down_kernel(int n, const int* __restrict__ parent, const uint8_t* __restrict__ pGood, const float* __restrict__ pLastHessian,
+                                                                 const float* __restrict__ pIR, uint8_t* __restrict__ isGood, float* __restrict__ iR, float* __restrict__ idepth,
+                                                                 float* __restrict__ idepth_new, float* __restrict__ lastHessian) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int par = parent[i];
+    const float pH = pLastHessian[par], pR = pIR[par];
+    if (!pGood[par] || pH < 0.1f) return;
+    if (!isGood[i]) { iR[i] = pR; idepth[i] = pR; idepth_new[i] = pR; isGood[i] = 1; lastHessian[i] = 0.f; }
+    else {
+        const float r = iR[i], lh = lastHessian[i];
+        const float fused = __fadd_rn(__fmul_rn(__fmul_rn(r, lh), 2.f), __fmul_rn(pR, pH)) / __fadd_rn(__fmul_rn(lh, 2.f), pH);
+        iR[i] = fused; idepth[i] = fused; idepth_new[i] = fused;
+    }
+}
+// propagateUp (:695-734) without its optReg: one lane per parent, its children in index order (child_off / child_idx: the host's counting sort of `parent`)
+__global__ __launch_bounds__(256) void init_propagate_up_kernel(int nT, const int* __restrict__ child_off, const int* __restrict__ child_idx, const uint8_t* __restrict__ cGood,
+                                                               const float* __restrict__ cIR, const float* __restrict__ cLastHessian, uint8_t* __restrict__ isGood,
+                                                               float* __restrict__ iR, float* __restrict__ idepth) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nT) return;
+    float acc = 0.f, num = 0.f;
+    for (int k = child_off[p]; k < child_off[p + 1]; ++k) {
+        const int ch = child_idx[k];
+        if (!cGood[ch]) continue;
+        const float lh = cLastHessian[ch];
+        acc = __fadd_rn(acc, __fmul_rn(cIR[ch], lh));
+        num = __fadd_rn(num, lh);
+    }
+    if (num > 0) { const float r = acc / num; iR[p] = r; idepth[p] = r; isGood[p] = 1; }
+    else iR[p] = 0.f;
+}
+
+int init_sweep_launch(nalo_ctx* c, int mode, int n, int nsteps, const int* off, const int* rec, float* iR, uint8_t* isGood, float* idepth, float* idepth_new, float regWeight, float* scratch) {
+    if (n <= 0 || nsteps <= 0) return NALO_OK;
+    const size_t npad = ((size_t)n + 4) & ~(size_t)3;                               // n values + the +inf slot, in float4s
+    const size_t soff_words = (size_t)((nsteps + 3) & ~3) + 8;
+    const size_t lds_bytes = (npad + soff_words) * 4;
+    const bool lds = lds_bytes <= kSweepLdsBytes;
+    const size_t sm = lds ? lds_bytes : soff_words * 4;
+    if (!scratch) return fail(c, NALO_ERR_STATE, "init_sweep_launch: no scratch block");
+    float *gval = scratch, *idp_s = scratch + npad;                                 // scratch: 2 * npad floats, 16-byte aligned
+    static bool attr_done = false;
+    if (!attr_done) {
+        NALO_HIP(c, hipFuncSetAttribute((const void*)init_sweep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLdsBytes));
+        NALO_HIP(c, hipFuncSetAttribute((const void*)init_sweep_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLdsBytes));
+        attr_done = true;
+    }
+    const float w = regWeight, omw = 1 - regWeight;
+    const int4* r4 = (const int4*)rec;
+    const int nb = (n + 4 + 255) / 256;
+    if (mode == 0) {
+        init_sweep_pre_kernel<0><<<nb, 256, 0, c->stream>>>(n, (int)npad, r4, iR, isGood, idepth, gval, idp_s);
+        if (lds) init_sweep_kernel<0, true><<<1, kSweepNT, sm, c->stream>>>(n, nsteps, off, r4, w, omw, gval, idp_s);
+        else init_sweep_kernel<0, false><<<1, kSweepNT, sm, c->stream>>>(n, nsteps, off, r4, w, omw, gval, idp_s);
+        init_sweep_post_kernel<0><<<nb, 256, 0, c->stream>>>(n, gval, iR, isGood, idepth, idepth_new);
+    } else {
+        init_sweep_pre_kernel<1><<<nb, 256, 0, c->stream>>>(n, (int)npad, r4, iR, isGood, idepth, gval, idp_s);
+        if (lds) init_sweep_kernel<1, true><<<1, kSweepNT, sm, c->stream>>>(n, nsteps, off, r4, w, omw, gval, idp_s);
+        else init_sweep_kernel<1, false><<<1, kSweepNT, sm, c->stream>>>(n, nsteps, off, r4, w, omw, gval, idp_s);
+        init_sweep_post_kernel<1><<<nb, 256, 0, c->stream>>>(n, gval, iR, isGood, idepth, idepth_new);
+    }
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+int init_reset_launch(nalo_ctx* c, int n, float* energy, float* idepth_new, const float* idepth) {
+    if (n > 0) init_reset_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, energy, idepth_new, idepth);
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+int init_fill_launch(nalo_ctx* c, int n, float* iR, float* idepth_new, float* lastHessian) {
+    if (n > 0) init_fill_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, iR, idepth_new, lastHessian);
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+int init_propagate_down_launch(nalo_ctx* c, int n, const int* parent, const uint8_t* pGood, const float* pLastHessian, const float* pIR, uint8_t* isGood, float* iR, float* idepth,
+                               float* idepth_new, float* lastHessian) {
+    if (n > 0) init_propagate_down_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(n, parent, pGood, pLastHessian, pIR, isGood, iR, idepth, idepth_new, lastHessian);
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+int init_propagate_up_launch(nalo_ctx* c, int nT, const int* child_off, const int* child_idx, const uint8_t* cGood, const float* cIR, const float* cLastHessian, uint8_t* isGood,
+                             float* iR, float* idepth) {
+    if (nT > 0) init_propagate_up_kernel<<<(nT + 255) / 256, 256, 0, c->stream>>>(nT, child_off, child_idx, cGood, cIR, cLastHessian, isGood, iR, idepth);
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
 }
 
 int init_calc_launch(nalo_ctx* c, InitParams& P, int lvl, double* sums) {

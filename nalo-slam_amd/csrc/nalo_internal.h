@@ -193,6 +193,16 @@ int init_calc_launch(nalo_ctx* c, InitParams& P, int lvl, double* sums);
 int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float inc[8], float* idepth_new);
 int init_apply_step_launch(nalo_ctx* c, int n, uint8_t* isGood, const uint8_t* isGood_new, float* idepth, float* idepth_new, const float* iR, float* energy, const float* energy_new,
                            float* lastHessian, const float* lastHessian_new);
+// the dependency-ordered sweeps (optReg: mode 0, the top level's resetPoints: mode 1) and the per-point parts of resetPoints / propagateDown / propagateUp
+constexpr int kSweepNT = 128;                          // lanes of the sweep workgroup = the most points a schedule step may hold
+constexpr size_t kSweepLdsBytes = 158 * 1024;          // of the 160 KB per workgroup
+int init_sweep_launch(nalo_ctx* c, int mode, int n, int nsteps, const int* off, const int* rec, float* iR, uint8_t* isGood, float* idepth, float* idepth_new, float regWeight, float* scratch);
+int init_reset_launch(nalo_ctx* c, int n, float* energy, float* idepth_new, const float* idepth);
+int init_fill_launch(nalo_ctx* c, int n, float* iR, float* idepth_new, float* lastHessian);
+int init_propagate_down_launch(nalo_ctx* c, int n, const int* parent, const uint8_t* pGood, const float* pLastHessian, const float* pIR, uint8_t* isGood, float* iR, float* idepth,
+                               float* idepth_new, float* lastHessian);
+int init_propagate_up_launch(nalo_ctx* c, int nT, const int* child_off, const int* child_idx, const uint8_t* cGood, const float* cIR, const float* cLastHessian, uint8_t* isGood,
+                             float* iR, float* idepth);
 // host_init.hip: the host arithmetic either side of that pass (pose / affine / alpha terms in, Accumulator9 sums -> H, b, Hsc, bsc, E out), shared by the staged
 // entry point (nalo_init_calc_res_and_gs) and the resident trackFrame
 struct InitPose { float alphaEnergy; };

@@ -715,6 +715,14 @@ class Initializer:
     def num(self, lvl):
         return self.L.orc_initf_num(self.h_, lvl)
 
+    SWEEPS = dict(opt_reg=0, propagate_up=1, propagate_down=2, reset_points=3)
+
+    def sweep(self, which, lvl):
+        """one of trackFrame's sweeps alone: optReg(lvl), propagateUp(srcLvl), propagateDown(srcLvl), resetPoints(lvl)"""
+        self.L.orc_initf_sweep.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.L.orc_initf_sweep.restype = None
+        self.L.orc_initf_sweep(self.h_, self.SWEEPS[which], lvl)
+
     def get(self, lvl, field):
         dt, m = self.FIELDS[field]
         n = self.num(lvl)

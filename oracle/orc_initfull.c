@@ -564,6 +564,15 @@ int orc_initf_track_frame(void* p, const float* const* dI, float exposure_first,
     return I->snapped && I->frameID > I->snappedAt + 5;
 }
 
+/* one sweep alone (tests): 0 optReg(lvl), 1 propagateUp(srcLvl = lvl), 2 propagateDown(srcLvl = lvl), 3 resetPoints(lvl) */
+void orc_initf_sweep(void* p, int which, int lvl) {
+    OrcInit* I = (OrcInit*)p;
+    I->regWeight = 0.8f;
+    if (which == 0) initf_opt_reg(I, lvl);
+    else if (which == 1) initf_propagate_up(I, lvl);
+    else if (which == 2) initf_propagate_down(I, lvl);
+    else if (which == 3) initf_reset_points(I, lvl);
+}
 int orc_initf_num(void* p, int lvl) { return ((OrcInit*)p)->L[lvl].n; }
 /* field: one of the Pnt members; out must hold n (x2 for energy, x10 for neighbours / neighboursDist) entries of float, int (parent, neighbours) or bytes (isGood) */
 int orc_initf_get(void* p, int lvl, const char* field, void* out) {
