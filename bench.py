@@ -739,13 +739,15 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     lin = job.ctx.profile_get("ba_linearize")
-    job.ctx.profile_select(None); job.ctx.profile_reset()        # the other scopes: one more, untimed keyframe on every rank
-    job.step(False)
+    job.ctx.profile_select(None); job.ctx.profile_reset()        # the other scopes: three more, untimed keyframes on every rank (averages over ~20 launches each;
+    for _ in range(3):                                           # "ba_reduce" brackets the reduce + stitch kernels only, the threshold chain and the collectives are outside)
+        job.step(False)
     job.ctx.sync()
     R, P = int((part.exists > 0).sum()), len(part.host)
     res = {"workload": "shard1m", "scaling": "strong", "n_gpus": world, "keyframes_per_s": round(steps / dt, 3),
            "ms_per_keyframe": round(dt / steps * 1e3, 3), "window_frames": win.W, "active_points": int(len(win.host)),
            "residuals": int((win.exists > 0).sum()), "points_per_rank": P, "allreduce_doubles": 2 * (8 * win.W + 5) ** 2 + 2 * win.W ** 2 + 5,
+           "collectives_per_linearize": "2: hi histogram of the newest frame's energy threshold (16384 doubles, side stream), then [systems | lo histogram] (+32768 doubles) in one sum",
            "exchange": "libnalo_gpu.so -> ncclAllReduce (RCCL) on its own streams, no host callback" if backend == "nccl" else "python hook (rehearsal)"}
     ms, n = lin
     if n:

@@ -93,6 +93,9 @@ struct BAWindow {
     nalo_allreduce_fn hook_side = nullptr; void* hook_side_user = nullptr;   // same sum, enqueued on nalo_side_stream(ctx): the threshold's histograms
     DevBuf<double> th_buf;                                          // a histogram as doubles (all-reduce payload)
     hipEvent_t ev_lin = nullptr, ev_th = nullptr; bool th_side_inflight = false;   // sharded windows run the quantile kernels on the side stream, under the SC kernel
+    bool th_lo_pending = false;                                     // the lo histogram sits behind the stitched systems (lo_off), not yet summed over the ranks: the next
+                                                                    // stitch sums it WITH the systems in one all-reduce, anything else that needs the threshold sums it alone
+    size_t lo_off = 0;
     bool never_break = false;
     DevBuf<double> noapply_E; std::vector<double> noapply_h;          // energy partials of a linearisation that is not applied (forceAcceptStep = false)
     int opt_iterations = 0, opt_rejected = 0;
@@ -315,6 +318,13 @@ static int upload_frame_th(nalo_ctx* c) {
 static int flush_th(nalo_ctx* c) {
     BAWindow& w = *c->ba;
     if (w.th_side_inflight) { NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0)); w.th_side_inflight = false; }
+    if (w.th_lo_pending) {                                            // no stitch took the lo histogram along: its own all-reduce, then the search
+        w.th_lo_pending = false;
+        if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
+        { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + w.lo_off, kThLoDoubles); if (rh) return rh; }
+        ba_launch_energy_th_sharded(c->stream, w.dev, w.stitched.p + w.lo_off, 3);
+        NALO_HIP(c, hipGetLastError());
+    }
     if (!w.th_pending) return NALO_OK;
     ba_launch_energy_th(c->stream, w.dev);
     w.th_pending = false;
@@ -354,32 +364,22 @@ static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false)
     if (mode == 0 && w.hook) {
         // sharded window: the threshold is part of the all-reduced tail, i.e. on the critical path: run its kernels on the side stream under SC
         if (!w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming)); }
-        if (!(w.hook_stream_ordered && !w.hook_side)) {
-            // the EXACT order statistic over all ranks' residuals (what one GPU holding the whole window computes): both radix histograms are summed
-            // across ranks before their search. On the side stream, under SC / reduce / stitch; a blocking hook is called with that stream drained.
-            nalo_allreduce_fn fn = w.hook_side ? w.hook_side : w.hook;
-            void* user = w.hook_side ? w.hook_side_user : w.hook_user;
-            NALO_HIP(c, w.th_buf.reserve(65536));
-            NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream));
-            NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0));
-            ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 0);
-            if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->side));
-            { int rh = call_hook(c, fn, user, w.th_buf.p, 32768); if (rh) return rh; }
-            ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 1);
-            if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->side));
-            { int rh = call_hook(c, fn, user, w.th_buf.p, 65536); if (rh) return rh; }
-            ba_launch_energy_th_sharded(c->side, w.dev, w.th_buf.p, 2);
-            NALO_HIP(c, hipEventRecord(w.ev_th, c->side));
-            w.th_side_inflight = true;
-        } else {
-            // stream-ordered main hook without a side hook: the same exact search, in line on the main stream
-            NALO_HIP(c, w.th_buf.reserve(65536));
-            ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 0);
-            { int rh = call_hook(c, w.hook, w.hook_user, w.th_buf.p, 32768); if (rh) return rh; }
-            ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 1);
-            { int rh = call_hook(c, w.hook, w.hook_user, w.th_buf.p, 65536); if (rh) return rh; }
-            ba_launch_energy_th_sharded(c->stream, w.dev, w.th_buf.p, 2);
-        }
+        // The EXACT order statistic over all ranks' residuals (what one GPU holding the whole window computes): both radix histograms are summed across ranks before
+        // their search. The hi histogram's sum and search and the lo histogram's fill run here - on the side stream under SC / reduce / stitch when there is a side
+        // hook or the main hook blocks, in line otherwise -; the lo histogram is left behind the stitched systems and summed together with them (stitch_and_fetch).
+        const bool on_side = !(w.hook_stream_ordered && !w.hook_side);
+        hipStream_t st = on_side ? c->side : c->stream;
+        nalo_allreduce_fn fn = (on_side && w.hook_side) ? w.hook_side : w.hook;
+        void* user = (on_side && w.hook_side) ? w.hook_side_user : w.hook_user;
+        NALO_HIP(c, w.th_buf.reserve(kThHiDoubles));
+        if (on_side) { NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream)); NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0)); }
+        ba_launch_energy_th_sharded(st, w.dev, w.th_buf.p, 0);
+        if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(st));
+        { int rh = call_hook(c, fn, user, w.th_buf.p, kThHiDoubles); if (rh) return rh; }
+        ba_launch_energy_th_sharded(st, w.dev, w.th_buf.p, 1);
+        ba_launch_energy_th_sharded(st, w.dev, w.stitched.p + w.lo_off, 2);
+        if (on_side) { NALO_HIP(c, hipEventRecord(w.ev_th, c->side)); w.th_side_inflight = true; }
+        w.th_lo_pending = true;
     } else if (mode == 0) w.th_pending = true;
     if (fix != 2) { w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false; }
     NALO_HIP(c, hipGetLastError());
@@ -453,13 +453,14 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
     const double seq = (double)(w.pub_seq + 1);
     double* dmap = nullptr;
     NALO_HIP(c, hipHostGetDevicePointer((void**)&dmap, w.stitched_host, 0));
+    const bool fuse_lo = w.hook && w.th_lo_pending;                  // this stitch's all-reduce takes the newest frame's lo histogram along
     {
-        ProfScope ps(c, "ba_reduce");
         const bool top = want_top && !w.stitched_top, sc = want_sc && !w.stitched_sc;
-        if ((top || sc) && (th_to_host || w.hook)) {                  // the threshold rides in the tail {TH, 1.0}: compute it before the publish
+        if ((top || sc) && (th_to_host || w.hook) && !fuse_lo) {      // the threshold rides in the tail {TH, 1.0}: compute it before the publish
             int rc = flush_th(c); if (rc) return rc;
             ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
         }
+        ProfScope ps(c, "ba_reduce");                                 // reduce + stitch only: the threshold search above is its own chain (and holds collectives)
         if (top || sc) {
             // misc {count, energy} per bin lands in the tail of the stitched buffer; without a cross-rank hook step B publishes
             // rows + tail + sequence number straight into host-mapped memory
@@ -482,9 +483,19 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
             // sharded window: tail = {step sums (3), frameEnergyTH of the newest frame, 1.0}. Every rank already holds the SAME threshold (the order
             // statistic over all ranks' residuals, linearize_async), so sum / count below re-installs that value; the tail keeps its layout.
             const size_t off = misc_only ? 2 * blk : 0;               // misc_only: only the tail is summed and published
-            if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
-            { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + off, npub - (int)off); if (rh) return rh; }
-            ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // more than one rank: the common threshold
+            if (fuse_lo) {
+                // [systems | tail | lo histogram]: one sum over the ranks, then the search on the summed histogram gives every rank the same threshold
+                if (w.th_side_inflight) { NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0)); w.th_side_inflight = false; }
+                w.th_lo_pending = false;
+                if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
+                { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + off, (int)(w.lo_off - off) + kThLoDoubles); if (rh) return rh; }
+                ba_launch_energy_th_sharded(c->stream, w.dev, w.stitched.p + w.lo_off, 3);
+                ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);        // what tail_th() reads: {TH, 1.0}
+            } else {
+                if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
+                { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + off, npub - (int)off); if (rh) return rh; }
+                ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // more than one rank: the common threshold
+            }
             ba_launch_publish(c->stream, w.stitched.p + off, dmap + off, npub - (int)off, seq, w.st_ticket.p + 1);
             NALO_HIP(c, hipGetLastError());
         }
@@ -768,8 +779,10 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     const size_t blk = (size_t)w.n1 * w.n1;
     NALO_HIP(c, w.acc13.reserve((size_t)W * W * 169));
     NALO_HIP(c, w.G.reserve((size_t)W * w.NPL * w.NPL));
-    NALO_HIP(c, w.stitched.reserve(2 * blk + 2 * W * W + 16));
-    NALO_HIP(c, hipMemsetAsync(w.stitched.p, 0, (2 * blk + 2 * W * W + 16) * 8, c->stream));
+    w.lo_off = (2 * blk + 2 * W * W + 5 + 15) & ~(size_t)15;                       // behind the published doubles: the lo histogram of a sharded window's threshold search
+    NALO_HIP(c, w.stitched.reserve(w.lo_off + kThLoDoubles));
+    NALO_HIP(c, hipMemsetAsync(w.stitched.p, 0, (w.lo_off + kThLoDoubles) * 8, c->stream));
+    w.th_lo_pending = false;
     w.sd.M_top = w.acc13.p; w.sd.M_sc = w.G.p; w.sd.H = w.stitched.p;
     if (w.stitched_host) { (void)hipHostFree(w.stitched_host); w.stitched_host = nullptr; }
     NALO_HIP(c, hipHostMalloc((void**)&w.stitched_host, (2 * blk + 2 * W * W + 16) * 8, hipHostMallocMapped));

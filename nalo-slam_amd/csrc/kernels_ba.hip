@@ -996,23 +996,27 @@ void ba_launch_energy_th(hipStream_t s, const BADev& B) {
     ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo);
     ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1));
 }
-// Sharded window: the order statistic is taken over ALL ranks' residuals, so each of the two histograms is summed across ranks before its search
-// (the all-reduce hook sums doubles: counts go through fp64, exact below 2^53). step 0: hi histogram -> buf; 1: buf -> hi histogram, search, fill the
-// lo histogram of the (global) bin, lo histogram -> buf; 2: buf -> lo histogram, search, threshold.
-__global__ __launch_bounds__(256) void ba_th_cvt_kernel(unsigned* __restrict__ hist, double* __restrict__ buf, int n, int to_hist) {
+// Sharded window: the order statistic is taken over ALL ranks' residuals, so each of the two histograms is summed across ranks before its search. The all-reduce
+// hook sums doubles: TWO bins ride in one double (lo + hi * 2^26, exact while a bin's global count stays below 2^26 = 67 M residuals towards the newest frame, and
+// the sum below 2^52), which halves the payload: 16384 doubles for the hi histogram, 32768 for the lo one.
+// step 0: hi histogram -> buf; 1: buf -> hi histogram, search, fill the lo histogram of the (global) bin, lo histogram -> buf; 2: buf -> lo histogram, search,
+// threshold. The caller picks buf per step: the lo histogram is written behind the stitched systems so that ONE all-reduce sums both (host_ba.hip).
+constexpr double kThPack = 67108864.0;                        // 2^26
+__global__ __launch_bounds__(256) void ba_th_cvt_kernel(unsigned* __restrict__ hist, double* __restrict__ buf, int npair, int to_hist) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (to_hist) hist[i] = (unsigned)(buf[i] + 0.5); else buf[i] = (double)hist[i];
+    if (i >= npair) return;
+    if (to_hist) { const unsigned long long v = (unsigned long long)(buf[i] + 0.5); hist[2 * i] = (unsigned)(v & 0x3FFFFFFull); hist[2 * i + 1] = (unsigned)(v >> 26); }
+    else buf[i] = (double)hist[2 * i] + (double)hist[2 * i + 1] * kThPack;
 }
 void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int step) {
-    constexpr int NHI = 32768, NLO = 65536;                    // energies are >= 0: the upper half of the hi histogram (sign bit) stays empty
+    constexpr int NHI = kThHiDoubles, NLO = kThLoDoubles;      // pairs of bins; energies are >= 0: the upper half of the hi histogram (sign bit) stays empty
     if (step == 0) ba_th_cvt_kernel<<<NHI / 256, 256, 0, s>>>(B.th_hist_hi, buf, NHI, 0);
     else if (step == 1) {
         ba_th_cvt_kernel<<<NHI / 256, 256, 0, s>>>(B.th_hist_hi, buf, NHI, 1);
         ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr);
         ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo);
-        ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 0);
-    } else {
+    } else if (step == 2) ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 0);
+    else {
         ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 1);
         ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1));
     }

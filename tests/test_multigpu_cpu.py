@@ -85,5 +85,12 @@ def test_sharded_threshold_rule_is_the_global_order_statistic():
     bin_lo = int(np.searchsorted(np.cumsum(lo), k_lo, side="right"))
     got = np.array([(bin_hi << 16) | bin_lo], np.uint32).view(np.float32)[0]
     assert got == want
+    # the payload rule (kernels_ba.hip: ba_th_cvt_kernel): two bins per double, a + b * 2^26, summed as doubles, split again - exact while a bin stays below 2^26
+    his = [np.bincount(b >> 16, minlength=65536).astype(np.float64) for b in bits]
+    his[0][[6, 7]] = 2 ** 26 - 1 - his[1][[6, 7]] - his[2][[6, 7]]                # the largest totals the packing admits, in both halves of one pair
+    packed = sum(h[0::2] + h[1::2] * 2.0 ** 26 for h in his)
+    v = (packed + 0.5).astype(np.uint64)
+    back = np.empty(65536, np.uint64); back[0::2] = v & np.uint64(2 ** 26 - 1); back[1::2] = v >> np.uint64(26)
+    assert np.array_equal(back, sum(his).astype(np.uint64))
     mean_of_quantiles = np.mean([np.sort(s)[int(np.float32(0.7) * np.float32(len(s)))] for s in shards])
     assert abs(mean_of_quantiles - want) > 0.05 * want                            # the shortcut this replaces is visibly off on unequal shards

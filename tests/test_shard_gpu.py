@@ -78,8 +78,14 @@ def test_two_shards_agree_with_the_whole_window():
     assert not err, err
     a, b = out
     assert a["n"] + b["n"] == len(win.host) and min(a["n"], b["n"]) > 0.3 * len(win.host)
-    # per linearisation: the two histogram sums, then the systems
-    assert calls[0][:3] == [32768, 65536, calls[0][2]] and calls[0] == calls[1]
+    # per linearisation TWO collectives: the hi histogram of the threshold search (two bins per double), then [systems | tail | lo histogram] in one sum. A pass whose
+    # systems nobody fetches (the last one of optimize) sums its lo histogram alone when the threshold is next needed; a second fetch of a pass sums the systems alone.
+    n_sys = 2 * (8 * win.W + 5) ** 2 + 2 * win.W ** 2 + 5
+    sizes = calls[0]
+    assert calls[0] == calls[1] and sizes[:2] == [16384, sizes[1]] and n_sys + 32768 <= sizes[1] <= n_sys + 32768 + 16, sizes
+    fused, alone, hi = sum(n > 32768 for n in sizes), sizes.count(32768), sizes.count(16384)
+    assert hi == fused + alone and fused >= 4 and alone <= 2, sizes
+    assert all(n in (16384, 32768) or n > 32768 or n <= n_sys for n in sizes), sizes
     # the threshold is the whole window's order statistic, bit for bit, on both ranks; after the optimisation too (7 passes later)
     assert a["th"] == b["th"] == th_full
     assert a["th2"] == b["th2"]
