@@ -16,6 +16,7 @@ void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NP
 void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial, const XadArg* karg = nullptr);
 int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg = nullptr);
+void ba_launch_put(hipStream_t s, float* dst, const float* src, int n);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
 void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
@@ -357,22 +358,28 @@ static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false)
     }
     int rc = flush_th(c); if (rc) return rc;                          // frameEnergyTH of the previous pass feeds this one
     if (fix || mode == 2) NALO_HIP(c, hipMemsetAsync(w.pt_relbs.p, 0, (size_t)w.Ppad * 4, c->stream));
+    const bool th_sharded = mode == 0 && w.hook;
+    const bool on_side = th_sharded && !(w.hook_stream_ordered && !w.hook_side);
+    // (device-scope events: both sides of these dependencies are kernels of this context; a system-scope release behind the linearisation writes its output back first)
+    if (th_sharded && !w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming | hipEventDisableSystemFence)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming | hipEventDisableSystemFence)); }
+    hipEvent_t lin_done = nullptr;
     {
+        // the side stream's dependency on this pass is the dispatch's own completion signal (hipExtLaunchKernelGGL's stop event): an event RECORDED behind the kernel
+        // is a marker packet of its own, and the next kernel of the main stream stood 14 us behind it
         ProfScope ps(c, "ba_linearize", true);
-        ba_launch_linearize(c->stream, w.dev, mode, fix, ps.a, ps.b);
+        lin_done = ps.b ? ps.b : (on_side ? w.ev_lin : nullptr);
+        ba_launch_linearize(c->stream, w.dev, mode, fix, ps.a, lin_done);
     }
-    if (mode == 0 && w.hook) {
+    if (th_sharded) {
         // sharded window: the threshold is part of the all-reduced tail, i.e. on the critical path: run its kernels on the side stream under SC
-        if (!w.ev_lin) { NALO_HIP(c, hipEventCreateWithFlags(&w.ev_lin, hipEventDisableTiming)); NALO_HIP(c, hipEventCreateWithFlags(&w.ev_th, hipEventDisableTiming)); }
         // The EXACT order statistic over all ranks' residuals (what one GPU holding the whole window computes): both radix histograms are summed across ranks before
         // their search. The hi histogram's sum and search and the lo histogram's fill run here - on the side stream under SC / reduce / stitch when there is a side
         // hook or the main hook blocks, in line otherwise -; the lo histogram is left behind the stitched systems and summed together with them (stitch_and_fetch).
-        const bool on_side = !(w.hook_stream_ordered && !w.hook_side);
         hipStream_t st = on_side ? c->side : c->stream;
         nalo_allreduce_fn fn = (on_side && w.hook_side) ? w.hook_side : w.hook;
         void* user = (on_side && w.hook_side) ? w.hook_side_user : w.hook_user;
         NALO_HIP(c, w.th_buf.reserve(kThHiDoubles));
-        if (on_side) { NALO_HIP(c, hipEventRecord(w.ev_lin, c->stream)); NALO_HIP(c, hipStreamWaitEvent(c->side, w.ev_lin, 0)); }
+        if (on_side) NALO_HIP(c, hipStreamWaitEvent(c->side, lin_done, 0));
         ba_launch_energy_th_sharded(st, w.dev, w.th_buf.p, 0);
         if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(st));
         { int rh = call_hook(c, fn, user, w.th_buf.p, kThHiDoubles); if (rh) return rh; }
@@ -454,6 +461,7 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
     double* dmap = nullptr;
     NALO_HIP(c, hipHostGetDevicePointer((void**)&dmap, w.stitched_host, 0));
     const bool fuse_lo = w.hook && w.th_lo_pending;                  // this stitch's all-reduce takes the newest frame's lo histogram along
+    bool th_after_publish = false;
     {
         const bool top = want_top && !w.stitched_top, sc = want_sc && !w.stitched_sc;
         if ((top || sc) && (th_to_host || w.hook) && !fuse_lo) {      // the threshold rides in the tail {TH, 1.0}: compute it before the publish
@@ -489,14 +497,17 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
                 w.th_lo_pending = false;
                 if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
                 { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + off, (int)(w.lo_off - off) + kThLoDoubles); if (rh) return rh; }
-                ba_launch_energy_th_sharded(c->stream, w.dev, w.stitched.p + w.lo_off, 3);
-                ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);        // what tail_th() reads: {TH, 1.0}
+                if (th_to_host) {                                    // the caller reads the threshold from the published tail: search first
+                    ba_launch_energy_th_sharded(c->stream, w.dev, w.stitched.p + w.lo_off, 3);
+                    ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);    // what tail_th() reads: {TH, 1.0}
+                } else th_after_publish = true;                      // optimize(): the host only waits for the systems; the search runs under its solve
             } else {
                 if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
                 { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + off, npub - (int)off); if (rh) return rh; }
                 ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // more than one rank: the common threshold
             }
             ba_launch_publish(c->stream, w.stitched.p + off, dmap + off, npub - (int)off, seq, w.st_ticket.p + 1);
+            if (th_after_publish) ba_launch_energy_th_sharded(c->stream, w.dev, w.stitched.p + w.lo_off, 3);
             NALO_HIP(c, hipGetLastError());
         }
         { int rc = flush_th(c); if (rc) return rc; }                  // behind the publish: overlaps the host's solve
@@ -667,7 +678,7 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     if (W <= 8) {                                              // small window: {xc, xAd} travel as kernel arguments, no copy
         std::memcpy(karg.v, xc, 16); std::memcpy(karg.v + 4, xAd, (size_t)W * W * 8 * 4);
         kp = &karg;
-    } else NALO_HIP(c, hipMemcpyAsync(w.xad.p, xc, ((size_t)W * W * 8 + 64) * 4, hipMemcpyHostToDevice, c->stream));
+    } else ba_launch_put(c->stream, w.xad.p, xc, W * W * 8 + 64);      // larger windows: as arguments of two or three one-block kernels (a copy packet costs more)
     {
         ProfScope ps(c, "ba_resub");
         if (fuse_step) {

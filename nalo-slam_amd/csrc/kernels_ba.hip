@@ -809,6 +809,17 @@ void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int
     const int nb = n > 32768 ? 32 : (n + 1023) / 1024;
     ba_publish_kernel<<<nb < 1 ? 1 : nb, 256, 0, s>>>(src, dst_mapped, n, seq, ticket);
 }
+// up to 992 floats as kernel arguments -> device memory: the step of a window too large for XadArg reaches the device without a copy packet (and the bubble around it)
+struct BaPutArg { float v[992]; };
+__global__ __launch_bounds__(1024) void ba_put_kernel(float* __restrict__ dst, BaPutArg a, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = a.v[threadIdx.x]; }
+void ba_launch_put(hipStream_t s, float* dst, const float* src, int n) {
+    for (int o = 0; o < n; o += 992) {
+        BaPutArg a;
+        const int m = n - o < 992 ? n - o : 992;
+        std::memcpy(a.v, src + o, (size_t)m * 4);
+        ba_put_kernel<<<1, 1024, 0, s>>>(dst + o, a, m);
+    }
+}
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg) {
     static const XadArg none{};
     if (karg) ba_resub_kernel<false, true><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, nullptr, nullptr, *karg, 0.f, nullptr);

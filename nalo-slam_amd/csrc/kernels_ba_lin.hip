@@ -484,7 +484,7 @@ void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix, hipEv
     const unsigned grid = 8u * (unsigned)sub * (unsigned)B.xcd_len * (unsigned)B.W;
 #define NALO_LIN_LAUNCH(MODE_, FIX_, WG_)                                                                                                          \
     do {                                                                                                                                           \
-        if (ev_start) hipExtLaunchKernelGGL((ba_linearize_kernel<MODE_, FIX_, WG_>), dim3(grid), dim3(WG_), 0, s, ev_start, ev_stop, 0, B);         \
+        if (ev_start || ev_stop) hipExtLaunchKernelGGL((ba_linearize_kernel<MODE_, FIX_, WG_>), dim3(grid), dim3(WG_), 0, s, ev_start, ev_stop, 0, B);         \
         else ba_linearize_kernel<MODE_, FIX_, WG_><<<grid, WG_, 0, s>>>(B);                                                                        \
     } while (0)
     // fix: 0 = linearizeAll(false) + applyRes, 1 = linearizeAll(true), 2 = linearizeAll(false) without applyRes (energy only)
