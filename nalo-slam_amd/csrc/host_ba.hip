@@ -1352,6 +1352,12 @@ int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
     c->ba->hook = hook; c->ba->hook_user = user;
     return NALO_OK;
 }
+// a caller-supplied hook has no return value: this is how it reports that its collective failed (the built-in RCCL hooks set the same latch, host_rccl.hip)
+int nalo_ba_exchange_failed(nalo_ctx* c, const char* what) {
+    if (!c) return NALO_ERR_ARG;
+    if (!c->xchg_failed) { c->xchg_failed = true; c->err = std::string("cross-rank sum: ") + (what ? what : "reported as failed by the hook"); }
+    return NALO_OK;
+}
 int nalo_ba_set_allreduce_side(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
     if (!c) return NALO_ERR_ARG;
     if (!c->ba) c->ba = new BAWindow();

@@ -95,3 +95,27 @@ def test_two_shards_agree_with_the_whole_window():
     for f in range(win.W):
         d = np.abs(a["w2c"][f] - w2c_full[f]).max()
         assert d < 1e-5 and np.array_equal(a["w2c"][f], b["w2c"][f])
+
+
+def test_failed_exchange_stops_the_context():
+    """a collective that fails must not be ignored. The hook has no return value; it reports through nalo_ba_exchange_failed (what the built-in RCCL hooks
+    do on an ncclAllReduce error, host_rccl.hip): the call that issued the hook and every later BA call of the context fail with NALO_ERR_HIP instead of solving with
+    sums the other ranks never received."""
+    win = synth.make_window(w=640, h=480, W=4, P=600, seed=3)
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    c = make_ctx(win, st6)
+    n_calls = [0]
+
+    def hook(ptr, n):                                      # a 1-rank "sum" is the identity; the third call reports a failure
+        n_calls[0] += 1
+        if n_calls[0] == 3:
+            c.ba_exchange_failed("link down (test)")
+    c.ba_set_allreduce(hook)
+    c.ba_linearize()                                       # two collectives, both fine
+    with pytest.raises(RuntimeError, match="link down"):
+        c.ba_optimize(2, never_break=True)                 # its first pass issues the third call
+    with pytest.raises(RuntimeError, match="cross-rank sum"):
+        c.ba_linearize()                                   # latched: nothing of this context runs a BA pass any more
+    assert n_calls[0] == 3
+    c.ba_set_allreduce(None)
+    c.close()

@@ -210,3 +210,10 @@ def test_lost_workgroup_degrades_to_the_host_driven_loop(ctx, small_window, tmp_
     assert p.stderr.count("drives the tracker's LM loop from the host") == 1          # latched: the second frame did not try the persistent kernel again
     acct = [l for l in p.stderr.splitlines() if l.startswith("[nalo host]")]
     assert any("trk_track" in l and "calls=     2" in l for l in acct) and any("trk_set_ref" in l for l in acct), p.stderr[-1500:]
+    # the third switch of the library: NALO_TRK_HOST_LM=1 selects the host-driven loop from the first frame on (no lost launch, no message), same poses
+    env = dict({k: v for k, v in os.environ.items() if k not in ("NALO_LM_TEST_TIMEOUT", "NALO_HOST_TIMING")}, NALO_TRK_HOST_LM="1")
+    p = subprocess.run([sys.executable, str(script), root, json.dumps(np.asarray(T0).tolist())], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "drives the tracker's LM loop from the host" not in p.stderr and "[nalo host]" not in p.stderr
+    for r in json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]):
+        assert r["ok"] == 1 and pose_dist(np.asarray(r["T"]), T) < 1e-5 and np.abs(np.asarray(r["aff"]) - aff).max() < 1e-3
