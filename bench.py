@@ -766,7 +766,7 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
 
 def load_traffic(workload):
     """HBM bytes per ba_linearize launch from the committed PMC summary (profiles/traffic_*.json), or None."""
-    for name in ("traffic_r02.json", "traffic_r01.json"):          # the newest committed measurement wins
+    for name in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):          # the newest committed measurement wins
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
