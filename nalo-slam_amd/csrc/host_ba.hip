@@ -17,6 +17,7 @@ void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const
 int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg = nullptr);
 void ba_launch_put(hipStream_t s, float* dst, const float* src, int n);
+void ba_launch_pull(hipStream_t s, float* dst, const float* src_mapped, int n);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
 void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
@@ -72,9 +73,7 @@ struct BAWindow {
     double* ad_host = nullptr; size_t ad_cap = 0;                   // pinned staging of AD
     hipEvent_t ev_ad = nullptr;
     double* stitched_host = nullptr;                                // pinned mirror
-    float* up_host = nullptr;                                       // pinned upload staging: [precalc records | calib 16 | xc 64 | xAd]
-    float* up_host2 = nullptr;                                      // second precalc staging block: set_precalc alternates between the two, each guarded by
-    hipEvent_t ev_up[2] = {nullptr, nullptr}; int up_idx = 0;       // the event of its last H2D copy (a copy queued behind a long kernel may still be pending)
+    float* up_host = nullptr;                                       // pinned staging of the step: [- | calib 16 | xc 64 | xAd] (the precalc records live in pre_map)
     size_t up_cap = 0;
     // small windows: the precalc records are not copied at all - ba_linearize reads them (scalar loads, one record per workgroup) straight from mapped host
     // memory; four rotating blocks, a block is rewritten only after the host has seen the stream drain past its last reader (pre_synced)
@@ -118,9 +117,7 @@ void ba_destroy(nalo_ctx* c) {
     w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
-    if (w->up_host2) (void)hipHostFree(w->up_host2);
     for (float* p : w->pre_map) if (p) (void)hipHostFree(p);
-    for (hipEvent_t e : w->ev_up) if (e) (void)hipEventDestroy(e);
     if (w->ad_host) (void)hipHostFree(w->ad_host);
     if (w->ev_ad) (void)hipEventDestroy(w->ev_ad);
     delete w;
@@ -231,38 +228,33 @@ static int set_precalc(nalo_ctx* c) {
     const size_t nfl = (size_t)W * W * kPreStride;
     if (w.up_cap < nfl + 80) {                                             // [pre | calib 16 | xc 64 | xAd]; hipHostFree waits for copies in flight
         if (w.up_host) (void)hipHostFree(w.up_host);
-        if (w.up_host2) (void)hipHostFree(w.up_host2);
-        w.up_host = w.up_host2 = nullptr; w.up_cap = 0;
+        w.up_host = nullptr; w.up_cap = 0;
         NALO_HIP(c, hipHostMalloc((void**)&w.up_host, (nfl + 80 + (size_t)W * W * 8) * 4));
-        NALO_HIP(c, hipHostMalloc((void**)&w.up_host2, (nfl + 16) * 4));
         w.up_cap = nfl + 80;
     }
     // Small windows (the KITTI-sized ones, latency bound): no copy. The H2D blit of these 8 KB sat between the back-substitution and the next linearisation
     // with ~10 us of pipeline gaps around it plus ~5 us of runtime calls on the host; the kernels read the records from mapped host memory instead (scalar
     // loads, a few hundred bytes per workgroup over PCIe: +2 us inside ba_linearize). Large windows keep the device copy (thousands of workgroups).
     const bool direct = w.points_set && w.Ppad <= 32768;
+    // Either way the records are written into a ring of four mapped, coherent host blocks (a block's last readers may still run: the ring is what lets do_step ->
+    // set_precalc and the epilogue's set_precalc follow each other without a wait). Large windows: ONE workgroup pulls the block into device memory (ba_pull_kernel)
+    // instead of a copy packet + its event.
     float* rec;
-    if (direct) {
-        if (w.pre_map_cap < nfl + 16) {
+    {
+        const size_t nfl4 = (nfl + 16 + 3) & ~(size_t)3;
+        if (w.pre_map_cap < nfl4) {
             NALO_HIP(c, hipStreamSynchronize(c->stream));
             for (int i = 0; i < 4; ++i) {
                 if (w.pre_map[i]) (void)hipHostFree(w.pre_map[i]);
                 w.pre_map[i] = nullptr;
-                NALO_HIP(c, hipHostMalloc((void**)&w.pre_map[i], (nfl + 16) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+                NALO_HIP(c, hipHostMalloc((void**)&w.pre_map[i], nfl4 * 4, hipHostMallocMapped | hipHostMallocCoherent));
                 NALO_HIP(c, hipHostGetDevicePointer((void**)&w.pre_map_dev[i], w.pre_map[i], 0));
             }
-            w.pre_map_cap = nfl + 16; w.pre_synced = w.pre_pos;
+            w.pre_map_cap = nfl4; w.pre_synced = w.pre_pos;
         }
         ++w.pre_pos;
         if (w.pre_pos - 4 > w.pre_synced) { NALO_HIP(c, hipStreamSynchronize(c->stream)); w.pre_synced = w.pre_pos - 1; }   // the block's last readers may still run
         rec = w.pre_map[w.pre_pos & 3];
-    } else {
-    // the records are rewritten while the previous copy may still be queued behind a kernel (optimize: do_step -> set_precalc, then the epilogue's
-    // set_precalc with no wait in between; nalo_ba_restore likewise): alternate two staging blocks, each guarded by the event of its last copy
-    w.up_idx ^= 1;
-    if (!w.ev_up[w.up_idx]) NALO_HIP(c, hipEventCreateWithFlags(&w.ev_up[w.up_idx], hipEventDisableTiming));
-    else NALO_HIP(c, hipEventSynchronize(w.ev_up[w.up_idx]));
-    rec = w.up_idx ? w.up_host2 : w.up_host;
     }
     const float fx = w.c_scaledf[0], fy = w.c_scaledf[1], cx = w.c_scaledf[2], cy = w.c_scaledf[3];
     const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1.0f / fx, 0, -cx / fx, 0, 1.0f / fy, -cy / fy, 0, 0, 1};
@@ -285,10 +277,10 @@ static int set_precalc(nalo_ctx* c) {
     float* cal = rec + nfl;                                               // CalibHessian::value_scaledf / value_scaledi + cDeltaF travel with the records
     cal[0] = fx; cal[1] = fy; cal[2] = cx; cal[3] = cy; cal[4] = w.c_scaledi[0]; cal[5] = w.c_scaledi[1];
     for (int i = 0; i < 4; ++i) cal[6 + i] = w.cDeltaF[i];
-    NALO_HIP(c, w.pre.reserve(nfl + 16));
+    NALO_HIP(c, w.pre.reserve(nfl + 32));
     if (direct) { w.dev.pre = w.pre_map_dev[w.pre_pos & 3]; w.dev.calib = w.dev.pre + nfl; return NALO_OK; }
-    NALO_HIP(c, hipMemcpyAsync(w.pre.p, rec, (nfl + 16) * 4, hipMemcpyHostToDevice, c->stream));
-    NALO_HIP(c, hipEventRecord(w.ev_up[w.up_idx], c->stream));
+    ba_launch_pull(c->stream, w.pre.p, w.pre_map_dev[w.pre_pos & 3], (int)(nfl + 16));
+    NALO_HIP(c, hipGetLastError());
     w.dev.pre = w.pre.p; w.dev.calib = w.pre.p + nfl;
 
     return NALO_OK;

@@ -820,6 +820,12 @@ void ba_launch_put(hipStream_t s, float* dst, const float* src, int n) {
         ba_put_kernel<<<1, 1024, 0, s>>>(dst + o, a, m);
     }
 }
+// mapped host memory -> device memory by ONE workgroup: the precalc records of a large window (10-23 KB). A copy packet of that size costs 4 us plus ~6 us of
+// pipeline bubble before the next kernel of the stream; the workgroup pulls the block over PCIe in one round of 16-byte loads
+__global__ __launch_bounds__(1024) void ba_pull_kernel(float4* __restrict__ dst, const float4* __restrict__ src_mapped, int n4) {
+    for (int i = threadIdx.x; i < n4; i += 1024) dst[i] = src_mapped[i];
+}
+void ba_launch_pull(hipStream_t s, float* dst, const float* src_mapped, int n) { ba_pull_kernel<<<1, 1024, 0, s>>>((float4*)dst, (const float4*)src_mapped, (n + 3) / 4); }
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg) {
     static const XadArg none{};
     if (karg) ba_resub_kernel<false, true><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, nullptr, nullptr, *karg, 0.f, nullptr);
