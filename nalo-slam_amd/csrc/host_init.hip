@@ -230,6 +230,7 @@ struct Initializer {
     bool dev_valid = false, host_valid = true;           // which side holds the current Pnt state
     int jb_cur = 0;
     float* pin = nullptr; size_t pin_half = 0;           // pinned staging: [0, pin_half) host -> device, [pin_half, 2 pin_half) device -> host
+    double* sums_host = nullptr; double* sums_dev = nullptr; double sums_seq = 0;    // an evaluation's 94 sums land in mapped host memory, sequence number last: polled, no copy, no sync
 };
 
 // word offsets inside a level's device block: the static members, then the members a level's LM loop changes ("dyn": one packed upload / download per level), the last
@@ -253,6 +254,7 @@ void init_destroy(nalo_ctx* c) {
     c->init->sweep_scratch.release();
     for (auto& b : c->init->jb_dev) b.release();
     if (c->init->pin) (void)hipHostFree(c->init->pin);
+    if (c->init->sums_host) (void)hipHostFree(c->init->sums_host);
     delete c->init; c->init = nullptr;
 }
 
@@ -321,6 +323,11 @@ static int dev_prepare(nalo_ctx* c, Initializer& I) {                           
         I.pin = nullptr; I.pin_half = 0;
         NALO_HIP(c, hipHostMalloc((void**)&I.pin, 2 * maxtot * sizeof(float)));
         I.pin_half = maxtot;
+    }
+    if (!I.sums_host) {
+        NALO_HIP(c, hipHostMalloc((void**)&I.sums_host, 96 * sizeof(double), hipHostMallocMapped));
+        std::memset(I.sums_host, 0, 96 * sizeof(double));
+        NALO_HIP(c, hipHostGetDevicePointer((void**)&I.sums_dev, I.sums_host, 0));
     }
     if (I.static_on_dev) return NALO_OK;
     HostTimer ht(c, "init.tables");
@@ -455,11 +462,10 @@ static int calc(nalo_ctx* c, Initializer& I, int lvl, int slot_new, const SE3& T
         P.colorRef = c->slots[I.slot_first].dI[lvl]; P.colorNew = c->slots[slot_new].dI[lvl];
         P.u = d + o.u; P.v = d + o.v; P.outlierTH = d + o.outlierTH; P.idepth = q.idepth; P.idepth_new = q.idepth_new; P.iR = q.iR; P.energy = q.energy;
         P.isGood = q.isGood; P.isGood_new = q.isGood_new; P.energy_new = q.energy_new; P.maxstep = q.maxstep; P.lastHessian_new = q.lastHessian_new; P.Jb = I.jb_dev[1 - I.jb_cur].p;
-        int rc = init_calc_launch(c, P, lvl, (double*)(d + o.sums)); if (rc) return rc;
-        float* hd = I.pin + I.pin_half;
-        NALO_HIP(c, hipMemcpyAsync(hd, d + o.sums, 94 * 8, hipMemcpyDeviceToHost, c->stream));
-        NALO_HIP(c, hipStreamSynchronize(c->stream));
-        std::memcpy(sums, hd, 94 * 8);
+        I.sums_seq += 1;
+        int rc = init_calc_launch(c, P, lvl, I.sums_dev, 1, I.sums_seq); if (rc) return rc;
+        if (!poll_flag(c, &I.sums_host[95], I.sums_seq)) return NALO_ERR_HIP;
+        std::memcpy(sums, I.sums_host, 94 * 8);
     }
     double E3[3];
     init_sums_to_system(sums, T, L.n, P, X, H, b, Hsc, bsc, E3);

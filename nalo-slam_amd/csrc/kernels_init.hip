@@ -129,14 +129,22 @@ __global__ __launch_bounds__(256) void init_calc_kernel(InitParams P, double* __
     block_reduce_cols<kInitVals, 256>(acc, smem, bsum);
     if (threadIdx.x < kInitVals) partial[(size_t)blockIdx.x * kInitStride + threadIdx.x] = (double)bsum[threadIdx.x];
 }
-__global__ __launch_bounds__(1024) void init_finish_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+// out: device memory, or (mapped != 0) host-mapped memory the host polls: the 94 sums, then the sequence number in slot 95 behind a system-scope release
+__global__ __launch_bounds__(1024) void init_finish_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ out, int mapped, double seq) {
     __shared__ double part[8][128];
     const int j = threadIdx.x & 127, g = threadIdx.x >> 7;
     double s = 0;
     if (j < kInitVals) for (int b = g; b < nblocks; b += 8) s += partial[(size_t)b * kInitStride + j];
     part[g][j] = s;
     __syncthreads();
-    if (g == 0 && j < kInitVals) { double t = 0; for (int k = 0; k < 8; ++k) t += part[k][j]; out[j] = t; }
+    if (g == 0 && j < kInitVals) {
+        double t = 0; for (int k = 0; k < 8; ++k) t += part[k][j];
+        if (mapped) __hip_atomic_store(&out[j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else out[j] = t;
+    }
+    if (mapped) {
+        __syncthreads();
+        if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(&out[95], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+    }
 }
 // CoarseInitializer::doStep (:910-938)
 __global__ __launch_bounds__(256) void init_do_step_kernel(int n, const uint8_t* __restrict__ isGood, const float* __restrict__ Jb, const float* __restrict__ maxstep,
@@ -400,13 +408,13 @@ int init_propagate_up_launch(nalo_ctx* c, int nT, const int* child_off, const in
     return NALO_OK;
 }
 
-int init_calc_launch(nalo_ctx* c, InitParams& P, int lvl, double* sums) {
+int init_calc_launch(nalo_ctx* c, InitParams& P, int lvl, double* sums, int mapped, double seq) {
     P.wl = c->wl[lvl]; P.hl = c->hl[lvl];
     const int nb = (P.n + 255) / 256;
     NALO_HIP(c, c->trk_partial.reserve(((size_t)nb * kInitStride + 128) * 2));          // doubles in a float buffer
     double* partial = (double*)c->trk_partial.p;
     init_calc_kernel<<<nb, 256, 0, c->stream>>>(P, partial);
-    init_finish_kernel<<<1, 1024, 0, c->stream>>>(partial, nb, sums);
+    init_finish_kernel<<<1, 1024, 0, c->stream>>>(partial, nb, sums, mapped, seq);
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }

@@ -181,7 +181,7 @@ void pixsel_invalidate_hists(nalo_ctx* c, int slot);
 int imm_stage(nalo_ctx* c, size_t words);
 int imm_put_launch(nalo_ctx* c, float* dst, const float* src, int n);
 // kernels_init.hip: one calcResAndGS pass over one level. Every per-point array is a device pointer; idepth (the current inverse depths) may be NULL, then calcEC's
-// three sums (slots 91..93) stay zero. sums: 94 doubles on the device.
+// three sums (slots 91..93) stay zero. sums: 96 doubles, on the device or (mapped) in host-mapped memory the caller polls.
 struct InitParams {
     const float4 *colorRef, *colorNew; int wl, hl, n;
     float fx, fy, cx, cy, RKi[9], t[3], r2new0, r2new1, alphaOpt, couplingWeight;
@@ -189,7 +189,7 @@ struct InitParams {
     uint8_t* isGood_new; float *energy_new, *maxstep, *lastHessian_new, *Jb;
 };
 struct InitInc { float v[8]; };
-int init_calc_launch(nalo_ctx* c, InitParams& P, int lvl, double* sums);
+int init_calc_launch(nalo_ctx* c, InitParams& P, int lvl, double* sums, int mapped = 0, double seq = 0);   // mapped: sums is host-mapped, [95] receives seq last
 int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* Jb, const float* maxstep, const float* idepth, float lambda, const float inc[8], float* idepth_new);
 int init_apply_step_launch(nalo_ctx* c, int n, uint8_t* isGood, const uint8_t* isGood_new, float* idepth, float* idepth_new, const float* iR, float* energy, const float* energy_new,
                            float* lastHessian, const float* lastHessian_new);
