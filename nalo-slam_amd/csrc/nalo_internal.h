@@ -195,7 +195,11 @@ int init_apply_step_launch(nalo_ctx* c, int n, uint8_t* isGood, const uint8_t* i
                            float* lastHessian, const float* lastHessian_new);
 // the dependency-ordered sweeps (optReg: mode 0, the top level's resetPoints: mode 1) and the per-point parts of resetPoints / propagateDown / propagateUp
 constexpr int kThHiDoubles = 16384, kThLoDoubles = 32768;   // setNewFrameEnergyTH on a sharded window: the two radix histograms as all-reduce payloads, two bins per double
-constexpr int kSweepNT = 128;                          // lanes of the sweep workgroup = the most points a schedule step may hold
+#ifndef NALO_SWEEP_NT
+#define NALO_SWEEP_NT 128
+#endif
+constexpr int kSweepNT = NALO_SWEEP_NT;                // lanes of the sweep workgroup = the most points a schedule step may hold. trackFrame at 1224x368, same box:
+                                                       // 64 lanes (no second wave at the barrier, 37 % more steps) 8.1 ms, 128: 7.4 ms, 256: 8.0 ms
 constexpr size_t kSweepLdsBytes = 158 * 1024;          // of the 160 KB per workgroup
 int init_sweep_launch(nalo_ctx* c, int mode, int n, int nsteps, const int* off, const int* rec, float* iR, uint8_t* isGood, float* idepth, float* idepth_new, float regWeight, float* scratch);
 int init_reset_launch(nalo_ctx* c, int n, float* energy, float* idepth_new, const float* idepth);
