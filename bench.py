@@ -424,7 +424,7 @@ def main():
             alg = job.trk_bytes / job.trk_frames
             ach = alg / (tms / tn * 1e-3) / 1e9
             out["roofline_headline"] = dict(kernel="trk_lm", workload=args.workload, bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
-                                            traffic=None, avg_us=round(tms / tn * 1e3, 2), launches=tn, alg_bytes=int(alg),
+                                            traffic=load_traffic(args.workload + "_trk_lm"), avg_us=round(tms / tn * 1e3, 2), launches=tn, alg_bytes=int(alg),
                                             share_of_step=round(TRACKED_PER_KF * (tms / tn) / (dt / args.steps * 1e3), 3),
                                             note="one persistent launch per tracked frame runs the whole LM descent (%.1f evaluations): a serial chain of ~8 us per evaluation (gather 1.3 + block "
                                                  "reduction 1.8 + exchange between workgroups 2.6 + the 8x8 solve / SE3 on one wave 2.3), latency bound by construction on ~25 k points; "

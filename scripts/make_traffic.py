@@ -7,15 +7,17 @@ def mean_counter(tag, ctr, kernel):
     vals = []
     for f in glob.glob(f"gpurun_out/{tag}/{ctr}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel_Name"] and ("<0, 0>" in r["Kernel_Name"] or "<0, 0, " in r["Kernel_Name"]) and r["Counter_Name"] == ctr:
+            if kernel in r["Kernel_Name"] and (kernel != "ba_linearize" or "<0, 0>" in r["Kernel_Name"] or "<0, 0, " in r["Kernel_Name"]) and r["Counter_Name"] == ctr:
                 vals.append(float(r["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 out_path = os.environ.get("NALO_TRAFFIC_OUT", "profiles/traffic_r02.json")
 out = json.load(open(out_path)) if os.path.exists(out_path) else {}
-for tag, wl in [a.split(":") for a in sys.argv[1:]]:
-    f, nf = mean_counter(tag, "FETCH_SIZE", "ba_linearize")
-    w, nw = mean_counter(tag, "WRITE_SIZE", "ba_linearize")
+for tag, wl, kern in [(a.split(":") + ["ba_linearize"])[:3] for a in sys.argv[1:]]:      # tag:workload[:kernel] - another kernel's entry is keyed workload_kernel
+    f, nf = mean_counter(tag, "FETCH_SIZE", kern)
+    w, nw = mean_counter(tag, "WRITE_SIZE", kern)
+    if kern != "ba_linearize":
+        wl = wl + "_" + kern
     if f is None or w is None:
         print("no counters for", tag); continue
     out[wl] = int((2 * f + w) * 1024)
