@@ -148,6 +148,14 @@ int nalo_trk_get_pc(nalo_ctx* ctx, int lvl, int* n, float* u, float* v, float* i
 int nalo_trk_append_plane_points(nalo_ctx* ctx, const float dir[3], float dis_plane, int refMaskColor, const int rect[4], int* n_added);
 int nalo_trk_get_depth(nalo_ctx* ctx, int lvl, float* idepth, float* weight_sums);
 
+/* Sharded tracker (the reference's analogue is the per-thread sum of calcGSSSE, CoarseTracker.cpp:828-885): with world > 1 every rank evaluates
+ * points [n rank / world, n (rank + 1) / world) of every pyramid level and the 52 sums of an evaluation (45 H entries, E and the six counters, as doubles) are summed
+ * over the ranks by hook(user, device_buf, 52) - same contract as nalo_ba_set_allreduce; stream_ordered != 0: the hook enqueues on nalo_stream(ctx) and returns.
+ * nalo_trk_set_ref stays replicated (every rank passes all reference points). nalo_trk_eval and nalo_trk_track both honour it; nalo_trk_track then runs its
+ * host-driven LM loop (one launch + one all-reduce per evaluation), every rank ends with the same pose. world = 1 switches it off. */
+typedef void (*nalo_allreduce_fn)(void* user, double* device_buf, int n);
+int nalo_trk_set_shard(nalo_ctx* ctx, int rank, int world, nalo_allreduce_fn hook, void* user, int stream_ordered);
+
 /* a3+a4 fused  CoarseTracker::calcRes (CoarseTracker.cpp:891-1049) + calcGSSSE (:828-885), call sites
  * CoarseTracker.cpp:1104,1109,1115,1184,1204. R,t = refToNew; affLL = fromToVecExposure(ref,new) as float;
  * b0 = lastRef_aff_g2l.b. stats6 = {E, numTermsInE, shiftT/(n+.1), 0, shiftRT/(n+.1), saturatedRatio}.
@@ -298,7 +306,7 @@ int nalo_ba_restore(nalo_ctx* ctx);
  * A hook returns nothing: when its collective fails it calls nalo_ba_exchange_failed(ctx, message) before returning (the built-in RCCL hooks of
  * nalo_ba_rccl_init do the same). The call that issued the hook and every later nalo_ba_* call of the context then return NALO_ERR_HIP - a rank must not
  * solve with sums the others never received; the window has to be rebuilt on a new context. */
-typedef void (*nalo_allreduce_fn)(void* user, double* device_buf, int n);
+/* nalo_allreduce_fn: declared with nalo_trk_set_shard above */
 int nalo_ba_set_allreduce(nalo_ctx* ctx, nalo_allreduce_fn hook, void* user);
 int nalo_ba_exchange_failed(nalo_ctx* ctx, const char* what);
 /* stream_ordered = 1: the hook ENQUEUES its collective on nalo_stream(ctx) (e.g. ncclAllReduce(..., (hipStream_t)nalo_stream(ctx))) and returns

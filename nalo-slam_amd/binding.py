@@ -27,7 +27,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 EXPORTS = [
     "nalo_create", "nalo_destroy", "nalo_last_error", "nalo_levels", "nalo_sync", "nalo_stream",
     "nalo_frame_upload", "nalo_frame_upload_raw", "nalo_frame_upload_raw_async", "nalo_undist_set", "nalo_frame_upload_async", "nalo_frame_wait", "nalo_host_alloc", "nalo_host_free", "nalo_frame_rebuild", "nalo_frame_download",
-    "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_append_plane_points", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track", "nalo_trk_last_evals",
+    "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_append_plane_points", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track", "nalo_trk_last_evals", "nalo_trk_set_shard",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_set_prior_carry", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_plane_scale_fix", "nalo_ba_sw_gray_optimize", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_constants", "nalo_constants_device", "nalo_ba_get_frames", "nalo_ba_get_points",
@@ -319,6 +319,12 @@ class Context:
         self._ck(self.L.nalo_trk_eval(self.h_, slot_new, lvl, _d(R), _d(t), _f(np.asarray(affLL, np.float32)), b0, cutoff,
                                       int(want_gs), _d(st), _d(H), _d(b)))
         return st, H.reshape(8, 8), b
+
+    def trk_set_shard(self, rank, world, fn=None, stream_ordered=False):
+        """sharded tracker: this context evaluates rank / world of every level's points; fn(device_ptr:int, n:int) sums n doubles in place across ranks. world = 1: off"""
+        self._trk_hook = ALLREDUCE_FN(lambda user, ptr, n: fn(ptr, n)) if fn is not None else C.cast(None, ALLREDUCE_FN)
+        self.L.nalo_trk_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p, C.c_int]
+        self._ck(self.L.nalo_trk_set_shard(self.h_, int(rank), int(world), self._trk_hook, None, int(bool(stream_ordered))))
 
     def trk_track(self, slot_new, T0, aff0, ref_aff, exposures, coarsest, min_res=None):
         T = np.ascontiguousarray(T0, np.float64).reshape(-1).copy()

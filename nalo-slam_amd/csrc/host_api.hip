@@ -73,7 +73,7 @@ void nalo_destroy(nalo_ctx* c) {
         c->trk_idepth[l].release(); c->trk_wsum[l].release(); c->trk_wbak[l].release();
         c->pc_u[l].release(); c->pc_v[l].release(); c->pc_id[l].release(); c->pc_col[l].release();
     }
-    c->dense_lb.release(); c->trk_partial.release(); c->trk_out.release(); c->lm_partial.release(); c->scan_tmp.release(); c->trk_cnt.release(); c->upload_tmp.release();
+    c->dense_lb.release(); c->trk_partial.release(); c->trk_out.release(); c->lm_partial.release(); c->trk_shard_sums.release(); c->scan_tmp.release(); c->trk_cnt.release(); c->upload_tmp.release();
     if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
     if (c->pinned_f) (void)hipHostFree(c->pinned_f);
     if (c->imm_host) (void)hipHostFree(c->imm_host);
@@ -413,6 +413,16 @@ int nalo_trk_get_depth(nalo_ctx* c, int lvl, float* idepth, float* wsum) {
     return NALO_OK;
 }
 
+// SURVEY 8(e), tracker: every rank holds the whole reference (nalo_trk_set_ref is replicated: makeCoarseDepthL0's dilation and normalisation need every point's
+// neighbours) and evaluates rank/world of every level's point cloud; the 45 + 7 sums of an evaluation are all-reduced through the hook, so every rank takes the same LM
+// step. Worth it for level sizes of ~1e5 points and more (CoarseTracker.cpp:828-885 sums per thread in the reference).
+int nalo_trk_set_shard(nalo_ctx* c, int rank, int world, nalo_allreduce_fn hook, void* user, int stream_ordered) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return fail(c, NALO_ERR_ARG, "nalo_trk_set_shard: bad argument");
+    if (world > 1 && !hook) return fail(c, NALO_ERR_ARG, "nalo_trk_set_shard: a sharded tracker needs the all-reduce hook");
+    c->trk_rank = rank; c->trk_world = world; c->trk_hook = world > 1 ? hook : nullptr; c->trk_hook_user = user; c->trk_hook_stream_ordered = stream_ordered != 0;
+    return NALO_OK;
+}
+
 int nalo_trk_eval(nalo_ctx* c, int slot_new, int lvl, const double R[9], const double t[3], const float affLL[2], float b0,
                   float cutoffTH, int want_gs, double stats6[6], double H[64], double b[8]) {
     if (!c || !R || !t || !affLL || !stats6 || lvl < 0 || lvl >= c->levels || slot_new < 0 || slot_new >= (int)c->slots.size())
@@ -469,7 +479,8 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
     {
         // a fixed affine parameter changes the system the LM solves (:1140-1162): those variants live in the host loop below
         static const bool env_host = std::getenv("NALO_TRK_HOST_LM") != nullptr;
-        const bool force_host = env_host || c->lm_host_only || c->set.affineOptModeA < 0 || c->set.affineOptModeB < 0;
+        const bool sharded = c->trk_world > 1 && c->trk_hook;          // the persistent kernel cannot exchange sums with other GPUs: a sharded tracker runs the host-driven loop
+        const bool force_host = env_host || sharded || c->lm_host_only || c->set.affineOptModeA < 0 || c->set.affineOptModeB < 0;
         const int stop = 0;                                            // levels coarsestLvl..0 on the device
         if (!force_host) {
             if (c->slot_ref < 0 || slot_new < 0 || slot_new >= (int)c->slots.size() || !c->slots[slot_new].valid)

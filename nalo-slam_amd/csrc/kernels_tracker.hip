@@ -15,6 +15,7 @@ struct TrkEvalParams {
     const float *u, *v, *id, *col;
     const float4* dI;
     int n, wl, hl, lvl;
+    int i0, i1;                     // this rank's share [i0, i1) of the level's points (all of them unless the tracker is sharded, nalo_trk_set_shard)
     float fx, fy, cx, cy;
     float RKi[9], t[3], Ki[9];
     float affa, affb, b0, cutoff, maxEnergy;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* _
 #pragma unroll
     for (int k = 0; k < kTrkVals; ++k) acc[k] = 0.f;
     const float wlm3 = (float)(P.wl - 3), hlm3 = (float)(P.hl - 3);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x) {
+    for (int i = P.i0 + blockIdx.x * blockDim.x + threadIdx.x; i < P.i1; i += gridDim.x * blockDim.x) {
         const float id = P.id[i], x = P.u[i], y = P.v[i];
         const float pt0 = P.RKi[0] * x + P.RKi[1] * y + P.RKi[2] + P.t[0] * id;
         const float pt1 = P.RKi[3] * x + P.RKi[4] * y + P.RKi[5] + P.t[1] * id;
@@ -111,6 +112,13 @@ __global__ __launch_bounds__(1024) void trk_finish_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) { __hip_atomic_store(&out[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
+// sharded tracker ("all-reduce of 45 + 6 floats per evaluation"): the finish kernel leaves this rank's 52 fp64 sums in DEVICE memory (out = device buffer,
+// seq unused), the caller's hook sums them over the ranks in place, and this kernel publishes the result the way trk_finish_kernel does
+__global__ __launch_bounds__(64) void trk_publish_kernel(const double* __restrict__ src, double* __restrict__ out, double seq) {
+    if (threadIdx.x < kTrkVals) __hip_atomic_store(&out[threadIdx.x], src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence_system(); __hip_atomic_store(&out[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
 
 int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], const float t[3], const float Ki[9],
                     float affa, float affb, float b0, float cutoff, float maxEnergy, double out64[64]) {
@@ -118,11 +126,14 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
     P.u = c->pc_u[lvl].p; P.v = c->pc_v[lvl].p; P.id = c->pc_id[lvl].p; P.col = c->pc_col[lvl].p;
     P.dI = c->slots[slot_new].dI[lvl];
     P.n = c->pc_n[lvl]; P.wl = c->wl[lvl]; P.hl = c->hl[lvl]; P.lvl = lvl;
+    const bool sharded = c->trk_world > 1 && c->trk_hook;
+    P.i0 = sharded ? (int)((long long)P.n * c->trk_rank / c->trk_world) : 0;
+    P.i1 = sharded ? (int)((long long)P.n * (c->trk_rank + 1) / c->trk_world) : P.n;
     P.fx = c->fx[lvl]; P.fy = c->fy[lvl]; P.cx = c->cx[lvl]; P.cy = c->cy[lvl];
     for (int i = 0; i < 9; ++i) { P.RKi[i] = RKi[i]; P.Ki[i] = Ki[i]; }
     for (int i = 0; i < 3; ++i) P.t[i] = t[i];
     P.affa = affa; P.affb = affb; P.b0 = b0; P.cutoff = cutoff; P.maxEnergy = maxEnergy;
-    int nblocks = (P.n + 255) / 256;
+    int nblocks = (P.i1 - P.i0 + 255) / 256;
     nblocks = nblocks < 1 ? 1 : (nblocks > 512 ? 512 : nblocks);
     NALO_HIP(c, c->trk_partial.reserve((size_t)2048 * 64));
     {
@@ -132,7 +143,14 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
     double* dout = nullptr;
     NALO_HIP(c, hipHostGetDevicePointer((void**)&dout, c->trk_out_host, 0));
     const double seq = (double)(++c->trk_seq);
-    trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, dout, seq);
+    if (sharded) {
+        // every rank evaluated its share: the 52 sums meet in the hook (in place, device memory), every rank then reads the same totals and runs the same LM step
+        NALO_HIP(c, c->trk_shard_sums.reserve(64));
+        trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, c->trk_shard_sums.p, 0.0);
+        if (!c->trk_hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
+        c->trk_hook(c->trk_hook_user, c->trk_shard_sums.p, kTrkVals);
+        trk_publish_kernel<<<1, 64, 0, c->stream>>>(c->trk_shard_sums.p, dout, seq);
+    } else trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, dout, seq);
     NALO_HIP(c, hipGetLastError());
     if (!poll_flag(c, &c->trk_out_host[63], seq)) return NALO_ERR_HIP;
     std::memcpy(out64, c->trk_out_host, sizeof(double) * kTrkVals);

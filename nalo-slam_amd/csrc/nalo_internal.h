@@ -80,6 +80,8 @@ struct nalo_ctx {
     nalo::DevBuf<unsigned long long> lm_partial;   // persistent LM kernel: [2][blocks][64] block partials {fp32, tag}
     unsigned long long lm_launches = 0;
     int lm_evals_lvl[5] = {};                // LM evaluations per pyramid level of the last persistent-kernel launch (nalo_trk_last_evals)
+    int trk_rank = 0, trk_world = 1; nalo_allreduce_fn trk_hook = nullptr; void* trk_hook_user = nullptr; bool trk_hook_stream_ordered = false;   // nalo_trk_set_shard
+    nalo::DevBuf<double> trk_shard_sums;     // a sharded evaluation's 52 sums on the device, summed over the ranks in place by the hook
     bool lm_host_only = false;                 // latched when a trk_lm launch lost a workgroup (CUs taken by another context): the host-driven LM loop from then on
     nalo::DevBuf<int> scan_tmp;              // compaction counts
     nalo::DevBuf<unsigned long long> dense_lb;   // nalo_dense_make_map scratch: row table | chunk aggregates | last[2] | ticket

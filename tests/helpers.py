@@ -57,3 +57,30 @@ def sim3_aligned_dist(A, B):
     ta, tb = np.array([r[:, 3] for r in ra]), np.array([r[:, 3] for r in rb])
     s = (ta * tb).sum() / max((tb * tb).sum(), 1e-300)
     return max(pose_dist(x, np.c_[y[:, :3], s * y[:, 3]]) for x, y in zip(ra, rb))
+
+
+_HIP = None
+
+
+def _hip():
+    """the HIP runtime libnalo_gpu.so itself is linked against (ctypes; no torch): device <-> host copies for test hooks that are handed raw device pointers"""
+    global _HIP
+    if _HIP is None:
+        import ctypes
+        _HIP = ctypes.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        _HIP.hipMemcpy.restype = ctypes.c_int
+    return _HIP
+
+
+def dev_read_f64(ptr, n):
+    out = np.zeros(n, np.float64)
+    rc = _hip().hipMemcpy(out.ctypes.data, ptr, n * 8, 2)         # hipMemcpyDeviceToHost
+    assert rc == 0, rc
+    return out
+
+
+def dev_write_f64(ptr, arr):
+    arr = np.ascontiguousarray(arr, np.float64)
+    rc = _hip().hipMemcpy(ptr, arr.ctypes.data, arr.size * 8, 1)  # hipMemcpyHostToDevice
+    assert rc == 0, rc
