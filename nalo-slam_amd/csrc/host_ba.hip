@@ -1341,6 +1341,10 @@ int nalo_ba_set_allreduce_mode(nalo_ctx* c, int stream_ordered) {
 int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
     if (!c) return NALO_ERR_ARG;
     if (!c->ba) c->ba = new BAWindow();
+    // a pass whose lo histogram has not been summed yet (the last linearisation of optimize(), say) is finished with the hook it was started under: every rank
+    // changes its hook at the same point of the program, so the collective still matches
+    if (c->ba->th_lo_pending && c->ba->hook && hook != c->ba->hook && !c->xchg_failed) { NALO_HIP(c, hipSetDevice(c->device)); const int rc = flush_th(c); if (rc) return rc; }
+    c->ba->th_lo_pending = false;
     c->ba->hook = hook; c->ba->hook_user = user;
     return NALO_OK;
 }

@@ -66,7 +66,8 @@ def test_two_shards_agree_with_the_whole_window():
             c.ba_optimize(3, never_break=True)
             fr = c.ba_get_frames()
             out[r] = dict(e=e, th=th, H=H, b=b, th2=fr[0][win.W - 1].frameEnergyTH, w2c=fr[1].copy(), n=len(part.host))
-            c.ba_set_allreduce(None)
+            c.ba_set_allreduce(None)                             # finishes the last pass's pending lo-histogram sum under the old hook (both ranks: it still matches)
+            out[r]["e_alone"] = c.ba_linearize()                 # the context goes on as a single-GPU one (its shard only)
             c.close()
         except Exception as ex:                                  # never leave the other rank waiting in the barrier
             err.append(ex)
@@ -78,6 +79,7 @@ def test_two_shards_agree_with_the_whole_window():
     assert not err, err
     a, b = out
     assert a["n"] + b["n"] == len(win.host) and min(a["n"], b["n"]) > 0.3 * len(win.host)
+    assert a["e_alone"] > 0 and b["e_alone"] > 0 and a["e_alone"] != b["e_alone"]
     # per linearisation TWO collectives: the hi histogram of the threshold search (two bins per double), then [systems | tail | lo histogram] in one sum. A pass whose
     # systems nobody fetches (the last one of optimize) sums its lo histogram alone when the threshold is next needed; a second fetch of a pass sums the systems alone.
     n_sys = 2 * (8 * win.W + 5) ** 2 + 2 * win.W ** 2 + 5
