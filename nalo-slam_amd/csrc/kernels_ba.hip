@@ -552,15 +552,17 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
 }
 
 #ifndef NALO_STITCH_SC_SPLIT
-#define NALO_STITCH_SC_SPLIT 2
+#define NALO_STITCH_SC_SPLIT 8
 #endif
-constexpr int kScSplit = NALO_STITCH_SC_SPLIT;       // workgroups per frame for the Schur-complement rows (8 / kScSplit rows each)
+constexpr int kScSplit = NALO_STITCH_SC_SPLIT;       // workgroups per frame for the Schur-complement rows (8 / kScSplit rows each). Round 3, kernel trace: 2 / 4 / 8 workgroups
+                                                     // = 13.6 / 12.1 / 11.3 us at W = 8 and 22.7 / 17.0 / 14.4 us at W = 12 (phase 2 is LDS-bandwidth bound; the operand
+                                                     // staging every workgroup repeats is the smaller part). Same loops per output element: bit-identical results
 __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, int ad_in_lds, double* mapped, int ntail, double seq) {
     extern __shared__ double lds[];
     __shared__ int is_last;
     const int W = D.W, n1 = D.n1, n = n1 - 1, NPL = D.NPL, tid = threadIdx.x, NT = blockDim.x;
-    // workgroups: [0, W] the top system (W frame rows + the corner), then 2 W for the Schur-complement system - TWO per frame, four of its eight rows each (phase 2
-    // is bound by LDS bandwidth: 2 x 112 fp64 operands per output; two workgroups on two CUs halve it: 18 -> 11 us at W = 8) - then its corner
+    // workgroups: [0, W] the top system (W frame rows + the corner), then kScSplit W for the Schur-complement system - kScSplit per frame, 8 / kScSplit of its eight
+    // rows each (phase 2 is bound by LDS bandwidth: 2 x 112 fp64 operands per output; more workgroups on more CUs divide it) - then its corner
     const int sys = blockIdx.x > W ? 1 : 0;
     const int gb = blockIdx.x - (W + 1), g = sys ? (gb < kScSplit * W ? gb / kScSplit : W) : (int)blockIdx.x, r0 = sys ? (gb % kScSplit) * (8 / kScSplit) : 0;
     const double* __restrict__ adH = D.AD;
