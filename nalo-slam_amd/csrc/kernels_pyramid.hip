@@ -76,12 +76,12 @@ __global__ __launch_bounds__(256) void pyr_grad_all_kernel(PyrLevels P, const fl
 }
 
 // ---- round 3: ONE pass over level 0 for the whole pyramid. pyr_down_all + pyr_grad_all read level 0 twice and every upper level twice more
-// (37 B of traffic per level-0 pixel against 25.3 algorithmic: 0.30 of the HBM roofline at 1920x1072). Here a workgroup owns a 64x32 tile of level 0 and
+// (37 B of traffic per level-0 pixel against 25.3 algorithmic: 0.30 of the HBM roofline at 1920x1072). Here a workgroup owns a 64x16 tile (round 3, late: was 64x32) of level 0 and
 // stages it in LDS WITH a halo of H = 2^(NL-1) pixels, walks the box pyramid up inside LDS (the same 0.25f * (((p00 + p10) + p01) + p11) nesting: the values
 // of the level-by-level loop bit for bit) and writes {I, dx, dy} + absSquaredGrad of the levels 0 .. NL-1 from there; the halo is what the central differences of
-// level l need of the neighbouring tiles (one pixel at level l = 2^l at level 0). The levels >= NL only get their planar box values here (a 64x32 tile still
-// holds whole pixels of level 5) and their gradients in one small second launch (pyr_grad_all over those levels: 1/64 of the pixels). NL = all levels for
-// pyramids of <= 4 levels (a KITTI frame: ONE launch), 3 otherwise (read amplification (72 x 40) / (64 x 32) = 1.4 on 4 of ~30 bytes per pixel).
+// level l need of the neighbouring tiles (one pixel at level l = 2^l at level 0). The levels >= NL only get their planar box values here (the tile still
+// holds whole pixels of them: pyramid_build checks) and their gradients in one small second launch (pyr_grad_all over those levels: 1/64 of the pixels). NL = all levels for
+// pyramids of <= 4 levels (a KITTI frame: ONE launch), 3 otherwise (read amplification (72 x 24) / (64 x 16) = 1.7 on 4 of ~30 bytes per pixel).
 // The reference's gradient runs over the FLAT index (HessianBlocks.cpp:168-181): column 0 differences against the last pixel of the row above, column w-1
 // against the first pixel of the row below. Those two neighbours lie in no tile halo: the edge lanes rebuild them from level 0 (pyr_box_at, same nesting).
 template <int L>
@@ -94,8 +94,8 @@ __device__ __forceinline__ float pyr_box_at(const float* __restrict__ I0, int w0
     }
 }
 #ifndef NALO_PYR_TW
-#define NALO_PYR_TW 64
-#define NALO_PYR_TH 32
+#define NALO_PYR_TW 64      // tile of level 0 per workgroup. Same box, 1920x1072 (5 levels) / 1224x368 (4 levels, one launch): 64x32 17.9 / 8.3 us, 32x32 19.0 / 7.2,
+#define NALO_PYR_TH 16      // **64x16 17.7 / 6.6**, 32x16 21.2 / 7.1, 128x16 18.2 / 8.4: twice the workgroups of 64x32 for the KITTI frame's 240 tiles (< 256 CUs)
 #endif
 #ifndef NALO_PYR_NT
 #define NALO_PYR_NT 1      // nontemporal stores of the texels: 14.6 -> 12.9 us at 1920x1072 (the pyramid is written once, read by later kernels)
@@ -408,8 +408,10 @@ int pyramid_build(nalo_ctx* c, FrameSlot& s, const float* gammaB_dev) {
         P.blk0[l] = nb; nb += (c->wl[l] * c->hl[l] + 255) / 256;
     }
     P.blk0[c->levels] = nb;
-    // the hierarchical pass needs even parents all the way up (true for DSO pyramids: a level is only added while w and h are even) and <= 6 levels
-    bool fused = c->levels >= 2 && c->levels <= 6;
+    // the hierarchical pass needs even parents all the way up (true for DSO pyramids: a level is only added while w and h are even) and a tile that still holds a
+    // whole pixel of the coarsest level (2^(L-1) <= min(tile width, tile height): 5 levels with the 64x16 tile; a 6-level pyramid - 4096x2048 and beyond - takes
+    // the level-by-level path below)
+    bool fused = c->levels >= 2 && c->levels <= 6 && (1 << (c->levels - 1)) <= (kPyrTW < kPyrTH ? kPyrTW : kPyrTH);
     for (int l = 1; l < c->levels && fused; ++l) fused = (c->wl[l - 1] % 2 == 0) && (c->hl[l - 1] % 2 == 0);
     if (fused) {
         // one pass over level 0 (pyr_one_pass_kernel): every level of a pyramid of <= 4 levels, the three finest + the planar values of the rest otherwise

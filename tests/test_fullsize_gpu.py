@@ -276,3 +276,23 @@ def test_image_sizes_with_odd_pyramid_levels():
         ths_o, sm_o = orc.pixsel_make_hists(ab_ref[:w * h], w, h)
         assert np.array_equal(ths, ths_o) and np.array_equal(sm, sm_o)
         c.close()
+
+
+def test_pyramid_six_levels_bit_exact():
+    """A pyramid of PYR_LEVELS = 6 (4096x2048: the levels rule adds a level while w * h > 5000): the coarsest pixel covers 32x32 pixels of level 0, more than the
+    one-pass kernel's 64x16 tile holds, so pyramid_build takes the level-by-level path - every level bit-exact against the oracle there too."""
+    w, h = 4096, 2048
+    rng = np.random.RandomState(11)
+    img = (rng.rand(h // 8, w // 8).astype(np.float32) * 255).repeat(8, 0).repeat(8, 1) + rng.rand(h, w).astype(np.float32) * 3
+    K = (0.52 * w, 0.52 * w, (w - 1) / 2.0, (h - 1) / 2.0)
+    c = binding.Context(w, h, K, n_slots=1)
+    assert c.levels == 6
+    c.frame_upload(0, img)
+    dI_ref, ab_ref = orc.make_images(img, 6)
+    L = orc.lib()
+    for lvl in range(6):
+        dI, ab = c.frame_download(0, lvl)
+        o, n = L.orc_pyr_offset(w, h, lvl), (w >> lvl) * (h >> lvl)
+        assert np.array_equal(dI, dI_ref[o:o + n]), "level %d texels differ" % lvl
+        assert np.array_equal(ab, ab_ref[o:o + n])
+    c.close()
