@@ -554,6 +554,12 @@ __device__ __forceinline__ void stitch_sc_rows(const StitchDev& D, double* lds, 
 #ifndef NALO_STITCH_SC_SPLIT
 #define NALO_STITCH_SC_SPLIT 8
 #endif
+#ifndef NALO_STITCH_TOP_SPLIT
+#define NALO_STITCH_TOP_SPLIT 8
+#endif
+constexpr int kTopSplit = NALO_STITCH_TOP_SPLIT;     // workgroups per frame for the rows of the top system (8 / kTopSplit rows each): with the Schur-complement rows on
+                                                     // eight workgroups the top system's one workgroup per frame was the long pole. 1 / 2 / 4 / 8: 11.2 / 10.3 / 11.3 / 10.7 us
+                                                     // at W = 8 (noise ~0.5), 14.3 / 13.1 / 12.0 / 10.9 us at W = 12
 constexpr int kScSplit = NALO_STITCH_SC_SPLIT;       // workgroups per frame for the Schur-complement rows (8 / kScSplit rows each). Round 3, kernel trace: 2 / 4 / 8 workgroups
                                                      // = 13.6 / 12.1 / 11.3 us at W = 8 and 22.7 / 17.0 / 14.4 us at W = 12 (phase 2 is LDS-bandwidth bound; the operand
                                                      // staging every workgroup repeats is the smaller part). Same loops per output element: bit-identical results
@@ -563,8 +569,12 @@ __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, 
     const int W = D.W, n1 = D.n1, n = n1 - 1, NPL = D.NPL, tid = threadIdx.x, NT = blockDim.x;
     // workgroups: [0, W] the top system (W frame rows + the corner), then kScSplit W for the Schur-complement system - kScSplit per frame, 8 / kScSplit of its eight
     // rows each (phase 2 is bound by LDS bandwidth: 2 x 112 fp64 operands per output; more workgroups on more CUs divide it) - then its corner
-    const int sys = blockIdx.x > W ? 1 : 0;
-    const int gb = blockIdx.x - (W + 1), g = sys ? (gb < kScSplit * W ? gb / kScSplit : W) : (int)blockIdx.x, r0 = sys ? (gb % kScSplit) * (8 / kScSplit) : 0;
+    const int ntop = kTopSplit * W + 1;                        // top-system workgroups: kTopSplit per frame, then the corner
+    const int sys = (int)blockIdx.x >= ntop ? 1 : 0;
+    const int gb = blockIdx.x - ntop;
+    const int g = sys ? (gb < kScSplit * W ? gb / kScSplit : W) : ((int)blockIdx.x < kTopSplit * W ? (int)blockIdx.x / kTopSplit : W);
+    const int r0 = sys ? (gb % kScSplit) * (8 / kScSplit) : ((int)blockIdx.x % kTopSplit) * (8 / kTopSplit);
+    const int nr_top = 8 / kTopSplit;
     const double* __restrict__ adH = D.AD;
     const double* __restrict__ adT = D.AD + (size_t)W * W * 64;
     double* Hs = D.H + (size_t)sys * n1 * n1;
@@ -589,16 +599,16 @@ __global__ __launch_bounds__(1024) void ba_stitch_kernel(StitchDev D, int mask, 
                 Ao[q * kAdMat + (o >> 3) * kAdRow + (o & 7)] = (host_role ? adT : adH)[(size_t)bin * 64 + o];
             }
             __syncthreads();
-            for (int e = tid; e < nb * 104; e += NT) {
-                const int q = e / 104, o = e - q * 104, r = o / 13, l = o - r * 13;
+            for (int e = tid; e < nb * nr_top * 13; e += NT) {          // rows r0 .. r0 + nr_top - 1 of this workgroup only
+                const int q = e / (nr_top * 13), o = e - q * (nr_top * 13), r = r0 + o / 13, l = o % 13;
                 double s = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) s += As[q * kAdMat + r * kAdRow + k] * Mb[q * 169 + (4 + k) * 13 + l];
-                U[e] = s;
+                U[q * 104 + r * 13 + l] = s;
             }
             __syncthreads();
-            for (int e = tid; e < 8 * n1; e += NT) {
-                const int r = e / n1, c = e - r * n1;
+            for (int e = tid; e < nr_top * n1; e += NT) {
+                const int r = r0 + e / n1, c = e % n1;
                 double s = 0;
                 if (c < 4) { for (int q = 0; q < nb; ++q) s += U[q * 104 + r * 13 + c]; }
                 else if (c == n) { for (int q = 0; q < nb; ++q) s += U[q * 104 + r * 13 + 12]; }
@@ -680,7 +690,7 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
         if (hipFuncSetAttribute((const void*)ba_stitch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
         lds_allowed = lds;
     }
-    ba_stitch_kernel<<<(kScSplit + 1) * D.W + 2, 1024, lds, s>>>(D, mask, ad_in_lds, mapped, ntail, seq);
+    ba_stitch_kernel<<<(kScSplit + kTopSplit) * D.W + 2, 1024, lds, s>>>(D, mask, ad_in_lds, mapped, ntail, seq);
     return 0;
 }
 
