@@ -297,9 +297,74 @@ def cpu_baseline(win, st6, trk, budget_s=20.0, track=True, nthreads=6, linearize
                       "MatrixAccumulators.h:1091-1166 writes them, a persistent worker pool handing out chunks of 50 points (IndexThreadReduce.h:76-137)")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment): start N fresh rank processes, one GPU each, BEFORE this process
+    makes any GPU call - it never makes one, it only waits for its children (never a re-exec of a process that has touched HIP). The ranks rendezvous on
+    127.0.0.1; rank 0 prints the JSON line on the inherited stdout. A rank that dies takes the others with it (they would wait in a collective for ever)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs between processes on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    log("self-launch: %d ranks on 127.0.0.1:%d (pids %s)" % (n, port, [p.pid for p in procs]))
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            for i, p in enumerate(procs):                          # exactly the processes started above
+                if rcs[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill(); rcs[i] = p.wait()
+            log("self-launch: rank(s) %s failed (exit codes %s)" % (bad, rcs))
+            return 1
+        time.sleep(0.05)
+    return 0
+
+
+def launch_check(rank, world):
+    """--launch-check: the rendezvous alone (gloo, CPU only): every rank joins the group, the ranks are counted with an all-reduce, a barrier-bracketed empty
+    region is timed with the max over the ranks, rank 0 prints one JSON line. What tests/test_multigpu_cpu.py drives through `--gpus 2` on a box without a GPU."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("NALO_BENCH_TEST_DIE_RANK") == str(rank):       # test hook (tests/test_multigpu_cpu.py): a rank that dies before the rendezvous
+        os._exit(7)
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    seen = torch.ones(1)
+    t = torch.zeros(1)
+    if world > 1:
+        dist.all_reduce(seen)
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    t[0] = time.perf_counter() - t0
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(seen.item()), "barrier_s": float(t.item()),
+                          "launcher": os.environ.get("NALO_BENCH_LAUNCHER", "external")}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if int(seen.item()) == world else 4
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node. Without a launcher around it (no WORLD_SIZE) bench.py starts the N rank processes itself")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="kitti00_8kf", choices=sorted(WORKLOADS))
@@ -307,14 +372,27 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + NALO_BENCH_ONE_DEVICE=1 rehearses the multi-rank flow on a single GPU (all ranks on device 0)")
     ap.add_argument("--no-extra", action="store_true", help="skip the stress250k roofline leg appended to the kitti00 line")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): proves that --gpus N starts N ranks")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        os.environ["NALO_BENCH_LAUNCHER"] = "self"
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("NALO_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is not None and args.gpus != world:
+        # a line that says n_gpus: 1 for --gpus 8 (or the reverse) would be void: refuse instead of measuring something else than what was asked for
+        log("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d) or drop WORLD_SIZE" % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
+    if args.launch_check:
+        sys.exit(launch_check(rank, world))
     import torch
+    if world > 1 and os.environ.get("NALO_BENCH_ONE_DEVICE") != "1" and torch.cuda.device_count() < world:
+        log("%d ranks but %d visible GPUs (NALO_BENCH_ONE_DEVICE=1 with --backend gloo rehearses on one device)" % (world, torch.cuda.device_count()))
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist_
@@ -329,6 +407,10 @@ def main():
     win, st6, trk = make_inputs(args.workload)
     hook = rccl_setup(dist, rank, world, args.backend) if (sharded and world > 1) else None
     job = GpuJob(shard(win, rank, world) if sharded else win, st6, trk, local_rank, hook)
+    main_rccl = job.ctx.ba_rccl_ranks() if isinstance(hook, tuple) else None      # --workload shard1m as the main line: its own communicators
+    if main_rccl is not None and min(main_rccl) != world:
+        log("rccl_ranks %s != n_gpus %d: the ranks did not join ONE communicator" % (main_rccl, world))
+        sys.exit(4)
     do_track = not sharded
 
     def barrier():
@@ -415,6 +497,7 @@ def main():
             "kernel_ms": {k: {"total_ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
             "kernel_ms_note": "ba_linearize: HIP events over the timed region (%d steps%s); the other scopes: %d untimed steps right after it" % (args.steps, ", one launch in %d bracketed" % lin_every if lin_every > 1 else "", nprof),
             "tracker_evals_per_step": job.evals / max(args.steps, 1),
+            "rccl_ranks": (min(main_rccl) if main_rccl else None),
             "fine_track_rmse": round(float(rm), 4),
         }
         if do_track and prof["trk_lm"][1] > 0 and job.trk_frames > 0:
@@ -515,8 +598,23 @@ def main():
         except Exception as e:                      # never lose the main line to the extra leg
             res = {"error": repr(e)}
         log("shard1m leg: %s" % (res,))
+        ranks_ok = True
+        if isinstance(res, dict) and args.backend == "nccl" and "error" not in res:
+            ranks_ok = res.get("rccl_ranks") == world        # every rank checks its own communicators
         if rank == 0:
             out["shard1m"] = res
+            out["rccl_ranks"] = res.get("rccl_ranks") if isinstance(res, dict) else None
+            out["launcher"] = os.environ.get("NALO_BENCH_LAUNCHER", "external (WORLD_SIZE set by the caller)" if "WORLD_SIZE" in os.environ else "none (single process)")
+            if world > 1:                                    # N > 1: the sharded window is what the N GPUs do TOGETHER (strong scaling); promoted beside `value` (replicas, weak)
+                out["value_shard1m"] = res.get("keyframes_per_s") if isinstance(res, dict) else None
+                out["value_shard1m_note"] = "configs[4]: ONE 1M-point / 12-keyframe window sharded over the %d ranks, keyframes/s of the whole job (strong scaling); `value` = %d replicas of the KITTI window (weak)" % (world, world)
+        if not ranks_ok:
+            log("rccl_ranks %s != n_gpus %d: the ranks did not join ONE communicator; the line is void" % (res.get("rccl_ranks"), world))
+            if rank == 0:
+                out["rccl_ranks_error"] = "rccl_ranks != n_gpus"
+                print(json.dumps(out, default=str), flush=True)
+            watchdog.cancel()
+            os._exit(4)
             if world == 1:
                 leg_state["leg"] = "stress250k"
                 try:
@@ -718,6 +816,9 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
     part = shard(win, 0, emu) if emu > 1 else shard(win, rank, world)
     log("shard1m: uploading %d points" % len(part.host))
     job = GpuJob(part, st6, trk, local_rank, hook)
+    # the ranks the exchange REALLY spans, read back from the communicators (ncclCommCount): an N-process job whose ranks never joined one communicator must not
+    # pass for an N-GPU run. Rehearsals over the Python hook have no communicator: the process group's size stands in, and the line says so.
+    rccl_ranks = job.ctx.ba_rccl_ranks() if backend == "nccl" else None
     for _ in range(warmup):
         job.step(False)
     if dist is not None:
@@ -750,7 +851,9 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
            "ms_per_keyframe": round(dt / steps * 1e3, 3), "window_frames": win.W, "active_points": int(len(win.host)),
            "residuals": int((win.exists > 0).sum()), "points_per_rank": P, "allreduce_doubles": 2 * (8 * win.W + 5) ** 2 + 2 * win.W ** 2 + 5,
            "collectives_per_linearize": "2: hi histogram of the newest frame's energy threshold (16384 doubles, side stream), then [systems | lo histogram] (+32768 doubles) in one sum",
-           "exchange": "libnalo_gpu.so -> ncclAllReduce (RCCL) on its own streams, no host callback" if backend == "nccl" else "python hook (rehearsal)"}
+           "exchange": "libnalo_gpu.so -> ncclAllReduce (RCCL) on its own streams, no host callback" if backend == "nccl" else "python hook (rehearsal)",
+           "rccl_ranks": (min(rccl_ranks) if rccl_ranks else None), "rccl_ranks_main_side": (list(rccl_ranks) if rccl_ranks else None),
+           "process_group_ranks": (dist.get_world_size() if dist is not None else 1)}
     ms, n = lin
     if n:
         alg = 424.0 * R + 104.0 * P

@@ -329,6 +329,9 @@ void* nalo_side_stream(nalo_ctx* ctx);
 int nalo_rccl_unique_id(char id[128]);
 int nalo_ba_rccl_init(nalo_ctx* ctx, int nranks, int rank, const char id_main[128], const char id_side[128]);
 int nalo_ba_set_rccl_comm(nalo_ctx* ctx, void* comm_main, void* comm_side);
+/* ncclCommCount of the context's two communicators (0 = none installed): the number of ranks the exchange REALLY spans, for a launcher to print beside the
+ * number of processes it started (the per-thread replica count the reference sums over at stitch, AccumulatedTopHessian.h:144-149, is NUM_THREADS there). */
+int nalo_ba_rccl_ranks(nalo_ctx* ctx, int* ranks_main, int* ranks_side);
 /* The partition a sharded window uses: which of the P active points rank `rank` of `world` keeps. Every rank gets the same share of every
  * host frame (all (host, target) bins stay evenly populated) as a contiguous range of the host's points in Hilbert order of their 8x8-pixel cells — a
  * spatially compact part of the image, so a rank's texel gathers keep the locality of the unsharded window. keep[] (capacity P) receives the ascending

@@ -31,7 +31,7 @@ EXPORTS = [
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_set_prior_carry", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_plane_scale_fix", "nalo_ba_sw_gray_optimize", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_constants", "nalo_constants_device", "nalo_ba_get_frames", "nalo_ba_get_points",
-    "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_ba_exchange_failed", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
+    "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_ba_exchange_failed", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_ba_rccl_ranks", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_init_set_state", "nalo_init_set_points", "nalo_init_get_carried", "nalo_init_sweep", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get", "nalo_profile_sample", "nalo_hbm_calibrate",
@@ -119,6 +119,7 @@ def load():
     L.nalo_rccl_unique_id.argtypes = [C.c_char_p]
     L.nalo_ba_rccl_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
     L.nalo_ba_set_rccl_comm.argtypes = [vp, vp, vp]
+    L.nalo_ba_rccl_ranks.argtypes = [vp, c_ip, c_ip]
     L.nalo_shard_points.argtypes = [C.c_int, C.c_int, c_ip, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_ip]
     L.nalo_ba_snapshot.argtypes = [vp]
     L.nalo_init_calc_res_and_gs.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp, c_u8p, c_fp, c_fp, c_dp, c_dp, C.c_float, C.c_float, C.c_float,
@@ -762,6 +763,12 @@ class Context:
         """what a caller's all-reduce hook calls when its collective failed (the hook has no return value)"""
         self.L.nalo_ba_exchange_failed.argtypes = [C.c_void_p, C.c_char_p]
         self._ck(self.L.nalo_ba_exchange_failed(self.h_, what.encode()))
+
+    def ba_rccl_ranks(self):
+        """(ranks of the main communicator, ranks of the side communicator) as RCCL reports them (ncclCommCount); 0 = none installed"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._ck(self.L.nalo_ba_rccl_ranks(self.h_, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def ba_rccl_init(self, nranks, rank, id_main, id_side=None):
         """native RCCL exchange (ncclCommInitRank on this context's device, collective over the ranks); ids from rccl_unique_id()"""

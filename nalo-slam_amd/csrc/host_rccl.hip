@@ -24,6 +24,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
@@ -37,6 +38,7 @@ static RcclApi& rccl() {
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.lib, "ncclCommInitRank"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.lib, "ncclCommDestroy"));
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.lib, "ncclAllReduce"));
+        a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(a.lib, "ncclCommCount"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.lib, "ncclGetErrorString"));
         if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce) a.err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
         return a;
@@ -120,6 +122,21 @@ int nalo_ba_set_rccl_comm(nalo_ctx* c, void* comm_main, void* comm_side) {
     if (!rccl().err.empty()) return fail(c, NALO_ERR_UNSUPPORTED, "nalo_ba_set_rccl_comm: " + rccl().err);
     if (!c->ba) return fail(c, NALO_ERR_STATE, "nalo_ba_set_rccl_comm: set the window first (nalo_ba_set_window)");
     return install(c, static_cast<ncclComm_t>(comm_main), static_cast<ncclComm_t>(comm_side), false);
+}
+
+// How many ranks the context's communicators really span, read back from RCCL (ncclCommCount): what a launcher prints next to the number of processes it
+// started, so that a job whose ranks never joined one communicator cannot pass for an N-GPU run. 0 = no communicator installed.
+int nalo_ba_rccl_ranks(nalo_ctx* c, int* ranks_main, int* ranks_side) {
+    if (!c) return NALO_ERR_ARG;
+    if (ranks_main) *ranks_main = 0;
+    if (ranks_side) *ranks_side = 0;
+    RcclState* st = static_cast<RcclState*>(c->rccl);
+    if (!st) return NALO_OK;
+    if (!rccl().CommCount) return fail(c, NALO_ERR_UNSUPPORTED, "nalo_ba_rccl_ranks: librccl lacks ncclCommCount");
+    int n = 0;
+    if (st->main) { if (rccl().CommCount(st->main, &n) != ncclSuccess) return fail(c, NALO_ERR_HIP, "ncclCommCount (main) failed"); if (ranks_main) *ranks_main = n; }
+    if (st->side) { if (rccl().CommCount(st->side, &n) != ncclSuccess) return fail(c, NALO_ERR_HIP, "ncclCommCount (side) failed"); if (ranks_side) *ranks_side = n; }
+    return NALO_OK;
 }
 
 // The partition of the active-point set over `world` ranks: points keep all their residuals, frames are replicated. Every rank gets the same
