@@ -850,7 +850,8 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
     res = {"workload": "shard1m", "scaling": "strong", "n_gpus": world, "keyframes_per_s": round(steps / dt, 3),
            "ms_per_keyframe": round(dt / steps * 1e3, 3), "window_frames": win.W, "active_points": int(len(win.host)),
            "residuals": int((win.exists > 0).sum()), "points_per_rank": P, "allreduce_doubles": 2 * (8 * win.W + 5) ** 2 + 2 * win.W ** 2 + 5,
-           "collectives_per_linearize": "2: hi histogram of the newest frame's energy threshold (16384 doubles, side stream), then [systems | lo histogram] (+32768 doubles) in one sum",
+           "collectives_per_linearize": "3: levels A and B of the threshold's radix select (1024 doubles = 8 KB each, side stream, under pt_acc / SC / reduce / stitch), then [systems | tail | level C] (+256 doubles) in ONE sum on the main stream",
+           "allreduce_bytes_per_linearize": 8 * (2 * 1024 + ((2 * (8 * win.W + 5) ** 2 + 2 * win.W ** 2 + 5 + 15) // 16) * 16 + 256),
            "exchange": "libnalo_gpu.so -> ncclAllReduce (RCCL) on its own streams, no host callback" if backend == "nccl" else "python hook (rehearsal)",
            "rccl_ranks": (min(rccl_ranks) if rccl_ranks else None), "rccl_ranks_main_side": (list(rccl_ranks) if rccl_ranks else None),
            "process_group_ranks": (dist.get_world_size() if dist is not None else 1)}
@@ -991,8 +992,8 @@ def frontend_legs(rounds=30):
     dm()
     bbox_px = int((rect[1] - rect[0]) * (rect[3] - rect[2]))
     res["dense_map"] = timed("dense_map", dm, 11.0 * bbox_px + 24.0 * n.value, n_rounds=10)
-    res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="ONE launch since round 3: ordered compaction by decoupled look-back with the accept test of MapPoint.cpp:403 "
-                            "(the reference's order-dependent maxy / maxz) riding along; the D2H copy of the point list is not in avg_us")
+    res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="three launches (row extents, chunk counts, ordered write; kernels_dense.hip), no atomics per lane and no look-back: every workgroup folds the "
+                            "chunk aggregates in front of it; the accept test of MapPoint.cpp:403 (the reference's order-dependent maxy / maxz) rides along; the D2H copy of the point list is not in avg_us")
     res["dense_bbox"] = timed("dense_bbox", dm, 4.0 * (w - 4) * (h - 4), n_rounds=10)
     # ---- raw-frame ingest (photometric undistortion + remap fused in front of makeImages): an 8-bit sensor frame slightly larger than the rectified image
     wo, ho = w + 64, h + 48

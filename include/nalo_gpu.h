@@ -297,12 +297,14 @@ int nalo_ba_snapshot(nalo_ctx* ctx);
 int nalo_ba_restore(nalo_ctx* ctx);
 
 /* multi-GPU: the active-point set is sharded by the caller (each rank sets only its points); the stitched
- * buffers {H_A, b_A, H_sc, b_sc, energy, counters} are summed across ranks through this hook before every solve, and so are the two
- * radix histograms of setNewFrameEnergyTH (FullSystemOptimize.cpp:95-143) after every linearisation: the newest frame's energy threshold is the
- * exact order statistic over ALL ranks' residuals, i.e. what one GPU holding the whole window computes. Per pass the hook is called TWICE, in the same
- * order on every rank: the hi histogram (16384 doubles: two bins per double, a + b * 2^26), then one buffer [stitched systems | tail | lo histogram]
- * (2 (8W+5)^2 + 2 W^2 + 5 doubles padded to a multiple of 16, + 32768); a pass whose systems are never fetched sums its lo histogram alone (32768) when the
- * threshold is next needed, a second fetch of a pass sums the systems alone. buf is a DEVICE pointer to n doubles. hook == NULL = single GPU.
+ * buffers {H_A, b_A, H_sc, b_sc, energy, counters} are summed across ranks through this hook before every solve (the replica sum of
+ * AccumulatedTopHessian.h:144-149 across GPUs), and so are the three radix histograms of setNewFrameEnergyTH (FullSystemOptimize.cpp:95-143) after every
+ * linearisation: the newest frame's energy threshold is the exact order statistic over ALL ranks' residuals, i.e. what one GPU holding the whole window
+ * computes. Per pass the hook is called THREE times, in the same order on every rank: level A and level B of the radix select (1024 doubles each: 2048 bins, two
+ * per double as a + b * 2^26; on the side stream when a side hook is set), then one buffer [stitched systems | tail | level C] (2 (8W+5)^2 + 2 W^2 + 5 doubles
+ * padded to a multiple of 16, + 256) = 166 KB + 2 KB at W = 12; a pass whose systems are never fetched sums level C alone (256) when the threshold is next
+ * needed; a second fetch of a pass (the Schur complement after the top system, or the reverse) sums ONLY the block it stitched - everything else already holds
+ * the window's totals. buf is a DEVICE pointer to n doubles. hook == NULL = single GPU.
  * A hook returns nothing: when its collective fails it calls nalo_ba_exchange_failed(ctx, message) before returning (the built-in RCCL hooks of
  * nalo_ba_rccl_init do the same). The call that issued the hook and every later nalo_ba_* call of the context then return NALO_ERR_HIP - a rank must not
  * solve with sums the others never received; the window has to be rebuilt on a new context. */

@@ -52,7 +52,8 @@ struct BADev {
     float4* rs_pp0; float2* rs_pp1;             // per-slot share of the point sums: {bd, Hdd, Hcd0, Hcd1}, {Hcd2, Hcd3}
     float4* rs_cpt;                             // {Ku, Kv, new_idepth, relBS} (centerProjectedTo), written when fix/marg
     float* en_new;                              // [Ppad] state_NewEnergyWithOutlier of residuals targeting frame W-1 (-1 = none)
-    unsigned *th_hist_hi, *th_hist_lo, *th_state;   // radix-select histograms (2 x 65536) + {count, k_rem, prefix_hi}
+    double *th_bufAB, *th_bufC;                 // radix-select histograms of setNewFrameEnergyTH, two bins per double: A | B (1024 doubles each), C (256, behind the stitched systems)
+    unsigned* th_state;                         // {count, k below bin A, bin A, empty, k below bin B, bin B}
     // partials
     double* top_partial;                        // [nblocks*lin_sub][W][kTopStride]: one partial per ba_linearize workgroup and target (fp64: one rounding less before the cancelling H_A - H_sc)
     double* sc_partial;                         // [sc_groups * sc_split][T(T+1)/2 upper tiles][256] (MFMA register order)

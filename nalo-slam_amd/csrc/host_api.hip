@@ -427,6 +427,7 @@ int nalo_trk_eval(nalo_ctx* c, int slot_new, int lvl, const double R[9], const d
                   float cutoffTH, int want_gs, double stats6[6], double H[64], double b[8]) {
     if (!c || !R || !t || !affLL || !stats6 || lvl < 0 || lvl >= c->levels || slot_new < 0 || slot_new >= (int)c->slots.size())
         return fail(c, NALO_ERR_ARG, "nalo_trk_eval: bad argument");
+    if (c->xchg_failed) return fail(c, NALO_ERR_HIP, "nalo_trk_eval: a cross-rank sum of this context failed earlier; rebuild on a new context");
     if (c->slot_ref < 0 || !c->slots[slot_new].valid) return fail(c, NALO_ERR_STATE, "nalo_trk_eval: no reference / empty frame slot");
     if (want_gs && (!H || !b)) return fail(c, NALO_ERR_ARG, "nalo_trk_eval: H/b required");
     // RKi = R.cast<float>() * Ki[lvl], t = translation.cast<float>() (CoarseTracker.cpp:907-908)
@@ -467,6 +468,7 @@ int nalo_trk_track(nalo_ctx* c, int slot_new, double T_io[12], double aff_io[2],
     if (!(coarsestLvl >= 0 && coarsestLvl < 5 && coarsestLvl < c->levels)) return fail(c, NALO_ERR_ARG, "nalo_trk_track: coarsestLvl out of range");
     if (slot_new < 0 || slot_new >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_trk_track: frame slot out of range");
     if (c->slot_ref < 0 || !c->slots[slot_new].valid) return fail(c, NALO_ERR_STATE, "nalo_trk_track: no reference (nalo_trk_set_ref) / empty frame slot");
+    if (c->xchg_failed) return fail(c, NALO_ERR_HIP, "nalo_trk_track: a cross-rank sum of this context failed earlier; rebuild on a new context");
     HostTimer ht(c, "trk_track");   // assert at :1083
     double lastRes[5] = {NAN, NAN, NAN, NAN, NAN}, flow[3] = {1000, 1000, 1000};
     SE3 cur = SE3::from(T_io);

@@ -24,7 +24,7 @@ void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
 void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
 void ba_launch_energy_th(hipStream_t s, const BADev& B);
 void ba_launch_set_th(hipStream_t s, float* dst, const float* th, int W);
-void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int step);
+void ba_launch_energy_th_step(hipStream_t s, const BADev& B, int step);
 void ba_launch_lenergy(hipStream_t s, const BADev& B, double* partial);
 void ba_launch_load_backup(hipStream_t s, const BADev& B);
 void ba_launch_swgray(hipStream_t s, const BADev& B, const double* Rt, double* partial);
@@ -64,7 +64,7 @@ struct BAWindow {
     DevBuf<float4> rs_pp0;
     DevBuf<uint8_t> pt_flags, pt_ngood, rs_state;
     DevBuf<int> blk_host, host_blk, blk_order, sc_grp;
-    DevBuf<unsigned> th_hist;                                        // 2 x 65536 + 64 (state, arrival counters, workgroup totals)
+    DevBuf<unsigned> th_hist;                                        // the radix select's state words (kernels_ba.hip: ba_th_fill_kernel)
     bool step_fused = false, step_sums_deferred = false;            // optimize(): resubstitute + point step in one kernel, its sums finished by the reduce launch
     bool th_pending = false;                                        // a linearize pass whose frameEnergyTH quantile has not been launched yet
     DevBuf<double> acc13, G, AD, stitched;                      // stitched: [H~_A ((n1)^2) | H~_sc ((n1)^2) | misc (2 W^2) | step sums (3) | TH sum, ranks]
@@ -91,9 +91,9 @@ struct BAWindow {
     void* hook_user = nullptr;
     bool hook_stream_ordered = false;                               // the hook enqueues its collective on nalo_stream(ctx): no host synchronisation around it
     nalo_allreduce_fn hook_side = nullptr; void* hook_side_user = nullptr;   // same sum, enqueued on nalo_side_stream(ctx): the threshold's histograms
-    DevBuf<double> th_buf;                                          // a histogram as doubles (all-reduce payload)
+    DevBuf<double> th_buf;                                          // level A | level B histograms of the radix select as doubles (2 x kThDblAB: the side stream's all-reduce payloads)
     hipEvent_t ev_lin = nullptr, ev_th = nullptr; bool th_side_inflight = false;   // sharded windows run the quantile kernels on the side stream, under the SC kernel
-    bool th_lo_pending = false;                                     // the lo histogram sits behind the stitched systems (lo_off), not yet summed over the ranks: the next
+    bool th_lo_pending = false;                                     // level C's histogram sits behind the stitched systems (lo_off), not yet summed over the ranks: the next
                                                                     // stitch sums it WITH the systems in one all-reduce, anything else that needs the threshold sums it alone
     size_t lo_off = 0;
     bool never_break = false;
@@ -295,7 +295,7 @@ static int call_hook(nalo_ctx* c, nalo_allreduce_fn fn, void* user, double* buf,
 static int flush_th(nalo_ctx* c);
 static int upload_frame_th(nalo_ctx* c) {
     BAWindow& w = *c->ba;
-    if (w.points_set && w.dev.th_hist_hi) { int rc = flush_th(c); if (rc) return rc; }   // a pending quantile pass also clears its histogram
+    if (w.points_set && w.dev.th_bufAB) { int rc = flush_th(c); if (rc) return rc; }   // a pending quantile pass also clears its histograms
     std::vector<float> th(w.W);
     for (int i = 0; i < w.W; ++i) th[i] = w.frames[i].frameEnergyTH;
     NALO_HIP(c, w.frameTH.reserve(16));
@@ -311,11 +311,11 @@ static int upload_frame_th(nalo_ctx* c) {
 static int flush_th(nalo_ctx* c) {
     BAWindow& w = *c->ba;
     if (w.th_side_inflight) { NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0)); w.th_side_inflight = false; }
-    if (w.th_lo_pending) {                                            // no stitch took the lo histogram along: its own all-reduce, then the search
+    if (w.th_lo_pending) {                                            // no stitch took level C's histogram along: its own all-reduce, then the search
         w.th_lo_pending = false;
         if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
-        { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + w.lo_off, kThLoDoubles); if (rh) return rh; }
-        ba_launch_energy_th_sharded(c->stream, w.dev, w.stitched.p + w.lo_off, 3);
+        { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + w.lo_off, kThDblC); if (rh) return rh; }
+        ba_launch_energy_th_step(c->stream, w.dev, 3);
         NALO_HIP(c, hipGetLastError());
     }
     if (!w.th_pending) return NALO_OK;
@@ -363,20 +363,21 @@ static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false)
         ba_launch_linearize(c->stream, w.dev, mode, fix, ps.a, lin_done);
     }
     if (th_sharded) {
-        // sharded window: the threshold is part of the all-reduced tail, i.e. on the critical path: run its kernels on the side stream under SC
-        // The EXACT order statistic over all ranks' residuals (what one GPU holding the whole window computes): both radix histograms are summed across ranks before
-        // their search. The hi histogram's sum and search and the lo histogram's fill run here - on the side stream under SC / reduce / stitch when there is a side
-        // hook or the main hook blocks, in line otherwise -; the lo histogram is left behind the stitched systems and summed together with them (stitch_and_fetch).
+        // sharded window: the threshold is the EXACT order statistic over all ranks' residuals (what one GPU holding the whole window computes): each level's
+        // histogram of the three-level radix select (kernels_ba.hip) is summed across the ranks before the next level's search. Levels A and B (8 KB each) are
+        // filled, summed and searched here - on the side stream under pt_acc / SC / reduce / stitch when there is a side hook or the main hook blocks, in line
+        // otherwise -; level C (2 KB) is left behind the stitched systems and summed together with them (stitch_and_fetch): three small kernels, two 8 KB
+        // collectives beside the main stream and ONE collective of the systems on it per pass.
         hipStream_t st = on_side ? c->side : c->stream;
         nalo_allreduce_fn fn = (on_side && w.hook_side) ? w.hook_side : w.hook;
         void* user = (on_side && w.hook_side) ? w.hook_side_user : w.hook_user;
-        NALO_HIP(c, w.th_buf.reserve(kThHiDoubles));
         if (on_side) NALO_HIP(c, hipStreamWaitEvent(c->side, lin_done, 0));
-        ba_launch_energy_th_sharded(st, w.dev, w.th_buf.p, 0);
-        if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(st));
-        { int rh = call_hook(c, fn, user, w.th_buf.p, kThHiDoubles); if (rh) return rh; }
-        ba_launch_energy_th_sharded(st, w.dev, w.th_buf.p, 1);
-        ba_launch_energy_th_sharded(st, w.dev, w.stitched.p + w.lo_off, 2);
+        for (int lvl = 0; lvl < 2; ++lvl) {
+            ba_launch_energy_th_step(st, w.dev, lvl);
+            if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(st));
+            { int rh = call_hook(c, fn, user, w.th_buf.p + lvl * kThDblAB, kThDblAB); if (rh) return rh; }
+        }
+        ba_launch_energy_th_step(st, w.dev, 2);
         if (on_side) { NALO_HIP(c, hipEventRecord(w.ev_th, c->side)); w.th_side_inflight = true; }
         w.th_lo_pending = true;
     } else if (mode == 0) w.th_pending = true;
@@ -452,10 +453,12 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
     const double seq = (double)(w.pub_seq + 1);
     double* dmap = nullptr;
     NALO_HIP(c, hipHostGetDevicePointer((void**)&dmap, w.stitched_host, 0));
-    const bool fuse_lo = w.hook && w.th_lo_pending;                  // this stitch's all-reduce takes the newest frame's lo histogram along
+    const bool top = want_top && !w.stitched_top, sc = want_sc && !w.stitched_sc;
+    const bool sc_was_summed = w.stitched_sc;                        // a hooked window: its block already holds the sum over the ranks
+    // this stitch's all-reduce takes level C's histogram of the newest frame's threshold along - when the summed range reaches the tail it sits behind
+    const bool fuse_lo = w.hook && w.th_lo_pending && (top || misc_only);
     bool th_after_publish = false;
     {
-        const bool top = want_top && !w.stitched_top, sc = want_sc && !w.stitched_sc;
         if ((top || sc) && (th_to_host || w.hook) && !fuse_lo) {      // the threshold rides in the tail {TH, 1.0}: compute it before the publish
             int rc = flush_th(c); if (rc) return rc;
             ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
@@ -483,23 +486,31 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
             // sharded window: tail = {step sums (3), frameEnergyTH of the newest frame, 1.0}. Every rank already holds the SAME threshold (the order
             // statistic over all ranks' residuals, linearize_async), so sum / count below re-installs that value; the tail keeps its layout.
             const size_t off = misc_only ? 2 * blk : 0;               // misc_only: only the tail is summed and published
+            // What is summed over the ranks is what THIS call produced, once: the freshly stitched block(s) and - with the top system, whose reduce writes it - the
+            // tail {per-bin count / energy, step sums, threshold pair}. A second fetch of the same linearisation (nalo_ba_linearize, then nalo_ba_accumulate_sc or
+            // nalo_ba_solve_system: the step-by-step mapping of ef->solveSystemF) stitches the Schur complement alone and sums ITS block alone:
+            // H_A, b_A and the tail already hold the window's totals (rounds 2-3 summed them again: world x H_A).
+            const size_t tail_end = fuse_lo ? w.lo_off + kThDblC : (size_t)npub;
+            size_t ra[2], rb[2]; int nr = 0;
+            if (misc_only) { ra[nr] = 2 * blk; rb[nr++] = tail_end; }
+            else if (top && (sc || !sc_was_summed)) { ra[nr] = 0; rb[nr++] = tail_end; }     // the SC block in between is fresh, or dead (re-stitched before anyone reads it)
+            else if (top) { ra[nr] = 0; rb[nr++] = blk; ra[nr] = 2 * blk; rb[nr++] = tail_end; }
+            else { ra[nr] = blk; rb[nr++] = 2 * blk; }
             if (fuse_lo) {
-                // [systems | tail | lo histogram]: one sum over the ranks, then the search on the summed histogram gives every rank the same threshold
+                // [systems | tail | level C]: one sum over the ranks, then the search on the summed histogram gives every rank the same threshold
                 if (w.th_side_inflight) { NALO_HIP(c, hipStreamWaitEvent(c->stream, w.ev_th, 0)); w.th_side_inflight = false; }
                 w.th_lo_pending = false;
-                if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
-                { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + off, (int)(w.lo_off - off) + kThLoDoubles); if (rh) return rh; }
+            }
+            if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
+            for (int i = 0; i < nr; ++i) { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + ra[i], (int)(rb[i] - ra[i])); if (rh) return rh; }
+            if (fuse_lo) {
                 if (th_to_host) {                                    // the caller reads the threshold from the published tail: search first
-                    ba_launch_energy_th_sharded(c->stream, w.dev, w.stitched.p + w.lo_off, 3);
+                    ba_launch_energy_th_step(c->stream, w.dev, 3);
                     ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);    // what tail_th() reads: {TH, 1.0}
                 } else th_after_publish = true;                      // optimize(): the host only waits for the systems; the search runs under its solve
-            } else {
-                if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
-                { int rh = call_hook(c, w.hook, w.hook_user, w.stitched.p + off, npub - (int)off); if (rh) return rh; }
-                ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // more than one rank: the common threshold
-            }
+            } else if (top || misc_only) ba_launch_th_install(c->stream, w.stitched.p + 2 * blk + 2 * W * W + 3, w.frameTH.p + (W - 1));   // the tail's {sum of TH, ranks}: the common threshold
             ba_launch_publish(c->stream, w.stitched.p + off, dmap + off, npub - (int)off, seq, w.st_ticket.p + 1);
-            if (th_after_publish) ba_launch_energy_th_sharded(c->stream, w.dev, w.stitched.p + w.lo_off, 3);
+            if (th_after_publish) ba_launch_energy_th_step(c->stream, w.dev, 3);
             NALO_HIP(c, hipGetLastError());
         }
         { int rc = flush_th(c); if (rc) return rc; }                  // behind the publish: overlaps the host's solve
@@ -763,8 +774,9 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     }
     w.dev.W = W; w.dev.w = c->w; w.dev.h = c->h;
     w.dev.fix_a = c->set.affineOptModeA < 0; w.dev.fix_b = c->set.affineOptModeB < 0; w.dev.no_th = 0;
-    NALO_HIP(c, w.th_hist.reserve(2 * 65536 + 64)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, (2 * 65536 + 64) * 4));
-    w.dev.th_hist_hi = w.th_hist.p; w.dev.th_hist_lo = w.th_hist.p + 65536; w.dev.th_state = w.th_hist.p + 2 * 65536;
+    NALO_HIP(c, w.th_hist.reserve(64)); NALO_HIP(c, hipMemset(w.th_hist.p, 0, 64 * 4));
+    NALO_HIP(c, w.th_buf.reserve(2 * kThDblAB)); NALO_HIP(c, hipMemset(w.th_buf.p, 0, 2 * kThDblAB * 8));      // zero = ready; ba_th_final_kernel leaves them zeroed again
+    w.dev.th_state = w.th_hist.p; w.dev.th_bufAB = w.th_buf.p;
     // HM / bM survive a nalo_ba_set_window only when that is asked for: right after nalo_ba_marginalize_frame (whose result is meant for this very call) or on a
     // context declared continuing (nalo_ba_set_prior_carry). Any other window starts from a zero prior, whatever an earlier, unrelated window left behind.
     const bool keep_prior = w.prior_next || w.prior_carry;
@@ -782,10 +794,11 @@ int nalo_ba_set_window(nalo_ctx* c, int W, const nalo_frame_state* frames, const
     const size_t blk = (size_t)w.n1 * w.n1;
     NALO_HIP(c, w.acc13.reserve((size_t)W * W * 169));
     NALO_HIP(c, w.G.reserve((size_t)W * w.NPL * w.NPL));
-    w.lo_off = (2 * blk + 2 * W * W + 5 + 15) & ~(size_t)15;                       // behind the published doubles: the lo histogram of a sharded window's threshold search
-    NALO_HIP(c, w.stitched.reserve(w.lo_off + kThLoDoubles));
-    NALO_HIP(c, hipMemsetAsync(w.stitched.p, 0, (w.lo_off + kThLoDoubles) * 8, c->stream));
-    w.th_lo_pending = false;
+    w.lo_off = (2 * blk + 2 * W * W + 5 + 15) & ~(size_t)15;                       // behind the published doubles: level C's histogram of the threshold's radix select (a sharded window sums it with the systems) search
+    NALO_HIP(c, w.stitched.reserve(w.lo_off + kThDblC));
+    NALO_HIP(c, hipMemsetAsync(w.stitched.p, 0, (w.lo_off + kThDblC) * 8, c->stream));
+    w.dev.th_bufC = w.stitched.p + w.lo_off;
+    w.th_lo_pending = false; w.th_pending = false; w.th_side_inflight = false;
     w.sd.M_top = w.acc13.p; w.sd.M_sc = w.G.p; w.sd.H = w.stitched.p;
     if (w.stitched_host) { (void)hipHostFree(w.stitched_host); w.stitched_host = nullptr; }
     NALO_HIP(c, hipHostMalloc((void**)&w.stitched_host, (2 * blk + 2 * W * W + 16) * 8, hipHostMallocMapped));
@@ -1341,9 +1354,10 @@ int nalo_ba_set_allreduce_mode(nalo_ctx* c, int stream_ordered) {
 int nalo_ba_set_allreduce(nalo_ctx* c, nalo_allreduce_fn hook, void* user) {
     if (!c) return NALO_ERR_ARG;
     if (!c->ba) c->ba = new BAWindow();
-    // a pass whose lo histogram has not been summed yet (the last linearisation of optimize(), say) is finished with the hook it was started under: every rank
+    // a pass whose level-C histogram has not been summed yet (the last linearisation of optimize(), say) is finished with the hook it was started under: every rank
     // changes its hook at the same point of the program, so the collective still matches
-    if (c->ba->th_lo_pending && c->ba->hook && hook != c->ba->hook && !c->xchg_failed) { NALO_HIP(c, hipSetDevice(c->device)); const int rc = flush_th(c); if (rc) return rc; }
+    // (also when the same function is registered again - with another user / communicator pointer, or idempotently per keyframe: the pending sum belongs to the OLD pair)
+    if (c->ba->th_lo_pending && c->ba->hook && !c->xchg_failed) { NALO_HIP(c, hipSetDevice(c->device)); const int rc = flush_th(c); if (rc) return rc; }
     c->ba->th_lo_pending = false;
     c->ba->hook = hook; c->ba->hook_user = user;
     return NALO_OK;

@@ -760,7 +760,7 @@ int nalo_init_set_points(nalo_ctx* c, int lvl, int n, const float* idepth, const
 
 int nalo_init_get_carried(nalo_ctx* c, int lvl, int cap, float* idepth_new, float* maxstep, float* lastHessian_new, float* energy_new2, uint8_t* isGood_new) {
     if (!c || !c->init) return fail(c, c ? NALO_ERR_STATE : NALO_ERR_ARG, "nalo_init_get_carried: no initialiser");
-    if (lvl < 0 || lvl >= c->init->levels) return fail(c, NALO_ERR_ARG, "nalo_init_get_carried: bad argument");
+    if (lvl < 0 || lvl >= c->init->levels || cap < 0) return fail(c, NALO_ERR_ARG, "nalo_init_get_carried: bad argument");
     { const int rc = host_sync(c, *c->init); if (rc) return rc; }
     const InitLevel& P = c->init->L[lvl];
     const size_t m = (size_t)std::min(cap, P.n);

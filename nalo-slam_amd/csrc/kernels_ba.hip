@@ -855,121 +855,111 @@ void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partia
 }
 
 // ------------------------------------------------------------------------------------------------ setNewFrameEnergyTH
-// Exact n-th element (nthIdx = (int)(0.7f * n), FullSystemOptimize.cpp:117-122) of the non-negative energies of the residuals
-// that target the newest frame, by a two-level 16+16-bit radix select on the float bit patterns (monotone for x >= 0):
-// the high-half histogram is filled by ba_linearize_kernel itself (integer atomics), then find-hi -> low-half histogram of the
-// matching entries -> find-lo + the threshold formula (:130-133). Runs on the side stream, overlapped with SC/reduce/stitch.
-// 16 workgroups of 256 lanes, one launch: workgroup g owns bins [4096 g, 4096 (g + 1)) in registers (wave w of it: 1024 bins = 4 rounds of coalesced 16-byte
-// loads), publishes its total, and after a 16-party arrival counter (the workgroups are co-resident: 16 x 256 lanes; the spin is bounded) the ONE workgroup whose
-// range holds the k-th entry locates the bin wave -> round -> lane -> bin with shuffles only. (Was: one workgroup of 1024 lanes pulling all 256 KB through one CU,
-// 13 us per search, two searches per pass: on the critical path of every sharded iteration.) state[4] = generation (selects the counter), state[5..6] = the two
-// arrival counters (the idle one is cleared by workgroup 0), state[7] = sticky timeout word, state[16..31] = the totals.
-constexpr int kThWG = 16;
-__global__ __launch_bounds__(256) void ba_th_find_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state, int level, float* __restrict__ frameTH_new) {
-    __shared__ unsigned wsum[4], tot[kThWG];
-    __shared__ unsigned s_bin, s_run, s_gen;
-    __shared__ int s_ok;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
-    // state[7] = sticky failure word: an earlier search of this window timed out at the arrival counter (its counters may be partly filled, its totals stale).
-    // Every later search then reports NaN instead of a threshold computed from them; the host sees it with the next threshold it fetches and fails the call
-    // (host_ba.hip check_th). nalo_ba_set_window clears the whole state.
-    if (state[7]) { if (wg == 0 && tid == 0 && frameTH_new) *frameTH_new = NAN; return; }
-    uint4* h4 = reinterpret_cast<uint4*>(hist + wg * 4096 + wave * 1024) + lane;
-    uint4 q[4];
-    unsigned ls[4], sum = 0;
+// Exact n-th element (nthIdx = (int)(0.7f * n), FullSystemOptimize.cpp:117-122) of the non-negative energies of the residuals that target the newest frame
+// (en_new[], written by ba_linearize_kernel; -1 = no residual), by a THREE-level radix select on the float bit patterns (monotone for x >= 0):
+//   level A = bits 30..20 (2048 bins), level B = bits 19..9 (2048 bins), level C = bits 8..0 (512 bins).
+// Every level is one pass over en_new[] (4 bytes per point slot) into a histogram that IS the cross-rank payload: two bins per double (a + b * 2^26: exact while
+// a bin's global count stays below 2^26 = 67 M residuals towards the newest frame and the sum below 2^52), built with fp64 atomics after an LDS pre-aggregation
+// - 1024 + 1024 + 256 doubles. A sharded window sums each of them over the ranks before the next level's search (host_ba.hip), so every rank holds the order
+// statistic of the WHOLE window, bit for bit what one GPU computes; level C is written behind the stitched systems and rides in their all-reduce.
+// (Rounds 1-3: 16 + 16 bits, two 65536-bin histograms = 16384 + 32768 doubles per pass = two thirds of a sharded iteration's 560 KB exchange, four conversion
+// kernels, a 16-party arrival counter per search and the hi histogram's atomics inside ba_linearize_kernel. Now 18 KB, no conversion, no inter-workgroup wait:
+// every workgroup of a fill kernel repeats the (tiny) search of the previous level itself.)
+// state[0] = count, [1] = k below level A's bin, [2] = bin A, [3] = empty flag, [4] = k below level B's bin, [5] = bin B.
+constexpr int kThBinsAB = 2048, kThBinsC = 512;
+constexpr double kThPack = 67108864.0;                        // 2^26
+// the bin of a packed histogram whose running count passes k (all 256 lanes call; s = 8 shared words). first: k = (int)(0.7f * total) of THIS histogram.
+template <int NBINS>
+__device__ __forceinline__ void th_search(const double* __restrict__ buf, bool first, unsigned k_in, unsigned* s, unsigned& total, unsigned& k, unsigned& bin, unsigned& before) {
+    constexpr int NB = NBINS / 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned cnt[NB], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { q[i] = h4[i * 64]; ls[i] = q[i].x + q[i].y + q[i].z + q[i].w; sum += ls[i]; }
+    for (int j = 0; j < NB / 2; ++j) {
+        const unsigned long long v = (unsigned long long)(buf[tid * (NB / 2) + j] + 0.5);
+        cnt[2 * j] = (unsigned)(v & 0x3FFFFFFull); cnt[2 * j + 1] = (unsigned)(v >> 26);
+        sum += cnt[2 * j] + cnt[2 * j + 1];
+    }
+    unsigned incl = sum;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h4[i * 64] = make_uint4(0u, 0u, 0u, 0u);                 // ready for the next pass
-    unsigned wtot = sum;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wtot += __shfl_xor(wtot, o);
-    if (lane == 0) wsum[wave] = wtot;
-    if (tid == 0) { s_bin = 65535u; s_run = 0xFFFFFFFFu; }
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) s[wave] = incl;
+    if (tid == 0) { s[4] = (unsigned)(NBINS - 1); s[5] = 0u; }                   // k beyond the last entry (empty histogram): last bin
     __syncthreads();
-    const unsigned gtot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (tid == 0) {
-        const unsigned g = __hip_atomic_load(state + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (wg == 0) __hip_atomic_store(state + 5 + ((g + 1) & 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the previous launch's counter: all of its workgroups are gone
-        __hip_atomic_store(state + 16 + wg, gtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(state + 5 + (g & 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 0;
-        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
-            if (__hip_atomic_load(state + 5 + (g & 1), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)kThWG) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        s_ok = ok; s_gen = g;
+    unsigned wpre = 0;
+    total = s[0] + s[1] + s[2] + s[3];
+    for (int i = 0; i < wave; ++i) wpre += s[i];
+    k = first ? (unsigned)(int)(kFrameEnergyTHN * (float)total) : k_in;
+    const unsigned excl = wpre + incl - sum;
+    if (excl <= k && k < excl + sum) {                                          // exactly one lane
+        unsigned run = excl; int b = 0; bool found = false;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { if (!found && k < run + cnt[j]) { b = j; found = true; } if (!found) run += cnt[j]; }
+        s[4] = (unsigned)(tid * NB + b); s[5] = run;
     }
     __syncthreads();
-    if (!s_ok) {                                                                               // a workgroup never arrived: make it visible downstream, for good
-        if (tid == 0) __hip_atomic_store(state + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (wg == 0 && tid == 0 && frameTH_new) *frameTH_new = NAN;
-        return;
+    bin = s[4]; before = s[5];
+}
+template <int LEVEL>
+__global__ __launch_bounds__(256) void ba_th_fill_kernel(const float* __restrict__ en, int n, const double* __restrict__ prev, unsigned* __restrict__ state, double* __restrict__ out) {
+    constexpr int NB = LEVEL == 2 ? kThBinsC : kThBinsAB;
+    __shared__ unsigned hist[NB];
+    __shared__ unsigned s[8];
+    const int tid = threadIdx.x;
+    unsigned prefix = 0;
+    if (LEVEL == 1) {                                                            // the search of level A on its (summed) histogram; workgroup 0 keeps the result
+        unsigned total, k, bin, before;
+        th_search<kThBinsAB>(prev, true, 0u, s, total, k, bin, before);
+        if (blockIdx.x == 0 && tid == 0) { state[0] = total; state[3] = total == 0 ? 1u : 0u; state[1] = k - before; state[2] = bin; }
+        prefix = bin;
     }
-    if (tid < kThWG) tot[tid] = __hip_atomic_load(state + 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LEVEL == 2) {
+        unsigned total, k, bin, before;
+        const unsigned binA = state[2];                                         // written by the previous launch of this stream
+        th_search<kThBinsAB>(prev, false, state[1], s, total, k, bin, before);
+        if (blockIdx.x == 0 && tid == 0) { state[4] = k - before; state[5] = bin; }
+        prefix = (binA << 11) | bin;
+    }
+    for (int b = tid; b < NB; b += 256) hist[b] = 0u;
     __syncthreads();
-    unsigned total = 0, gpre = 0;
-    for (int i = 0; i < kThWG; ++i) { if (i == wg) gpre = total; total += tot[i]; }
-    const unsigned k = (level == 0) ? (unsigned)(int)(kFrameEnergyTHN * (float)total) : state[1];
-    const bool owner = gpre <= k && k < gpre + gtot;                   // exactly one workgroup (none if k >= total: empty histogram -> the last one reports)
-    if (!owner && !(k >= total && wg == kThWG - 1)) return;
-    if (owner) {
-        unsigned wpre = gpre;
-        for (int i = 0; i < wave; ++i) wpre += wsum[i];
-        if (wpre <= k && k < wpre + wtot) {                            // exactly one wave
-            unsigned run = wpre;
-            bool done = false;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                unsigned isum = ls[i];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) isum += __shfl_xor(isum, o);
-                if (!done && k < run + isum) {                          // wave-uniform: this round holds the bin
-                    unsigned incl = ls[i];
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-                    const unsigned lexcl = run + incl - ls[i];
-                    if (lexcl <= k && k < lexcl + ls[i]) {
-                        unsigned r2 = lexcl; int bsel = 3;
-                        if (r2 + q[i].x > k) bsel = 0; else { r2 += q[i].x; if (r2 + q[i].y > k) bsel = 1; else { r2 += q[i].y; if (r2 + q[i].z > k) bsel = 2; else r2 += q[i].z; } }
-                        s_bin = (unsigned)(wg * 4096 + wave * 1024 + i * 256 + 4 * lane + bsel); s_run = r2;
-                    }
-                    done = true;
-                }
-                if (!done) run += isum;
-            }
-        }
+    for (int i = blockIdx.x * 256 + tid; i < n; i += gridDim.x * 256) {
+        const float f = en[i];
+        if (!(f >= 0.f)) continue;
+        const unsigned u = __float_as_uint(f);
+        if (LEVEL == 0) atomicAdd(&hist[u >> 20], 1u);
+        if (LEVEL == 1) { if ((u >> 20) == prefix) atomicAdd(&hist[(u >> 9) & 2047u], 1u); }
+        if (LEVEL == 2) { if ((u >> 9) == prefix) atomicAdd(&hist[u & 511u], 1u); }
     }
     __syncthreads();
-    if (tid == 0) {
-        const unsigned bin = s_bin, run = s_run == 0xFFFFFFFFu ? total : s_run;       // k beyond the last entry (empty histogram): last bin
-        if (level == 0) { state[0] = total; state[3] = total == 0 ? 1u : 0u; state[1] = k - run; state[2] = bin; }
-        else {
-            float th;
-            if (state[3]) th = 12.f * 12.f * (float)kPatternNum;                        // no residual on the newest frame (:110-114)
-            else {
-                const float nthElement = sqrtf(__uint_as_float((state[2] << 16) | bin));
-                th = nthElement * kFrameEnergyTHFacMedian;                              // FullSystemOptimize.cpp:130-133
-                th = 26.0f * kFrameEnergyTHConstWeight + th * (1.f - kFrameEnergyTHConstWeight);
-                th = th * th; th *= kOverallEnergyTHWeight * kOverallEnergyTHWeight;
-            }
-            *frameTH_new = th;
-        }
-        __hip_atomic_store(state + 4, s_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // next launch: the other counter
+    for (int b = tid; b < NB / 2; b += 256) {
+        const unsigned c0 = hist[2 * b], c1 = hist[2 * b + 1];
+        if (c0 | c1) unsafeAtomicAdd(&out[b], (double)c0 + (double)c1 * kThPack);          // integers in doubles: exact, order independent
     }
 }
-__global__ __launch_bounds__(256) void ba_th_lo_kernel(const float* __restrict__ en, int n, const unsigned* __restrict__ state, unsigned* __restrict__ hist_lo) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float f = en[i];
-    if (!(f >= 0.f)) return;
-    const unsigned u = __float_as_uint(f);
-    if ((u >> 16) == state[2]) atomicAdd(&hist_lo[u & 0xFFFFu], 1u);
+// level C's search + the threshold formula (:130-133); leaves all three histograms zeroed for the next pass (every reader of A and B has finished: stream order)
+__global__ __launch_bounds__(256) void ba_th_final_kernel(double* __restrict__ bufC, const unsigned* __restrict__ state, double* __restrict__ bufAB, float* __restrict__ frameTH_new) {
+    __shared__ unsigned s[8];
+    const int tid = threadIdx.x;
+    unsigned total, k, bin, before;
+    th_search<kThBinsC>(bufC, false, state[4], s, total, k, bin, before);
+    if (tid == 0) {
+        float th;
+        if (state[3]) th = 12.f * 12.f * (float)kPatternNum;                     // no residual on the newest frame (:110-114)
+        else {
+            const float nthElement = sqrtf(__uint_as_float((state[2] << 20) | (state[5] << 9) | bin));
+            th = nthElement * kFrameEnergyTHFacMedian;                           // FullSystemOptimize.cpp:130-133
+            th = 26.0f * kFrameEnergyTHConstWeight + th * (1.f - kFrameEnergyTHConstWeight);
+            th = th * th; th *= kOverallEnergyTHWeight * kOverallEnergyTHWeight;
+        }
+        *frameTH_new = th;
+    }
+    for (int i = tid; i < kThBinsAB; i += 256) bufAB[i] = 0.0;                   // A | B: 1024 doubles each
+    bufC[tid] = 0.0;                                                            // 256 doubles (th_search has read them: two barriers ago)
 }
 // Small windows (<= 16384 point slots, a KITTI-sized window has 2048): the same order statistic in ONE launch. The workgroup keeps the energies in
 // registers and runs a most-significant-first radix select with four 256-bin LDS histograms (5 us instead of the 40 us of the two 65536-bin
-// searches above, which sat between the publish and the next back-substitution). It also clears the bins ba_linearize_kernel counted into.
-__global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restrict__ en, int n, unsigned* __restrict__ hist_hi, float* __restrict__ frameTH_new) {
+// searches of round 1, which sat between the publish and the next back-substitution).
+__global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restrict__ en, int n, float* __restrict__ frameTH_new) {
     __shared__ unsigned hist[256], wtot[16];
     __shared__ unsigned s_bin, s_before;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -980,7 +970,7 @@ __global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restri
         const int i = tid + 1024 * j;
         const float f = i < n ? en[i] : -1.f;
         ok[j] = f >= 0.f; v[j] = __float_as_uint(f);
-        if (ok[j]) { ++cnt; hist_hi[v[j] >> 16] = 0u; }
+        if (ok[j]) ++cnt;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
@@ -1019,36 +1009,19 @@ __global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restri
         th = th * th; th *= kOverallEnergyTHWeight * kOverallEnergyTHWeight; *frameTH_new = th;
     }
 }
+static int th_grid(int n) { return std::min(64, std::max(1, (n + 4095) / 4096)); }
+// step 0 / 1 / 2: fill level A / B / C (B and C search the previous level first), 3: level C's search + the threshold. A sharded window sums A, B, C over the
+// ranks between the steps (host_ba.hip); a single GPU runs the four launches back to back behind the publish, under the host's solve.
+void ba_launch_energy_th_step(hipStream_t s, const BADev& B, int step) {
+    double *A = B.th_bufAB, *Bb = B.th_bufAB + kThDblAB, *Cc = B.th_bufC;
+    if (step == 0) ba_th_fill_kernel<0><<<th_grid(B.Ppad), 256, 0, s>>>(B.en_new, B.Ppad, nullptr, B.th_state, A);
+    else if (step == 1) ba_th_fill_kernel<1><<<th_grid(B.Ppad), 256, 0, s>>>(B.en_new, B.Ppad, A, B.th_state, Bb);
+    else if (step == 2) ba_th_fill_kernel<2><<<th_grid(B.Ppad), 256, 0, s>>>(B.en_new, B.Ppad, Bb, B.th_state, Cc);
+    else ba_th_final_kernel<<<1, 256, 0, s>>>(Cc, B.th_state, A, B.frameTH + (B.W - 1));
+}
 void ba_launch_energy_th(hipStream_t s, const BADev& B) {
-    if (B.Ppad <= 16384) { ba_th_small_kernel<<<1, 1024, 0, s>>>(B.en_new, B.Ppad, B.th_hist_hi, B.frameTH + (B.W - 1)); return; }
-    ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr);
-    ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo);
-    ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1));
-}
-// Sharded window: the order statistic is taken over ALL ranks' residuals, so each of the two histograms is summed across ranks before its search. The all-reduce
-// hook sums doubles: TWO bins ride in one double (lo + hi * 2^26, exact while a bin's global count stays below 2^26 = 67 M residuals towards the newest frame, and
-// the sum below 2^52), which halves the payload: 16384 doubles for the hi histogram, 32768 for the lo one.
-// step 0: hi histogram -> buf; 1: buf -> hi histogram, search, fill the lo histogram of the (global) bin, lo histogram -> buf; 2: buf -> lo histogram, search,
-// threshold. The caller picks buf per step: the lo histogram is written behind the stitched systems so that ONE all-reduce sums both (host_ba.hip).
-constexpr double kThPack = 67108864.0;                        // 2^26
-__global__ __launch_bounds__(256) void ba_th_cvt_kernel(unsigned* __restrict__ hist, double* __restrict__ buf, int npair, int to_hist) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npair) return;
-    if (to_hist) { const unsigned long long v = (unsigned long long)(buf[i] + 0.5); hist[2 * i] = (unsigned)(v & 0x3FFFFFFull); hist[2 * i + 1] = (unsigned)(v >> 26); }
-    else buf[i] = (double)hist[2 * i] + (double)hist[2 * i + 1] * kThPack;
-}
-void ba_launch_energy_th_sharded(hipStream_t s, const BADev& B, double* buf, int step) {
-    constexpr int NHI = kThHiDoubles, NLO = kThLoDoubles;      // pairs of bins; energies are >= 0: the upper half of the hi histogram (sign bit) stays empty
-    if (step == 0) ba_th_cvt_kernel<<<NHI / 256, 256, 0, s>>>(B.th_hist_hi, buf, NHI, 0);
-    else if (step == 1) {
-        ba_th_cvt_kernel<<<NHI / 256, 256, 0, s>>>(B.th_hist_hi, buf, NHI, 1);
-        ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_hi, B.th_state, 0, nullptr);
-        ba_th_lo_kernel<<<(B.Ppad + 255) / 256, 256, 0, s>>>(B.en_new, B.Ppad, B.th_state, B.th_hist_lo);
-    } else if (step == 2) ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 0);
-    else {
-        ba_th_cvt_kernel<<<NLO / 256, 256, 0, s>>>(B.th_hist_lo, buf, NLO, 1);
-        ba_th_find_kernel<<<kThWG, 256, 0, s>>>(B.th_hist_lo, B.th_state, 1, B.frameTH + (B.W - 1));
-    }
+    if (B.Ppad <= 16384) { ba_th_small_kernel<<<1, 1024, 0, s>>>(B.en_new, B.Ppad, B.frameTH + (B.W - 1)); return; }
+    for (int step = 0; step < 4; ++step) ba_launch_energy_th_step(s, B, step);
 }
 
 // EnergyFunctional::calcLEnergyPt (EnergyFunctional.cpp:332-392), the per-point part that can be non-zero when FullSystem::optimize calls it: deltaF^2 priorF

@@ -322,8 +322,7 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
         }
     }
     if (MODE == 0 && w.t == B.W - 1 && !B.no_th) {
-        B.en_new[w.d] = R.enew;
-        if (R.enew >= 0.f) atomicAdd(&B.th_hist_hi[__float_as_uint(R.enew) >> 16], 1u);               // integer atomics: order independent
+        B.en_new[w.d] = R.enew;                          // the input of setNewFrameEnergyTH's radix select (kernels_ba.hip: ba_th_fill_kernel)
     }
 }
 

@@ -4,6 +4,7 @@
 // weighted Schur accumulator acc9SC (:590-612) joins the same pass. 91 per-lane fp32 sums (45 + 45 + E) go through the usual quad-DPP -> LDS rows ->
 // fp64 column sums -> block partial -> fp64 finish. doStep (:910-938) is a thread-per-point kernel.
 #include "nalo_internal.h"
+#include <mutex>
 #include "reduce.h"
 #include <type_traits>
 
@@ -362,11 +363,15 @@ int init_sweep_launch(nalo_ctx* c, int mode, int n, int nsteps, const int* off, 
     const size_t sm = lds ? lds_bytes : soff_words * 4;
     if (!scratch) return fail(c, NALO_ERR_STATE, "init_sweep_launch: no scratch block");
     float *gval = scratch, *idp_s = scratch + npad;                                 // scratch: 2 * npad floats, 16-byte aligned
-    static bool attr_done = false;
-    if (!attr_done) {
-        NALO_HIP(c, hipFuncSetAttribute((const void*)init_sweep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLdsBytes));
-        NALO_HIP(c, hipFuncSetAttribute((const void*)init_sweep_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLdsBytes));
-        attr_done = true;
+    {   // the LDS opt-in of the sweep kernels is a property of the (device, function) pair: latched per device under a lock (contexts on several devices / host threads)
+        static std::mutex mu; static bool attr_done[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        const int dv = c->device >= 0 && c->device < 64 ? c->device : 0;
+        if (!attr_done[dv]) {
+            NALO_HIP(c, hipFuncSetAttribute((const void*)init_sweep_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLdsBytes));
+            NALO_HIP(c, hipFuncSetAttribute((const void*)init_sweep_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSweepLdsBytes));
+            attr_done[dv] = true;
+        }
     }
     const float w = regWeight, omw = 1 - regWeight;
     const int4* r4 = (const int4*)rec;

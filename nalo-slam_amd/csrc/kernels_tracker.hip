@@ -149,6 +149,9 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
         trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, c->trk_shard_sums.p, 0.0);
         if (!c->trk_hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
         c->trk_hook(c->trk_hook_user, c->trk_shard_sums.p, kTrkVals);
+        // the same latch as the BA's call_hook (host_ba.hip): a rank whose collective failed must not take an LM step on rank-local sums - the ranks would take
+        // different steps and evaluation counts, and the next collectives would mismatch or hang
+        if (c->xchg_failed) return NALO_ERR_HIP;                        // message already in c->err (nalo_ba_exchange_failed / the RCCL hooks)
         trk_publish_kernel<<<1, 64, 0, c->stream>>>(c->trk_shard_sums.p, dout, seq);
     } else trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, dout, seq);
     NALO_HIP(c, hipGetLastError());

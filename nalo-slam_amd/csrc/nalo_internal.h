@@ -196,7 +196,7 @@ int init_do_step_launch(nalo_ctx* c, int n, const uint8_t* isGood, const float* 
 int init_apply_step_launch(nalo_ctx* c, int n, uint8_t* isGood, const uint8_t* isGood_new, float* idepth, float* idepth_new, const float* iR, float* energy, const float* energy_new,
                            float* lastHessian, const float* lastHessian_new);
 // the dependency-ordered sweeps (optReg: mode 0, the top level's resetPoints: mode 1) and the per-point parts of resetPoints / propagateDown / propagateUp
-constexpr int kThHiDoubles = 16384, kThLoDoubles = 32768;   // setNewFrameEnergyTH on a sharded window: the two radix histograms as all-reduce payloads, two bins per double
+constexpr int kThDblAB = 1024, kThDblC = 256;   // setNewFrameEnergyTH: the three radix histograms (2048 + 2048 + 512 bins) as doubles, two bins per double = the cross-rank payloads of a sharded window
 #ifndef NALO_SWEEP_NT
 #define NALO_SWEEP_NT 128
 #endif

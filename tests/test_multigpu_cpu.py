@@ -63,9 +63,10 @@ def test_sharded_systems_sum_to_the_window_system():
 
 
 def test_sharded_threshold_rule_is_the_global_order_statistic():
-    """setNewFrameEnergyTH on a sharded window: the two radix histograms of the float bit patterns are SUMMED across ranks before their
-    searches. Pure arithmetic check of that rule in numpy: summed 16+16-bit histograms select exactly the n-th element (nthIdx = (int)(0.7f * n),
-    FullSystemOptimize.cpp:117-122) of the concatenated energies, whatever the split - which the mean of per-shard quantiles does not."""
+    """setNewFrameEnergyTH on a sharded window: the three radix histograms of the float bit patterns (bits 30..20 | 19..9 | 8..0: 2048 + 2048 + 512
+    bins, kernels_ba.hip: ba_th_fill_kernel) are SUMMED across ranks before their searches. Pure arithmetic check of that rule in numpy: the summed
+    histograms select exactly the n-th element (nthIdx = (int)(0.7f * n), FullSystemOptimize.cpp:117-122) of the concatenated energies, whatever the
+    split - which the mean of per-shard quantiles does not."""
     rng = np.random.RandomState(0)
     e = np.abs(rng.standard_cauchy(50000)).astype(np.float32) * 40.0            # heavy-tailed, like residual energies
     e[rng.rand(len(e)) < 0.01] = 0.0
@@ -77,20 +78,26 @@ def test_sharded_threshold_rule_is_the_global_order_statistic():
     want = np.sort(allv)[k]
 
     bits = [s.view(np.uint32) for s in shards]
-    hi = sum(np.bincount(b >> 16, minlength=65536) for b in bits)               # the first all-reduce
-    cum = np.cumsum(hi)
-    bin_hi = int(np.searchsorted(cum, k, side="right"))
-    k_lo = k - (cum[bin_hi - 1] if bin_hi else 0)
-    lo = sum(np.bincount(b[(b >> 16) == bin_hi] & 0xFFFF, minlength=65536) for b in bits)     # the second all-reduce
-    bin_lo = int(np.searchsorted(np.cumsum(lo), k_lo, side="right"))
-    got = np.array([(bin_hi << 16) | bin_lo], np.uint32).view(np.float32)[0]
+
+    def pick(hist, kk):
+        cum = np.cumsum(hist)
+        bn = int(np.searchsorted(cum, kk, side="right"))
+        return bn, kk - (cum[bn - 1] if bn else 0)
+    hA = sum(np.bincount(b >> 20, minlength=2048) for b in bits)                # the first all-reduce (side stream)
+    binA, kA = pick(hA, k)
+    hB = sum(np.bincount((b[(b >> 20) == binA] >> 9) & 2047, minlength=2048) for b in bits)      # the second (side stream)
+    binB, kB = pick(hB, kA)
+    pre = (binA << 11) | binB
+    hC = sum(np.bincount(b[(b >> 9) == pre] & 511, minlength=512) for b in bits)                 # the third: rides behind the stitched systems
+    binC, _ = pick(hC, kB)
+    got = np.array([(binA << 20) | (binB << 9) | binC], np.uint32).view(np.float32)[0]
     assert got == want
-    # the payload rule (kernels_ba.hip: ba_th_cvt_kernel): two bins per double, a + b * 2^26, summed as doubles, split again - exact while a bin stays below 2^26
-    his = [np.bincount(b >> 16, minlength=65536).astype(np.float64) for b in bits]
+    # the payload rule (kernels_ba.hip: two bins per double, a + b * 2^26, summed as doubles, split again) is exact while a bin stays below 2^26
+    his = [np.bincount(b >> 20, minlength=2048).astype(np.float64) for b in bits]
     his[0][[6, 7]] = 2 ** 26 - 1 - his[1][[6, 7]] - his[2][[6, 7]]                # the largest totals the packing admits, in both halves of one pair
     packed = sum(h[0::2] + h[1::2] * 2.0 ** 26 for h in his)
     v = (packed + 0.5).astype(np.uint64)
-    back = np.empty(65536, np.uint64); back[0::2] = v & np.uint64(2 ** 26 - 1); back[1::2] = v >> np.uint64(26)
+    back = np.empty(2048, np.uint64); back[0::2] = v & np.uint64(2 ** 26 - 1); back[1::2] = v >> np.uint64(26)
     assert np.array_equal(back, sum(his).astype(np.uint64))
     mean_of_quantiles = np.mean([np.sort(s)[int(np.float32(0.7) * np.float32(len(s)))] for s in shards])
     assert abs(mean_of_quantiles - want) > 0.05 * want                            # the shortcut this replaces is visibly off on unequal shards

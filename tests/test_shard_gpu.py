@@ -1,7 +1,7 @@
 """GPU test of the sharded window on ONE device: two contexts, each holding half of the active points (bench.shard), driven by two threads
 whose all-reduce hook sums the buffers through the host. What the ranks agree on must be what a single context holding the whole window computes:
 the stitched systems (sum of the shards), the energy, and -- exactly -- the newest frame's energy threshold (setNewFrameEnergyTH is an order statistic:
-both radix histograms are summed across ranks before their search)."""
+the radix histograms are summed across ranks before their searches)."""
 import threading
 
 import numpy as np
@@ -66,7 +66,7 @@ def test_two_shards_agree_with_the_whole_window():
             c.ba_optimize(3, never_break=True)
             fr = c.ba_get_frames()
             out[r] = dict(e=e, th=th, H=H, b=b, th2=fr[0][win.W - 1].frameEnergyTH, w2c=fr[1].copy(), n=len(part.host))
-            c.ba_set_allreduce(None)                             # finishes the last pass's pending lo-histogram sum under the old hook (both ranks: it still matches)
+            c.ba_set_allreduce(None)                             # finishes the last pass's pending level-C sum under the old hook (both ranks: it still matches)
             out[r]["e_alone"] = c.ba_linearize()                 # the context goes on as a single-GPU one (its shard only)
             c.close()
         except Exception as ex:                                  # never leave the other rank waiting in the barrier
@@ -80,14 +80,14 @@ def test_two_shards_agree_with_the_whole_window():
     a, b = out
     assert a["n"] + b["n"] == len(win.host) and min(a["n"], b["n"]) > 0.3 * len(win.host)
     assert a["e_alone"] > 0 and b["e_alone"] > 0 and a["e_alone"] != b["e_alone"]
-    # per linearisation TWO collectives: the hi histogram of the threshold search (two bins per double), then [systems | tail | lo histogram] in one sum. A pass whose
-    # systems nobody fetches (the last one of optimize) sums its lo histogram alone when the threshold is next needed; a second fetch of a pass sums the systems alone.
+    # per linearisation THREE collectives: levels A and B of the threshold's radix select (1024 doubles each: 2048 bins, two per double), then
+    # [systems | tail | level C] in one sum. A pass whose systems nobody fetches (the last one of optimize) sums level C alone (256) when the threshold is next needed.
     n_sys = 2 * (8 * win.W + 5) ** 2 + 2 * win.W ** 2 + 5
     sizes = calls[0]
-    assert calls[0] == calls[1] and sizes[:2] == [16384, sizes[1]] and n_sys + 32768 <= sizes[1] <= n_sys + 32768 + 16, sizes
-    fused, alone, hi = sum(n > 32768 for n in sizes), sizes.count(32768), sizes.count(16384)
-    assert hi == fused + alone and fused >= 4 and alone <= 2, sizes
-    assert all(n in (16384, 32768) or n > 32768 or n <= n_sys for n in sizes), sizes
+    assert calls[0] == calls[1] and sizes[:2] == [1024, 1024] and n_sys + 256 <= sizes[2] <= n_sys + 256 + 16, sizes
+    fused, alone, ab = sum(n > n_sys for n in sizes), sizes.count(256), sizes.count(1024)
+    assert ab == 2 * (fused + alone) and fused >= 4 and alone <= 2, sizes
+    assert all(n in (1024, 256) or n_sys + 256 <= n <= n_sys + 256 + 16 for n in sizes), sizes
     # the threshold is the whole window's order statistic, bit for bit, on both ranks; after the optimisation too (7 passes later)
     assert a["th"] == b["th"] == th_full
     assert a["th2"] == b["th2"]
@@ -99,6 +99,81 @@ def test_two_shards_agree_with_the_whole_window():
         assert d < 1e-5 and np.array_equal(a["w2c"][f], b["w2c"][f])
 
 
+def test_second_fetch_of_a_pass_sums_only_what_it_stitched():
+    """nalo_ba_linearize followed by nalo_ba_accumulate_sc / nalo_ba_solve_system (the step-by-step mapping of ef->solveSystemF,
+    INTEGRATION.md) fetches the SAME linearisation twice. The first fetch summed H_A, b_A and the tail over the ranks; the second stitches the Schur complement
+    alone and must sum ITS block alone (rounds 2-3 all-reduced the whole buffer again: world x H_A, world x b_A, world x energy / resInA). Both orders
+    (top first, Schur complement first), against one context holding the whole window."""
+    win = synth.make_window(w=640, h=480, W=4, P=900, seed=21)
+    st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+    full = make_ctx(win, st6)
+    ref = {}
+    ref["e"] = full.ba_linearize()
+    ref["HA"], ref["bA"] = full.ba_accumulate(0)
+    ref["Hs"], ref["bs"] = full.ba_accumulate_sc(True)
+    ref["x"] = full.ba_solve_system(0)
+    ref["counts"] = full.ba_counts()
+    full.close()
+    world = 2
+    bar = threading.Barrier(world)
+    bufs, calls, out, err = [None] * world, [[] for _ in range(world)], [None] * world, []
+
+    def rank_job(r):
+        try:
+            c = make_ctx(bench.shard(win, r, world), st6)
+
+            def hook(ptr, n):
+                t = torch.as_tensor(_Ptr(ptr, n), device="cuda")
+                bufs[r] = t.cpu()
+                bar.wait()
+                tot = bufs[0] + bufs[1]
+                bar.wait()
+                t.copy_(tot)
+                torch.cuda.synchronize()
+                calls[r].append(n)
+            c.ba_set_allreduce(hook)
+            o = {}
+            o["e"] = c.ba_linearize()                           # A, B, [H_A | (dead SC block) | tail | C]
+            o["HA"], o["bA"] = c.ba_accumulate(0)               # already stitched and summed: no collective
+            o["Hs"], o["bs"] = c.ba_accumulate_sc(True)         # second fetch: the Schur complement's block alone
+            o["x"] = c.ba_solve_system(0)                       # both stitched: no collective; solves with H_A and b_A as they are
+            o["counts"] = c.ba_counts()
+            n1 = len(calls[r])
+            c.ba_linearize()                                    # the other order: Schur complement first ...
+            o["Hs2"], _ = c.ba_accumulate_sc(True)
+            o["HA2"], o["bA2"] = c.ba_accumulate(0)             # ... (no-op: nalo_ba_linearize stitched the top system) ...
+            o["x2"] = c.ba_solve_system(0)
+            o["calls2"] = calls[r][n1:]
+            out[r] = o
+            c.ba_set_allreduce(None)
+            c.close()
+        except Exception as ex:
+            err.append(ex)
+            bar.abort()
+
+    ts = [threading.Thread(target=rank_job, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not err, err
+    a, b = out
+    blk = (8 * win.W + 5) ** 2
+    n_sys = 2 * blk + 2 * win.W ** 2 + 5
+    assert calls[0] == calls[1]
+    first = calls[0][:len(calls[0]) - len(a["calls2"])]
+    assert first[:2] == [1024, 1024] and n_sys + 256 <= first[2] <= n_sys + 272 and first[3:] == [blk], calls[0]     # the second fetch: ONE block
+    assert a["calls2"][:2] == [1024, 1024] and a["calls2"][3:] == [blk], a["calls2"]
+    for k in ("HA", "bA", "Hs", "bs", "x"):
+        assert np.array_equal(a[k], b[k]), k                                            # both ranks hold the same sums
+    sc = np.abs(ref["HA"]).max()
+    assert abs(a["e"] - ref["e"]) < 1e-5 * ref["e"] and a["counts"] == ref["counts"]      # resInA: not world x
+    assert np.abs(a["HA"] - ref["HA"]).max() < 2e-5 * sc and np.abs(a["bA"] - ref["bA"]).max() < 2e-5 * np.abs(ref["bA"]).max()
+    assert np.abs(a["Hs"] - ref["Hs"]).max() < 2e-5 * np.abs(ref["Hs"]).max() and np.abs(a["bs"] - ref["bs"]).max() < 5e-5 * np.abs(ref["bs"]).max()
+    # the step of the whole window, not of a system with world x H_A (that one is off by tens of percent); the bound is the fp32 shard-order noise of H_A - H_sc
+    assert np.abs(a["x"] - ref["x"]).max() < 2e-3 * np.abs(ref["x"]).max(), np.abs(a["x"] - ref["x"]).max() / np.abs(ref["x"]).max()
+    assert np.abs(a["Hs2"] - a["Hs"]).max() < 2e-5 * np.abs(a["Hs"]).max() and np.abs(a["HA2"] - a["HA"]).max() < 2e-5 * sc
+    assert np.abs(a["x2"] - ref["x"]).max() < 2e-3 * np.abs(ref["x"]).max()
+
+
 def test_failed_exchange_stops_the_context():
     """a collective that fails must not be ignored. The hook has no return value; it reports through nalo_ba_exchange_failed (what the built-in RCCL hooks
     do on an ncclAllReduce error, host_rccl.hip): the call that issued the hook and every later BA call of the context fail with NALO_ERR_HIP instead of solving with
@@ -108,16 +183,16 @@ def test_failed_exchange_stops_the_context():
     c = make_ctx(win, st6)
     n_calls = [0]
 
-    def hook(ptr, n):                                      # a 1-rank "sum" is the identity; the third call reports a failure
+    def hook(ptr, n):                                      # a 1-rank "sum" is the identity; the fourth call reports a failure
         n_calls[0] += 1
-        if n_calls[0] == 3:
+        if n_calls[0] == 4:
             c.ba_exchange_failed("link down (test)")
     c.ba_set_allreduce(hook)
-    c.ba_linearize()                                       # two collectives, both fine
+    c.ba_linearize()                                       # three collectives, all fine
     with pytest.raises(RuntimeError, match="link down"):
-        c.ba_optimize(2, never_break=True)                 # its first pass issues the third call
+        c.ba_optimize(2, never_break=True)                 # its first pass issues the fourth call
     with pytest.raises(RuntimeError, match="cross-rank sum"):
         c.ba_linearize()                                   # latched: nothing of this context runs a BA pass any more
-    assert n_calls[0] == 3
+    assert n_calls[0] == 4
     c.ba_set_allreduce(None)
     c.close()

@@ -279,3 +279,32 @@ def test_sharded_tracker_sums_and_tracks_like_one_gpu(small_window):
     # the LM loop amplifies the regrouped fp32 partials (measured 3.7e-7): a fifth of the 1e-5 bar of BASELINE.json is the bound
     d_aff = np.abs(np.asarray(a["aff"]) - aff1)                  # b is in grey levels and scaled by SCALE_B = 1000 inside the LM: measured 8.8e-5
     assert pose_dist(a["T"], T1) < 2e-6 and d_aff[0] < 1e-5 and d_aff[1] < 1e-3
+
+
+def test_sharded_tracker_stops_when_its_exchange_fails(small_window):
+    """the tracker's hook has the contract of nalo_ba_set_allreduce, failure included. A collective that fails (reported through
+    nalo_ba_exchange_failed, what the built-in RCCL hooks do) must end the call that issued it and latch the context: a rank that went on with rank-local
+    sums would take other LM steps and other evaluation counts than its peers, and the next collectives would mismatch or hang."""
+    win = small_window
+    Ku, Kv, nid, hdi = tracker_inputs(win)
+    T0 = orc.se3_exp(orc.se3_log(true_rel_pose(win, win.W - 1, win.W)) * 0.8)
+    c = binding.Context(win.w, win.h, win.K, n_slots=2)
+    c.frame_upload(0, win.images[win.W - 1]); c.frame_upload(1, win.images[win.W])
+    c.trk_set_ref(0, Ku, Kv, nid, hdi)
+    n_calls = [0]
+
+    def hook(ptr, n):                                           # the "sum" of a lone rank is the identity; the third collective reports a failure
+        n_calls[0] += 1
+        if n_calls[0] == 3:
+            c.ba_exchange_failed("link down (tracker test)")
+    c.trk_set_shard(0, 2, hook)                                 # rank 0 of 2: the host-driven LM loop with the hook per evaluation
+    c.trk_eval(1, 0, T0, np.array([1.0, 0.0], np.float32), 0.0, 20.0)           # collective 1: fine
+    with pytest.raises(RuntimeError, match="link down"):
+        c.trk_track(1, T0, [0, 0], [0, 0], [1, 1], win.levels - 1)               # collective 2 fine, collective 3 fails: the LM loop stops there
+    assert n_calls[0] == 3
+    with pytest.raises(RuntimeError, match="cross-rank sum"):
+        c.trk_track(1, T0, [0, 0], [0, 0], [1, 1], win.levels - 1)               # latched
+    with pytest.raises(RuntimeError, match="cross-rank sum"):
+        c.trk_eval(1, 0, T0, np.array([1.0, 0.0], np.float32), 0.0, 20.0)
+    assert n_calls[0] == 3                                      # nothing reached the hook any more
+    c.close()
