@@ -6,8 +6,8 @@
 //                                  (OptimizationBackend/AccumulatedTopHessian.cpp:39-162, MatrixAccumulators.h:754-915)
 //                                  and, in marginalisation mode, EFResidual::fixLinearizationF (EnergyFunctionalStructs.cpp:89-115).
 //                                  The 296-byte RawResidualJacobian never leaves registers.
-//  ba_pt_acc_kernel      a9        the per-point sums of AccumulatedSCHessianSSE::addPoint (Hdd/bd/Hcd over the active residuals, HdiF, bdSumF)
-//  ba_sc_kernel          a9        AccumulatedSCHessianSSE::addPoint (OptimizationBackend/AccumulatedSCHessian.cpp:34-77) as a
+//  ba_sc_kernel          a9        AccumulatedSCHessianSSE::addPoint (OptimizationBackend/AccumulatedSCHessian.cpp:34-77): the per-point sums
+//                                  (Hdd/bd/Hcd over the active residuals, HdiF, bdSumF) and a
 //                                  per-host weighted SYRK  G_h = sum_p HdiF_p a_p a_p^T,  a_p = [JpJdF(t) for t != h | Hcd | bdSum]:
 //                                  accD = the 8x8 blocks, accE = the Hcd columns, accEB = the bdSum column, accHcc/accbc = the corner.
 //                                  The one GEMM-shaped kernel of the path: fp32 MFMA (v_mfma_f32_16x16x4_f32) over the upper-triangular tiles.
@@ -37,61 +37,23 @@ __global__ __launch_bounds__(256) void ba_reset_oob_kernel(uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ a9: per-point sums, per-host weighted SYRK
-// ba_pt_acc_kernel: per point (AccumulatedSCHessian.cpp:36-57): EFPoint::{Hdd,bd,Hcd}_acc = sum over the point's active residuals in target order
-// (AccumulatedTopHessian.cpp:132-157), then HdiF, bdSumF. One thread per point, no LDS: the W strided 25-byte slot reads of a point are hidden by
-// occupancy instead of stalling the SYRK workgroups (they were the first phase of ba_sc_kernel: 87 of its 390 us on the 1M-point window).
-// SMALL (<= 64 point blocks): latency matters, all slots of 8 targets are fetched before any is used. Large windows are bandwidth bound: the plain
-// loop keeps the register count (and so the occupancy) where the memory system wants it.
-template <bool SMALL>
-__global__ __launch_bounds__(kBlk) void ba_pt_acc_kernel(BADev B, int shiftPriorToZero, float priorScaleMarg, int margOnly) {
-    const int b = blockIdx.x, h = B.blk_host[b], W = B.W, d = b * kBlk + threadIdx.x;
-    const uint8_t pf = B.pt_flags[d];
-    if (!((pf & PT_VALID) && (!margOnly || (pf & PT_MARG)))) return;
-    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), hc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int ngood = 0;
-    if constexpr (SMALL) {
-        for (int t0 = 0; t0 < W; t0 += 8) {                    // 8 targets' slots in flight at once, summed in target order
-            uint8_t rs[8]; float4 q0[8]; float2 q1[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                rs[i] = 0;
-                if (t0 + i < W) {                               // wave-uniform: a scalar branch around the loads, no wait
-                    const size_t si = (size_t)(t0 + i) * B.Ppad + d;
-                    rs[i] = B.rs_state[si]; q0[i] = B.rs_pp0[si]; q1[i] = B.rs_pp1[si];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int t = t0 + i;
-                if (t >= W || t == h || !(rs[i] & RS_ACTIVE)) continue;
-                pa.y += q0[i].x; pa.x += q0[i].y; hc.x += q0[i].z; hc.y += q0[i].w; hc.z += q1[i].x; hc.w += q1[i].y;
-                ++ngood;
-            }
-        }
-    } else {
-#pragma unroll 4
-        for (int t = 0; t < W; ++t) {
-            if (t == h) continue;
-            const size_t si = (size_t)t * B.Ppad + d;
-            const uint8_t rs = B.rs_state[si];
-            const float4 q0 = B.rs_pp0[si]; const float2 q1 = B.rs_pp1[si];     // unconditional loads, selected below
-            if (!(rs & RS_ACTIVE)) continue;
-            pa.y += q0.x; pa.x += q0.y; hc.x += q0.z; hc.y += q0.w; hc.z += q1.x; hc.w += q1.y;
-            ++ngood;
-        }
-    }
-    B.pt_hcd[d] = hc; B.pt_ngood[d] = (uint8_t)ngood;
-    if (ngood == 0) { pa.z = 0.f; pa.w = 0.f; }
+// The per-point part of AccumulatedSCHessianSSE::addPoint (AccumulatedSCHessian.cpp:36-57): EFPoint::{Hdd,bd,Hcd}_acc = the sum over the point's active
+// residuals IN TARGET ORDER of the 24-byte shares ba_linearize_kernel left per residual slot (AccumulatedTopHessian.cpp:132-157), then HdiF and bdSumF.
+// Rounds 1-3 ran it as its own launch (ba_pt_acc_kernel: 14 us at 250 k points, 60 us at 1 M - as much HBM time again as the SYRK has). It now lives INSIDE
+// ba_sc_kernel, pipelined with the SYRK passes (below): sc_point_finish is the arithmetic both forms of the kernel share.
+struct ScPoint { float4 pa; float4 hc; int ngood; };                // pa = {Hdd, bd, HdiF, bdSumF} (what ba_resub_kernel reads back as pt_acc)
+__device__ __forceinline__ void sc_point_finish(const BADev& B, int d, ScPoint& P, float prior, float idepth, float idepth_zero, int margOnly, float priorScaleMarg, int shiftPriorToZero) {
+    B.pt_hcd[d] = P.hc; B.pt_ngood[d] = (uint8_t)P.ngood;
+    if (P.ngood == 0) { P.pa.z = 0.f; P.pa.w = 0.f; }
     else {
-        float prior = B.pt_prior[d];
         if (margOnly) { prior *= priorScaleMarg; B.pt_prior[d] = prior; }          // EnergyFunctional.cpp:630
-        float Hs = pa.x + prior;                                                    // Hdd_accAF + Hdd_accLF + priorF (only one of AF/LF is live)
+        float Hs = P.pa.x + prior;                                                  // Hdd_accAF + Hdd_accLF + priorF (only one of AF/LF is live)
         if (Hs < 1e-10f) Hs = 1e-10f;
-        pa.z = (float)(1.0 / (double)Hs);
-        pa.w = pa.y;
-        if (shiftPriorToZero) { const float4 geo = B.pt_geo[d]; pa.w += prior * (geo.z - geo.w); }
+        P.pa.z = (float)(1.0 / (double)Hs);
+        P.pa.w = P.pa.y;
+        if (shiftPriorToZero) P.pa.w += prior * (idepth - idepth_zero);
     }
-    B.pt_acc[d] = pa;
+    B.pt_acc[d] = P.pa;
 }
 
 // ba_sc_kernel: G_h = sum over the host's points of HdiF * row row^T, row = [JpJdF(t != h) (8 each) | Hcd (4) | bdSum | 0..] (NPL = 16T columns).
@@ -110,20 +72,20 @@ typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
 template <int T> __device__ constexpr int sc_tile_i(int idx) { int ti = 0; while (idx >= T - ti) { idx -= T - ti; ++ti; } return ti; }
 template <int T> __device__ constexpr int sc_tile_j(int idx) { int ti = 0; while (idx >= T - ti) { idx -= T - ti; ++ti; } return ti + idx; }
 // the MFMAs of one 4-point step: tile indices are template constants, so x[ti] / xw[tj] are plain registers
-template <int T, int WAVE, int M, int MAXM>
+template <int T, int WAVE, int NW, int M, int MAXM>
 __device__ __forceinline__ void sc_mfma_tiles(const float (&x)[T], const float (&xw)[T], sc_f32x4 (&macc)[MAXM]) {
     if constexpr (M < MAXM) {
-        constexpr int idx = WAVE + 4 * M;
+        constexpr int idx = WAVE + NW * M;
         if constexpr (idx < T * (T + 1) / 2) {
             constexpr int ti = sc_tile_i<T>(idx), tj = sc_tile_j<T>(idx);
             macc[M] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[ti], xw[tj], macc[M], 0, 0, 0);
         }
-        sc_mfma_tiles<T, WAVE, M + 1, MAXM>(x, xw, macc);
+        sc_mfma_tiles<T, WAVE, NW, M + 1, MAXM>(x, xw, macc);
     }
 }
-// One staged pass (SUB points) of wave WAVE's tiles {WAVE, WAVE + 4, ...}. The tile list is a compile-time property of the wave, so per step of
-// 4 points the wave reads each of the T column blocks of the 4 rows ONCE (x[c]) and every a / w*b operand is a register pick.
-template <int T, int WAVE, int SUB, int NPLP, int RUN, int MAXM>
+// One staged pass (SUB points) of wave WAVE's tiles {WAVE, WAVE + NW, ...}. The tile list is a compile-time property of the wave, so per step of
+// 4 points the wave reads the column blocks its tiles touch ONCE (x[c]; the others are never loaded) and every a / w*b operand is a register pick.
+template <int T, int WAVE, int NW, int SUB, int NPLP, int RUN, int MAXM>
 __device__ __forceinline__ void sc_mfma_pass(const float* __restrict__ A, const float* __restrict__ Wt, int lane, sc_f32x4 (&macc)[MAXM], double (&macc64)[MAXM][4]) {
     constexpr int NTILES = T * (T + 1) / 2;
     const float* rowp = A + (lane >> 4) * NPLP + (lane & 15);  // the 4 points of an MFMA step: k = lane >> 4
@@ -138,40 +100,55 @@ __device__ __forceinline__ void sc_mfma_pass(const float* __restrict__ A, const 
             for (int c = 0; c < T; ++c) x[c] = rowp[k * NPLP + 16 * c];
 #pragma unroll
             for (int c = 0; c < T; ++c) xw[c] = wk * x[c];
-            sc_mfma_tiles<T, WAVE, 0, MAXM>(x, xw, macc);
+            sc_mfma_tiles<T, WAVE, NW, 0, MAXM>(x, xw, macc);
         }
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) {
-            if (WAVE + 4 * m >= NTILES) continue;
+            if (WAVE + NW * m >= NTILES) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) macc64[m][r] += (double)macc[m][r];
             macc[m] = (sc_f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
 }
-// KS == 4 (small windows, one pass of 64 points per workgroup) also computes the per-point sums of its 64 points itself (wave 0, under the operand
-// loads of the other columns): one launch less on the latency-bound path.
-template <int T, int KS>
-__global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly, int shiftPriorToZero, float priorScaleMarg) {
-    constexpr int NPL = 16 * T, ROWS = kBlk / KS;
+// The per-point sums ride in the same pipeline (round 4). KS == 4 (small windows, one pass of 64 points per workgroup): wave 0 sums its 64 points under the
+// operand loads of the other columns. KS == 1 (large windows): the 256 / SUB threads that share a point split its W - 1 targets' shares between them - fetched
+// with the pass' operand rows, i.e. in flight during the SYRK of the pass before -, park them in LDS (the region of the operand rows, which is dead between two
+// passes), and the point's seven sums {bd, Hdd, Hcd[4], count} are then taken IN TARGET ORDER from there (an inactive slot parks +0: bit-identical to skipping
+// it), one or two sums per thread; the threads of part 0 finish the point (HdiF, bdSumF), store what the back-substitution reads and write the point's two
+// operand columns and its weight. Four barriers per pass instead of two, one launch and a pipeline drain less, and the shares' bytes move under the matrix work.
+template <int T, int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void ba_sc_kernel(BADev B, int margOnly, int shiftPriorToZero, float priorScaleMarg) {
+    constexpr int NPL = 16 * T, ROWS = kBlk / KS, NT = 64 * NW;
     constexpr int SUB0 = T <= 2 ? 256 : (T <= 4 ? 128 : 64), SUB = SUB0 < ROWS ? SUB0 : ROWS, NSUB = ROWS / SUB;
     // padded LDS row: a wave reads 4 consecutive rows x 16 columns per operand, so the stride is an odd multiple of 16 floats (the 4 rows land on
     // disjoint bank quarters)
     constexpr int NPLP = NPL + ((T % 2 == 0) ? 16 : 32);
     __shared__ __attribute__((aligned(16))) float A[SUB * NPLP];
     __shared__ float Wt[SUB];
-    constexpr bool FUSE = KS == 4;
+    constexpr bool FUSE = KS == 4;                             // small windows: wave 0 sums its 64 points up front
+    constexpr bool PIPE = KS == 1;                             // large windows: the point sums ride in the pass pipeline
+    static_assert(FUSE || PIPE, "ba_sc_kernel: KS is 1 or 4");
     __shared__ __attribute__((aligned(16))) float4 Hc4[FUSE ? SUB : 1];
     __shared__ float Bd[FUSE ? SUB : 1];
+    constexpr int MAXG = 2 * T - 1;                            // targets other than the host: 8 (W - 1) + 5 <= 16 T
+    __shared__ float Rs[PIPE ? 7 * SUB : 1];                   // the seven sums of a pass' points
+    static_assert(!PIPE || MAXG * 7 <= NPLP, "the parked shares of a pass must fit the operand rows they alias");
     const int grp = blockIdx.x / KS, ks = blockIdx.x - grp * KS, tid = threadIdx.x, W = B.W;
     int h = 0;
     while (h + 1 < W && grp >= B.sc_grp[h + 1]) ++h;
     const int b0 = B.host_blk[h] + (grp - B.sc_grp[h]) * B.sc_bpw, b1 = min(b0 + B.sc_bpw, B.host_blk[h + 1]);
     // fp32 products in short runs of 16 points flushed into fp64: the block partial is good to ~1e-8 relative (the reference's AccumulatorXX runs its
-    // fp32 levels for 1000 adds, MatrixAccumulators.h), so the ~100x cancellation in H_A - H_sc does not amplify summation noise into the poses
+    // fp32 levels for 1000 adds, MatrixAccumulators.h), so the ~100x cancellation in H_A - H_sc does not amplify summation noise into the poses.
+    // Round 4 measured 64-point runs: 4 % (250 k points) to 9 % (1 M) faster on this kernel, but the solved step of the well-conditioned toy window moves from
+    // 1.0x to 1.6x the fp32 oracle's own distance to the fp64 truth (tests/test_ba_gpu.py::test_solve_and_step_on_the_well_conditioned_window): not taken.
+#ifdef SC_RUN
+    constexpr int RUN = SC_RUN < SUB ? SC_RUN : SUB;
+#else
     constexpr int RUN = 16;
+#endif
     // this wave's upper-triangular tiles (row-major enumeration of ti <= tj): wave, wave + 4, ...
-    constexpr int NTILES = T * (T + 1) / 2, MAXM = (NTILES + 3) / 4;
+    constexpr int NTILES = T * (T + 1) / 2, MAXM = (NTILES + NW - 1) / NW;
     const int wave = tid >> 6, lane = tid & 63;
     sc_f32x4 macc[MAXM];
     double macc64[MAXM][4];
@@ -183,16 +160,19 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly, int s
     }
     // ---- staging: lane <-> point (coalesced 16-byte loads from the [target][point] arrays), the NQ float4 columns of a row are split over the
     // 256/SUB threads that share a point; fully unrolled, so every load of a pass is in flight at once.
-    constexpr int NQ = NPL / 4, PARTS = kBlk / SUB, NV = (NQ + PARTS - 1) / PARTS;
+    constexpr int NQ = NPL / 4, PARTS = NT / SUB, NV = (NQ + PARTS - 1) / PARTS;
+    constexpr int NTG = PIPE ? (MAXG + PARTS - 1) / PARTS : 1;  // targets whose shares one thread fetches
     const int r = tid % SUB, part = __builtin_amdgcn_readfirstlane(tid / SUB);      // SUB >= 64: the column set of a thread is wave-uniform (scalar selects)
     const int qH = 2 * (W - 1);                                // float4 column of Hcd; qH + 1 = {bdSum, 0, 0, 0} (and carries HdiF to Wt)
     // fetch = loads only (one 16-byte + one state byte per column, source picked by pointer selects: no branches, no waits); the selects that need the
     // loaded bytes happen at commit time, after the SYRK of the previous pass
     float4 raw[NV];
     uint8_t rst[NV], rpf = 0;
+    float4 sh0[NTG]; float2 sh1[NTG]; uint8_t shs[NTG];         // PIPE: this thread's part of the point's shares
+    float pprior = 0.f; float4 pgeo = make_float4(0.f, 0.f, 0.f, 0.f); int dcur = 0;
     auto fetch = [&](int p) {
         const int pb = p / NSUB, d = (b0 + pb) * kBlk + ks * ROWS + (p - pb * NSUB) * SUB + r;
-        rpf = B.pt_flags[d];
+        rpf = B.pt_flags[d]; dcur = d;
 #pragma unroll
         for (int qi = 0; qi < NV; ++qi) {
             const int q = part + qi * PARTS, g = q >> 1;          // q-th float4 of the row, compact target slot g
@@ -200,23 +180,30 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly, int s
             const size_t si = (size_t)(isj ? (g < h ? g : g + 1) : 0) * B.Ppad + d;
             const float4* src = isj ? ((q & 1) ? B.rs_jp1 : B.rs_jp0) + si : (q == qH ? B.pt_hcd : B.pt_acc) + d;
             rst[qi] = RS_ACTIVE;
-            if (FUSE && !isj) { raw[qi] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }      // the point columns come from this workgroup's own sums (LDS)
+            if (!isj) { raw[qi] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }      // the point columns come from this workgroup's own sums (LDS)
             raw[qi] = *src;
-            if (isj) rst[qi] = B.rs_state[si];                     // scalar branch (q is wave-uniform)
+            rst[qi] = B.rs_state[si];                              // scalar branch (q is wave-uniform)
+        }
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int gi = 0; gi < NTG; ++gi) {
+                const int g = part + gi * PARTS;                   // wave-uniform: a scalar branch around the loads, no wait
+                shs[gi] = 0;
+                if (g < W - 1) { const size_t si = (size_t)(g < h ? g : g + 1) * B.Ppad + d; shs[gi] = B.rs_state[si]; sh0[gi] = B.rs_pp0[si]; sh1[gi] = B.rs_pp1[si]; }
+            }
+            if (part == 0) { pprior = B.pt_prior[d]; if (shiftPriorToZero) pgeo = B.pt_geo[d]; }
         }
     };
     const int npass = (b1 - b0) * NSUB;
     if (npass > 0) fetch(0);
     if constexpr (FUSE) {
-        // per point (AccumulatedSCHessian.cpp:36-57), exactly ba_pt_acc_kernel<true> for the 64 points of this workgroup
+        // per point (AccumulatedSCHessian.cpp:36-57) for the 64 points of this workgroup: all slots of 8 targets are fetched before any is used (latency matters here)
         if (tid < SUB && npass > 0) {
             const int d = b0 * kBlk + ks * ROWS + tid;
             const uint8_t pf = B.pt_flags[d];
             float wgt = 0.f, bds = 0.f;
-            float4 hc = make_float4(0.f, 0.f, 0.f, 0.f);
+            ScPoint P; P.pa = make_float4(0.f, 0.f, 0.f, 0.f); P.hc = make_float4(0.f, 0.f, 0.f, 0.f); P.ngood = 0;
             if ((pf & PT_VALID) && (!margOnly || (pf & PT_MARG))) {
-                float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
-                int ngood = 0;
                 for (int t0 = 0; t0 < W; t0 += 8) {
                     uint8_t rs[8]; float4 q0[8]; float2 q1[8];
 #pragma unroll
@@ -228,82 +215,117 @@ __global__ __launch_bounds__(256) void ba_sc_kernel(BADev B, int margOnly, int s
                     for (int i = 0; i < 8; ++i) {
                         const int t = t0 + i;
                         if (t >= W || t == h || !(rs[i] & RS_ACTIVE)) continue;
-                        pa.y += q0[i].x; pa.x += q0[i].y; hc.x += q0[i].z; hc.y += q0[i].w; hc.z += q1[i].x; hc.w += q1[i].y;
-                        ++ngood;
+                        P.pa.y += q0[i].x; P.pa.x += q0[i].y; P.hc.x += q0[i].z; P.hc.y += q0[i].w; P.hc.z += q1[i].x; P.hc.w += q1[i].y;
+                        ++P.ngood;
                     }
                 }
-                B.pt_hcd[d] = hc; B.pt_ngood[d] = (uint8_t)ngood;
-                if (ngood == 0) { pa.z = 0.f; pa.w = 0.f; }
-                else {
-                    float prior = B.pt_prior[d];
-                    if (margOnly) { prior *= priorScaleMarg; B.pt_prior[d] = prior; }      // EnergyFunctional.cpp:630
-                    float Hs = pa.x + prior;
-                    if (Hs < 1e-10f) Hs = 1e-10f;
-                    pa.z = (float)(1.0 / (double)Hs);
-                    pa.w = pa.y;
-                    if (shiftPriorToZero) { const float4 geo = B.pt_geo[d]; pa.w += prior * (geo.z - geo.w); }
-                    wgt = pa.z;
-                }
-                B.pt_acc[d] = pa;
-                bds = pa.w;
+                const float prior = B.pt_prior[d];
+                float4 geo = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (shiftPriorToZero && P.ngood) geo = B.pt_geo[d];
+                sc_point_finish(B, d, P, prior, geo.z, geo.w, margOnly, priorScaleMarg, shiftPriorToZero);
+                wgt = P.pa.z; bds = P.pa.w;
             }
-            Wt[tid] = wgt; Bd[tid] = bds; Hc4[tid] = hc;
+            Wt[tid] = wgt; Bd[tid] = bds; Hc4[tid] = P.hc;
         }
     }
     for (int p = 0; p < npass; ++p) {
         __syncthreads();                                       // the previous pass' rows / weights have been consumed
+        const bool pvalid = (rpf & PT_VALID) && (!margOnly || (rpf & PT_MARG));
+        if constexpr (PIPE) {
+            // park this thread's shares ([target][component][point]: conflict-free), then the seven sums in target order
+            float* S = A;
+#pragma unroll
+            for (int gi = 0; gi < NTG; ++gi) {
+                const int g = part + gi * PARTS;
+                if (g >= MAXG) continue;
+                const bool act = (shs[gi] & RS_ACTIVE) != 0;           // shs = 0 beyond the window's last target
+                float* sp = S + (g * 7) * SUB + r;
+                sp[0] = act ? sh0[gi].x : 0.f; sp[SUB] = act ? sh0[gi].y : 0.f; sp[2 * SUB] = act ? sh0[gi].z : 0.f; sp[3 * SUB] = act ? sh0[gi].w : 0.f;
+                sp[4 * SUB] = act ? sh1[gi].x : 0.f; sp[5 * SUB] = act ? sh1[gi].y : 0.f; sp[6 * SUB] = act ? 1.f : 0.f;
+            }
+            __syncthreads();
+            for (int cc = part; cc < 7; cc += PARTS) {
+                float sum = 0.f;
+                for (int g = 0; g < W - 1; ++g) sum += S[(g * 7 + cc) * SUB + r];
+                Rs[cc * SUB + r] = sum;
+            }
+            __syncthreads();                                   // the parked shares are consumed: the operand rows may overwrite them
+        }
         {
-            const bool pvalid = (rpf & PT_VALID) && (!margOnly || (rpf & PT_MARG));
 #pragma unroll
             for (int qi = 0; qi < NV; ++qi) {
                 const int q = part + qi * PARTS;
                 float4 v = raw[qi];
                 if constexpr (FUSE) { if (q == qH) v = Hc4[r]; else if (q == qH + 1) v = make_float4(Bd[r], 0.f, 0.f, 0.f); }
-                else if (q == qH + 1) { Wt[r] = pvalid ? v.z : 0.f; v = make_float4(v.w, 0.f, 0.f, 0.f); }  // pt_acc = {Hdd, bd, HdiF, bdSumF}
+                if constexpr (PIPE) { if (q == qH || q == qH + 1) continue; }       // written by the point's part-0 thread below
                 const bool keep = pvalid && (rst[qi] & RS_ACTIVE) != 0 && q <= qH + 1;
                 if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (q < NQ) *reinterpret_cast<float4*>(&A[r * NPLP + 4 * q]) = v;
+            }
+            if constexpr (PIPE) {
+                if (part == 0) {
+                    ScPoint P;
+                    P.pa = make_float4(Rs[SUB + r], Rs[r], 0.f, 0.f);                 // {Hdd, bd}
+                    P.hc = make_float4(Rs[2 * SUB + r], Rs[3 * SUB + r], Rs[4 * SUB + r], Rs[5 * SUB + r]);
+                    P.ngood = (int)Rs[6 * SUB + r];
+                    float wgt = 0.f; float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+                    if (pvalid) {
+                        sc_point_finish(B, dcur, P, pprior, pgeo.z, pgeo.w, margOnly, priorScaleMarg, shiftPriorToZero);
+                        wgt = P.pa.z; c0 = P.hc; c1.x = P.pa.w;
+                    }
+                    Wt[r] = wgt;
+                    *reinterpret_cast<float4*>(&A[r * NPLP + 4 * qH]) = c0;
+                    *reinterpret_cast<float4*>(&A[r * NPLP + 4 * (qH + 1)]) = c1;
+                }
             }
         }
         __syncthreads();
         if (p + 1 < npass) fetch(p + 1);                       // in flight during the SYRK below
         switch (wave) {
-            case 0: sc_mfma_pass<T, 0, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
-            case 1: sc_mfma_pass<T, 1, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
-            case 2: sc_mfma_pass<T, 2, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
-            default: sc_mfma_pass<T, 3, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 0: sc_mfma_pass<T, 0, NW, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 1: sc_mfma_pass<T, 1, NW, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 2: sc_mfma_pass<T, 2, NW, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 3: sc_mfma_pass<T, 3, NW, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 4: if constexpr (NW > 4) sc_mfma_pass<T, 4, NW, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 5: if constexpr (NW > 4) sc_mfma_pass<T, 5, NW, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            case 6: if constexpr (NW > 4) sc_mfma_pass<T, 6, NW, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
+            default: if constexpr (NW > 4) sc_mfma_pass<T, 7, NW, SUB, NPLP, RUN, MAXM>(A, Wt, lane, macc, macc64); break;
         }
     }
     // C/D layout of a 16x16 tile: col = lane & 15, row = (lane >> 4) * 4 + reg
     double* out = B.sc_partial + (size_t)blockIdx.x * (NTILES * 256);
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) {
-        const int idx = wave + 4 * m;
+        const int idx = wave + NW * m;
         if (idx >= NTILES) continue;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) out[idx * 256 + rr * 64 + lane] = macc64[m][rr];
     }
 }
 
+#ifndef SC_NW
+#define SC_NW 8
+#endif
+// large windows run the SYRK with SC_NW waves per workgroup: eight waves hold two or three 16x16 tiles each instead of five or six (the fp32 + fp64 accumulators
+// of six tiles cost 72 registers: two waves per SIMD), so four waves per SIMD take turns on the matrix pipe
 template <int KS>
 static void launch_sc_ks(hipStream_t s, const BADev& B, int T, int margOnly, int shift, float priorScaleMarg) {
+    constexpr int NW = KS == 1 ? SC_NW : 4;
     const int grid = B.sc_groups * KS;
     switch (T) {
-        case 1: ba_sc_kernel<1, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
-        case 2: ba_sc_kernel<2, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
-        case 3: ba_sc_kernel<3, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
-        case 4: ba_sc_kernel<4, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
-        case 5: ba_sc_kernel<5, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
-        case 6: ba_sc_kernel<6, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
-        case 7: ba_sc_kernel<7, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
-        default: ba_sc_kernel<8, KS><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 1: ba_sc_kernel<1, KS, 4><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;        // one tile: nothing to deal out
+        case 2: ba_sc_kernel<2, KS, 4><<<grid, 256, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 3: ba_sc_kernel<3, KS, NW><<<grid, 64 * NW, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 4: ba_sc_kernel<4, KS, NW><<<grid, 64 * NW, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 5: ba_sc_kernel<5, KS, NW><<<grid, 64 * NW, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 6: ba_sc_kernel<6, KS, NW><<<grid, 64 * NW, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        case 7: ba_sc_kernel<7, KS, NW><<<grid, 64 * NW, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
+        default: ba_sc_kernel<8, KS, NW><<<grid, 64 * NW, 0, s>>>(B, margOnly, shift, priorScaleMarg); break;
     }
 }
 void ba_launch_sc(hipStream_t s, const BADev& B, int T, int shift, float priorScaleMarg, int margOnly) {
-    if (B.sc_split == 4) { launch_sc_ks<4>(s, B, T, margOnly, shift, priorScaleMarg); return; }    // small window: the point sums are fused into the SYRK launch
-    if (B.nblocks <= 64) ba_pt_acc_kernel<true><<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
-    else ba_pt_acc_kernel<false><<<B.nblocks, kBlk, 0, s>>>(B, shift, priorScaleMarg, margOnly);
-    launch_sc_ks<1>(s, B, T, margOnly, shift, priorScaleMarg);
+    if (B.sc_split == 4) launch_sc_ks<4>(s, B, T, margOnly, shift, priorScaleMarg);     // either way ONE launch: the per-point sums are part of it
+    else launch_sc_ks<1>(s, B, T, margOnly, shift, priorScaleMarg);
 }
 // frameEnergyTH of every window frame as kernel arguments: no staging buffer, no synchronisation (window setup / restore)
 struct ThArg { float v[16]; };

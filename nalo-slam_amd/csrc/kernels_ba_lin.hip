@@ -303,7 +303,7 @@ __device__ __forceinline__ void lin_commit(const BADev& B, const LinWhere& w, Li
             j1.x = x[8] * a0 + y[8] * a1; j1.y = x[9] * a0 + y[9] * a1;
             j1.z = R.jab00 * R.Jpdd0 + R.jab01 * R.Jpdd1; j1.w = R.jab10 * R.Jpdd0 + R.jab11 * R.Jpdd1;
             lin_store(&B.rs_jp0[w.si], j0); lin_store(&B.rs_jp1[w.si], j1);
-            // per-slot share of EFPoint::{bd,Hdd,Hcd}_acc (AccumulatedTopHessian.cpp:132-135); summed over the targets by ba_pt_acc_kernel
+            // per-slot share of EFPoint::{bd,Hdd,Hcd}_acc (AccumulatedTopHessian.cpp:132-135); summed over the targets inside ba_sc_kernel
             lin_store(&B.rs_pp0[w.si], make_float4(R.JIr0 * R.Jpdd0 + R.JIr1 * R.Jpdd1, a0 * R.Jpdd0 + a1 * R.Jpdd1, x[0] * a0 + y[0] * a1, x[1] * a0 + y[1] * a1));
             lin_store(&B.rs_pp1[w.si], make_float2(x[2] * a0 + y[2] * a1, x[3] * a0 + y[3] * a1));
             if (FIX == 1 || MODE == 2) {
