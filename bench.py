@@ -164,8 +164,12 @@ class GpuJob:
                     self.trk_frames += 1
                 if keep:
                     self.last_T[k] = self._T.reshape(3, 4).copy()
-            c._ck(L.nalo_trk_set_ref(c.h_, W - 1, len(self._ref[0]), *self._ref_args))   # a2 for the new keyframe
-        return c.ba_optimize(6, never_break=True)
+        rm = c.ba_optimize(6, never_break=True)
+        if track:
+            # a2 for the new keyframe: setCoarseTrackingRef FOLLOWS the optimisation, as in makeKeyFrame (FullSystem.cpp:1404) - the next step's frames are tracked
+            # against it (its inputs are constants of the synthetic keyframe here; in the reference they are the optimised window's residuals)
+            c._ck(L.nalo_trk_set_ref(c.h_, W - 1, len(self._ref[0]), *self._ref_args))
+        return rm
 
 
 def synth_exp(xi):
@@ -371,7 +375,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + NALO_BENCH_ONE_DEVICE=1 rehearses the multi-rank flow on a single GPU (all ranks on device 0)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the stress250k roofline leg appended to the kitti00 line")
+    ap.add_argument("--no-extra", action="store_true", help="the main leg only: no pipelined / upload variants, no stress250k / shard1m / front-end legs (the command the rocprofv3 summaries are taken of)")
+    ap.add_argument("--ba-only", action="store_true", help="the step is optimize() alone (no tracked frames, no setCoarseTrackingRef)")
     ap.add_argument("--launch-check", action="store_true", help="rendezvous only (gloo, no GPU): proves that --gpus N starts N ranks")
     args = ap.parse_args()
 
@@ -411,7 +416,7 @@ def main():
     if main_rccl is not None and min(main_rccl) != world:
         log("rccl_ranks %s != n_gpus %d: the ranks did not join ONE communicator" % (main_rccl, world))
         sys.exit(4)
-    do_track = not sharded
+    do_track = not sharded and not args.ba_only
 
     def barrier():
         if dist is not None:
@@ -428,7 +433,7 @@ def main():
     job.ctx.profile_select("ba_linearize" if mode == "dominant" else None)
     # one launch in three is bracketed (co-prime with the 8 linearisations of a keyframe, so every position of the loop is sampled): all eight cost 4-6 % of a
     # step on this latency-bound window (NALO_BENCH_PROFILE=none vs dominant: 760-768 vs 715-740 keyframes/s on one box); the stress250k leg brackets every launch
-    lin_every = int(os.environ.get("NALO_BENCH_PROFILE_EVERY", "3")) if (mode == "dominant" and not sharded) else 1
+    lin_every = int(os.environ.get("NALO_BENCH_PROFILE_EVERY", "3")) if (mode == "dominant" and args.workload == "kitti00_8kf") else 1
     job.ctx.profile_sample(lin_every)
     job.ctx.profile_enable(mode != "none")
     job.ctx.profile_reset()
@@ -451,6 +456,7 @@ def main():
     value = units / dt
 
     prof = {"ba_linearize": job.ctx.profile_get("ba_linearize")}
+    lin_stats = launch_stats(job.ctx.profile_samples("ba_linearize"), every=lin_every)
     job.ctx.profile_sample(1)
     # the roofline's denominator measured on this device in the same run: streaming copy / triad over 1 GiB buffers
     try:
@@ -481,7 +487,8 @@ def main():
             ach = alg / (ms / n * 1e-3) / 1e9
             roof = dict(kernel="ba_linearize", bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(ach / HBM_PEAK_GBS, 5), traffic=load_traffic(args.workload),
-                        avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg))
+                        avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg), stats=lin_stats,
+                        measured_over="the timed region: full steps (%s), %s" % ("tracking + setCoarseTrackingRef + optimize" if do_track else "optimize only", "every launch" if lin_every == 1 else "one launch in %d" % lin_every))
             if hbm_copy:
                 roof.update(measured_copy_GBs=round(hbm_copy, 1), measured_triad_GBs=round(hbm_triad, 1), frac_of_measured_copy=round(ach / hbm_copy, 4))
         out = {
@@ -512,7 +519,7 @@ def main():
                                             note="one persistent launch per tracked frame runs the whole LM descent (%.1f evaluations): a serial chain of ~8 us per evaluation (gather 1.3 + block "
                                                  "reduction 1.8 + exchange between workgroups 2.6 + the 8x8 solve / SE3 on one wave 2.3), latency bound by construction on ~25 k points; "
                                                  "alg_bytes = sum_l evals_l n_l 64 B" % (job.evals / max(args.steps, 1) / TRACKED_PER_KF))
-        if world == 1 and do_track:
+        if world == 1 and do_track and not args.no_extra:       # --no-extra: the main leg only (the command the rocprofv3 summaries are taken of: nothing concurrent in the trace)
             try:
                 out["pipelined"] = pipelined_leg(win, st6, trk, local_rank, steps=max(20, min(200, args.steps)))
                 out["value_with_uploads"] = None                             # filled below (promoted beside value)
@@ -662,7 +669,9 @@ def main():
                                                              "which is the distance to this ceiling (DESIGN.md 3)"),
                                            bound="hbm", achieved=sl["achieved_GBs"], peak=HBM_PEAK_GBS,
                                            unit="GB/s", frac=sl["frac"], traffic=load_traffic("stress250k"), avg_us=sl["avg_us"],
-                                           launches=sl["launches"], alg_bytes=sl["alg_bytes"])
+                                           launches=sl["launches"], alg_bytes=sl["alg_bytes"], stats=sl.get("stats"), stats_ba_only_loop=sl.get("stats_ba_only_loop"),
+                                           measured_over=sl.get("measured_over"),
+                                           reproduce="python bench.py --workload stress250k --no-extra --no-cpu-baseline runs the same full steps as its main leg; its rocprofv3 --kernel-trace --stats summary is profiles/INDEX.json -> roofline")
                     if hbm_copy:
                         out["roofline"].update(measured_copy_GBs=round(hbm_copy, 1), measured_triad_GBs=round(hbm_triad, 1), frac_of_measured_copy=round(sl["achieved_GBs"] / hbm_copy, 4),
                                                measured_note="nalo_hbm_calibrate in this run: copy = 2 x 1 GiB / t, triad = 3 x 1 GiB / t, 10 passes, HIP events")
@@ -868,6 +877,18 @@ def shard_leg(rank, world, local_rank, dist, torch, steps=3, warmup=1, backend="
     return res
 
 
+def launch_stats(samples_us, per_keyframe=8, every=1):
+    """mean / spread of a kernel's bracketed launches (microseconds, launch order) and the mean by position inside a keyframe (a keyframe = 1 + 6 + 1 = 8
+    linearisations; with one launch in `every` bracketed, sample i is launch i * every). What a mean alone hides: the first launch behind the tracker is cold."""
+    s = np.asarray(samples_us, np.float64)
+    if len(s) == 0:
+        return None
+    pos = (np.arange(len(s)) * every) % per_keyframe
+    by_pos = [round(float(s[pos == k].mean()), 2) if (pos == k).any() else None for k in range(per_keyframe)]
+    return dict(mean_us=round(float(s.mean()), 2), p50_us=round(float(np.percentile(s, 50)), 2), p95_us=round(float(np.percentile(s, 95)), 2),
+                min_us=round(float(s.min()), 2), max_us=round(float(s.max()), 2), launches=int(len(s)), by_position_us=by_pos)
+
+
 def load_traffic(workload):
     """HBM bytes per ba_linearize launch from the committed PMC summary (profiles/traffic_*.json), or None."""
     for name in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):          # the newest committed measurement wins
@@ -883,6 +904,11 @@ def load_traffic(workload):
 
 
 def stress_leg(steps=5, warmup=2):
+    """configs[3]. keyframes_per_s: the BA alone (optimize(6): the Hessian-accumulation stress the config names). The ROOFLINE kernel is then measured over FULL
+    steps of the same window - three tracked frames against the 250 k-point reference and setCoarseTrackingRef in front of every optimize, as the headline's step -
+    so its mean includes the cold first launch behind the tracker (the mean of a BA-only loop is the profile's best case); every launch is
+    bracketed (dispatch-attached timestamps), mean / p50 / p95 and the mean by position are reported, and `python bench.py --workload stress250k --no-extra`
+    is the same loop as a command of its own (profiles/INDEX.json maps it to its rocprofv3 summary)."""
     win, st6, trk = make_inputs("stress250k")
     job = GpuJob(win, st6, trk, 0)
     for _ in range(warmup):
@@ -893,24 +919,39 @@ def stress_leg(steps=5, warmup=2):
         job.step(False)
     job.ctx.sync()
     dt = time.perf_counter() - t0
-    job.ctx.profile_select("ba_linearize")                       # the roofline kernel alone (dispatch-attached timestamps), every launch of `steps` more keyframes
+    job.step(True)                                               # full steps from here on
+    job.ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        job.step(True)
+    job.ctx.sync()
+    dt_full = time.perf_counter() - t0
+    job.ctx.profile_select("ba_linearize")                       # the roofline kernel alone (dispatch-attached timestamps), every launch of `steps` more FULL keyframes
     job.ctx.profile_enable(True)
     job.ctx.profile_reset()
-    for _ in range(steps):
-        job.step(False)
+    for _ in range(max(steps, 6)):
+        job.step(True)
     lin = job.ctx.profile_get("ba_linearize")
+    lin_stats = launch_stats(job.ctx.profile_samples("ba_linearize"))
+    job.ctx.profile_reset()
+    for _ in range(3):                                           # the same kernel in the BA-only loop, for comparison
+        job.step(False)
+    lin_ba_only = launch_stats(job.ctx.profile_samples("ba_linearize"))
     job.ctx.profile_select(None); job.ctx.profile_reset()        # the other scopes: a third pass
     for _ in range(2):
         job.step(False)
     job.ctx.sync()
     R, P = int((win.exists > 0).sum()), len(win.host)
     res = {"workload": "stress250k", "keyframes_per_s": round(steps / dt, 3), "ms_per_keyframe": round(dt / steps * 1e3, 3),
-           "active_points": P, "residuals": R, "note": "BA only (optimize), no front-end"}
+           "active_points": P, "residuals": R, "note": "keyframes_per_s: BA only (optimize), no front-end; keyframes_per_s_full_step: 3 tracked frames (250 k-point reference) + setCoarseTrackingRef + optimize",
+           "keyframes_per_s_full_step": round(steps / dt_full, 3), "ms_per_keyframe_full_step": round(dt_full / steps * 1e3, 3)}
     for k, alg in (("ba_linearize", 424.0 * R + 104.0 * P), ("ba_sc", 32.0 * R + 56.0 * P), ("ba_resub", 32.0 * R + 24.0 * P)):
         ms, n = lin if k == "ba_linearize" else job.ctx.profile_get(k)
         if n:
             ach = alg / (ms / n * 1e-3) / 1e9
             res[k] = dict(avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg), achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
+    if "ba_linearize" in res:
+        res["ba_linearize"].update(measured_over="full steps (tracking + setCoarseTrackingRef + optimize), every launch", stats=lin_stats, stats_ba_only_loop=lin_ba_only)
     res["traffic"] = load_traffic("stress250k")
     job.ctx.close()
     return res

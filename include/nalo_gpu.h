@@ -483,6 +483,9 @@ int nalo_profile_reset(nalo_ctx* ctx);
  * with a third of the perturbation. nalo_profile_get reports the bracketed launches only. */
 int nalo_profile_sample(nalo_ctx* ctx, int every);
 int nalo_profile_get(nalo_ctx* ctx, const char* kernel, double* total_ms, int* launches);
+/* every bracketed launch of a scope since the last nalo_profile_reset, in launch order (milliseconds; at most cap values are copied, *n = how many exist):
+ * the spread and the position inside a keyframe that the mean of nalo_profile_get hides */
+int nalo_profile_samples(nalo_ctx* ctx, const char* kernel, float* ms, int cap, int* n);
 
 /* Calibration of the roofline's denominator on THIS device ("fraction of the box's measured device-copy / triad bandwidth from a calibration
  * kernel in the same run"; no reference counterpart). Runs `iters` timed passes (after one untimed) of a streaming kernel over `bytes`-sized buffers on the

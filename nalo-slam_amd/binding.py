@@ -34,7 +34,7 @@ EXPORTS = [
     "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_ba_exchange_failed", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_ba_rccl_ranks", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
     "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_init_set_state", "nalo_init_set_points", "nalo_init_get_carried", "nalo_init_sweep", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
-    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get", "nalo_profile_sample", "nalo_hbm_calibrate",
+    "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get", "nalo_profile_samples", "nalo_profile_sample", "nalo_hbm_calibrate",
 ]
 
 
@@ -165,6 +165,7 @@ def load():
     L.nalo_profile_reset.argtypes = [vp]
     L.nalo_profile_select.argtypes = [vp, C.c_char_p]
     L.nalo_profile_get.argtypes = [vp, C.c_char_p, c_dp, c_ip]
+    L.nalo_profile_samples.argtypes = [vp, C.c_char_p, c_fp, C.c_int, c_ip]
     L.nalo_profile_sample.argtypes = [vp, C.c_int]
     L.nalo_hbm_calibrate.argtypes = [vp, C.c_size_t, C.c_int, c_dp, c_dp]
     _LIB = L
@@ -798,3 +799,11 @@ class Context:
         ms, n = C.c_double(0), C.c_int(0)
         self._ck(self.L.nalo_profile_get(self.h_, name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_samples(self, name):
+        """every bracketed launch of the scope since the last reset, in launch order (microseconds)"""
+        n = C.c_int(0)
+        self._ck(self.L.nalo_profile_samples(self.h_, name.encode(), None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.float32)
+        self._ck(self.L.nalo_profile_samples(self.h_, name.encode(), _f(out), n.value, C.byref(n)))
+        return out[:n.value].astype(np.float64) * 1e3

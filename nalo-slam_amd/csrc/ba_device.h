@@ -44,7 +44,8 @@ struct BADev {
     uint8_t* pt_ngood;
     float* pt_step;
     float* pt_backup;
-    float* pt_relbs;                            // max relBS over this pass' active residuals (fix mode)
+    float* pt_relbs;                            // max relBS over this pass' active residuals (fix mode): the pass' atomicMax target, all zero when the pass starts
+    float* pt_relbs_next;                       // the buffer of the NEXT fix pass: zeroed by this pass' idle (target == host) workgroups - no fill launch on the path
     // residual slots [W][Ppad]
     uint8_t* rs_state;
     float2* rs_energy;                          // {state_energy, state_NewEnergy}
@@ -69,6 +70,13 @@ struct BADev {
 
 // {xc (4) | xAd [W*W][8]} of resubstituteFPt for windows of up to 8 frames, passed by value as kernel arguments (ba_resub_kernel)
 struct XadArg { float v[4 + 8 * 64]; };
+
+// What may ride along with ba_reduce_kernel: the newest frame's energy threshold of a small window (one more workgroup: ba_th_small's body) and, on a misc-only
+// fetch, the publication of the tail {misc, step sums, TH, 1.0} + sequence number into host-mapped memory by the last workgroup to finish
+struct RedExtra {
+    const float* th_en; int th_n; float* th_out;             // th_en != NULL: one more workgroup computes setNewFrameEnergyTH from en_new[0..th_n)
+    double* pub; double seq; unsigned* ticket; const float* th_src;   // pub != NULL: mapped tail block; th_src = frameTH of the newest frame
+};
 
 // Stitch operands (kernels_ba.hip ba_stitch_kernel)
 struct StitchDev {

@@ -776,7 +776,7 @@ static void prof_drain(nalo_ctx* c) {
     for (auto& kv : c->prof) {
         for (auto& ev : kv.second.pending) {
             float ms = 0;
-            if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { kv.second.ms += ms; kv.second.n++; }
+            if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { kv.second.ms += ms; kv.second.n++; if (kv.second.samples.size() < (size_t)1 << 20) kv.second.samples.push_back(ms); }
             c->prof_pool.push_back(ev.first); c->prof_pool.push_back(ev.second);
         }
         kv.second.pending.clear();
@@ -798,6 +798,18 @@ int nalo_profile_get(nalo_ctx* c, const char* kernel, double* total_ms, int* lau
     auto it = c->prof.find(kernel);
     if (total_ms) *total_ms = it == c->prof.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == c->prof.end() ? 0 : it->second.n;
+    return NALO_OK;
+}
+
+// every bracketed launch of a scope since the last reset, in launch order (milliseconds): what a mean hides - the spread, and the position inside a keyframe
+int nalo_profile_samples(nalo_ctx* c, const char* kernel, float* ms, int cap, int* n) {
+    if (!c || !kernel || cap < 0 || (cap > 0 && !ms)) return NALO_ERR_ARG;
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    prof_drain(c);
+    auto it = c->prof.find(kernel);
+    const int have = it == c->prof.end() ? 0 : (int)it->second.samples.size();
+    if (n) *n = have;
+    if (ms && have) std::memcpy(ms, it->second.samples.data(), (size_t)std::min(cap, have) * sizeof(float));
     return NALO_OK;
 }
 

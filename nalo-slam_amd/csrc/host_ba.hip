@@ -12,7 +12,7 @@ void ba_launch_linearize(hipStream_t s, const BADev& B, int mode, int fix, hipEv
 void ba_launch_reset_oob(hipStream_t s, const BADev& B);
 void ba_launch_restore(hipStream_t s, const BADev& B, const float4* geo, const uint8_t* state, const uint8_t* flags, const float* prior, const float* th);
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
-                      const float* step_partial, int step_blocks, double* step_out);
+                      const float* step_partial, int step_blocks, double* step_out, bool with_th, double* pub, double seq, unsigned* ticket);
 void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial, const XadArg* karg = nullptr);
 int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
 void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg = nullptr);
@@ -46,6 +46,7 @@ struct BAWindow {
     float c_scaledf[4] = {}, c_scaledi[4] = {};
     std::vector<HostFrame> frames;
     std::vector<double> adHost, adTarget, HM, bM, lastX, Sproj, solve_scratch;
+    std::vector<double> ad_key; int ad_key_W = 0;                   // what the adjoints of a frame were last computed from (set_adjoints recomputes the pairs of changed frames only)
     std::vector<int> solve_perm;
     std::vector<float> adHostF, adTargetF, adHTdeltaF;
     float cDeltaF[4] = {};
@@ -56,7 +57,7 @@ struct BAWindow {
     std::vector<uint8_t> flags_h;
     // device
     BADev dev{};
-    DevBuf<float> pre, frameTH, pt_prior, pt_step, pt_backup, pt_relbs, en_new, xad, step_partial;
+    DevBuf<float> pre, frameTH, pt_prior, pt_step, pt_backup, pt_relbs, pt_relbs2, en_new, xad, step_partial;
     DevBuf<double> top_partial, sc_partial;
     unsigned long long pub_seq = 0; bool step_pending = false; int last_canbreak = 0; float st_sumA = 0, st_sumB = 0, st_sumT = 0, st_sumR = 0;
     DevBuf<float4> pt_geo, pt_col0, pt_col1, pt_w0, pt_w1, pt_acc, pt_hcd, rs_jp0, rs_jp1, rs_cpt;
@@ -106,7 +107,7 @@ struct BAWindow {
 void ba_destroy(nalo_ctx* c) {
     BAWindow* w = c->ba;
     if (!w) return;
-    w->pre.release(); w->frameTH.release(); w->pt_prior.release(); w->pt_step.release(); w->pt_backup.release(); w->pt_relbs.release();
+    w->pre.release(); w->frameTH.release(); w->pt_prior.release(); w->pt_step.release(); w->pt_backup.release(); w->pt_relbs.release(); w->pt_relbs2.release();
     w->th_buf.release(); w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
@@ -168,14 +169,31 @@ static int set_adjoints(nalo_ctx* c) {
     BAWindow& w = *c->ba;
     HostTimer ht(c, "ba.set_adjoints");
     const int W = w.W, n1 = w.n1;
-    w.adHost.assign((size_t)W * W * 64, 0.0); w.adTarget.assign((size_t)W * W * 64, 0.0);
-    w.adHostF.resize((size_t)W * W * 64); w.adTargetF.resize((size_t)W * W * 64);
+    // A pair (h, t) depends on the two frames' linearisation points, exposures and affine zero states only. The calls on the per-keyframe path change ONE frame (the
+    // epilogue of optimize() moves the newest frame's evalPT, FullSystemOptimize.cpp:550-557; a snapshot restore moves it back): 2W - 1 of the W^2 pairs, not all.
+    constexpr int KEY = 15;
+    std::vector<uint8_t> dirty(W, 1);
+    if (w.ad_key_W == W && w.ad_key.size() == (size_t)W * KEY && w.adHost.size() == (size_t)W * W * 64) {
+        for (int f = 0; f < W; ++f) {
+            double k[KEY]; std::memcpy(k, w.frames[f].evalPT.m, 12 * sizeof(double)); k[12] = w.frames[f].ab_exposure; k[13] = w.frames[f].state_zero[6]; k[14] = w.frames[f].state_zero[7];
+            dirty[f] = std::memcmp(k, &w.ad_key[(size_t)f * KEY], sizeof(k)) != 0;
+        }
+    } else {
+        w.adHost.assign((size_t)W * W * 64, 0.0); w.adTarget.assign((size_t)W * W * 64, 0.0);
+        w.adHostF.resize((size_t)W * W * 64); w.adTargetF.resize((size_t)W * W * 64);
+    }
+    w.ad_key.resize((size_t)W * KEY); w.ad_key_W = W;
+    for (int f = 0; f < W; ++f) { double* k = &w.ad_key[(size_t)f * KEY]; std::memcpy(k, w.frames[f].evalPT.m, 12 * sizeof(double)); k[12] = w.frames[f].ab_exposure; k[13] = w.frames[f].state_zero[6]; k[14] = w.frames[f].state_zero[7]; }
+    bool any = false;
     for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
+        if (!dirty[h] && !dirty[t]) continue;
+        any = true;
         const HostFrame &host = w.frames[h], &target = w.frames[t];
         const SE3 h2t = target.evalPT * host.evalPT.inverse();
         double Ad[36]; h2t.adjoint(Ad);
         double* AH = &w.adHost[(size_t)(h + t * W) * 64];
         double* AT = &w.adTarget[(size_t)(h + t * W) * 64];
+        std::fill(AH, AH + 64, 0.0); std::fill(AT, AT + 64, 0.0);
         for (int i = 0; i < 8; ++i) { AH[i * 8 + i] = 1; AT[i * 8 + i] = 1; }
         for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) AH[i * 8 + j] = -Ad[j * 6 + i];
         double a[2];
@@ -190,6 +208,10 @@ static int set_adjoints(nalo_ctx* c) {
         }
         for (int k = 0; k < 64; ++k) { w.adHostF[(size_t)(h + t * W) * 64 + k] = (float)AH[k]; w.adTargetF[(size_t)(h + t * W) * 64 + k] = (float)AT[k]; }
     }
+    w.proj_valid = false;
+    if (!w.st_ticket.p) { NALO_HIP(c, w.st_ticket.reserve(4)); NALO_HIP(c, hipMemset(w.st_ticket.p, 0, 16)); }
+    w.sd.ticket = w.st_ticket.p; w.sd.W = W; w.sd.n1 = n1; w.sd.NPL = w.NPL;
+    if (!any && w.sd.AD == w.AD.p && w.AD.p) return NALO_OK;        // nothing moved: the device copy is current
     // the stitch kernel reads the fp64 adjoints: AD = [adHost | adTarget]
     const size_t nad = (size_t)2 * W * W * 64;
     if (w.ad_cap < nad) { if (w.ad_host) (void)hipHostFree(w.ad_host); NALO_HIP(c, hipHostMalloc((void**)&w.ad_host, nad * 8)); w.ad_cap = nad; }
@@ -201,9 +223,6 @@ static int set_adjoints(nalo_ctx* c) {
     NALO_HIP(c, hipMemcpyAsync(w.AD.p, w.ad_host, nad * 8, hipMemcpyHostToDevice, c->stream));
     NALO_HIP(c, hipEventRecord(w.ev_ad, c->stream));
     w.sd.AD = w.AD.p;
-    if (!w.st_ticket.p) { NALO_HIP(c, w.st_ticket.reserve(4)); NALO_HIP(c, hipMemset(w.st_ticket.p, 0, 16)); }
-    w.sd.ticket = w.st_ticket.p; w.sd.W = W; w.sd.n1 = n1; w.sd.NPL = w.NPL;
-    w.proj_valid = false;
     return NALO_OK;
 }
 
@@ -349,7 +368,8 @@ static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false)
         return NALO_OK;
     }
     int rc = flush_th(c); if (rc) return rc;                          // frameEnergyTH of the previous pass feeds this one
-    if (fix || mode == 2) NALO_HIP(c, hipMemsetAsync(w.pt_relbs.p, 0, (size_t)w.Ppad * 4, c->stream));
+    // a pass that records relBS (fix / marginalisation) takes the clean buffer of the pair and leaves the other one clean (its idle workgroups zero it): no fill launch
+    if (fix == 1 || mode == 2) std::swap(w.dev.pt_relbs, w.dev.pt_relbs_next);
     const bool th_sharded = mode == 0 && w.hook;
     const bool on_side = th_sharded && !(w.hook_stream_ordered && !w.hook_side);
     // (device-scope events: both sides of these dependencies are kernels of this context; a system-scope release behind the linearisation writes its output back first)
@@ -459,19 +479,28 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
     const bool fuse_lo = w.hook && w.th_lo_pending && (top || misc_only);
     bool th_after_publish = false;
     {
-        if ((top || sc) && (th_to_host || w.hook) && !fuse_lo) {      // the threshold rides in the tail {TH, 1.0}: compute it before the publish
-            int rc = flush_th(c); if (rc) return rc;
-            ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
+        // small single-GPU windows: a pending threshold (setNewFrameEnergyTH of the last linearisation) is computed by one more workgroup of the reduce launch, and a
+        // misc-only fetch publishes its tail from the reduce launch too: the last pass of optimize() is [linearize | reduce] instead of [linearize | th | tail | reduce | publish]
+        // (only where the host waits for the threshold anyway: behind a regular iteration's publish the separate 7 us launch runs under the host's solve, inside the reduce
+        // launch it would sit on the critical path in front of the stitch)
+        const bool small_th = !w.hook && w.th_pending && th_to_host && w.dev.Ppad <= 16384 && (top || sc);
+        const bool pub_in_reduce = misc_only && !w.hook && (top || sc) && (small_th || !w.th_pending);
+        if ((top || sc) && (th_to_host || w.hook) && !fuse_lo && !pub_in_reduce) {      // the threshold rides in the tail {TH, 1.0}: compute it before the publish
+            if (!small_th) { int rc = flush_th(c); if (rc) return rc; }
+            if (!small_th) ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);
         }
         ProfScope ps(c, "ba_reduce");                                 // reduce + stitch only: the threshold search above is its own chain (and holds collectives)
         if (top || sc) {
             // misc {count, energy} per bin lands in the tail of the stitched buffer; without a cross-rank hook step B publishes
             // rows + tail + sequence number straight into host-mapped memory
             ba_launch_reduce(c->stream, w.dev, w.host_blk.p, NPL, w.acc13.p, w.stitched.p + 2 * blk, w.G.p, top, sc,
-                             w.step_sums_deferred ? w.step_partial.p : nullptr, (w.Ppad + 255) / 256, w.stitched.p + 2 * blk + 2 * W * W);
+                             w.step_sums_deferred ? w.step_partial.p : nullptr, (w.Ppad + 255) / 256, w.stitched.p + 2 * blk + 2 * W * W, small_th,
+                             pub_in_reduce ? dmap + 2 * blk : nullptr, seq, w.st_ticket.p + 2);
+            if (small_th) w.th_pending = false;
             w.step_sums_deferred = false;
-            if (misc_only) { if (!w.hook) ba_launch_publish(c->stream, w.stitched.p + 2 * blk, dmap + 2 * blk, npub - (int)(2 * blk), seq, w.st_ticket.p + 1); }
+            if (misc_only) { if (!w.hook && !pub_in_reduce) ba_launch_publish(c->stream, w.stitched.p + 2 * blk, dmap + 2 * blk, npub - (int)(2 * blk), seq, w.st_ticket.p + 1); }
             else {
+                if (small_th && th_to_host) ba_launch_th_tail(c->stream, w.frameTH.p + (W - 1), w.stitched.p + 2 * blk + 2 * W * W + 3);   // the stitch publishes the tail: {TH, 1.0} must be in it
                 if (ba_launch_stitch(c->stream, w.sd, top, sc, w.hook ? nullptr : dmap, npub - (int)(2 * blk), seq)) return fail(c, NALO_ERR_HIP, "ba_stitch_kernel: LDS size rejected");
                 if (top) w.stitched_top = true;
                 if (sc) w.stitched_sc = true;
@@ -605,6 +634,28 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     (void)lambda; lambda = 1e-5;                                            // SOLVER_FIX_LAMBDA (EnergyFunctional.cpp:779)
     if (!w.have_lin) return fail(c, NALO_ERR_STATE, "solve_system before linearize");
     if (!w.have_sc || w.sc_shift != 1) { int rc = sc_async(c, 1, 1.f, 0); if (rc) return rc; }
+    // What the assembly needs from the HOST side only - delta, bL + (bM + HM delta), HL + diag(HM) - is computed here, while the device still works on the systems
+    // (the products HM delta are n chains of n dependent multiply-adds: 5 of the 8 us the assembly took at n = 68 when it ran behind the wait, round 3)
+    const int lda = (n + 7) & ~7;
+    w.solve_scratch.resize((size_t)lda * lda + 10 * (size_t)lda + n); w.solve_perm.resize(n);
+    double* HF = w.solve_scratch.data(); double* bF = HF + (size_t)lda * lda; double* sv = bF + lda; double* delta = sv + lda; double* yv = delta + lda;   // yv: 3 lda
+    double* rhs0 = yv + 3 * (size_t)lda; double* dg0 = rhs0 + lda;
+    float* xF = reinterpret_cast<float*>(dg0 + lda);
+    {
+        HostTimer hp(c, "ba.solve.host_pre");
+        for (int i = 0; i < 4; ++i) delta[i] = (double)w.cDeltaF[i];
+        for (int h = 0; h < W; ++h) for (int i = 0; i < 8; ++i) delta[4 + 8 * h + i] = w.frames[h].delta[i];
+        for (int r = 0; r < n; ++r) {                                       // accumulateLF with usePrior (AccumulatedTopHessian.cpp:292-302): diagonal only
+            double HLd, bLr;
+            if (r < 4) { HLd = kInitialCalibHessian; bLr = kInitialCalibHessian * (double)w.cDeltaF[r]; }
+            else { const HostFrame& f = w.frames[(r - 4) >> 3]; const int i = (r - 4) & 7; HLd = f.prior[i]; bLr = f.prior[i] * f.delta_prior[i]; }
+            const double* hm = &w.HM[(size_t)r * n];
+            double sdot = 0;
+            for (int cc = 0; cc < n; ++cc) sdot += hm[cc] * delta[cc];
+            dg0[r] = HLd + hm[r];
+            rhs0[r] = bLr + (w.bM[r] + sdot);
+        }
+    }
     int rc;
     { HostTimer h2(c, "ba.solve.fetch_wait"); rc = stitch_and_fetch(c, true, true); }
     if (rc) return rc;
@@ -614,30 +665,19 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     // factorisation works on. Eigen's LDLT (the reference, :880) reads the LOWER triangle only; H_sc carries fp32-rounding asymmetry (w*a_j*a_k vs
     // w*a_k*a_j), so the upper triangle the factorisation reads is filled from the lower one: entry (r, c >= r) is computed from the sources' (c, r).
     // Scratch lives in the window: no allocation per iteration.
-    const int lda = (n + 7) & ~7;
-    w.solve_scratch.resize((size_t)lda * lda + 8 * (size_t)lda + n); w.solve_perm.resize(n);
-    double* HF = w.solve_scratch.data(); double* bF = HF + (size_t)lda * lda; double* sv = bF + lda; double* delta = sv + lda; double* yv = delta + lda;   // yv: 3 lda
-    float* xF = reinterpret_cast<float*>(yv + 3 * (size_t)lda);
     std::vector<double>& x = w.lastX; x.resize(n);
     const double* HAp = w.stitched_host; const double* HSp = w.stitched_host + (size_t)n1 * n1;
     misc_totals(w, nullptr, &w.resInA);
-    for (int i = 0; i < 4; ++i) delta[i] = (double)w.cDeltaF[i];
-    for (int h = 0; h < W; ++h) for (int i = 0; i < 8; ++i) delta[4 + 8 * h + i] = w.frames[h].delta[i];
     const double fsc = 1.0 / (1 + lambda);
     { HostTimer hl(c, "ba.solve.math.assemble");
-    for (int r = 0; r < n; ++r) {                                           // diagonal + right-hand side; accumulateLF with usePrior (AccumulatedTopHessian.cpp:292-302): diagonal only
-        double HLd, bLr;
-        if (r < 4) { HLd = kInitialCalibHessian; bLr = kInitialCalibHessian * (double)w.cDeltaF[r]; }
-        else { const HostFrame& f = w.frames[(r - 4) >> 3]; const int i = (r - 4) & 7; HLd = f.prior[i]; bLr = f.prior[i] * f.delta_prior[i]; }
-        const double* hm = &w.HM[(size_t)r * n]; const double* ha = HAp + (size_t)r * n1; const double* hs = HSp + (size_t)r * n1;
-        double sdot = 0;
-        for (int cc = 0; cc < n; ++cc) sdot += hm[cc] * delta[cc];
-        double dg = (HLd + hm[r]) + ha[r];
+    for (int r = 0; r < n; ++r) {                                           // diagonal + right-hand side (the host-only terms were prepared above, in the same operation order)
+        const double* ha = HAp + (size_t)r * n1; const double* hs = HSp + (size_t)r * n1;
+        double dg = dg0[r] + ha[r];
         dg *= (1 + lambda);
         dg -= hs[r] * fsc;
         sv[r] = 1.0 / std::sqrt(dg + 10);
         HF[(size_t)r * lda + r] = dg;
-        bF[r] = (bLr + (w.bM[r] + sdot) + ha[n] - hs[n]) * sv[r];
+        bF[r] = (rhs0[r] + ha[n] - hs[n]) * sv[r];
     }
     for (int r = 0; r < n; ++r) {                                           // lower-triangle entries (r, cc < r), stored mirrored at (cc, r) and scaled
         const double* hm = &w.HM[(size_t)r * n]; const double* ha = HAp + (size_t)r * n1; const double* hs = HSp + (size_t)r * n1;
@@ -866,7 +906,7 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
     }
     NALO_HIP(c, w.pt_geo.reserve(N)); NALO_HIP(c, w.pt_col0.reserve(N)); NALO_HIP(c, w.pt_col1.reserve(N)); NALO_HIP(c, w.pt_w0.reserve(N)); NALO_HIP(c, w.pt_w1.reserve(N));
     NALO_HIP(c, w.pt_acc.reserve(N)); NALO_HIP(c, w.pt_hcd.reserve(N)); NALO_HIP(c, w.pt_prior.reserve(N)); NALO_HIP(c, w.pt_step.reserve(N)); NALO_HIP(c, w.pt_backup.reserve(N));
-    NALO_HIP(c, w.pt_relbs.reserve(N)); NALO_HIP(c, w.en_new.reserve(N)); NALO_HIP(c, w.pt_flags.reserve(N)); NALO_HIP(c, w.pt_ngood.reserve(N));
+    NALO_HIP(c, w.pt_relbs.reserve(N)); NALO_HIP(c, w.pt_relbs2.reserve(N)); NALO_HIP(c, w.en_new.reserve(N)); NALO_HIP(c, w.pt_flags.reserve(N)); NALO_HIP(c, w.pt_ngood.reserve(N));
     NALO_HIP(c, w.blk_host.reserve(w.nblocks)); NALO_HIP(c, w.host_blk.reserve(W + 1));
     const size_t NS = (size_t)W * N;
     NALO_HIP(c, w.rs_state.reserve(NS)); NALO_HIP(c, w.rs_energy.reserve(NS)); NALO_HIP(c, w.rs_jp0.reserve(NS)); NALO_HIP(c, w.rs_jp1.reserve(NS)); NALO_HIP(c, w.rs_cpt.reserve(NS)); NALO_HIP(c, w.rs_pp0.reserve(NS)); NALO_HIP(c, w.rs_pp1.reserve(NS));
@@ -911,13 +951,13 @@ int nalo_ba_set_points(nalo_ctx* c, int P, const int* host, const float* u, cons
         w.dev.blk_order = w.blk_order.p; w.dev.xcd_len = (int)len;
     }
     NALO_HIP(c, hipMemset(w.pt_acc.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_hcd.p, 0, N * 16)); NALO_HIP(c, hipMemset(w.pt_step.p, 0, N * 4));
-    NALO_HIP(c, hipMemset(w.pt_backup.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_relbs.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_ngood.p, 0, N));
+    NALO_HIP(c, hipMemset(w.pt_backup.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_relbs.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_relbs2.p, 0, N * 4)); NALO_HIP(c, hipMemset(w.pt_ngood.p, 0, N));
     NALO_HIP(c, hipMemset(w.rs_state.p, 0, NS)); NALO_HIP(c, hipMemset(w.rs_energy.p, 0, NS * 8)); NALO_HIP(c, hipMemset(w.rs_jp0.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.rs_jp1.p, 0, NS * 16));
     NALO_HIP(c, hipMemset(w.rs_cpt.p, 0, NS * 16)); NALO_HIP(c, hipMemset(w.top_partial.p, 0, (size_t)w.nblocks * w.dev.lin_sub * W * kTopStride * 8));
     BADev& D = w.dev;
     D.P = P; D.Ppad = w.Ppad; D.nblocks = w.nblocks; D.blk_host = w.blk_host.p; D.host_blk = w.host_blk.p;
     D.pt_geo = w.pt_geo.p; D.pt_col0 = w.pt_col0.p; D.pt_col1 = w.pt_col1.p; D.pt_w0 = w.pt_w0.p; D.pt_w1 = w.pt_w1.p; D.pt_prior = w.pt_prior.p;
-    D.pt_flags = w.pt_flags.p; D.pt_acc = w.pt_acc.p; D.pt_hcd = w.pt_hcd.p; D.pt_ngood = w.pt_ngood.p; D.pt_step = w.pt_step.p; D.pt_backup = w.pt_backup.p; D.pt_relbs = w.pt_relbs.p;
+    D.pt_flags = w.pt_flags.p; D.pt_acc = w.pt_acc.p; D.pt_hcd = w.pt_hcd.p; D.pt_ngood = w.pt_ngood.p; D.pt_step = w.pt_step.p; D.pt_backup = w.pt_backup.p; D.pt_relbs = w.pt_relbs.p; D.pt_relbs_next = w.pt_relbs2.p;
     D.rs_state = w.rs_state.p; D.rs_energy = w.rs_energy.p; D.rs_jp0 = w.rs_jp0.p; D.rs_jp1 = w.rs_jp1.p; D.rs_cpt = w.rs_cpt.p; D.rs_pp0 = w.rs_pp0.p; D.rs_pp1 = w.rs_pp1.p; D.en_new = w.en_new.p;
     D.top_partial = w.top_partial.p; D.sc_partial = w.sc_partial.p;
     w.points_set = true; w.res_set = false; w.have_lin = w.have_sc = false;
@@ -1291,7 +1331,7 @@ int nalo_ba_get_points(nalo_ctx* c, float* idepth, float* step, float* HdiF, flo
     std::vector<float> stp(N), rel(N);
     NALO_HIP(c, hipMemcpy(geo.data(), w.pt_geo.p, N * 16, hipMemcpyDeviceToHost)); NALO_HIP(c, hipMemcpy(acc.data(), w.pt_acc.p, N * 16, hipMemcpyDeviceToHost));
     NALO_HIP(c, hipMemcpy(hcd.data(), w.pt_hcd.p, N * 16, hipMemcpyDeviceToHost)); NALO_HIP(c, hipMemcpy(stp.data(), w.pt_step.p, N * 4, hipMemcpyDeviceToHost));
-    NALO_HIP(c, hipMemcpy(rel.data(), w.pt_relbs.p, N * 4, hipMemcpyDeviceToHost));
+    NALO_HIP(c, hipMemcpy(rel.data(), w.dev.pt_relbs, N * 4, hipMemcpyDeviceToHost));      // the buffer of the last pass that recorded relBS
     for (int p = 0; p < w.P; ++p) {
         const int d = w.p2d[p];
         if (idepth) idepth[p] = geo[d].z; if (step) step[p] = stp[d]; if (HdiF) HdiF[p] = acc[d].z; if (bdSumF) bdSumF[p] = acc[d].w;

@@ -358,6 +358,62 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
     ba_reset_oob_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(B.rs_state, B.rs_energy, n);
 }
 
+// Small windows (<= 16384 point slots, a KITTI-sized window has 2048): the same order statistic in ONE launch. The workgroup keeps the energies in
+// registers and runs a most-significant-first radix select with four 256-bin LDS histograms (5 us instead of the 40 us of the two 65536-bin
+// searches of round 1, which sat between the publish and the next back-substitution).
+__device__ __forceinline__ void th_small_body(const float* __restrict__ en, int n, float* __restrict__ frameTH_new) {
+    __shared__ unsigned hist[256], wtot[16];
+    __shared__ unsigned s_bin, s_before;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned v[16]; bool ok[16];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = tid + 1024 * j;
+        const float f = i < n ? en[i] : -1.f;
+        ok[j] = f >= 0.f; v[j] = __float_as_uint(f);
+        if (ok[j]) ++cnt;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane == 0) wtot[wave] = cnt;
+    __syncthreads();
+    unsigned total = 0;
+    for (int i = 0; i < 16; ++i) total += wtot[i];
+    if (total == 0) { if (tid == 0) __hip_atomic_store(frameTH_new, 12.f * 12.f * (float)kPatternNum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }       // no residual on the newest frame (:110-114)
+    unsigned k = (unsigned)(int)(kFrameEnergyTHN * (float)total), prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (ok[j] && (v[j] & mask) == prefix) atomicAdd(&hist[(v[j] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (wave == 0) {                                        // 4 bins per lane, shuffle scan, the lane and then the bin whose running count passes k
+            const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3], sum = h0 + h1 + h2 + h3;
+            unsigned incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            const unsigned excl = incl - sum;
+            if (excl <= k && k < incl) {
+                unsigned run = excl; int b = 3;
+                if (run + h0 > k) b = 0; else { run += h0; if (run + h1 > k) b = 1; else { run += h1; if (run + h2 > k) b = 2; else run += h2; } }
+                s_bin = 4u * lane + b; s_before = run;
+            }
+        }
+        __syncthreads();
+        prefix |= s_bin << shift; mask |= 255u << shift; k -= s_before;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float nthElement = sqrtf(__uint_as_float(prefix));
+        float th = nthElement * kFrameEnergyTHFacMedian;        // FullSystemOptimize.cpp:130-133
+        th = 26.0f * kFrameEnergyTHConstWeight + th * (1.f - kFrameEnergyTHConstWeight);
+        th = th * th; th *= kOverallEnergyTHWeight * kOverallEnergyTHWeight;
+        __hip_atomic_store(frameTH_new, th, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // agent scope: ba_reduce_kernel's publishing workgroup may read it in the same launch
+    }
+}
+__global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restrict__ en, int n, float* __restrict__ frameTH_new) { th_small_body(en, n, frameTH_new); }
+
 // ------------------------------------------------------------------------------------------------ fp64 finish of the partials
 // ONE launch for both systems (blocks [0, W*W) = top bins, the rest = 64 entries of one upper SC tile of one host):
 //   acc13[(h + t*W)][169] (full symmetric 13x13, AccumulatorApprox::finish layout MatrixAccumulators.h:626-647), misc[h+t*W] = {count, energy}
@@ -366,11 +422,14 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B) {
 __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restrict__ top_partial, const double* __restrict__ sc_partial,
                                                          const int* __restrict__ host_blk /* [W+1] */, const int* __restrict__ sc_grp /* [W+1] */, int W, int NPL, int sc_tiles, int mask, int KS, int lin_sub,
                                                          double* __restrict__ acc13, double* __restrict__ misc, double* __restrict__ G,
-                                                         const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out) {
+                                                         const float* __restrict__ step_partial, int step_blocks, double* __restrict__ step_out, RedExtra X) {
     __shared__ double part[16][64];
     __shared__ double sums[128];
-    if ((int)blockIdx.x < W * W) {
-        if (!(mask & 1)) return;
+    __shared__ int is_last;
+    const int nsc = W * sc_tiles, b_step = W * W + nsc, b_th = b_step + (step_partial ? 1 : 0);
+    if (X.th_en && (int)blockIdx.x == b_th) th_small_body(X.th_en, X.th_n, X.th_out);      // the newest frame's threshold rides along (small windows)
+    else if ((int)blockIdx.x < W * W) {
+        if (mask & 1) {
         double (*part8)[128] = reinterpret_cast<double (*)[128]>(&part[0][0]);
         const int h = blockIdx.x % W, t = blockIdx.x / W, j = threadIdx.x & 127, g = threadIdx.x >> 7;     // 8 groups stride over the blocks
         double s = 0;
@@ -399,10 +458,10 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
             else { const int rr = r - 10, cc = c - 10; idx = 85 + (rr == 0 ? cc : rr + cc + 1); }   // BotRight: 00 01 02 11 12 22
             H[e] = sums[idx];
         }
-        if (threadIdx.x == 0) { misc[2 * (h + t * W)] = sums[91]; misc[2 * (h + t * W) + 1] = sums[92]; }
-        return;
-    }
-    if ((int)blockIdx.x == W * W + W * sc_tiles) {             // the deferred sums of doStepFromBackup's break test ride along (optimize())
+        // (agent-scope stores: the workgroup that publishes the tail of a misc-only fetch reads them below, without a device-wide fence = an L2 write-back per workgroup)
+        if (threadIdx.x == 0) { __hip_atomic_store(&misc[2 * (h + t * W)], sums[91], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&misc[2 * (h + t * W) + 1], sums[92], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+    } else if (step_partial && (int)blockIdx.x == b_step) {     // the deferred sums of doStepFromBackup's break test ride along (optimize())
         // all 1024 lanes stride over the blocks (a 1M-point window has 3907: 16 lanes walking them was an 85 us serial chain), fixed-order tree
         const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
         double s0 = 0, s1 = 0, s2 = 0;
@@ -414,10 +473,8 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
         for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o); s1 += __shfl_down(s1, o); s2 += __shfl_down(s2, o); }
         if (j == 0) { part[g][0] = s0; part[g][1] = s1; part[g][2] = s2; }
         __syncthreads();
-        if (threadIdx.x < 3) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x]; step_out[threadIdx.x] = t; }
-        return;
-    }
-    if (!(mask & 2)) return;
+        if (threadIdx.x < 3) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x]; __hip_atomic_store(&step_out[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    } else if (mask & 2) {
     const int q = blockIdx.x - W * W, h = q / sc_tiles, tile = q - h * sc_tiles;      // tile = 4 * (upper tile index) + MFMA register
     const int j = threadIdx.x & 63, g = threadIdx.x >> 6, e = tile * 64 + j, psz = sc_tiles * 64;
     double s = 0;
@@ -436,12 +493,42 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(const double* __restric
         Gh[row * NPL + col] = tt;
         if (ti != tj) Gh[col * NPL + row] = tt;
     }
+    }
+    // misc-only fetch (the last pass of optimize(): energy, residual count, threshold - no systems): the last workgroup to finish publishes the tail
+    // {misc (2 W^2), step sums (3), TH, 1.0} and the sequence number the host polls, instead of a th_tail + a publish launch behind this one
+    if (!X.pub) return;
+    // the stores above are agent-scope atomics, acknowledged before this workgroup's ticket (release fence = s_waitcnt; the idiom of ba_stitch_kernel's tail)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(X.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (!is_last) return;
+    const int ntail = 2 * W * W + 5;
+    for (int i = threadIdx.x; i < ntail; i += blockDim.x) {
+        double v;
+        if (i == ntail - 2) v = (double)__hip_atomic_load(X.th_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // what tail_th() reads: {TH, 1.0}
+        else if (i == ntail - 1) v = 1.0;
+        else v = __hip_atomic_load(&misc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        misc[i] = v;                                           // the device copy keeps the same tail (a later publish re-sends it)
+        __hip_atomic_store(&X.pub[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(X.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                  // re-armed for the next (stream-ordered) launch
+        __hip_atomic_store(&X.pub[ntail], X.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
+// with_th: the window is small and a linearisation's threshold is pending - it is computed by one more workgroup of this launch. pub: misc-only fetch, the tail is
+// published from here (the Schur-complement blocks are not launched at all then)
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
-                      const float* step_partial, int step_blocks, double* step_out) {
-    const int T = NPL / 16, tiles = T * (T + 1) / 2 * 4;
-    ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.sc_grp, B.W, NPL, tiles, (top ? 1 : 0) | (sc ? 2 : 0),
-                                                                                       B.sc_split, B.lin_sub, acc13, misc, G, step_partial, step_blocks, step_out);
+                      const float* step_partial, int step_blocks, double* step_out, bool with_th, double* pub, double seq, unsigned* ticket) {
+    const int T = NPL / 16, tiles = pub ? 0 : T * (T + 1) / 2 * 4;
+    RedExtra X{};
+    if (with_th) { X.th_en = B.en_new; X.th_n = B.Ppad; X.th_out = B.frameTH + (B.W - 1); }
+    X.pub = pub; X.seq = seq; X.ticket = ticket; X.th_src = B.frameTH + (B.W - 1);
+    ba_reduce_kernel<<<B.W * B.W + B.W * tiles + (step_partial ? 1 : 0) + (with_th ? 1 : 0), 1024, 0, s>>>(B.top_partial, B.sc_partial, host_blk, B.sc_grp, B.W, NPL, tiles,
+                                                                                       (top ? 1 : 0) | (sc && !pub ? 2 : 0), B.sc_split, B.lin_sub, acc13, misc, G, step_partial, step_blocks, step_out, X);
 }
 
 // ------------------------------------------------------------------------------------------------ stitch:  H~ = sum_b S_b M_b S_b^T  (fp64)
@@ -977,59 +1064,6 @@ __global__ __launch_bounds__(256) void ba_th_final_kernel(double* __restrict__ b
     }
     for (int i = tid; i < kThBinsAB; i += 256) bufAB[i] = 0.0;                   // A | B: 1024 doubles each
     bufC[tid] = 0.0;                                                            // 256 doubles (th_search has read them: two barriers ago)
-}
-// Small windows (<= 16384 point slots, a KITTI-sized window has 2048): the same order statistic in ONE launch. The workgroup keeps the energies in
-// registers and runs a most-significant-first radix select with four 256-bin LDS histograms (5 us instead of the 40 us of the two 65536-bin
-// searches of round 1, which sat between the publish and the next back-substitution).
-__global__ __launch_bounds__(1024) void ba_th_small_kernel(const float* __restrict__ en, int n, float* __restrict__ frameTH_new) {
-    __shared__ unsigned hist[256], wtot[16];
-    __shared__ unsigned s_bin, s_before;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned v[16]; bool ok[16];
-    unsigned cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int i = tid + 1024 * j;
-        const float f = i < n ? en[i] : -1.f;
-        ok[j] = f >= 0.f; v[j] = __float_as_uint(f);
-        if (ok[j]) ++cnt;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if (lane == 0) wtot[wave] = cnt;
-    __syncthreads();
-    unsigned total = 0;
-    for (int i = 0; i < 16; ++i) total += wtot[i];
-    if (total == 0) { if (tid == 0) *frameTH_new = 12.f * 12.f * (float)kPatternNum; return; }       // no residual on the newest frame (:110-114)
-    unsigned k = (unsigned)(int)(kFrameEnergyTHN * (float)total), prefix = 0, mask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) if (ok[j] && (v[j] & mask) == prefix) atomicAdd(&hist[(v[j] >> shift) & 255u], 1u);
-        __syncthreads();
-        if (wave == 0) {                                        // 4 bins per lane, shuffle scan, the lane and then the bin whose running count passes k
-            const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3], sum = h0 + h1 + h2 + h3;
-            unsigned incl = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-            const unsigned excl = incl - sum;
-            if (excl <= k && k < incl) {
-                unsigned run = excl; int b = 3;
-                if (run + h0 > k) b = 0; else { run += h0; if (run + h1 > k) b = 1; else { run += h1; if (run + h2 > k) b = 2; else run += h2; } }
-                s_bin = 4u * lane + b; s_before = run;
-            }
-        }
-        __syncthreads();
-        prefix |= s_bin << shift; mask |= 255u << shift; k -= s_before;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const float nthElement = sqrtf(__uint_as_float(prefix));
-        float th = nthElement * kFrameEnergyTHFacMedian;        // FullSystemOptimize.cpp:130-133
-        th = 26.0f * kFrameEnergyTHConstWeight + th * (1.f - kFrameEnergyTHConstWeight);
-        th = th * th; th *= kOverallEnergyTHWeight * kOverallEnergyTHWeight; *frameTH_new = th;
-    }
 }
 static int th_grid(int n) { return std::min(64, std::max(1, (n + 4095) / 4096)); }
 // step 0 / 1 / 2: fill level A / B / C (B and C search the previous level first), 3: level C's search + the threshold. A sharded window sums A, B, C over the

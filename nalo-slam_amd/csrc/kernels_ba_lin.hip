@@ -370,6 +370,7 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
     if (w.skip) return;
     if (w.t == w.h) {                                                   // no self residuals; the newest frame's own points have no entry
         if (MODE == 0 && w.t == B.W - 1 && !B.no_th) B.en_new[w.d] = -1.f;
+        if (FIX == 1 || MODE == 2) B.pt_relbs_next[w.d] = 0.f;          // every point has exactly one such workgroup lane: the other buffer is clean for the next fix pass
         return;
     }
     const bool fixA = B.fix_a != 0, fixB = B.fix_b != 0;

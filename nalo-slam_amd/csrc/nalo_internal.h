@@ -43,7 +43,7 @@ struct FrameSlot {
     float* dI0t = nullptr; bool tiled_valid = false;    // level 0 again as 12-byte texels in 5x2 tiles of 128 bytes (ba_linearize's gathers), made on demand (frame_tile_level0)
 };
 
-struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+struct ProfEntry { double ms = 0; int n = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; std::vector<float> samples; };   // samples: every bracketed launch, in launch order (nalo_profile_samples)
 
 // precalc record per (host,target), 32 floats: KRKi(9) Kt(3) R0(9) t0(3) aff(2) b0 thmax dp(8)... see kernels_ba.hip
 struct BAWindow;
