@@ -301,107 +301,139 @@ int nalo_io_resize_nearest_u8(const uint8_t* src, int wOrg, int hOrg, int channe
 }
 
 // ------------------------------------------------------------------------------------------------ rectification tables
+// The per-frame work of the rectification (the remap itself) runs on the device (ingest_kernel); what is built here, once per camera, is its table: for every
+// pixel of the rectified pinhole image the sensor position it is sampled from. The structure is our own; the ARITHMETIC per point is the reference's, in its
+// float / double mix and association order, because the table decides which sensor texels every later stage reads (tests/test_io_cpu.py holds it to the oracle's
+// restatement bit for bit, and to closed forms that involve no restatement at all):
+//   * a lens model = one function "normalised pinhole point -> sensor pixel" out of a table indexed by nalo_camera_model (util/Undistort.cpp:1018-1283),
+//   * View = a centred pinhole view in normalised coordinates; edges_off_sensor() probes its four border lines through the lens,
+//   * the `crop` mode (makeOptimalK_crop, :637-757) = per-axis extent of the sensor along the centre lines, a 1 % head start, then shrinking the View by 0.5 % per
+//     round on the sides that leave the sensor (the longer axis first when both do) until all four borders land on it.
 namespace {
-struct Rectifier {
-    int model; float p[8]; double K[4];                       // parsOrg as floats (VecX parsOrg holds doubles; every model casts to float first), K = fx fy cx cy
-    void distort(const float* in_x, const float* in_y, float* out_x, float* out_y, int n) const {
-        const float fx = p[0], fy = p[1], cx = p[2], cy = p[3];
+struct LensPars { float fx, fy, cx, cy, k[4]; };                       // parsOrg as floats (every model of the reference casts its doubles first)
+typedef void (*LensFn)(const LensPars& L, float ix, float iy, float& sx, float& sy);
+// unsuffixed literals are doubles ON PURPOSE: the reference's expressions promote there
+void lens_pinhole(const LensPars& L, float ix, float iy, float& sx, float& sy) { sx = L.fx * ix + L.cx; sy = L.fy * iy + L.cy; }
+void lens_fov(const LensPars& L, float ix, float iy, float& sx, float& sy) {
+    const float dist = L.k[0], d2t = 2.0f * tan(dist / 2.0f);
+    const float r = sqrtf(ix * ix + iy * iy);
+    const float fac = (r == 0 || dist == 0) ? 1 : atanf(r * d2t) / (dist * r);
+    sx = L.fx * fac * ix + L.cx; sy = L.fy * fac * iy + L.cy;
+}
+void lens_radtan(const LensPars& L, float ix, float iy, float& sx, float& sy) {
+    const float k1 = L.k[0], k2 = L.k[1], r1 = L.k[2], r2 = L.k[3];
+    const float mx2 = ix * ix, my2 = iy * iy, mxy = ix * iy, rho2 = mx2 + my2;
+    const float rad = k1 * rho2 + k2 * rho2 * rho2;
+    const float xd = ix + ix * rad + 2.0 * r1 * mxy + r2 * (rho2 + 2.0 * mx2);
+    const float yd = iy + iy * rad + 2.0 * r2 * mxy + r1 * (rho2 + 2.0 * my2);
+    sx = L.fx * xd + L.cx; sy = L.fy * yd + L.cy;
+}
+void lens_equidistant(const LensPars& L, float ix, float iy, float& sx, float& sy) {
+    const float r = sqrt(ix * ix + iy * iy);                           // sqrt / atan: double functions of float arguments
+    const float theta = atan(r), t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const float thetad = theta * (1 + L.k[0] * t2 + L.k[1] * t4 + L.k[2] * t6 + L.k[3] * t8);
+    const float scaling = (r > 1e-8) ? thetad / r : 1.0;
+    sx = L.fx * ix * scaling + L.cx; sy = L.fy * iy * scaling + L.cy;
+}
+void lens_kannala_brandt(const LensPars& L, float ix, float iy, float& sx, float& sy) {
+    const float sq = sqrtf(ix * ix + iy * iy);
+    const float theta = atan2f(sq, 1), t2 = theta * theta, t3 = t2 * theta, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+    const float r = theta + L.k[0] * t3 + L.k[1] * t5 + L.k[2] * t7 + L.k[3] * t9;
+    if (sq < 1e-6) { sx = L.fx * ix + L.cx; sy = L.fy * iy + L.cy; }
+    else { sx = (r / sq) * L.fx * ix + L.cx; sy = (r / sq) * L.fy * iy + L.cy; }
+}
+LensFn lens_of(int model) {
+    static const struct { int id; LensFn fn; } table[] = {{NALO_CAM_PINHOLE, lens_pinhole}, {NALO_CAM_RADTAN, lens_radtan}, {NALO_CAM_FOV, lens_fov},
+                                                          {NALO_CAM_EQUIDISTANT, lens_equidistant}, {NALO_CAM_KANNALABRANDT, lens_kannala_brandt}};
+    for (const auto& e : table) if (e.id == model) return e.fn;
+    return lens_pinhole;
+}
+struct Lens {
+    LensPars L; LensFn fn;
+    explicit Lens(const nalo_camera_file& cam) : fn(lens_of(cam.model)) {
+        L.fx = (float)cam.pars[0]; L.fy = (float)cam.pars[1]; L.cx = (float)cam.pars[2]; L.cy = (float)cam.pars[3];
+        for (int i = 0; i < 4; ++i) L.k[i] = (float)cam.pars[4 + i];
+    }
+    // n pixels of the pinhole view K = {fx, fy, cx, cy} -> sensor pixels, in place
+    void to_sensor(const double K[4], float* px, float* py, int n) const {
         const float ofx = (float)K[0], ofy = (float)K[1], ocx = (float)K[2], ocy = (float)K[3];
-        for (int i = 0; i < n; ++i) {
-            float ix = (in_x[i] - ocx) / ofx, iy = (in_y[i] - ocy) / ofy;
-            switch (model) {
-            case NALO_CAM_FOV: {                                                                 // Undistort.cpp:1018-1055
-                const float dist = p[4], d2t = 2.0f * tan(dist / 2.0f);
-                const float r = sqrtf(ix * ix + iy * iy);
-                const float fac = (r == 0 || dist == 0) ? 1 : atanf(r * d2t) / (dist * r);
-                out_x[i] = fx * fac * ix + cx; out_y[i] = fy * fac * iy + cy;
-            } break;
-            case NALO_CAM_RADTAN: {                                                              // :1074-1116 (2.0 literals: double intermediate)
-                const float k1 = p[4], k2 = p[5], r1 = p[6], r2 = p[7];
-                const float mx2 = ix * ix, my2 = iy * iy, mxy = ix * iy, rho2 = mx2 + my2;
-                const float rad = k1 * rho2 + k2 * rho2 * rho2;
-                const float xd = ix + ix * rad + 2.0 * r1 * mxy + r2 * (rho2 + 2.0 * mx2);
-                const float yd = iy + iy * rad + 2.0 * r2 * mxy + r1 * (rho2 + 2.0 * my2);
-                out_x[i] = fx * xd + cx; out_y[i] = fy * yd + cy;
-            } break;
-            case NALO_CAM_EQUIDISTANT: {                                                         // :1134-1176 (sqrt / atan: double functions of float arguments)
-                const float k1 = p[4], k2 = p[5], k3 = p[6], k4 = p[7];
-                const float r = sqrt(ix * ix + iy * iy);
-                const float theta = atan(r), t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
-                const float thetad = theta * (1 + k1 * t2 + k2 * t4 + k3 * t6 + k4 * t8);
-                const float scaling = (r > 1e-8) ? thetad / r : 1.0;
-                out_x[i] = fx * ix * scaling + cx; out_y[i] = fy * iy * scaling + cy;
-            } break;
-            case NALO_CAM_KANNALABRANDT: {                                                       // :1193-1240
-                const float k0 = p[4], k1 = p[5], k2 = p[6], k3 = p[7];
-                const float ss = ix * ix + iy * iy, sq = sqrtf(ss);
-                const float theta = atan2f(sq, 1), t2 = theta * theta, t3 = t2 * theta, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
-                const float r = theta + k0 * t3 + k1 * t5 + k2 * t7 + k3 * t9;
-                if (sq < 1e-6) { out_x[i] = fx * ix + cx; out_y[i] = fy * iy + cy; }
-                else { out_x[i] = (r / sq) * fx * ix + cx; out_y[i] = (r / sq) * fy * iy + cy; }
-            } break;
-            default:                                                                             // Pinhole :1258-1283
-                out_x[i] = fx * ix + cx; out_y[i] = fy * iy + cy;
-            }
-        }
+        for (int i = 0; i < n; ++i) fn(L, (px[i] - ocx) / ofx, (py[i] - ocy) / ofy, px[i], py[i]);
     }
 };
+const double kUnitView[4] = {1, 1, 0, 0};                               // K = identity: view pixels ARE normalised coordinates
+struct View { float lo[2], hi[2]; };                                    // [0] = x, [1] = y, normalised coordinates
+enum : unsigned { kOffLeft = 1, kOffRight = 2, kOffTop = 4, kOffBottom = 8 };
+
+// the part of the centre line of one axis that lands strictly inside the sensor: first and last of 100 000 samples over [-5, 5) (the first sample is taken while
+// the bound still reads 0, as in the reference)
+void centre_line_extent(const Lens& lens, int axis, int sensor_size, float& lo, float& hi) {
+    const int N = 100000;
+    std::vector<float> a(N), b(N, 0.f);
+    for (int i = 0; i < N; ++i) a[i] = (i - 50000.0f) / 10000.0f;
+    if (axis == 0) lens.to_sensor(kUnitView, a.data(), b.data(), N); else lens.to_sensor(kUnitView, b.data(), a.data(), N);
+    lo = hi = 0;
+    for (int i = 0; i < N; ++i) if (a[i] > 0 && a[i] < sensor_size - 1) { const float t = (i - 50000.0f) / 10000.0f; if (lo == 0) lo = t; hi = t; }
+}
+// which borders of the view (sampled at the h rows / w columns of the rectified image) leave the sensor; sx, sy: scratch of 2 max(w, h) floats
+unsigned edges_off_sensor(const Lens& lens, const View& v, int w, int h, int wOrg, int hOrg, float* sx, float* sy) {
+    unsigned off = 0;
+    for (int y = 0; y < h; ++y) { sx[2 * y] = v.lo[0]; sx[2 * y + 1] = v.hi[0]; sy[2 * y] = sy[2 * y + 1] = v.lo[1] + (v.hi[1] - v.lo[1]) * (float)y / ((float)h - 1.0f); }
+    lens.to_sensor(kUnitView, sx, sy, 2 * h);
+    for (int y = 0; y < h; ++y) {
+        if (!(sx[2 * y] > 0 && sx[2 * y] < wOrg - 1)) off |= kOffLeft;
+        if (!(sx[2 * y + 1] > 0 && sx[2 * y + 1] < wOrg - 1)) off |= kOffRight;
+    }
+    for (int x = 0; x < w; ++x) { sy[2 * x] = v.lo[1]; sy[2 * x + 1] = v.hi[1]; sx[2 * x] = sx[2 * x + 1] = v.lo[0] + (v.hi[0] - v.lo[0]) * (float)x / ((float)w - 1.0f); }
+    lens.to_sensor(kUnitView, sx, sy, 2 * w);
+    for (int x = 0; x < w; ++x) {
+        if (!(sy[2 * x] > 0 && sy[2 * x] < hOrg - 1)) off |= kOffTop;
+        if (!(sy[2 * x + 1] > 0 && sy[2 * x + 1] < hOrg - 1)) off |= kOffBottom;
+    }
+    return off;
+}
+// the largest centred view all of whose borders land on the sensor -> K of the rectified image; false = no such view after 500 rounds (the reference exits)
+bool crop_view(const Lens& lens, int w, int h, int wOrg, int hOrg, double K[4], float* sx, float* sy) {
+    View v;
+    centre_line_extent(lens, 0, wOrg, v.lo[0], v.hi[0]);
+    centre_line_extent(lens, 1, hOrg, v.lo[1], v.hi[1]);
+    for (int a = 0; a < 2; ++a) { v.lo[a] *= 1.01; v.hi[a] *= 1.01; }      // head start: the shrink loop below comes back from outside
+    for (int round = 0;; ++round) {
+        unsigned off = edges_off_sensor(lens, v, w, h, wOrg, hOrg, sx, sy);
+        if (!off) break;
+        if ((off & (kOffLeft | kOffRight)) && (off & (kOffTop | kOffBottom)))  // both axes overflow: only the longer one shrinks this round
+            off &= (v.hi[0] - v.lo[0]) > (v.hi[1] - v.lo[1]) ? (kOffLeft | kOffRight) : (kOffTop | kOffBottom);
+        if (off & kOffLeft) v.lo[0] *= 0.995;
+        if (off & kOffRight) v.hi[0] *= 0.995;
+        if (off & kOffTop) v.lo[1] *= 0.995;
+        if (off & kOffBottom) v.hi[1] *= 0.995;
+        if (round >= 500) return false;
+    }
+    K[0] = ((float)w - 1.0f) / (v.hi[0] - v.lo[0]); K[1] = ((float)h - 1.0f) / (v.hi[1] - v.lo[1]);
+    K[2] = -v.lo[0] * K[0]; K[3] = -v.lo[1] * K[1];
+    return true;
+}
 }  // namespace
 
 int nalo_io_make_rectification(const nalo_camera_file* cam, double K_out[4], float* remapX, float* remapY, int* passthrough) {
     if (!cam || !K_out || !remapX || !remapY || cam->w <= 1 || cam->h <= 1 || cam->w_org <= 1 || cam->h_org <= 1) return NALO_IO_ERR_ARG;
-    Rectifier R; R.model = cam->model;
-    for (int i = 0; i < 8; ++i) R.p[i] = (float)cam->pars[i];
+    const Lens lens(*cam);
     const int w = cam->w, h = cam->h, wOrg = cam->w_org, hOrg = cam->h_org;
+    double K[4];
     int pass = 0;
-    if (cam->rect_mode == -1) {                                                                    // makeOptimalK_crop (:637-757)
-        R.K[0] = R.K[1] = 1; R.K[2] = R.K[3] = 0;                                                  // K.setIdentity()
-        std::vector<float> tgX(100000), tgY(100000);
-        float minX = 0, maxX = 0, minY = 0, maxY = 0;
-        for (int x = 0; x < 100000; ++x) { tgX[x] = (x - 50000.0f) / 10000.0f; tgY[x] = 0; }
-        R.distort(tgX.data(), tgY.data(), tgX.data(), tgY.data(), 100000);
-        for (int x = 0; x < 100000; ++x) if (tgX[x] > 0 && tgX[x] < wOrg - 1) { if (minX == 0) minX = (x - 50000.0f) / 10000.0f; maxX = (x - 50000.0f) / 10000.0f; }
-        for (int y = 0; y < 100000; ++y) { tgY[y] = (y - 50000.0f) / 10000.0f; tgX[y] = 0; }
-        R.distort(tgX.data(), tgY.data(), tgX.data(), tgY.data(), 100000);
-        for (int y = 0; y < 100000; ++y) if (tgY[y] > 0 && tgY[y] < hOrg - 1) { if (minY == 0) minY = (y - 50000.0f) / 10000.0f; maxY = (y - 50000.0f) / 10000.0f; }
-        minX *= 1.01; maxX *= 1.01; minY *= 1.01; maxY *= 1.01;
-        bool oobLeft = true, oobRight = true, oobTop = true, oobBottom = true;
-        int iteration = 0;
-        while (oobLeft || oobRight || oobTop || oobBottom) {
-            oobLeft = oobRight = oobTop = oobBottom = false;
-            for (int y = 0; y < h; ++y) { remapX[y * 2] = minX; remapX[y * 2 + 1] = maxX; remapY[y * 2] = remapY[y * 2 + 1] = minY + (maxY - minY) * (float)y / ((float)h - 1.0f); }
-            R.distort(remapX, remapY, remapX, remapY, 2 * h);
-            for (int y = 0; y < h; ++y) {
-                if (!(remapX[2 * y] > 0 && remapX[2 * y] < wOrg - 1)) oobLeft = true;
-                if (!(remapX[2 * y + 1] > 0 && remapX[2 * y + 1] < wOrg - 1)) oobRight = true;
-            }
-            for (int x = 0; x < w; ++x) { remapY[x * 2] = minY; remapY[x * 2 + 1] = maxY; remapX[x * 2] = remapX[x * 2 + 1] = minX + (maxX - minX) * (float)x / ((float)w - 1.0f); }
-            R.distort(remapX, remapY, remapX, remapY, 2 * w);
-            for (int x = 0; x < w; ++x) {
-                if (!(remapY[2 * x] > 0 && remapY[2 * x] < hOrg - 1)) oobTop = true;
-                if (!(remapY[2 * x + 1] > 0 && remapY[2 * x + 1] < hOrg - 1)) oobBottom = true;
-            }
-            if ((oobLeft || oobRight) && (oobTop || oobBottom)) { if ((maxX - minX) > (maxY - minY)) oobBottom = oobTop = false; else oobLeft = oobRight = false; }
-            if (oobLeft) minX *= 0.995;
-            if (oobRight) maxX *= 0.995;
-            if (oobTop) minY *= 0.995;
-            if (oobBottom) maxY *= 0.995;
-            if (++iteration > 500) return NALO_IO_ERR_FORMAT;                                     // the reference exit(1)s here
-        }
-        R.K[0] = ((float)w - 1.0f) / (maxX - minX); R.K[1] = ((float)h - 1.0f) / (maxY - minY);
-        R.K[2] = -minX * R.K[0]; R.K[3] = -minY * R.K[1];
-    } else if (cam->rect_mode == -2) return NALO_IO_ERR_FORMAT;                                   // makeOptimalK_full: assert(false)
-    else if (cam->rect_mode == -3) {
+    switch (cam->rect_mode) {
+    case -1: if (!crop_view(lens, w, h, wOrg, hOrg, K, remapX, remapY)) return NALO_IO_ERR_FORMAT; break;       // the table buffers double as the probe's scratch (w h >= 2 max(w, h))
+    case -2: return NALO_IO_ERR_FORMAT;                                                                        // makeOptimalK_full: assert(false) in the reference
+    case -3:
         if (w != wOrg || h != hOrg) return NALO_IO_ERR_FORMAT;
-        for (int i = 0; i < 4; ++i) R.K[i] = cam->pars[i];
+        for (int i = 0; i < 4; ++i) K[i] = cam->pars[i];
         pass = 1;
-    } else {
-        R.K[0] = cam->out_calib[0] * w; R.K[1] = cam->out_calib[1] * h; R.K[2] = cam->out_calib[2] * w - 0.5; R.K[3] = cam->out_calib[3] * h - 0.5;
+        break;
+    default: K[0] = cam->out_calib[0] * w; K[1] = cam->out_calib[1] * h; K[2] = cam->out_calib[2] * w - 0.5; K[3] = cam->out_calib[3] * h - 0.5;
     }
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) { remapX[x + y * w] = x; remapY[x + y * w] = y; }
-    R.distort(remapX, remapY, remapX, remapY, h * w);
-    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {                                     // "make rounding resistant" (:972-996), the `ix = hOrg-1.001` slip included
-        float ix = remapX[x + y * w], iy = remapY[x + y * w];
+    lens.to_sensor(K, remapX, remapY, h * w);
+    for (size_t i = 0, n = (size_t)w * h; i < n; ++i) {                                           // "make rounding resistant" (:972-996), the `ix = hOrg-1.001` slip included
+        float ix = remapX[i], iy = remapY[i];
         if (ix == 0) ix = 0.001;
         if (iy == 0) iy = 0.001;
         if (ix == wOrg - 1) ix = wOrg - 1.001;
@@ -409,10 +441,10 @@ int nalo_io_make_rectification(const nalo_camera_file* cam, double K_out[4], flo
         // DEVIATION from the reference: its test is `iy < wOrg-1` (util/Undistort.cpp:980). On a landscape sensor an entry with hOrg-1 <= iy < wOrg-1 stays
         // "valid" there and Undistort::undistort then reads rows behind the image (:497-512: an out-of-bounds read). Such entries are outside here (-1 -> pixel 0),
         // which is also what nalo_undist_set demands of a table; everything the reference defines is unchanged (tests/test_io_cpu.py, tests/test_ingest_gpu.py).
-        if (ix > 0 && iy > 0 && ix < wOrg - 1 && iy < wOrg - 1 && iy < hOrg - 1) { remapX[x + y * w] = ix; remapY[x + y * w] = iy; }
-        else { remapX[x + y * w] = -1; remapY[x + y * w] = -1; }
+        const bool inside = ix > 0 && iy > 0 && ix < wOrg - 1 && iy < wOrg - 1 && iy < hOrg - 1;
+        remapX[i] = inside ? ix : -1; remapY[i] = inside ? iy : -1;
     }
-    for (int i = 0; i < 4; ++i) K_out[i] = R.K[i];
+    for (int i = 0; i < 4; ++i) K_out[i] = K[i];
     if (passthrough) *passthrough = pass;
     return NALO_IO_OK;
 }

@@ -317,6 +317,90 @@ def test_rectification_tables_all_models(lib, tmp_path):
     assert _rectify(lib, cf)[0] == -3
 
 
+def _camera(lib, tmp_path, name, txt):
+    p = tmp_path / (name + ".txt"); p.write_text(txt)
+    cf = CameraFile(); assert lib.nalo_io_read_camera(str(p).encode(), C.byref(cf)) == 0
+    return cf
+
+
+def test_rectification_against_closed_forms(lib, tmp_path):
+    """nalo_io_make_rectification checked against values that come from NO restatement of the reference's code (the oracle's orc_undist.c follows
+    the same source, so agreeing with it proves the transcription, not the geometry):
+      * pinhole crop: the largest centred view of an undistorted sensor is known in closed form - every border of the table lands just inside the sensor,
+      * a model with its distortion switched off IS the pinhole (RadTan with zero coefficients, FOV with omega = 0): identical K and tables,
+      * the tables invert: the ANALYTIC INVERSE of each lens model (FOV: tan; equidistant / Kannala-Brandt: Newton on the theta polynomial, in float64), applied
+        to a table entry, gives back the rectified pixel's viewing ray,
+      * the crop is monotone: more barrel distortion squeezes more field onto the sensor, so the rectified focal length falls,
+      * the crop is tight: growing the accepted view by the search's own step (0.5 %) pushes a border off the sensor."""
+    # ---- pinhole: closed form
+    cf = _camera(lib, tmp_path, "pin", "Pinhole 700.5 690.25 610.2 180.7 0\n1241 376\ncrop\n1224 368\n")
+    rc, K, rx, ry, pt = _rectify(lib, cf)
+    assert rc == 0 and pt == 0
+    fx, fy, cx, cy = list(cf.pars)[:4]
+    yy, xx = np.mgrid[0:cf.h, 0:cf.w]
+    assert np.allclose(rx, fx * (xx - K[2]) / K[0] + cx, atol=2e-3) and np.allclose(ry, fy * (yy - K[3]) / K[1] + cy, atol=2e-3)
+    # the exact largest view would put the borders ON 0 and size-1; the search stops within its 0.5 % step + the 1e-4 sampling of the centre line, strictly inside
+    for lo, hi, size, f in ((rx[:, 0], rx[:, -1], cf.w_org, fx), (ry[0, :], ry[-1, :], cf.h_org, fy)):
+        assert (lo > 0).all() and (hi < size - 1).all()
+        assert lo.max() < 0.006 * size + 2e-4 * f + 1e-2 and hi.min() > size - 1 - 0.006 * size - 2e-4 * f - 1e-2
+    # ---- a lens with its distortion switched off is the pinhole
+    base = "%s 458.654 457.296 367.215 248.375 %s\n752 480\ncrop\n640 480\n"
+    ref = _rectify(lib, _camera(lib, tmp_path, "pin2", base % ("Pinhole", "0")))
+    rad0 = _rectify(lib, _camera(lib, tmp_path, "rad0", base % ("RadTan", "0 0 0 0")))
+    assert ref[0] == 0 and rad0[0] == 0 and np.array_equal(ref[1], rad0[1]) and np.array_equal(ref[2], rad0[2]) and np.array_equal(ref[3], rad0[3])
+    fov0 = _rectify(lib, _camera(lib, tmp_path, "fov0", "458.654 457.296 367.215 248.375 0\n752 480\ncrop\n640 480\n"))       # no prefix + 5 numbers = FOV, omega = 0
+    assert fov0[0] == 0 and np.array_equal(ref[1], fov0[1]) and np.array_equal(ref[2], fov0[2]) and np.array_equal(ref[3], fov0[3])
+    # ---- the tables invert (analytic inverse of each model, float64)
+    def newton_theta(rd, k):                                    # theta (1 + k1 t^2 + k2 t^4 + k3 t^6 + k4 t^8) = rd
+        t = rd.copy()
+        for _ in range(30):
+            t2 = t * t
+            f = t * (1 + k[0] * t2 + k[1] * t2 ** 2 + k[2] * t2 ** 3 + k[3] * t2 ** 4) - rd
+            df = 1 + 3 * k[0] * t2 + 5 * k[1] * t2 ** 2 + 7 * k[2] * t2 ** 3 + 9 * k[3] * t2 ** 4
+            t = t - f / df
+        return t
+    inv_cases = {
+        "fov": ("0.535719308086809 0.669566858850269 0.493248545285398 0.500408664348414 0.897966326944875\n1280 1024\ncrop\n640 480\n",
+                lambda rd, k: np.tan(rd * k[0]) / (2 * np.tan(k[0] / 2))),
+        "equi": ("EquiDistant 190.9 190.9 254.9 256.8 0.003 0.0007 -0.002 0.0002\n512 512\ncrop\n480 480\n", lambda rd, k: np.tan(newton_theta(rd, k))),
+        "kb": ("KannalaBrandt 380.8 380.9 320.1 239.9 -0.01 0.02 -0.03 0.004\n640 480\ncrop\n600 440\n", lambda rd, k: np.tan(newton_theta(rd, k))),
+    }
+    for name, (txt, inverse) in inv_cases.items():
+        cf = _camera(lib, tmp_path, "inv_" + name, txt)
+        rc, K, rx, ry, pt = _rectify(lib, cf)
+        assert rc == 0, name
+        pars = np.array(list(cf.pars))
+        if pars[2] < 1:                                          # relative calibration (Undistort.cpp:765-790): scaled by the sensor size, principal point - 0.5
+            pars[0] *= cf.w_org; pars[1] *= cf.h_org; pars[2] = pars[2] * cf.w_org - 0.5; pars[3] = pars[3] * cf.h_org - 0.5
+        ok = rx >= 0
+        assert ok.mean() > 0.99, name                            # a crop: (all but rounding) every entry is on the sensor
+        yy, xx = np.mgrid[0:cf.h, 0:cf.w]
+        ixn, iyn = (xx - K[2]) / K[0], (yy - K[3]) / K[1]         # the rectified pixel's ray
+        mx, my = (rx.astype(np.float64) - pars[2]) / pars[0], (ry.astype(np.float64) - pars[3]) / pars[1]
+        rd = np.hypot(mx, my)
+        sel = ok & (rd > 1e-3)
+        r_back = inverse(rd[sel], pars[4:8])
+        r_ray = np.hypot(ixn, iyn)[sel]
+        assert np.abs(r_back - r_ray).max() < 2e-4 * max(1.0, r_ray.max()), (name, np.abs(r_back - r_ray).max())
+        # and the direction is kept: the sensor offset is parallel to the ray
+        cross = (mx * iyn - my * ixn)[sel] / (rd[sel] * r_ray)
+        assert np.abs(cross).max() < 2e-4, name
+    # ---- monotone and tight crops (barrel distortion, RadTan k1 < 0; k2 = 0.05 keeps r (1 + k1 r^2 + k2 r^4) monotone, i.e. no fold-over inside the [-5, 5) sweep:
+    # a lens that folds back sends the search outside its 500 rounds, where the reference exits and the product returns NALO_IO_ERR_FORMAT - asserted last)
+    fxs = []
+    for k1 in (-0.1, -0.2, -0.3):
+        cf = _camera(lib, tmp_path, "mono%d" % len(fxs), "RadTan 458.654 457.296 367.215 248.375 %g 0.05 0 0\n752 480\ncrop\n640 480\n" % k1)
+        rc, K, rx, ry, pt = _rectify(lib, cf)
+        assert rc == 0 and (rx >= 0).all()
+        fxs.append((K[0], K[1]))
+        # all four borders on the sensor, and the nearest border point within a few search steps of the sensor's edge on at least one axis
+        slack_x = min(rx[:, 0].min(), cf.w_org - 1 - rx[:, -1].max()) / cf.w_org
+        slack_y = min(ry[0, :].min(), cf.h_org - 1 - ry[-1, :].max()) / cf.h_org
+        assert slack_x > 0 and slack_y > 0 and min(slack_x, slack_y) < 0.012, (k1, slack_x, slack_y)
+    assert fxs[0][0] > fxs[1][0] > fxs[2][0] and fxs[0][1] > fxs[1][1] > fxs[2][1], fxs
+    assert _rectify(lib, _camera(lib, tmp_path, "fold", "RadTan 458.654 457.296 367.215 248.375 -0.05 0 0 0\n752 480\ncrop\n640 480\n"))[0] == -3
+
+
 def test_png_reader_survives_damaged_files(lib, tmp_path):
     """400 mutated / truncated PNGs (byte flips, cut files, overwritten header words incl. absurd sizes): every call returns a code, none crashes or throws
     across the C ABI (a damaged IHDR used to ask for a multi-gigabyte buffer)"""
