@@ -44,6 +44,7 @@ struct BADev {
     uint8_t* pt_ngood;
     float* pt_step;
     float* pt_backup;
+    const float* adF;                           // float adjoints [adHostF (W*W*64) | adTargetF (W*W*64)], index (h + t*W)*64 + i*8 + j (ba_resub_kernel, XMODE 2)
     float* pt_relbs;                            // max relBS over this pass' active residuals (fix mode): the pass' atomicMax target, all zero when the pass starts
     float* pt_relbs_next;                       // the buffer of the NEXT fix pass: zeroed by this pass' idle (target == host) workgroups - no fill launch on the path
     // residual slots [W][Ppad]

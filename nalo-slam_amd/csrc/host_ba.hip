@@ -13,10 +13,9 @@ void ba_launch_reset_oob(hipStream_t s, const BADev& B);
 void ba_launch_restore(hipStream_t s, const BADev& B, const float4* geo, const uint8_t* state, const uint8_t* flags, const float* prior, const float* th);
 void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NPL, double* acc13, double* misc, double* G, bool top, bool sc,
                       const float* step_partial, int step_blocks, double* step_out, bool with_th, double* pub, double seq, unsigned* ticket);
-void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial, const XadArg* karg = nullptr);
+void ba_launch_resub_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, const XadArg& karg, bool karg_is_x);
 int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
-void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg = nullptr);
-void ba_launch_put(hipStream_t s, float* dst, const float* src, int n);
+void ba_launch_resub(hipStream_t s, const BADev& B, const XadArg& karg, bool karg_is_x);
 void ba_launch_pull(hipStream_t s, float* dst, const float* src_mapped, int n);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
@@ -57,7 +56,7 @@ struct BAWindow {
     std::vector<uint8_t> flags_h;
     // device
     BADev dev{};
-    DevBuf<float> pre, frameTH, pt_prior, pt_step, pt_backup, pt_relbs, pt_relbs2, en_new, xad, step_partial;
+    DevBuf<float> pre, frameTH, pt_prior, pt_step, pt_backup, pt_relbs, pt_relbs2, en_new, step_partial;
     DevBuf<double> top_partial, sc_partial;
     unsigned long long pub_seq = 0; bool step_pending = false; int last_canbreak = 0; float st_sumA = 0, st_sumB = 0, st_sumT = 0, st_sumR = 0;
     DevBuf<float4> pt_geo, pt_col0, pt_col1, pt_w0, pt_w1, pt_acc, pt_hcd, rs_jp0, rs_jp1, rs_cpt;
@@ -108,7 +107,7 @@ void ba_destroy(nalo_ctx* c) {
     BAWindow* w = c->ba;
     if (!w) return;
     w->pre.release(); w->frameTH.release(); w->pt_prior.release(); w->pt_step.release(); w->pt_backup.release(); w->pt_relbs.release(); w->pt_relbs2.release();
-    w->th_buf.release(); w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->xad.release(); w->step_partial.release();
+    w->th_buf.release(); w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
     w->blk_host.release(); w->host_blk.release(); w->sc_grp.release(); w->blk_order.release(); w->acc13.release(); w->G.release(); w->AD.release(); w->st_ticket.release();
@@ -213,14 +212,19 @@ static int set_adjoints(nalo_ctx* c) {
     w.sd.ticket = w.st_ticket.p; w.sd.W = W; w.sd.n1 = n1; w.sd.NPL = w.NPL;
     if (!any && w.sd.AD == w.AD.p && w.AD.p) return NALO_OK;        // nothing moved: the device copy is current
     // the stitch kernel reads the fp64 adjoints: AD = [adHost | adTarget]
+    // (behind them, in the same upload: the float adjoints the back-substitution of a window of more than 8 frames builds its xAd rows from)
     const size_t nad = (size_t)2 * W * W * 64;
-    if (w.ad_cap < nad) { if (w.ad_host) (void)hipHostFree(w.ad_host); NALO_HIP(c, hipHostMalloc((void**)&w.ad_host, nad * 8)); w.ad_cap = nad; }
+    if (w.ad_cap < nad) { if (w.ad_host) (void)hipHostFree(w.ad_host); NALO_HIP(c, hipHostMalloc((void**)&w.ad_host, nad * 12)); w.ad_cap = nad; }
     if (!w.ev_ad) NALO_HIP(c, hipEventCreateWithFlags(&w.ev_ad, hipEventDisableTiming));
     else NALO_HIP(c, hipEventSynchronize(w.ev_ad));                  // the previous upload has left the staging buffer
     std::memcpy(w.ad_host, w.adHost.data(), (size_t)W * W * 64 * 8);
     std::memcpy(w.ad_host + (size_t)W * W * 64, w.adTarget.data(), (size_t)W * W * 64 * 8);
-    NALO_HIP(c, w.AD.reserve(nad));
-    NALO_HIP(c, hipMemcpyAsync(w.AD.p, w.ad_host, nad * 8, hipMemcpyHostToDevice, c->stream));
+    float* adf = reinterpret_cast<float*>(w.ad_host + nad);
+    std::memcpy(adf, w.adHostF.data(), (size_t)W * W * 64 * 4);
+    std::memcpy(adf + (size_t)W * W * 64, w.adTargetF.data(), (size_t)W * W * 64 * 4);
+    NALO_HIP(c, w.AD.reserve(nad + nad / 2));
+    NALO_HIP(c, hipMemcpyAsync(w.AD.p, w.ad_host, nad * 12, hipMemcpyHostToDevice, c->stream));
+    w.dev.adF = reinterpret_cast<const float*>(w.AD.p + nad);
     NALO_HIP(c, hipEventRecord(w.ev_ad, c->stream));
     w.sd.AD = w.AD.p;
     return NALO_OK;
@@ -707,6 +711,7 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     for (int h = 0; h < W; ++h) {
         for (int i = 0; i < 8; ++i) w.frames[h].step[i] = -x[4 + 8 * h + i];
         w.frames[h].step[8] = w.frames[h].step[9] = 0;
+        if (W > 8) continue;                                   // larger windows: every back-substitution workgroup builds its host's rows of xAd from x (ba_resub_kernel, XMODE 2)
         for (int t = 0; t < W; ++t) {
             const float *AH = &w.adHostF[(size_t)(h + W * t) * 64], *AT = &w.adTargetF[(size_t)(h + W * t) * 64];
             // xAd = x_h^T adHost + x_t^T adTarget: rows of the adjoints are contiguous in j, so j is the inner (vector) loop; per entry the same
@@ -716,19 +721,16 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
             for (int j = 0; j < 8; ++j) xAd[(size_t)(W * h + t) * 8 + j] = s1[j] + s2[j];
         }
     }
-    NALO_HIP(c, w.xad.reserve((size_t)W * W * 8 + 64));
-    XadArg karg; const XadArg* kp = nullptr;
-    if (W <= 8) {                                              // small window: {xc, xAd} travel as kernel arguments, no copy
-        std::memcpy(karg.v, xc, 16); std::memcpy(karg.v + 4, xAd, (size_t)W * W * 8 * 4);
-        kp = &karg;
-    } else ba_launch_put(c->stream, w.xad.p, xc, W * W * 8 + 64);      // larger windows: as arguments of two or three one-block kernels (a copy packet costs more)
+    XadArg karg;
+    if (W <= 8) { std::memcpy(karg.v, xc, 16); std::memcpy(karg.v + 4, xAd, (size_t)W * W * 8 * 4); }      // small window: {xc, xAd} travel as kernel arguments, no copy
+    else std::memcpy(karg.v, xF, (size_t)n * 4);                 // larger windows: x itself (8W + 4 floats); xAd is built on the device from the float adjoints
     {
         ProfScope ps(c, "ba_resub");
         if (fuse_step) {
             NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
-            ba_launch_resub_step(c->stream, w.dev, w.xad.p + 64, w.xad.p, 1.f, w.step_partial.p, kp);
+            ba_launch_resub_step(c->stream, w.dev, 1.f, w.step_partial.p, karg, W > 8);
             w.step_fused = true;
-        } else ba_launch_resub(c->stream, w.dev, w.xad.p + 64, w.xad.p, kp);
+        } else ba_launch_resub(c->stream, w.dev, karg, W > 8);
     }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;

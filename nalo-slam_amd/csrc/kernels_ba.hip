@@ -809,11 +809,30 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
 // for the break test in `partial` - one launch instead of resubstitute, doStep and a sum kernel.
 // KARG: windows of up to 8 frames get {xc, xAd} (2 KB) as kernel ARGUMENTS (block-uniform: scalar loads from the kernarg segment) - no H2D copy, and
 // its few microseconds of blit + bubble, between the host's solve and this launch.
-template <bool STEP, bool KARG>
-__global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __restrict__ xAd_p, const float* __restrict__ xc_p, XadArg X, float stepfacD, float* __restrict__ partial) {
+// XMODE 2 (round 4): windows of more than 8 frames get x itself (8W + 4 floats) as kernel arguments and every workgroup builds the 8W entries of xAd its host
+// needs from the device copy of the float adjoints (EnergyFunctional.cpp:268-280: xAd[h][t] = x_h^T adHostF + x_t^T adTargetF, the same mul / add sequence as the
+// host loop, uncontracted): the two or three one-block ba_put launches in front of every back-substitution of a 12-frame window are gone.
+template <bool STEP, int XMODE>
+__global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, XadArg X, float stepfacD, float* __restrict__ partial) {
     __shared__ float smem[64 * 4];
-    const float* xc = KARG ? X.v : xc_p;
-    const float* xAd = KARG ? X.v + 4 : xAd_p;
+    __shared__ float xrow[XMODE == 2 ? NALO_MAX_WINDOW * 8 : 1];
+    constexpr bool KARG = XMODE == 1;
+    static_assert(XMODE == 1 || XMODE == 2, "x or xAd arrive as kernel arguments");
+    const float* xc = X.v;
+    const float* xAd = X.v + 4;                                // XMODE 1 only
+    if constexpr (XMODE == 2) {
+        const int hb = B.blk_host[blockIdx.x], W = B.W, tid = threadIdx.x;
+        if (tid < W * 8) {
+            const int t = tid >> 3, j = tid & 7;
+            const float* AH = B.adF + (size_t)(hb + W * t) * 64 + j;
+            const float* AT = B.adF + (size_t)W * W * 64 + (size_t)(hb + W * t) * 64 + j;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1 = __fadd_rn(s1, __fmul_rn(X.v[4 + 8 * hb + i], AH[i * 8])); s2 = __fadd_rn(s2, __fmul_rn(X.v[4 + 8 * t + i], AT[i * 8])); }
+            xrow[tid] = __fadd_rn(s1, s2);
+        }
+        __syncthreads();
+    }
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     float v[3] = {0.f, 0.f, 0.f};
     if (d < B.Ppad && (B.pt_flags[d] & PT_VALID)) {
@@ -861,7 +880,7 @@ __global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, const float* __r
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int t = t0 + i;
-                        const float* xa = xAd + (size_t)(h * W + min(t, W - 1)) * 8;
+                        const float* xa = XMODE == 2 ? xrow + min(t, W - 1) * 8 : xAd + (size_t)(h * W + min(t, W - 1)) * 8;
                         const float term = xa[0] * j0[i].x + xa[1] * j0[i].y + xa[2] * j0[i].z + xa[3] * j0[i].w + xa[4] * j1[i].x + xa[5] * j1[i].y + xa[6] * j1[i].z + xa[7] * j1[i].w;
                         if (rs[i] & RS_ACTIVE) bsum -= term;
                     }
@@ -930,32 +949,20 @@ void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int
     const int nb = n > 32768 ? 32 : (n + 1023) / 1024;
     ba_publish_kernel<<<nb < 1 ? 1 : nb, 256, 0, s>>>(src, dst_mapped, n, seq, ticket);
 }
-// up to 992 floats as kernel arguments -> device memory: the step of a window too large for XadArg reaches the device without a copy packet (and the bubble around it)
-struct BaPutArg { float v[992]; };
-__global__ __launch_bounds__(1024) void ba_put_kernel(float* __restrict__ dst, BaPutArg a, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = a.v[threadIdx.x]; }
-void ba_launch_put(hipStream_t s, float* dst, const float* src, int n) {
-    for (int o = 0; o < n; o += 992) {
-        BaPutArg a;
-        const int m = n - o < 992 ? n - o : 992;
-        std::memcpy(a.v, src + o, (size_t)m * 4);
-        ba_put_kernel<<<1, 1024, 0, s>>>(dst + o, a, m);
-    }
-}
 // mapped host memory -> device memory by ONE workgroup: the precalc records of a large window (10-23 KB). A copy packet of that size costs 4 us plus ~6 us of
 // pipeline bubble before the next kernel of the stream; the workgroup pulls the block over PCIe in one round of 16-byte loads
 __global__ __launch_bounds__(1024) void ba_pull_kernel(float4* __restrict__ dst, const float4* __restrict__ src_mapped, int n4) {
     for (int i = threadIdx.x; i < n4; i += 1024) dst[i] = src_mapped[i];
 }
 void ba_launch_pull(hipStream_t s, float* dst, const float* src_mapped, int n) { ba_pull_kernel<<<1, 1024, 0, s>>>((float4*)dst, (const float4*)src_mapped, (n + 3) / 4); }
-void ba_launch_resub(hipStream_t s, const BADev& B, const float* xAd, const float* xc, const XadArg* karg) {
-    static const XadArg none{};
-    if (karg) ba_resub_kernel<false, true><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, nullptr, nullptr, *karg, 0.f, nullptr);
-    else ba_resub_kernel<false, false><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, none, 0.f, nullptr);
+// karg: {xc, xAd} of a window of <= 8 frames, or (karg_is_x) the solution x itself for larger ones
+void ba_launch_resub(hipStream_t s, const BADev& B, const XadArg& karg, bool karg_is_x) {
+    if (karg_is_x) ba_resub_kernel<false, 2><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, 0.f, nullptr);
+    else ba_resub_kernel<false, 1><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, 0.f, nullptr);
 }
-void ba_launch_resub_step(hipStream_t s, const BADev& B, const float* xAd, const float* xc, float stepfacD, float* partial, const XadArg* karg) {
-    static const XadArg none{};
-    if (karg) ba_resub_kernel<true, true><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, nullptr, nullptr, *karg, stepfacD, partial);
-    else ba_resub_kernel<true, false><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, xAd, xc, none, stepfacD, partial);
+void ba_launch_resub_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, const XadArg& karg, bool karg_is_x) {
+    if (karg_is_x) ba_resub_kernel<true, 2><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, stepfacD, partial);
+    else ba_resub_kernel<true, 1><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, stepfacD, partial);
 }
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3) {
     const int nb = (B.Ppad + 255) / 256;
