@@ -891,7 +891,7 @@ def launch_stats(samples_us, per_keyframe=8, every=1):
 
 def load_traffic(workload):
     """HBM bytes per ba_linearize launch from the committed PMC summary (profiles/traffic_*.json), or None."""
-    for name in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):          # the newest committed measurement wins
+    for name in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):          # the newest committed measurement wins
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
@@ -1127,6 +1127,10 @@ def imm_leg(per_host=1500, rounds=5, cpu=True):
     c.sync()
     t_res = (time.perf_counter() - t0) / rounds
     t0 = time.perf_counter()
+    for _ in range(rounds):                                     # the same call, completion of every frame's trace waited for (a caller that needs the result per frame)
+        c.imm_resident_trace(W, KRKi, Kt, aff); c.sync()
+    t_res_sync = (time.perf_counter() - t0) / rounds
+    t0 = time.perf_counter()
     c.imm_resident_get()
     t_get = time.perf_counter() - t0
     idt = true_idepth(win, u, v, host)
@@ -1140,7 +1144,11 @@ def imm_leg(per_host=1500, rounds=5, cpu=True):
     ms2, nl2 = c.profile_get("imm_optimize")
     c.close()
     res = {"points": n, "hosts": W, "image": "%dx%d" % (win.w, win.h),
-           "trace_kernel_us": round(ms / max(nl, 1) * 1e3, 1), "trace_call_us": round(t_call * 1e6, 1), "trace_Mpoints_per_s_kernel": round(n / (ms / max(nl, 1) * 1e-3) / 1e6, 2),
+           # trace_call_us = the DEFAULT path: the device-resident set (uploaded once per keyframe by makeNewTraces / activation), one call per frame,
+           # completion waited for; trace_resident_us_per_frame = the same calls queued without waiting; trace_staged_call_us = the one-call form that moves all
+           # 30 floats per point of the caller-owned arrays both ways on every call (rounds 1-3 reported that one as trace_call_us)
+           "trace_kernel_us": round(ms / max(nl, 1) * 1e3, 1), "trace_call_us": round(t_res_sync * 1e6, 1), "trace_staged_call_us": round(t_call * 1e6, 1),
+           "trace_Mpoints_per_s_kernel": round(n / (ms / max(nl, 1) * 1e-3) / 1e6, 2),
            "trace_resident_us_per_frame": round(t_res * 1e6, 1), "resident_get_us": round(t_get * 1e6, 1),
            "trace_status_counts": np.bincount(g[2], minlength=6).tolist(),
            "optimize_kernel_us": round(ms2 / max(nl2, 1) * 1e3, 1), "optimize_call_us": round(t_opt * 1e6, 1), "activated": int((ro[0] == 1).sum())}

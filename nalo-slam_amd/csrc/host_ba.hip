@@ -281,11 +281,13 @@ static int set_precalc(nalo_ctx* c) {
     }
     const float fx = w.c_scaledf[0], fy = w.c_scaledf[1], cx = w.c_scaledf[2], cy = w.c_scaledf[3];
     const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1}, Ki[9] = {1.0f / fx, 0, -cx / fx, 0, 1.0f / fy, -cy / fy, 0, 0, 1};
+    SE3 evalInv[NALO_MAX_WINDOW];                                          // W inverses, not W^2 (this runs between the back-substitution and the next linearisation of every iteration)
+    for (int h = 0; h < W; ++h) evalInv[h] = w.frames[h].evalPT.inverse();
     for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {
         float* o = rec + (size_t)(h * W + t) * kPreStride;
         std::memset(o, 0, kPreStride * 4);
         const HostFrame &host = w.frames[h], &target = w.frames[t];
-        const SE3 l0 = target.evalPT * host.evalPT.inverse();
+        const SE3 l0 = target.evalPT * evalInv[h];
         const SE3 ll = target.PRE_worldToCam * host.PRE_camToWorld;
         float R[9], tt[3], KR[9];
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) { o[12 + i * 3 + j] = (float)l0.R(i, j); R[i * 3 + j] = (float)ll.R(i, j); } o[21 + i] = (float)l0.t(i); tt[i] = (float)ll.t(i); }
