@@ -42,6 +42,24 @@ WORKLOADS = {
 }
 
 
+class c_stdout_to_stderr:
+    """librccl prints a version banner on the C-level stdout when its first communicator is made; stdout belongs to the ONE JSON line: file descriptor 1 points
+    at stderr while RCCL initialises"""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.keep = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.keep, 1)
+        os.close(self.keep)
+
+
 def log(msg):
     print("[bench rank %s] %s" % (os.environ.get("RANK", "0"), msg), file=sys.stderr, flush=True)
 
@@ -81,7 +99,8 @@ class GpuJob:
         self.ctx.ba_set_residuals(win.exists)
         if isinstance(hook, tuple):                                      # ("rccl", nranks, rank, id_main, id_side): the library's own RCCL exchange
             _, nranks, rk, id_main, id_side = hook
-            self.ctx.ba_rccl_init(nranks, rk, id_main, id_side)
+            with c_stdout_to_stderr():
+                self.ctx.ba_rccl_init(nranks, rk, id_main, id_side)
         elif hook is not None:                                           # rehearsal path: hook = factory(ctx) -> Python all-reduce callable
             fn = hook(self.ctx)
             so = getattr(fn, "stream_ordered", False)
@@ -622,59 +641,59 @@ def main():
                 print(json.dumps(out, default=str), flush=True)
             watchdog.cancel()
             os._exit(4)
-            if world == 1:
-                leg_state["leg"] = "stress250k"
-                try:
-                    out["stress250k"] = stress_leg()
-                except Exception as e:              # never lose the main line to an extra leg
-                    out["stress250k"] = {"error": repr(e)}
-                log("stress250k leg done")
-                leg_state["leg"] = "frontend"
-                try:
-                    out["frontend_rooflines"] = frontend_legs()
-                except Exception as e:
-                    out["frontend_rooflines"] = {"error": repr(e)}
-                log("front-end roofline legs done")
-                leg_state["leg"] = "immature"
-                try:
-                    out["immature"] = imm_leg(cpu=not args.no_cpu_baseline)
-                except Exception as e:
-                    out["immature"] = {"error": repr(e)}
-                log("immature leg done")
-                leg_state["leg"] = "pixel_selector"
-                try:
-                    out["pixel_selector"] = pixsel_leg(cpu=not args.no_cpu_baseline)
-                except Exception as e:
-                    out["pixel_selector"] = {"error": repr(e)}
-                log("pixel selector leg done")
-                leg_state["leg"] = "initializer"
-                try:
-                    out["initializer"] = init_leg(cpu=not args.no_cpu_baseline)
-                except Exception as e:
-                    out["initializer"] = {"error": repr(e)}
-                log("initializer leg done")
-                # The KITTI-sized launch moves 6 MB (0.8 us at 8 TB/s): it is launch-latency bound by construction. The kernel's
-                # roofline position is therefore reported on the largest single-GPU window of this same run (configs[3]);
-                # the figure of the headline workload stays next to it.
-                sl = out["stress250k"].get("ba_linearize")
-                if sl:
-                    out["roofline_kitti00_8kf"] = out["roofline"]
-                    out["roofline"] = dict(kernel="ba_linearize", workload="stress250k", note="the KITTI-sized launch is latency bound (see roofline_kitti00_8kf, same kernel, measured over the timed region); "
-                                           "this is the same kernel on the largest single-GPU window (configs[3]) inside this run",
-                                           ceiling=dict(what="pure tap gathers of the same residual list, nothing else, from the layout the kernel uses: 12-byte texels in 5x2 tiles of 128 bytes (scripts/ubench/gather.hip layout J, "
-                                                             "profiles/r02_ubench_gather_12B.log; 16-byte texels row major: 175 us, in 4x2 tiles: 153 us, 12-byte row major: 152 us)",
-                                                        gather_only_us=131.5, frac_of_hbm_roofline=round(768e6 / 131.5e-6 / 1e9 / HBM_PEAK_GBS, 3),
-                                                        note="the gather rate saturates at 3-4 waves/SIMD (row major: 1: 252, 2: 199, 3: 180, 4: 176, 8: 175 us): bound by the miss path of sparse gathers (31 k points per 2 Mpx frame), not by latency, "
-                                                             "vector ALU (IEEE vs rcp division: same time) or HBM (traffic < algorithmic bytes); the kernel's waves spend ~40 % of their life outside the gather phase, "
-                                                             "which is the distance to this ceiling (DESIGN.md 3)"),
-                                           bound="hbm", achieved=sl["achieved_GBs"], peak=HBM_PEAK_GBS,
-                                           unit="GB/s", frac=sl["frac"], traffic=load_traffic("stress250k"), avg_us=sl["avg_us"],
-                                           launches=sl["launches"], alg_bytes=sl["alg_bytes"], stats=sl.get("stats"), stats_ba_only_loop=sl.get("stats_ba_only_loop"),
-                                           measured_over=sl.get("measured_over"),
-                                           reproduce="python bench.py --workload stress250k --no-extra --no-cpu-baseline runs the same full steps as its main leg; its rocprofv3 --kernel-trace --stats summary is profiles/INDEX.json -> roofline")
-                    if hbm_copy:
-                        out["roofline"].update(measured_copy_GBs=round(hbm_copy, 1), measured_triad_GBs=round(hbm_triad, 1), frac_of_measured_copy=round(sl["achieved_GBs"] / hbm_copy, 4),
-                                               measured_note="nalo_hbm_calibrate in this run: copy = 2 x 1 GiB / t, triad = 3 x 1 GiB / t, 10 passes, HIP events")
+        if rank == 0 and world == 1:
+            leg_state["leg"] = "stress250k"
+            try:
+                out["stress250k"] = stress_leg()
+            except Exception as e:              # never lose the main line to an extra leg
+                out["stress250k"] = {"error": repr(e)}
+            log("stress250k leg done")
+            leg_state["leg"] = "frontend"
+            try:
+                out["frontend_rooflines"] = frontend_legs()
+            except Exception as e:
+                out["frontend_rooflines"] = {"error": repr(e)}
+            log("front-end roofline legs done")
+            leg_state["leg"] = "immature"
+            try:
+                out["immature"] = imm_leg(cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                out["immature"] = {"error": repr(e)}
+            log("immature leg done")
+            leg_state["leg"] = "pixel_selector"
+            try:
+                out["pixel_selector"] = pixsel_leg(cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                out["pixel_selector"] = {"error": repr(e)}
+            log("pixel selector leg done")
+            leg_state["leg"] = "initializer"
+            try:
+                out["initializer"] = init_leg(cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                out["initializer"] = {"error": repr(e)}
+            log("initializer leg done")
+            # The KITTI-sized launch moves 6 MB (0.8 us at 8 TB/s): it is launch-latency bound by construction. The kernel's
+            # roofline position is therefore reported on the largest single-GPU window of this same run (configs[3]);
+            # the figure of the headline workload stays next to it.
+            sl = out["stress250k"].get("ba_linearize")
+            if sl:
+                out["roofline_kitti00_8kf"] = out["roofline"]
+                out["roofline"] = dict(kernel="ba_linearize", workload="stress250k", note="the KITTI-sized launch is latency bound (see roofline_kitti00_8kf, same kernel, measured over the timed region); "
+                                       "this is the same kernel on the largest single-GPU window (configs[3]) inside this run",
+                                       ceiling=dict(what="pure tap gathers of the same residual list, nothing else, from the layout the kernel uses: 12-byte texels in 5x2 tiles of 128 bytes (scripts/ubench/gather.hip layout J, "
+                                                         "profiles/r02_ubench_gather_12B.log; 16-byte texels row major: 175 us, in 4x2 tiles: 153 us, 12-byte row major: 152 us)",
+                                                    gather_only_us=131.5, frac_of_hbm_roofline=round(768e6 / 131.5e-6 / 1e9 / HBM_PEAK_GBS, 3),
+                                                    note="the gather rate saturates at 3-4 waves/SIMD (row major: 1: 252, 2: 199, 3: 180, 4: 176, 8: 175 us): bound by the miss path of sparse gathers (31 k points per 2 Mpx frame), not by latency, "
+                                                         "vector ALU (IEEE vs rcp division: same time) or HBM (traffic < algorithmic bytes); the kernel's waves spend ~40 % of their life outside the gather phase, "
+                                                         "which is the distance to this ceiling (DESIGN.md 3)"),
+                                       bound="hbm", achieved=sl["achieved_GBs"], peak=HBM_PEAK_GBS,
+                                       unit="GB/s", frac=sl["frac"], traffic=load_traffic("stress250k"), avg_us=sl["avg_us"],
+                                       launches=sl["launches"], alg_bytes=sl["alg_bytes"], stats=sl.get("stats"), stats_ba_only_loop=sl.get("stats_ba_only_loop"),
+                                       measured_over=sl.get("measured_over"),
+                                       reproduce="python bench.py --workload stress250k --no-extra --no-cpu-baseline runs the same full steps as its main leg; its rocprofv3 --kernel-trace --stats summary is profiles/INDEX.json -> roofline")
+                if hbm_copy:
+                    out["roofline"].update(measured_copy_GBs=round(hbm_copy, 1), measured_triad_GBs=round(hbm_triad, 1), frac_of_measured_copy=round(sl["achieved_GBs"] / hbm_copy, 4),
+                                           measured_note="nalo_hbm_calibrate in this run: copy = 2 x 1 GiB / t, triad = 3 x 1 GiB / t, 10 passes, HIP events")
         watchdog.cancel()
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -777,7 +796,8 @@ def rccl_setup(dist, rank, world, backend="nccl"):
     if backend != "nccl":
         import torch
         return lambda ctx, side=False: make_hook(dist, torch, backend, stream=ctx.side_stream if side else ctx.stream)
-    ids = [binding.rccl_unique_id(), binding.rccl_unique_id()] if rank == 0 else [None, None]
+    with c_stdout_to_stderr():
+        ids = [binding.rccl_unique_id(), binding.rccl_unique_id()] if rank == 0 else [None, None]
     if world > 1:
         dist.broadcast_object_list(ids, src=0)
     return ("rccl", world, rank, ids[0], ids[1])
