@@ -44,6 +44,7 @@ struct BADev {
     uint8_t* pt_ngood;
     float* pt_step;
     float* pt_backup;
+    const unsigned* gate_p; unsigned* gate_err; unsigned gate_p_want;   // ba_linearize_kernel: NULL, or the gate of its precalc records (GateBlock::p_seq)
     const float* adF;                           // float adjoints [adHostF (W*W*64) | adTargetF (W*W*64)], index (h + t*W)*64 + i*8 + j (ba_resub_kernel, XMODE 2)
     float* pt_relbs;                            // max relBS over this pass' active residuals (fix mode): the pass' atomicMax target, all zero when the pass starts
     float* pt_relbs_next;                       // the buffer of the NEXT fix pass: zeroed by this pass' idle (target == host) workgroups - no fill launch on the path
@@ -71,6 +72,37 @@ struct BADev {
 
 // {xc (4) | xAd [W*W][8]} of resubstituteFPt for windows of up to 8 frames, passed by value as kernel arguments (ba_resub_kernel)
 struct XadArg { float v[4 + 8 * 64]; };
+
+// Gate of a kernel that is enqueued BEFORE its inputs exist (round 4, small single-GPU windows): the host still solves the system while the back-substitution and
+// the next linearisation already sit in the stream; each spins (one lane per workgroup, bounded) on a word of host-mapped memory until the host has written the
+// inputs - the step {xc, xAd}, the precalc records - and then the sequence number. What it saves per Gauss-Newton iteration is the launch latency of the two
+// kernels on the critical path (the device starts ~1.5 us after the host's store instead of 5-6 us after its launch call). 0xFFFFFFFF = cancelled: the kernel returns
+// without touching anything (the host's error paths), as it does when the bound expires (and then raises err).
+struct GateBlock { unsigned x_seq, p_seq, err, pad[13]; float x[4 + NALO_MAX_WINDOW * NALO_MAX_WINDOW * 8]; };
+constexpr unsigned kGateCancel = 0xFFFFFFFFu;
+struct GateArg { const unsigned* flag; unsigned* err; const float* x; unsigned want; };
+__device__ __forceinline__ bool gate_wait(const unsigned* flag, unsigned want, unsigned* err) {      // one lane; true = the inputs are there
+    // RELAXED system-scope loads (always served by the host's memory) + a compiler barrier: an ACQUIRE at system scope invalidates the L2 on every poll, and the
+    // kernel behind the gate then finds its points, residuals and texels gone (measured: 46 -> 96 us per iteration). Nothing the gate orders lives in a device
+    // cache: the inputs are in host-mapped memory, read after the loop in program order (the hardware does not issue loads past an unresolved branch).
+    // First a SCALAR load - the path the precalc records themselves take (scalar cache + L2, shared by the workgroups): a gate that is already open (the
+    // linearisation's usually is: the host wrote its records while the back-substitution ran) then costs what one more record word costs. 256 workgroups asking
+    // the host for one word with cache-bypassing loads are served one after the other, ~75 ns each (measured: 15 -> 34 us per gated linearisation; a volatile load is
+    // the same sc0 sc1 access). The value is unique per launch: a cached copy can only be an older, closed one, and falls through to the polling loop.
+    {
+        unsigned v0;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v0) : "s"(flag) : "memory");
+        if (v0 == want) { __atomic_signal_fence(__ATOMIC_ACQUIRE); return true; }
+    }
+    for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+        const unsigned v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v == want) { __atomic_signal_fence(__ATOMIC_ACQUIRE); return true; }
+        if (v == kGateCancel) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return false;
+}
 
 // What may ride along with ba_reduce_kernel: the newest frame's energy threshold of a small window (one more workgroup: ba_th_small's body) and, on a misc-only
 // fetch, the publication of the tail {misc, step sums, TH, 1.0} + sequence number into host-mapped memory by the last workgroup to finish

@@ -16,6 +16,7 @@ void ba_launch_reduce(hipStream_t s, const BADev& B, const int* host_blk, int NP
 void ba_launch_resub_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, const XadArg& karg, bool karg_is_x);
 int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, double* mapped, int ntail, double seq);
 void ba_launch_resub(hipStream_t s, const BADev& B, const XadArg& karg, bool karg_is_x);
+void ba_launch_resub_step_gated(hipStream_t s, const BADev& B, float stepfacD, float* partial, const GateArg& gate);
 void ba_launch_pull(hipStream_t s, float* dst, const float* src_mapped, int n);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
@@ -87,6 +88,9 @@ struct BAWindow {
     std::vector<HostFrame> snap_frames; std::vector<double> snap_HM, snap_bM; std::vector<uint8_t> snap_flags_h; bool have_snap = false;
     double snap_calib[4] = {}, snap_calib_scaled[4] = {}; float snap_scaledf[4] = {}, snap_scaledi[4] = {};   // CalibHessian as it is: a fresh window holds value_scaled = K exactly,
                                                                     // setValue(value) would round it through SCALE_F * (SCALE_F_INVERSE * K)
+    // small single-GPU windows: the back-substitution and the next linearisation of optimize() are enqueued BEFORE the host has solved the system (ba_device.h: GateBlock)
+    GateBlock* gate_h = nullptr; GateBlock* gate_d = nullptr; unsigned gate_x_seq = 0, gate_p_seq = 0;
+    bool want_prelaunch = false, resub_pre = false, lin_pre = false;
     nalo_allreduce_fn hook = nullptr;
     void* hook_user = nullptr;
     bool hook_stream_ordered = false;                               // the hook enqueues its collective on nalo_stream(ctx): no host synchronisation around it
@@ -115,6 +119,7 @@ void ba_destroy(nalo_ctx* c) {
     if (w->ev_lin) (void)hipEventDestroy(w->ev_lin);
     if (w->ev_th) (void)hipEventDestroy(w->ev_th);
     w->snap_geo.release(); w->snap_state.release(); w->snap_flags.release(); w->snap_prior.release();
+    if (w->gate_h) (void)hipHostFree(w->gate_h);
     if (w->stitched_host) (void)hipHostFree(w->stitched_host);
     if (w->up_host) (void)hipHostFree(w->up_host);
     for (float* p : w->pre_map) if (p) (void)hipHostFree(p);
@@ -303,7 +308,12 @@ static int set_precalc(nalo_ctx* c) {
     cal[0] = fx; cal[1] = fy; cal[2] = cx; cal[3] = cy; cal[4] = w.c_scaledi[0]; cal[5] = w.c_scaledi[1];
     for (int i = 0; i < 4; ++i) cal[6 + i] = w.cDeltaF[i];
     NALO_HIP(c, w.pre.reserve(nfl + 32));
-    if (direct) { w.dev.pre = w.pre_map_dev[w.pre_pos & 3]; w.dev.calib = w.dev.pre + nfl; return NALO_OK; }
+    if (direct) {
+        w.dev.pre = w.pre_map_dev[w.pre_pos & 3]; w.dev.calib = w.dev.pre + nfl;
+        // a linearisation that was enqueued ahead of these records waits for this word (x86 stores are not reordered with earlier stores; the fence keeps the compiler honest)
+        if (w.lin_pre && w.gate_h) { __atomic_thread_fence(__ATOMIC_RELEASE); __atomic_store_n(&w.gate_h->p_seq, w.gate_p_seq, __ATOMIC_RELEASE); }
+        return NALO_OK;
+    }
     ba_launch_pull(c->stream, w.pre.p, w.pre_map_dev[w.pre_pos & 3], (int)(nfl + 16));
     NALO_HIP(c, hipGetLastError());
     w.dev.pre = w.pre.p; w.dev.calib = w.pre.p + nfl;
@@ -364,6 +374,14 @@ static int ensure_tiled(nalo_ctx* c) {
 }
 static int linearize_async(nalo_ctx* c, int mode, int fix, bool keep_th = false) {
     BAWindow& w = *c->ba;
+    if (w.lin_pre) {
+        // the kernel of this pass is already in the stream (prelaunch_iteration), and set_precalc has just opened its gate: what is left is the bookkeeping
+        w.lin_pre = false;
+        if (mode != 0 || fix != 0 || keep_th) return fail(c, NALO_ERR_STATE, "linearize_async: a pre-enqueued pass is a plain linearizeAll(false)");
+        w.th_pending = true;
+        w.have_lin = true; w.have_sc = false; w.stitched_top = false; w.stitched_sc = false;
+        return NALO_OK;
+    }
     { int rc = ensure_tiled(c); if (rc) return rc; }
     if (keep_th) {
         w.dev.no_th = 1;
@@ -468,6 +486,53 @@ static int sc_async(nalo_ctx* c, int shift, float margScale, int margOnly) {
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;
 }
+// optimize() on a small single-GPU window: with the systems of iteration k on their way to the host, the two kernels that will follow the host's solve - the
+// back-substitution + point step and the linearisation at the stepped states - are enqueued NOW, each behind a gate in host-mapped memory (ba_device.h: GateBlock).
+// The host then solves, writes {xc, xAd} and opens the first gate (solve_system), steps its frame states, writes the precalc records and opens the second
+// (set_precalc): the device picks both up ~1.5 us after the stores instead of 5-6 us after a launch call - the two launch latencies that sat on the critical
+// path of every Gauss-Newton iteration (FullSystemOptimize.cpp:478-545 is one serial chain of such steps).
+static bool prelaunch_eligible(const nalo_ctx* c, const BAWindow& w) {
+    return !w.hook && c->set.forceAcceptStep && w.points_set && w.Ppad <= 32768 && w.W <= 8;
+}
+static int prelaunch_iteration(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    if (!w.gate_h) {
+        NALO_HIP(c, hipHostMalloc((void**)&w.gate_h, sizeof(GateBlock), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(w.gate_h, 0, sizeof(GateBlock));
+        NALO_HIP(c, hipHostGetDevicePointer((void**)&w.gate_d, w.gate_h, 0));
+    }
+    if (w.pre_pos + 1 - 4 > w.pre_synced || !w.pre_map_dev[0]) return NALO_OK;    // the ring slot of the next records may still have readers: this iteration launches the ordinary way
+    if (++w.gate_x_seq == kGateCancel) w.gate_x_seq = 1;
+    if (++w.gate_p_seq == kGateCancel) w.gate_p_seq = 1;
+    {
+        ProfScope ps(c, "ba_resub");
+        NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
+        const GateArg g{&w.gate_d->x_seq, &w.gate_d->err, w.gate_d->x, w.gate_x_seq};
+        ba_launch_resub_step_gated(c->stream, w.dev, 1.f, w.step_partial.p, g);
+    }
+    w.resub_pre = true;
+    {
+        BADev D = w.dev;                                       // the records this pass will read: the ring slot set_precalc takes next
+        const size_t nfl = (size_t)w.W * w.W * kPreStride;
+        D.pre = w.pre_map_dev[(w.pre_pos + 1) & 3]; D.calib = D.pre + nfl;
+        D.gate_p = &w.gate_d->p_seq; D.gate_err = &w.gate_d->err; D.gate_p_want = w.gate_p_seq;
+        ProfScope ps(c, "ba_linearize", true);
+        ba_launch_linearize(c->stream, D, 0, 0, ps.a, ps.b);
+    }
+    w.lin_pre = true;
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+// error paths: no kernel may be left spinning on a gate nobody will open
+static void prelaunch_cancel(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    if (!(w.resub_pre || w.lin_pre) || !w.gate_h) return;
+    __atomic_store_n(&w.gate_h->x_seq, kGateCancel, __ATOMIC_RELEASE); __atomic_store_n(&w.gate_h->p_seq, kGateCancel, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize(c->stream);
+    w.resub_pre = w.lin_pre = false; w.want_prelaunch = false;
+    w.have_lin = false; w.have_sc = false;
+}
+
 // fp64 finish + stitch of whichever system is not stitched yet; then (optionally) the cross-rank sum and the D2H copy
 // misc_only: the caller wants the per-bin {count, energy} and the threshold, not the systems: finish the partials, skip the stitch, publish the tail
 static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to_host = false, bool misc_only = false) {
@@ -549,7 +614,9 @@ static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to
             NALO_HIP(c, hipGetLastError());
         }
         { int rc = flush_th(c); if (rc) return rc; }                  // behind the publish: overlaps the host's solve
+        if (w.want_prelaunch) { w.want_prelaunch = false; int rc = prelaunch_iteration(c); if (rc) return rc; }
         if (!poll_flag(c, &w.stitched_host[npub], seq)) return NALO_ERR_HIP;
+        if (w.gate_h && w.gate_h->err) return fail(c, NALO_ERR_HIP, "a pre-enqueued kernel gave up waiting for its inputs (gate timeout)");
         w.pre_synced = w.pre_pos;                               // everything launched on the main stream so far has run (the side stream reads no precalc record)
         if (w.step_pending) {                                   // finish doStepFromBackup's break test with the sums of the last step
             const double* s3 = w.stitched_host + 2 * blk + 2 * W * W;
@@ -663,7 +730,9 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
         }
     }
     int rc;
+    w.want_prelaunch = fuse_step && W <= 8 && prelaunch_eligible(c, w);
     { HostTimer h2(c, "ba.solve.fetch_wait"); rc = stitch_and_fetch(c, true, true); }
+    w.want_prelaunch = false;
     if (rc) return rc;
     HostTimer h3(c, "ba.solve.host_math");
     // H = (HL + HM + HA) with the diagonal * (1+lambda), minus Hsc/(1+lambda); b = bL + (bM + HM delta) + bA - bsc   (:795-868), then the Jacobi scaling
@@ -722,6 +791,14 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
             for (int i = 0; i < 8; ++i) { const float xh = xF[4 + 8 * h + i], xt = xF[4 + 8 * t + i]; for (int j = 0; j < 8; ++j) { s1[j] += xh * AH[i * 8 + j]; s2[j] += xt * AT[i * 8 + j]; } }
             for (int j = 0; j < 8; ++j) xAd[(size_t)(W * h + t) * 8 + j] = s1[j] + s2[j];
         }
+    }
+    if (w.resub_pre) {                                          // the kernel is already in the stream, spinning on its gate: hand it {xc, xAd} and open
+        w.resub_pre = false;
+        std::memcpy(w.gate_h->x, xc, 16); std::memcpy(w.gate_h->x + 4, xAd, (size_t)W * W * 8 * 4);
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        __atomic_store_n(&w.gate_h->x_seq, w.gate_x_seq, __ATOMIC_RELEASE);
+        w.step_fused = true;
+        return NALO_OK;
     }
     XadArg karg;
     if (W <= 8) { std::memcpy(karg.v, xc, 16); std::memcpy(karg.v + 4, xAd, (size_t)W * W * 8 * 4); }      // small window: {xc, xAd} travel as kernel arguments, no copy
@@ -1064,7 +1141,13 @@ static int optimize_epilogue(nalo_ctx* c, double* rmse) {
     return NALO_OK;
 }
 
+static int optimize_impl(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse);
 int nalo_ba_optimize(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse) {
+    const int rc = optimize_impl(c, mnumOptIts, never_break, rmse);
+    if (c && c->ba && (c->ba->resub_pre || c->ba->lin_pre)) prelaunch_cancel(c);      // an error between the pre-launch and its gates: nothing stays behind spinning
+    return rc;
+}
+static int optimize_impl(nalo_ctx* c, int mnumOptIts, int never_break, double* rmse) {
     NALO_BA_READY("nalo_ba_optimize")
     HostTimer ht(c, "ba_optimize");
     const int W = w.W;

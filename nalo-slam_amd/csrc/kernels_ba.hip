@@ -813,13 +813,25 @@ int ba_launch_stitch(hipStream_t s, const StitchDev& D, bool top, bool sc, doubl
 // needs from the device copy of the float adjoints (EnergyFunctional.cpp:268-280: xAd[h][t] = x_h^T adHostF + x_t^T adTargetF, the same mul / add sequence as the
 // host loop, uncontracted): the two or three one-block ba_put launches in front of every back-substitution of a 12-frame window are gone.
 template <bool STEP, int XMODE>
-__global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, XadArg X, float stepfacD, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, XadArg X, GateArg G, float stepfacD, float* __restrict__ partial) {
     __shared__ float smem[64 * 4];
-    __shared__ float xrow[XMODE == 2 ? NALO_MAX_WINDOW * 8 : 1];
+    __shared__ float xrow[XMODE >= 2 ? NALO_MAX_WINDOW * 8 + 4 : 1];
     constexpr bool KARG = XMODE == 1;
-    static_assert(XMODE == 1 || XMODE == 2, "x or xAd arrive as kernel arguments");
-    const float* xc = X.v;
+    static_assert(XMODE >= 1 && XMODE <= 3, "x or xAd arrive as kernel arguments, or (3) through the gate block");
+    const float* xc = XMODE == 3 ? xrow + NALO_MAX_WINDOW * 8 : X.v;
     const float* xAd = X.v + 4;                                // XMODE 1 only
+    if constexpr (XMODE == 3) {
+        // enqueued while the host still solves the system (ba_device.h: GateBlock): wait for {xc, xAd} in host-mapped memory, then this host's row of xAd -> LDS
+        __shared__ int gate_ok;
+        const int tid = threadIdx.x, W = B.W;
+        if (tid == 0) gate_ok = gate_wait(G.flag, G.want, G.err) ? 1 : 0;
+        __syncthreads();
+        if (!gate_ok) return;
+        const int hb = B.blk_host[blockIdx.x];
+        if (tid < W * 8) xrow[tid] = __hip_atomic_load(&G.x[4 + (size_t)hb * W * 8 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else if (tid >= 252) xrow[NALO_MAX_WINDOW * 8 + tid - 252] = __hip_atomic_load(&G.x[tid - 252], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+    }
     if constexpr (XMODE == 2) {
         const int hb = B.blk_host[blockIdx.x], W = B.W, tid = threadIdx.x;
         if (tid < W * 8) {
@@ -842,7 +854,7 @@ __global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, XadArg X, float 
             const float4 pa = B.pt_acc[d], hc = B.pt_hcd[d];
             float bsum = pa.w;
             bsum -= xc[0] * hc.x + xc[1] * hc.y + xc[2] * hc.z + xc[3] * hc.w;
-            if constexpr (KARG) {                               // small window: 8 targets' slots in flight at once, subtracted in target order
+            if constexpr (KARG || XMODE == 3) {                 // small window: 8 targets' slots in flight at once, subtracted in target order
                 for (int t0 = 0; t0 < W; t0 += 8) {
                     uint8_t rs[8]; float4 j0[8], j1[8];
 #pragma unroll
@@ -856,7 +868,7 @@ __global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, XadArg X, float 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int t = t0 + i;
-                        const float* xa = xAd + (size_t)(h * W + min(t, W - 1)) * 8;           // uniform address, loaded whatever the lane's residual state
+                        const float* xa = XMODE == 3 ? xrow + min(t, W - 1) * 8 : xAd + (size_t)(h * W + min(t, W - 1)) * 8;           // uniform address, loaded whatever the lane's residual state
                         const float term = xa[0] * j0[i].x + xa[1] * j0[i].y + xa[2] * j0[i].z + xa[3] * j0[i].w + xa[4] * j1[i].x + xa[5] * j1[i].y + xa[6] * j1[i].z + xa[7] * j1[i].w;
                         if (t < W && t != h && (rs[i] & RS_ACTIVE)) bsum -= term;
                     }
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, XadArg X, float 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int t = t0 + i;
-                        const float* xa = XMODE == 2 ? xrow + min(t, W - 1) * 8 : xAd + (size_t)(h * W + min(t, W - 1)) * 8;
+                        const float* xa = XMODE >= 2 ? xrow + min(t, W - 1) * 8 : xAd + (size_t)(h * W + min(t, W - 1)) * 8;
                         const float term = xa[0] * j0[i].x + xa[1] * j0[i].y + xa[2] * j0[i].z + xa[3] * j0[i].w + xa[4] * j1[i].x + xa[5] * j1[i].y + xa[6] * j1[i].z + xa[7] * j1[i].w;
                         if (rs[i] & RS_ACTIVE) bsum -= term;
                     }
@@ -957,12 +969,19 @@ __global__ __launch_bounds__(1024) void ba_pull_kernel(float4* __restrict__ dst,
 void ba_launch_pull(hipStream_t s, float* dst, const float* src_mapped, int n) { ba_pull_kernel<<<1, 1024, 0, s>>>((float4*)dst, (const float4*)src_mapped, (n + 3) / 4); }
 // karg: {xc, xAd} of a window of <= 8 frames, or (karg_is_x) the solution x itself for larger ones
 void ba_launch_resub(hipStream_t s, const BADev& B, const XadArg& karg, bool karg_is_x) {
-    if (karg_is_x) ba_resub_kernel<false, 2><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, 0.f, nullptr);
-    else ba_resub_kernel<false, 1><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, 0.f, nullptr);
+    const GateArg none{};
+    if (karg_is_x) ba_resub_kernel<false, 2><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, none, 0.f, nullptr);
+    else ba_resub_kernel<false, 1><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, none, 0.f, nullptr);
 }
 void ba_launch_resub_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, const XadArg& karg, bool karg_is_x) {
-    if (karg_is_x) ba_resub_kernel<true, 2><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, stepfacD, partial);
-    else ba_resub_kernel<true, 1><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, stepfacD, partial);
+    const GateArg none{};
+    if (karg_is_x) ba_resub_kernel<true, 2><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, none, stepfacD, partial);
+    else ba_resub_kernel<true, 1><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, karg, none, stepfacD, partial);
+}
+// the same back-substitution + step, enqueued AHEAD of the solve: {xc, xAd} arrive through the gate block (small windows, <= 8 frames)
+void ba_launch_resub_step_gated(hipStream_t s, const BADev& B, float stepfacD, float* partial, const GateArg& gate) {
+    static const XadArg none{};
+    ba_resub_kernel<true, 3><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, none, gate, stepfacD, partial);
 }
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3) {
     const int nb = (B.Ppad + 255) / 256;

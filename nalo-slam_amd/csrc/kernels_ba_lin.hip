@@ -366,6 +366,18 @@ __global__ __launch_bounds__(WG, NALO_LIN_COOP_WAVES) void ba_linearize_kernel(B
     __shared__ __attribute__((aligned(16))) float smem[(WG / 4) * kTopStride];
     static_assert(16 * kTopStride * 4 >= 4 * 65 * 16, "a wave's reduction rows must hold its exchange buffer");
     const int tid = threadIdx.x;
+    if (B.gate_p) {                                                     // enqueued ahead of its precalc records (ba_device.h: GateBlock): wait for the host's word, bounded
+        if constexpr (WG == 64) {
+            int ok = 1;
+            if (tid == 0) ok = gate_wait(B.gate_p, B.gate_p_want, B.gate_err) ? 1 : 0;
+            if (!__builtin_amdgcn_readfirstlane(ok)) return;
+        } else {
+            __shared__ int gate_ok;
+            if (tid == 0) gate_ok = gate_wait(B.gate_p, B.gate_p_want, B.gate_err) ? 1 : 0;
+            __syncthreads();
+            if (!gate_ok) return;
+        }
+    }
     const LinWhere w = lin_where<WG>(B, tid);
     if (w.skip) return;
     if (w.t == w.h) {                                                   // no self residuals; the newest frame's own points have no entry
