@@ -1069,6 +1069,14 @@ def frontend_legs(rounds=30):
     res["ingest"]["note"] = ("nalo_frame_upload_raw: G[raw] * vignetteMapInv at the four taps of every rectified pixel (bilinear remap), one pass; the frame crosses PCIe "
                              "at 1 B/px (%.2f MB) instead of 4 B/px; avg_us is the kernel, the call also pays the copy and the pyramid" % (wo * ho / 1e6))
     c.close()
+    # HBM traffic per launch from the committed counter passes (profiles/traffic_r04.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of scripts/diag/frontend_prof.py)
+    for leg, keys in (("pyramid", ("fe_pyramid", "fe_pyramid_tail")), ("ingest", ("fe_ingest",)), ("dense_map", ("fe_dense_rows", "fe_dense_count", "fe_dense_write")),
+                      ("trk_eval_250k", ("fe_trk_eval",)), ("trk_eval_full_density", ("fe_trk_eval",))):
+        if isinstance(res.get(leg), dict):
+            t = [load_traffic(k2) for k2 in keys]
+            res[leg]["traffic"] = None if any(v is None for v in t) else int(sum(t))
+            if leg.startswith("trk_eval"):
+                res[leg]["traffic_note"] = "counter mean over BOTH tracker-evaluation legs of the profiled script (250 k points and full density)"
     return res
 
 

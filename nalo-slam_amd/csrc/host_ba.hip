@@ -734,6 +734,11 @@ static int solve_system(nalo_ctx* c, int iteration, double lambda, double* x_out
     { HostTimer h2(c, "ba.solve.fetch_wait"); rc = stitch_and_fetch(c, true, true); }
     w.want_prelaunch = false;
     if (rc) return rc;
+    {   // tests: the error path BETWEEN a pre-launch and its gates (tests/test_ba_gpu.py, child process): the second solve of the process fails here, once
+        static const bool test_cancel = std::getenv("NALO_BA_TEST_GATE_CANCEL") != nullptr;
+        static int solves = 0;
+        if (test_cancel && w.resub_pre && ++solves == 2) return fail(c, NALO_ERR_HIP, "test: failure between a pre-launch and its gates");
+    }
     HostTimer h3(c, "ba.solve.host_math");
     // H = (HL + HM + HA) with the diagonal * (1+lambda), minus Hsc/(1+lambda); b = bL + (bM + HM delta) + bA - bsc   (:795-868), then the Jacobi scaling
     // (:872-885): TWO passes over the published systems (the diagonal first: the scaling needs it), written straight into the padded, scaled matrix the

@@ -266,3 +266,57 @@ def test_profile_select_brackets_one_scope(small_window):
     assert c.profile_get("ba_linearize")[1] == 1 and c.profile_get("ba_sc")[1] == 1
     c.profile_enable(False)
     c.close()
+
+
+_GATE_CANCEL_SCRIPT = r"""
+import json, sys
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, root + "/tests")
+import numpy as np
+import nalo_pkg; nalo_pkg.load()
+from nalo_slam_amd import binding, synth
+win = synth.make_window(w=640, h=480, W=5, P=1200, seed=31)
+st6 = synth.perturbed_poses(win, sigma_t=0.004, sigma_r=0.0004)
+def make():
+    c = binding.Context(win.w, win.h, win.K, n_slots=win.W)
+    for i in range(win.W):
+        c.frame_upload(i, win.images[i])
+    c.ba_set_window(list(range(win.W)), win.world_to_cam[:win.W], state6=st6)
+    c.ba_set_points(win.host, win.u, win.v, win.idepth, win.color, win.weights)
+    c.ba_set_residuals(win.exists)
+    c.ba_snapshot()
+    return c
+c = make()
+out = {}
+try:
+    c.ba_optimize(6, never_break=True)
+    out["first"] = "no error"
+except RuntimeError as e:
+    out["first"] = str(e)
+c.sync()                                    # nothing is left spinning: the stream drains
+c.ba_restore()
+out["rmse_after"] = c.ba_optimize(6, never_break=True)
+out["w2c_after"] = np.asarray(c.ba_get_frames()[1]).tolist()
+c.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_error_between_a_prelaunch_and_its_gates_leaves_nothing_spinning(tmp_path):
+    """optimize() enqueues the back-substitution and the next linearisation of a small window AHEAD of the host's solve, each behind a gate in host-mapped memory
+    (host_ba.hip: prelaunch_iteration). An error between the pre-launch and the gates must not leave those kernels waiting: nalo_ba_optimize cancels them (they
+    return without touching anything), the stream drains, and the context goes on - a restore + optimize gives, bit for bit, what a fresh process computes.
+    NALO_BA_TEST_GATE_CANCEL makes the second solve of a process fail in exactly that spot; the env is read once per process, hence the child process."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "gate_cancel.py"
+    script.write_text(_GATE_CANCEL_SCRIPT)
+    runs = {}
+    for name, extra in (("plain", {}), ("cancel", {"NALO_BA_TEST_GATE_CANCEL": "1"})):
+        env = dict({k: v for k, v in os.environ.items() if k != "NALO_BA_TEST_GATE_CANCEL"}, **extra)
+        p = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert runs["plain"]["first"] == "no error"
+    assert "between a pre-launch and its gates" in runs["cancel"]["first"]
+    assert runs["cancel"]["rmse_after"] == runs["plain"]["rmse_after"] and np.array_equal(np.asarray(runs["cancel"]["w2c_after"]), np.asarray(runs["plain"]["w2c_after"]))
