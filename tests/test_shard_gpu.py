@@ -202,3 +202,26 @@ def test_failed_exchange_stops_the_context():
     assert n_calls[0] == 4
     c.ba_set_allreduce(None)
     c.close()
+
+
+def test_bench_gpus_2_runs_two_ranks_end_to_end(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it must run two ranks end to end: the parent starts fresh rank processes before any GPU call,
+    the ranks rendezvous on 127.0.0.1, every rank runs the headline window (replicas) and its share of the sharded window with the exchange through the
+    all-reduce hooks, and rank 0 prints ONE line with n_gpus = 2. One GPU here, so both ranks sit on device 0 and the exchange is the gloo rehearsal hook
+    (RCCL refuses two ranks on one device): the line says so (rccl_ranks null, exchange 'python hook'); with --backend nccl on N GPUs the same code prints
+    rccl_ranks = ncclCommCount and exits non-zero when it differs from N."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NALO_BENCH_ONE_DEVICE="1", NALO_BENCH_SHARD_P="40000")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launcher"] == "self" and d["scaling"] == "weak" and d["value"] > 0
+    s = d["shard1m"]
+    assert s["n_gpus"] == 2 and s["process_group_ranks"] == 2 and s["scaling"] == "strong" and s["keyframes_per_s"] > 0 and d["value_shard1m"] == s["keyframes_per_s"]
+    assert s["rccl_ranks"] is None and "rehearsal" in s["exchange"]
+    assert abs(s["points_per_rank"] - 20000) <= 8 and s["active_points"] == 40000
