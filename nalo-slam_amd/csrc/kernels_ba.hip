@@ -828,8 +828,9 @@ __global__ __launch_bounds__(256) void ba_resub_kernel(BADev B, XadArg X, GateAr
         __syncthreads();
         if (!gate_ok) return;
         const int hb = B.blk_host[blockIdx.x];
-        if (tid < W * 8) xrow[tid] = __hip_atomic_load(&G.x[4 + (size_t)hb * W * 8 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        else if (tid >= 252) xrow[NALO_MAX_WINDOW * 8 + tid - 252] = __hip_atomic_load(&G.x[tid - 252], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ordinary coalesced loads (first touch of these lines in this kernel, after the gate: what the host wrote); cache-bypassing loads are one host request per lane
+        if (tid < W * 8) xrow[tid] = G.x[4 + (size_t)hb * W * 8 + tid];
+        else if (tid >= 252) xrow[NALO_MAX_WINDOW * 8 + tid - 252] = G.x[tid - 252];
         __syncthreads();
     }
     if constexpr (XMODE == 2) {
