@@ -450,9 +450,9 @@ def main():
     # measured in a separate, untimed pass right after.
     mode = os.environ.get("NALO_BENCH_PROFILE", "dominant")      # dominant | all | none
     job.ctx.profile_select("ba_linearize" if mode == "dominant" else None)
-    # one launch in three is bracketed (co-prime with the 8 linearisations of a keyframe, so every position of the loop is sampled): all eight cost 4-6 % of a
-    # step on this latency-bound window (NALO_BENCH_PROFILE=none vs dominant: 760-768 vs 715-740 keyframes/s on one box); the stress250k leg brackets every launch
-    lin_every = int(os.environ.get("NALO_BENCH_PROFILE_EVERY", "3")) if (mode == "dominant" and args.workload == "kitti00_8kf") else 1
+    # one launch in NINE is bracketed (co-prime with the 8 linearisations of a keyframe, so every position of the loop is sampled): all eight cost 4-6 % of a
+    # step on this latency-bound window, one in three 0.7 %, one in nine 0.3 % (round 4, same box: 881.9 / 885.7 / 888.3 keyframes/s for 3 / 9 / none); the stress250k leg brackets every launch
+    lin_every = int(os.environ.get("NALO_BENCH_PROFILE_EVERY", "9")) if (mode == "dominant" and args.workload == "kitti00_8kf") else 1
     job.ctx.profile_sample(lin_every)
     job.ctx.profile_enable(mode != "none")
     job.ctx.profile_reset()
