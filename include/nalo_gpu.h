@@ -60,7 +60,8 @@ void* nalo_stream(nalo_ctx* ctx);                 /* hipStream_t every kernel of
  * the reference's CLI (main_dso_pangolin.cpp:400-460 changes exactly these: mode=1 sets the affine modes to 0, mode=2 to -1).
  *   forceAcceptStep   setting_forceAceptStep (:71, default 1). 0: FullSystem::optimize linearises WITHOUT applyRes, compares
  *                     E + calcLEnergy + calcMEnergy against the last accepted values and either applies the step or restores the backup
- *                     (FullSystemOptimize.cpp:511-541). Not offered on a sharded window (NALO_ERR_UNSUPPORTED).
+ *                     (FullSystemOptimize.cpp:511-541). On a sharded window the scalars of that test are summed over the ranks through the all-reduce hook
+ *                     (three more calls of 1, 1 and 3 doubles per evaluation), so every rank takes the same branch.
  *   affineOptModeA/B  setting_affineOptModeA / B (:128-129, defaults 1e12 / 1e8): >= 0 = prior on a / b of every frame but the first
  *                     (FrameHessian::getPrior, HessianBlocks.h:286-312), < 0 = fixed: the prior becomes setting_initialAffAPrior / BPrior, JabF[0] / JabF[1]
  *                     are zeroed (Residuals.cpp:241-242), the tracker solves the reduced 6x6 / 7x7 system (CoarseTracker.cpp:1140-1162, host LM loop) and

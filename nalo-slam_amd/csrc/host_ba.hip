@@ -19,6 +19,7 @@ void ba_launch_resub(hipStream_t s, const BADev& B, const XadArg& karg, bool kar
 void ba_launch_resub_step_gated(hipStream_t s, const BADev& B, float stepfacD, float* partial, const GateArg& gate);
 void ba_launch_pull(hipStream_t s, float* dst, const float* src_mapped, int n);
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3);
+void ba_launch_step_sums(hipStream_t s, const BADev& B, const float* partial, double* out3);
 void ba_launch_publish(hipStream_t s, const double* src, double* dst_mapped, int n, double seq, unsigned* ticket);
 void ba_launch_th_install(hipStream_t s, const double* tail2, float* th);
 void ba_launch_th_tail(hipStream_t s, const float* th, double* tail2);
@@ -101,6 +102,7 @@ struct BAWindow {
                                                                     // stitch sums it WITH the systems in one all-reduce, anything else that needs the threshold sums it alone
     size_t lo_off = 0;
     bool never_break = false;
+    DevBuf<double> small_sum;                                        // a few scalars on their way through the all-reduce hook (sum_over_ranks)
     DevBuf<double> noapply_E; std::vector<double> noapply_h;          // energy partials of a linearisation that is not applied (forceAcceptStep = false)
     int opt_iterations = 0, opt_rejected = 0;
     bool prior_next = false;                                        // nalo_ba_marginalize_frame has left HM / bM for the NEXT nalo_ba_set_window (kept or extended there)
@@ -111,7 +113,7 @@ void ba_destroy(nalo_ctx* c) {
     BAWindow* w = c->ba;
     if (!w) return;
     w->pre.release(); w->frameTH.release(); w->pt_prior.release(); w->pt_step.release(); w->pt_backup.release(); w->pt_relbs.release(); w->pt_relbs2.release();
-    w->th_buf.release(); w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->step_partial.release();
+    w->small_sum.release(); w->th_buf.release(); w->en_new.release(); w->top_partial.release(); w->sc_partial.release(); w->step_partial.release();
     w->pt_geo.release(); w->pt_col0.release(); w->pt_col1.release(); w->pt_w0.release(); w->pt_w1.release(); w->pt_acc.release(); w->pt_hcd.release();
     w->rs_jp0.release(); w->rs_jp1.release(); w->rs_cpt.release(); w->rs_energy.release(); w->rs_pp0.release(); w->rs_pp1.release(); w->pt_flags.release(); w->pt_ngood.release(); w->rs_state.release();
     w->blk_host.release(); w->host_blk.release(); w->sc_grp.release(); w->blk_order.release(); w->acc13.release(); w->G.release(); w->AD.release(); w->st_ticket.release();
@@ -327,6 +329,20 @@ static int call_hook(nalo_ctx* c, nalo_allreduce_fn fn, void* user, double* buf,
     if (c->xchg_failed) return NALO_ERR_HIP;                          // message already in c->err
     return NALO_OK;
 }
+// n (<= 8) host scalars summed over the ranks of a sharded window, in place; a single-GPU window returns at once. What the energy test of
+// setting_forceAceptStep = false needs beyond the systems: the energy of a linearisation that is not applied, the point part of calcLEnergyPt and the step sums of
+// doStepFromBackup's break test are all sums over the active points, i.e. over the shards (FullSystemOptimize.cpp:511-541, EnergyFunctional.cpp:332-392)
+static int sum_over_ranks(nalo_ctx* c, double* v, int n) {
+    BAWindow& w = *c->ba;
+    if (!w.hook) return NALO_OK;
+    NALO_HIP(c, w.small_sum.reserve(8));
+    NALO_HIP(c, hipMemcpyAsync(w.small_sum.p, v, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    if (!w.hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
+    { int rh = call_hook(c, w.hook, w.hook_user, w.small_sum.p, n); if (rh) return rh; }
+    NALO_HIP(c, hipMemcpyAsync(v, w.small_sum.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    return NALO_OK;
+}
 static int flush_th(nalo_ctx* c);
 static int upload_frame_th(nalo_ctx* c) {
     BAWindow& w = *c->ba;
@@ -441,6 +457,7 @@ static int linearize_noapply(nalo_ctx* c, double* E) {
     NALO_HIP(c, hipMemcpyAsync(w.noapply_h.data(), w.noapply_E.p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     double s = 0; for (double v : w.noapply_h) s += v;
+    { int rs = sum_over_ranks(c, &s, 1); if (rs) return rs; }
     *E = s;
     return NALO_OK;
 }
@@ -457,6 +474,7 @@ static int calc_l_energy(nalo_ctx* c, double* E) {
     NALO_HIP(c, hipMemcpyAsync(part.data(), w.noapply_E.p, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     double ep = 0; for (double v : part) ep += v;
+    { int rs = sum_over_ranks(c, &ep, 1); if (rs) return rs; }         // the frame / calibration part above is the same on every rank (frames replicate)
     *E = e + (double)(float)ep;                                       // E.finish(): Accumulator11 holds a float
     return NALO_OK;
 }
@@ -842,8 +860,11 @@ static int do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float fD
     }
     NALO_HIP(c, w.step_partial.reserve((size_t)(w.Ppad / 256 + 1) * 4));
     double* out3 = w.stitched.p + 2 * (size_t)w.n1 * w.n1 + 2 * w.W * w.W;      // scratch tail of the stitched buffer
-    if (w.step_fused) { w.step_fused = false; w.step_sums_deferred = true; }     // points already stepped by solve_system (fD = 1); sums follow with the reduce
-    else ba_launch_step(c->stream, w.dev, fD, w.step_partial.p, out3);
+    if (w.step_fused) {                                                        // points already stepped by solve_system (fD = 1)
+        w.step_fused = false;
+        if (canbreak) ba_launch_step_sums(c->stream, w.dev, w.step_partial.p, out3);     // the caller wants the break test now (round 4: it read the sums of the step before)
+        else w.step_sums_deferred = true;                                      // optimize(): the sums follow with the next reduce launch
+    } else ba_launch_step(c->stream, w.dev, fD, w.step_partial.p, out3);
     int rc = set_precalc(c);
     if (rc) return rc;
     sumA /= w.W; sumB /= w.W; sumR /= w.W; sumT /= w.W;
@@ -853,6 +874,7 @@ static int do_step(nalo_ctx* c, float fC, float fT, float fR, float fA, float fD
         double s3[3];
         NALO_HIP(c, hipMemcpyAsync(s3, out3, 24, hipMemcpyDeviceToHost, c->stream));
         NALO_HIP(c, hipStreamSynchronize(c->stream));
+        { int rs = sum_over_ranks(c, s3, 3); if (rs) return rs; }
         const float numID = (float)s3[2];
         const float sumNID = numID > 0 ? (float)(s3[1] / numID) : 0.f;
         const float th = kThOptIterations;
@@ -1162,7 +1184,7 @@ static int optimize_impl(nalo_ctx* c, int mnumOptIts, int never_break, double* r
     if (!c->set.forceAcceptStep) {
         // setting_forceAceptStep = false: every linearisation is an energy evaluation first (FIX = 2: nothing but state_NewEnergy and the threshold input
         // changes) and is applied only if E + E_L + E_M decreased; a rejected step restores the backup (:511-541). Host-driven, one sync per evaluation.
-        if (w.hook) return fail(c, NALO_ERR_UNSUPPORTED, "nalo_ba_optimize: forceAcceptStep = 0 is not offered on a sharded window");
+        // (a sharded window: the three scalars of the energy test are summed over the ranks, sum_over_ranks; every rank then takes the same accept / reject branch)
         ba_launch_reset_oob(c->stream, w.dev);
         double lastE, lastL, lastM;
         int rc = linearize_noapply(c, &lastE); if (rc) return rc;            // :436-438

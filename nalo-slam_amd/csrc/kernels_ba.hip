@@ -984,6 +984,8 @@ void ba_launch_resub_step_gated(hipStream_t s, const BADev& B, float stepfacD, f
     static const XadArg none{};
     ba_resub_kernel<true, 3><<<(B.Ppad + 255) / 256, 256, 0, s>>>(B, none, gate, stepfacD, partial);
 }
+// the three step sums of a back-substitution that stepped the points itself (ba_resub_kernel<true, ..>), for a caller that wants the break test NOW
+void ba_launch_step_sums(hipStream_t s, const BADev& B, const float* partial, double* out3) { ba_sum_partials_kernel<<<1, 1024, 0, s>>>(partial, (B.Ppad + 255) / 256, 4, 3, out3); }
 void ba_launch_step(hipStream_t s, const BADev& B, float stepfacD, float* partial, double* out3) {
     const int nb = (B.Ppad + 255) / 256;
     ba_step_kernel<<<nb, 256, 0, s>>>(B, stepfacD, partial);

@@ -71,20 +71,6 @@ def test_optimize_with_energy_test(carried, sigma):
     c.close()
 
 
-def test_energy_test_rejected_on_sharded_window(carried):
-    win, x = carried
-    ba, c = make_pair(win, x["st6"], x["aff"], x["has_prior"], x["idz"], x["calib_zero"], x["HM"], x["bM"])
-    c.set_settings(force_accept_step=False)
-    hook = binding.ALLREDUCE_FN(lambda user, buf, n: None) if hasattr(binding, "ALLREDUCE_FN") else None
-    if hook is None:
-        pytest.skip("no hook type exported by the binding")
-    c._hook_keepalive = hook
-    c._ck(c.L.nalo_ba_set_allreduce(c.h_, hook, None))
-    with pytest.raises(binding.NaloError):
-        c.ba_optimize(6)
-    c.close()
-
-
 @pytest.mark.parametrize("modes", [(0.0, 0.0), (-1.0, -1.0), (1e12, -1.0), (-1.0, 1e8)], ids=["no_prior", "fix_ab", "fix_b", "fix_a"])
 def test_affine_modes_in_the_bundle_adjustment(carried, modes):
     win, x = carried

@@ -180,6 +180,61 @@ def test_second_fetch_of_a_pass_sums_only_what_it_stitched():
     assert np.abs(a["x2"] - ref["x2"]).max() < 2e-3 * np.abs(ref["x2"]).max()
 
 
+@pytest.mark.parametrize("sigma", [0.004, 0.03])
+def test_energy_test_on_a_sharded_window(sigma):
+    """setting_forceAceptStep = false on a SHARDED window (missing #4: rounds 2-3 returned NALO_ERR_UNSUPPORTED): every linearisation is an energy
+    evaluation first and is applied only if E + E_L + E_M decreased (FullSystemOptimize.cpp:511-541). The three scalars of that test - the energy of the
+    unapplied linearisation, the point part of calcLEnergyPt (EnergyFunctional.cpp:332-392), the step sums of the break test - are sums over the active points,
+    so each is summed over the ranks (host_ba.hip: sum_over_ranks) and every rank takes the same branch: same accept / reject sequence and poses as ONE context
+    holding the whole window; the ranks agree bit for bit."""
+    win = synth.make_window(w=640, h=480, W=5, P=1500, seed=12)
+    st6 = synth.perturbed_poses(win, sigma_t=sigma, sigma_r=sigma / 10)
+    full = make_ctx(win, st6)
+    full.set_settings(force_accept_step=False)
+    r_full = full.ba_optimize(6)
+    stats_full = full.ba_optimize_stats()
+    w2c_full = full.ba_get_frames()[1].copy()
+    full.close()
+    world = 2
+    bar = threading.Barrier(world)
+    bufs, out, err = [None] * world, [None] * world, []
+
+    def rank_job(r):
+        try:
+            c = make_ctx(bench.shard(win, r, world), st6)
+            c.set_settings(force_accept_step=False)
+
+            def hook(ptr, n):
+                t = torch.as_tensor(_Ptr(ptr, n), device="cuda")
+                bufs[r] = t.cpu()
+                bar.wait()
+                tot = bufs[0] + bufs[1]
+                bar.wait()
+                t.copy_(tot)
+                torch.cuda.synchronize()
+            c.ba_set_allreduce(hook)
+            rm = c.ba_optimize(6)
+            out[r] = dict(rmse=rm, stats=c.ba_optimize_stats(), w2c=c.ba_get_frames()[1].copy())
+            c.ba_set_allreduce(None)
+            c.close()
+        except Exception as ex:
+            err.append(ex)
+            bar.abort()
+
+    ts = [threading.Thread(target=rank_job, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not err, err
+    a, b = out
+    assert a["stats"] == b["stats"] == stats_full, (a["stats"], stats_full)                 # the same iterations, the same rejections
+    assert a["rmse"] == b["rmse"] and abs(a["rmse"] - r_full) < 1e-4 * r_full
+    for f in range(win.W):
+        assert np.array_equal(a["w2c"][f], b["w2c"][f])
+        assert np.abs(a["w2c"][f] - w2c_full[f]).max() < 3e-5
+    if sigma > 0.01:
+        assert stats_full[1] > 0, stats_full                                             # the large perturbation really exercises the reject branch
+
+
 def test_failed_exchange_stops_the_context():
     """a collective that fails must not be ignored. The hook has no return value; it reports through nalo_ba_exchange_failed (what the built-in RCCL hooks
     do on an ncclAllReduce error, host_rccl.hip): the call that issued the hook and every later BA call of the context fail with NALO_ERR_HIP instead of solving with
