@@ -264,11 +264,11 @@ static int set_precalc(nalo_ctx* c) {
     }
     // Small windows (the KITTI-sized ones, latency bound): no copy. The H2D blit of these 8 KB sat between the back-substitution and the next linearisation
     // with ~10 us of pipeline gaps around it plus ~5 us of runtime calls on the host; the kernels read the records from mapped host memory instead (scalar
-    // loads, a few hundred bytes per workgroup over PCIe: +2 us inside ba_linearize).
-    // Round 4: the records are fetched from the host once per XCD (its L2 keeps them for the launch), i.e. W^2 x 160 B x 8 over PCIe per linearisation: 3 us at W = 8,
-    // 7 us at W = 12, against ~10 us of pull kernel + kernel boundary + its launch on the host's path. Same-box A/B: stress250k (W = 8, 7.8 k workgroups) 2.064 -> 2.002 ms
-    // per keyframe with the records read in place; the emulated N = 8 shard of the 12-frame window 1.72 -> 1.76 ms: windows of more than 8 frames keep the pull.
-    const bool direct = w.points_set && (w.Ppad <= 32768 || W <= 8);
+    // loads, a few hundred bytes per workgroup over PCIe: +2 us inside ba_linearize). Large windows keep the device copy (thousands of workgroups).
+    // Round 4, measured and NOT kept for large windows: read in place there too, the records are fetched from the host once per XCD (its L2 keeps them for the launch),
+    // W^2 x 160 B x 8 over PCIe per linearisation = 3 us at W = 8, 7 us at W = 12, INSIDE ba_linearize (the roofline kernel: 161 -> 164-171 us on stress250k), against ~10 us
+    // of pull kernel + boundary beside it: stress250k 2.064 -> 2.002 ms per keyframe, the emulated N = 8 shard of the 12-frame window 1.72 -> 1.76 ms (same-box A/B).
+    const bool direct = w.points_set && w.Ppad <= 32768;
     // Either way the records are written into a ring of four mapped, coherent host blocks (a block's last readers may still run: the ring is what lets do_step ->
     // set_precalc and the epilogue's set_precalc follow each other without a wait). Large windows: ONE workgroup pulls the block into device memory (ba_pull_kernel)
     // instead of a copy packet + its event.
