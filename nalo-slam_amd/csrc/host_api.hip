@@ -73,7 +73,7 @@ void nalo_destroy(nalo_ctx* c) {
         c->trk_idepth[l].release(); c->trk_wsum[l].release(); c->trk_wbak[l].release();
         c->pc_u[l].release(); c->pc_v[l].release(); c->pc_id[l].release(); c->pc_col[l].release();
     }
-    c->dense_lb.release(); c->trk_partial.release(); c->trk_out.release(); c->lm_partial.release(); c->trk_shard_sums.release(); c->scan_tmp.release(); c->trk_cnt.release(); c->upload_tmp.release();
+    c->dense_lb.release(); c->trk_partial.release(); c->trk_ticket.release(); c->trk_out.release(); c->lm_partial.release(); c->trk_shard_sums.release(); c->scan_tmp.release(); c->trk_cnt.release(); c->upload_tmp.release();
     if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
     if (c->pinned_f) (void)hipHostFree(c->pinned_f);
     if (c->imm_host) (void)hipHostFree(c->imm_host);

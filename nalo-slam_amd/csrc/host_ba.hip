@@ -52,6 +52,7 @@ struct BAWindow {
     std::vector<float> adHostF, adTargetF, adHTdeltaF;
     float cDeltaF[4] = {};
     bool proj_valid = false;
+    bool ad_pending = false;               // the host adjoint tables are newer than the device copy (upload_adjoints)
     int resInA = 0, resInL = 0, resInM = 0;
     // permutation: device slot d -> caller point (or -1), caller point -> device slot
     std::vector<int> d2p, p2d, blk_host_h, host_blk_h;
@@ -171,7 +172,9 @@ static void frame_take_data(const nalo_settings& set, HostFrame& f) {     // EFF
 }
 
 // EnergyFunctional::setAdjointsF (OptimizationBackend/EnergyFunctional.cpp:46-106); the values feed the stitch matrices
-static int set_adjoints(nalo_ctx* c) {
+static int upload_adjoints(nalo_ctx* c);
+// defer = true (the epilogue of optimize()): the host tables are rebuilt now, the device copy follows behind the epilogue's own kernels (none of them reads it)
+static int set_adjoints(nalo_ctx* c, bool defer = false) {
     BAWindow& w = *c->ba;
     HostTimer ht(c, "ba.set_adjoints");
     const int W = w.W, n1 = w.n1;
@@ -217,7 +220,14 @@ static int set_adjoints(nalo_ctx* c) {
     w.proj_valid = false;
     if (!w.st_ticket.p) { NALO_HIP(c, w.st_ticket.reserve(4)); NALO_HIP(c, hipMemset(w.st_ticket.p, 0, 16)); }
     w.sd.ticket = w.st_ticket.p; w.sd.W = W; w.sd.n1 = n1; w.sd.NPL = w.NPL;
-    if (!any && w.sd.AD == w.AD.p && w.AD.p) return NALO_OK;        // nothing moved: the device copy is current
+    if (!any && w.sd.AD == w.AD.p && w.AD.p && !w.ad_pending) return NALO_OK;        // nothing moved: the device copy is current
+    w.ad_pending = true;
+    return defer ? NALO_OK : upload_adjoints(c);
+}
+static int upload_adjoints(nalo_ctx* c) {
+    BAWindow& w = *c->ba;
+    if (!w.ad_pending) return NALO_OK;
+    const int W = w.W;
     // the stitch kernel reads the fp64 adjoints: AD = [adHost | adTarget]
     // (behind them, in the same upload: the float adjoints the back-substitution of a window of more than 8 frames builds its xAd rows from)
     const size_t nad = (size_t)2 * W * W * 64;
@@ -234,6 +244,7 @@ static int set_adjoints(nalo_ctx* c) {
     w.dev.adF = reinterpret_cast<const float*>(w.AD.p + nad);
     NALO_HIP(c, hipEventRecord(w.ev_ad, c->stream));
     w.sd.AD = w.AD.p;
+    w.ad_pending = false;
     return NALO_OK;
 }
 
@@ -1159,12 +1170,13 @@ static int optimize_epilogue(nalo_ctx* c, double* rmse) {
     const double nsz[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
     nf.evalPT = nf.PRE_worldToCam;
     frame_set_state(nf, nsz); frame_set_state_zero(nf, nsz);
-    int rc = set_adjoints(c); if (rc) return rc;
-    rc = set_precalc(c); if (rc) return rc;
+    int rc = set_adjoints(c, true); if (rc) return rc;                      // the device copy of the adjoints follows the fetch below (round 4: the copy packet and its event stood ~25 us between the last
+    rc = set_precalc(c); if (rc) return rc;                                 // linearisation of the loop and this one; nothing in the epilogue reads them)
     rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
     w.pt_acc_on_read = false;                                               // the per-point sums stay those of the last solve
     rc = stitch_and_fetch(c, true, false, true, true); if (rc) return rc;  // energy, residual count and the threshold: no stitch
     { const float th = tail_th(w); rc = check_th(c, th); if (rc) return rc; nf.frameEnergyTH = th; }
+    rc = upload_adjoints(c); if (rc) return rc;
     double e = 0; int nres = 0; misc_totals(w, &e, &nres);
     // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)
     if (rmse) *rmse = std::sqrt((float)(e / (kPatternNum * (double)w.resInA)));

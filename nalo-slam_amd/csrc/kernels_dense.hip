@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const float* __restrict
 }
 
 struct DenseParams {
-    const float* mask; const float4* dI; const uint8_t* bgr;
+    const float* mask; const float* I0; const uint8_t* bgr;
     int w, h;
     const int2* rows;                            // dense_rows_kernel
     int* rect;                                   // {minx, maxx, miny, maxy}: written by block 0 of dense_count_kernel, read by dense_write_kernel and the host
@@ -58,7 +58,17 @@ struct DenseParams {
     float* out6;                                 // {minx, maxx, miny, maxy, minz, maxz} of the serial loop
     int* n_out;
 };
-constexpr int kDenseChunk = 2048;
+#ifndef NALO_DENSE_CHUNK
+#define NALO_DENSE_CHUNK 1024    // pixels of the box per workgroup. Round 4: 2048 -> 1024 (twice the workgroups for the 256 CUs: 764 instead of 382 on the 460 x 1700 box of the bench)
+#endif
+constexpr int kDenseChunk = NALO_DENSE_CHUNK;
+// e / rw and e % rw for 0 <= e < 2^24 without the ~40-instruction integer division: float quotient, one correction step either way
+struct DnDiv { int rw; float rcp; };
+__device__ __forceinline__ void dn_divmod(const DnDiv& d, int e, int& q, int& r) {
+    if (d.rcp == 0.f) { q = e / d.rw; r = e - q * d.rw; return; }          // a box of >= 2^24 pixels: (float) e is no longer exact
+    q = (int)((float)e * d.rcp); r = e - q * d.rw;
+    if (r < 0) { --q; r += d.rw; } else if (r >= d.rw) { ++q; r -= d.rw; }
+}
 
 __device__ __forceinline__ void dn_world(const DenseParams& P, int i, int j, float idepth, double (&m)[3]) {
     float c0 = P.fxi * j + (-P.cx * P.fxi), c1 = P.fyi * i + (-P.cy * P.fyi), c2 = 1.f;       // cP = Ki * (j,i,1) / idepth (float), mP = camToWorld * cP (double)  (:390-394)
@@ -68,19 +78,22 @@ __device__ __forceinline__ void dn_world(const DenseParams& P, int i, int j, flo
 }
 // which pixels of this lane's R rounds are kept (MapPoint.cpp:366-380); the mask loads are issued together, an out-of-range lane reads pixel (rx0, ry0) and drops it
 template <int R>
-__device__ __forceinline__ void dn_keep(const DenseParams& P, int b, int tid, int rx0, int ry0, int rw, int total, bool (&keep)[R], float (&idp)[R]) {
+__device__ __forceinline__ void dn_keep(const DenseParams& P, int b, int tid, int rx0, int ry0, int rw, int total, bool (&keep)[R], float (&idp)[R], int (&pi)[R], int (&pj)[R]) {
     float mv[R];
+    const DnDiv dv{rw, total < (1 << 24) ? 1.0f / (float)rw : 0.f};
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = b * kDenseChunk + r * 256 + tid, ee = e < total ? e : 0;
-        mv[r] = P.mask[(rx0 + ee % rw) + (ry0 + ee / rw) * P.w];
+        int q, m; dn_divmod(dv, ee, q, m);
+        pi[r] = ry0 + q; pj[r] = rx0 + m;
+        mv[r] = P.mask[pj[r] + pi[r] * P.w];
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = b * kDenseChunk + r * 256 + tid;
         keep[r] = false; idp[r] = 0.f;
         if (e < total) {
-            const int i = ry0 + e / rw, j = rx0 + e % rw;
+            const int i = pi[r], j = pj[r];
             if (mv[r] == P.pcolor && (i % 3 == 0 || j % 3 == 0)) {
                 const float ddepth = P.p0 * (j * P.fxi - P.cx * P.fxi) + P.p1 * (i * P.fyi - P.cy * P.fyi) + P.p2;   // MapPoint.cpp:377
                 if (ddepth != 0.f) { const float depth = -P.p3 / ddepth; if (depth != 0.f) { idp[r] = 1.f / depth; keep[r] = true; } }
@@ -114,15 +127,14 @@ __global__ __launch_bounds__(256) void dense_count_kernel(DenseParams P) {
     const bool any = rx0 != INT_MAX && rx1 > rx0 && ry1 > ry0;
     const int rw = any ? rx1 - rx0 : 1, total = any ? rw * (ry1 - ry0) : 0, nb = (total + kDenseChunk - 1) / kDenseChunk;
     if (b >= nb) return;
-    bool keep[R]; float idp[R];
-    dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp);
+    bool keep[R]; float idp[R]; int pi[R], pj[R];
+    dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp, pi, pj);
     int cnt = 0;
     float mnx = FLT_MAX, mny = FLT_MAX, mnz = FLT_MAX, mxx = FLT_MIN;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         if (!keep[r]) continue;
-        const int e = b * kDenseChunk + r * 256 + tid;
-        double m[3]; dn_world(P, ry0 + e / rw, rx0 + e % rw, idp[r], m);
+        double m[3]; dn_world(P, pi[r], pj[r], idp[r], m);
         const float fx = (float)m[0];
         mnx = fminf(mnx, fx); mxx = fmaxf(mxx, fx); mny = fminf(mny, (float)m[1]); mnz = fminf(mnz, (float)m[2]);
         ++cnt;
@@ -158,14 +170,13 @@ __global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ecnt += __shfl_xor(ecnt, o); e1 = fminf(e1, __shfl_xor(e1, o)); e2 = fminf(e2, __shfl_xor(e2, o)); e3 = fminf(e3, __shfl_xor(e3, o)); e4 = fmaxf(e4, __shfl_xor(e4, o)); }
         if (lane == 0) { red[wave][0] = __int_as_float(ecnt); red[wave][1] = e1; red[wave][2] = e2; red[wave][3] = e3; red[wave][4] = e4; }
-        bool keep[R]; float idp[R]; int rank[R];
-        dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp);
+        bool keep[R]; float idp[R]; int rank[R], pi[R], pj[R];
+        dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp, pi, pj);
         double wy[R], wz[R];                     // world y, z of the kept points (compared as doubles against the float running minima)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int e = b * kDenseChunk + r * 256 + tid;
             float fy = FLT_MAX, fz = FLT_MAX; wy[r] = 0; wz[r] = 0;
-            if (keep[r]) { double m[3]; dn_world(P, ry0 + e / rw, rx0 + e % rw, idp[r], m); wy[r] = m[1]; wz[r] = m[2]; fy = (float)m[1]; fz = (float)m[2]; }
+            if (keep[r]) { double m[3]; dn_world(P, pi[r], pj[r], idp[r], m); wy[r] = m[1]; wz[r] = m[2]; fy = (float)m[1]; fz = (float)m[2]; }
             const unsigned long long mk = __ballot(keep[r]);
             rank[r] = __popcll(mk & ((1ull << lane) - 1ull));
             float gy = fy, gz = fz;
@@ -195,11 +206,11 @@ __global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const float ty = __shfl_up(py, o), tz = __shfl_up(pz, o); if (lane >= o) { py = fminf(py, ty); pz = fminf(pz, tz); } }
             if (keep[r]) {
-                const int e = b * kDenseChunk + r * 256 + tid, i = ry0 + e / rw, j = rx0 + e % rw;
+                const int i = pi[r], j = pj[r];
                 const int o = goff + rank[r];
                 if (o < cap) {
                     const int px = j + i * P.w;
-                    ou[o] = j; ov[o] = i; oid[o] = idp[r]; ocol[o] = P.dI[px].x;
+                    ou[o] = j; ov[o] = i; oid[o] = idp[r]; ocol[o] = P.I0[px];                             // = dI[px][0] (makeImages keeps level 0's planar image): 4 instead of 64 bytes of sector traffic per point
                     if (P.bgr) { obgr[3 * o] = P.bgr[3 * px]; obgr[3 * o + 1] = P.bgr[3 * px + 1]; obgr[3 * o + 2] = P.bgr[3 * px + 2]; }
                 }
                 const float ry_ = fminf(gy, py), rz_ = fminf(gz, pz);       // the running minima AFTER this point's own update
@@ -262,7 +273,7 @@ extern "C" int nalo_dense_make_map(nalo_ctx* c, int slot, const float plane[4], 
     uint8_t* dbgr = (uint8_t*)(dcol + capz);
     NALO_HIP(c, c->trk_partial.reserve(16));
     DenseParams P;
-    P.mask = s.mask; P.dI = s.dI[0]; P.bgr = s.bgr; P.w = c->w; P.h = c->h; P.rows = rows; P.rect = c->scan_tmp.p;
+    P.mask = s.mask; P.I0 = s.I[0]; P.bgr = s.bgr; P.w = c->w; P.h = c->h; P.rows = rows; P.rect = c->scan_tmp.p;
     P.p0 = plane[0]; P.p1 = plane[1]; P.p2 = plane[2]; P.p3 = plane[3]; P.pcolor = mask_value;
     P.fxi = 1.0f / c->fx[0]; P.fyi = 1.0f / c->fy[0]; P.cx = c->cx[0]; P.cy = c->cy[0];            // DenseMapping::makeK level 0
     std::memcpy(P.c2w, camToWorld, sizeof(P.c2w));

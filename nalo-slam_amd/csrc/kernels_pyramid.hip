@@ -174,9 +174,48 @@ __device__ __forceinline__ void pyr_emit_level(const PyrLevels& P, const float* 
     }
 }
 template <int NL>
+__device__ __forceinline__ void pyr_box_level(const PyrLevels& P, float* __restrict__ lds, int l, int x0, int y0, int tid) {
+    using Lay = PyrLds<NL>;
+    constexpr int H = Lay::H;
+    const bool halo = l < NL, phalo = l - 1 < NL;
+    const int RW = halo ? Lay::rw(l) : (kPyrTW >> l), RH = halo ? Lay::rh(l) : (kPyrTH >> l);
+    const int PW = phalo ? Lay::rw(l - 1) : (kPyrTW >> (l - 1));
+    // a halo-free level above a haloed parent (l == NL) starts at the parent's interior
+    const int po = (!halo && phalo) ? (H >> (l - 1)) * PW + (H >> (l - 1)) : 0;
+    const float* __restrict__ src = lds + Lay::off(l - 1) + po;
+    float* __restrict__ dst = lds + Lay::off(l);
+    for (int i = tid; i < RW * RH; i += 256) {
+        const int rx = i % RW, ry = i / RW;
+        const float* q = src + 2 * ry * PW + 2 * rx;
+        const float v = 0.25f * (((q[0] + q[1]) + q[PW]) + q[PW + 1]);
+        dst[i] = v;
+        if (!halo) {                                    // planar box value of an upper level: input of the second launch
+            const int x = (x0 >> l) + rx, y = (y0 >> l) + ry;
+            if (x < P.wl[l] && y < P.hl[l]) P.I[l][x + y * P.wl[l]] = v;
+        }
+    }
+}
+#ifndef NALO_PYR_EARLY
+#define NALO_PYR_EARLY 1
+#endif
+#ifndef NALO_PYR_LD4
+#define NALO_PYR_LD4 1
+#endif
+template <int NL, int LV>
+__device__ __forceinline__ void pyr_walk(const PyrLevels& P, float* __restrict__ lds, const float* __restrict__ edge, const float* __restrict__ gammaB, int x0, int y0, int tid) {
+    if constexpr (LV <= NALO_MAX_LEVELS) {                      // step LV: emit level LV - 1 (complete since the last barrier), box level LV out of it
+        if constexpr (LV - 1 < NL) pyr_emit_level<NL, LV - 1>(P, lds, edge, gammaB, x0, y0, tid);
+        if constexpr (LV < NALO_MAX_LEVELS) {
+            if (LV < P.L) pyr_box_level<NL>(P, lds, LV, x0, y0, tid);
+            __syncthreads();
+            pyr_walk<NL, LV + 1>(P, lds, edge, gammaB, x0, y0, tid);
+        }
+    }
+}
+template <int NL>
 __global__ __launch_bounds__(256) void pyr_one_pass_kernel(PyrLevels P, const float* __restrict__ gammaB) {
     using Lay = PyrLds<NL>;
-    __shared__ float lds[Lay::total];
+    __shared__ __attribute__((aligned(16))) float lds[Lay::total];
     __shared__ float edge[4 * kPyrTH];                          // 2 x (TH + TH/2 + TH/4 + TH/8) <= 4 TH
     constexpr int H = Lay::H;
     const int tid = threadIdx.x, tiles_x = (P.wl[0] + kPyrTW - 1) / kPyrTW;
@@ -187,6 +226,25 @@ __global__ __launch_bounds__(256) void pyr_one_pass_kernel(PyrLevels P, const fl
         const float* __restrict__ I0 = P.I[0];
         // all loads of the tile first (registers), then the LDS stores: a rolled loop waits for every load before its own LDS store, i.e. a dozen
         // dependent HBM round trips per tile (measured: 8 us for ONE tile of a KITTI frame)
+#if NALO_PYR_LD4
+        // round 4: the haloed tile starts H = 4 or 8 pixels left of a multiple of 64, so with w0 % 4 == 0 every aligned group of four pixels lies wholly inside or
+        // wholly outside the image: 16-byte loads (432 / 640 per tile instead of 1728 / 2560 4-byte ones); any other width takes the scalar loop
+        static_assert(RW % 4 == 0 && H % 4 == 0 || NL < 3, "haloed row in whole float4s");
+        if ((NL >= 3) && (w0 & 3) == 0) {
+            constexpr int RW4 = RW / 4, N4 = (RW4 * RH + 255) / 256;
+            pyr_f4 v4[N4];
+            bool in4[N4];
+#pragma unroll
+            for (int k = 0; k < N4; ++k) {
+                const int i = tid + 256 * k, rx = (i % RW4) * 4, ry = i / RW4, gx = x0 - H + rx, gy = y0 - H + ry;
+                in4[k] = i < RW4 * RH && gx >= 0 && gx < w0 && gy >= 0 && gy < h0;
+                v4[k] = *reinterpret_cast<const pyr_f4*>(I0 + (in4[k] ? gx + gy * w0 : 0));
+            }
+#pragma unroll
+            for (int k = 0; k < N4; ++k) { const int i = tid + 256 * k; if (i < RW4 * RH) { pyr_f4 t = v4[k]; if (!in4[k]) t = pyr_f4{0.f, 0.f, 0.f, 0.f}; *reinterpret_cast<pyr_f4*>(lds + 4 * i) = t; } }
+        } else
+#endif
+        {
         constexpr int NLD = (RW * RH + 255) / 256;
         float v[NLD];
         bool inb[NLD];
@@ -200,6 +258,7 @@ __global__ __launch_bounds__(256) void pyr_one_pass_kernel(PyrLevels P, const fl
         for (int k = 0; k < NLD; ++k) v[k] = inb[k] ? v[k] : 0.f;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) { const int i = tid + 256 * k; if (i < RW * RH) lds[i] = v[k]; }
+        }
         // the flat-index neighbours of the border columns (only border tiles load anything): wave l owns level l, so the four levels' dependent loads run
         // side by side instead of as four masked branches of one wave
         static_assert(2 * kPyrTH <= 64, "one wave holds a level's edge values");
@@ -212,33 +271,21 @@ __global__ __launch_bounds__(256) void pyr_one_pass_kernel(PyrLevels P, const fl
 
     }
     __syncthreads();
+#if NALO_PYR_EARLY
+    // round 4: level l leaves for HBM while level l + 1 is being boxed out of it (both only READ level l's LDS image): the texel stores drain under the rest of
+    // the LDS walk instead of forming one store phase at the end of every (lockstep) workgroup
+    pyr_walk<NL, 1>(P, lds, edge, gammaB, x0, y0, tid);
+#else
 #pragma unroll
     for (int l = 1; l < NALO_MAX_LEVELS; ++l) {                 // the box pyramid inside LDS: levels < NL over the haloed region, the ones above over the tile only
-        if (l < P.L) {
-            const bool halo = l < NL, phalo = l - 1 < NL;
-            const int RW = halo ? Lay::rw(l) : (kPyrTW >> l), RH = halo ? Lay::rh(l) : (kPyrTH >> l);
-            const int PW = phalo ? Lay::rw(l - 1) : (kPyrTW >> (l - 1));
-            // a halo-free level above a haloed parent (l == NL) starts at the parent's interior
-            const int po = (!halo && phalo) ? (H >> (l - 1)) * PW + (H >> (l - 1)) : 0;
-            const float* __restrict__ src = lds + Lay::off(l - 1) + po;
-            float* __restrict__ dst = lds + Lay::off(l);
-            for (int i = tid; i < RW * RH; i += 256) {
-                const int rx = i % RW, ry = i / RW;
-                const float* q = src + 2 * ry * PW + 2 * rx;
-                const float v = 0.25f * (((q[0] + q[1]) + q[PW]) + q[PW + 1]);
-                dst[i] = v;
-                if (!halo) {                                    // planar box value of an upper level: input of the second launch
-                    const int x = (x0 >> l) + rx, y = (y0 >> l) + ry;
-                    if (x < P.wl[l] && y < P.hl[l]) P.I[l][x + y * P.wl[l]] = v;
-                }
-            }
-        }
+        if (l < P.L) pyr_box_level<NL>(P, lds, l, x0, y0, tid);
         __syncthreads();
     }
     pyr_emit_level<NL, 0>(P, lds, edge, gammaB, x0, y0, tid);
     if constexpr (NL > 1) pyr_emit_level<NL, 1>(P, lds, edge, gammaB, x0, y0, tid);
     if constexpr (NL > 2) pyr_emit_level<NL, 2>(P, lds, edge, gammaB, x0, y0, tid);
     if constexpr (NL > 3) pyr_emit_level<NL, 3>(P, lds, edge, gammaB, x0, y0, tid);
+#endif
 }
 // gradients of the levels >= l0 from their planar box values (the second launch of a pyramid with more than four levels)
 __global__ __launch_bounds__(256) void pyr_grad_tail_kernel(PyrLevels P, const float* __restrict__ gammaB, int l0) {
@@ -293,49 +340,76 @@ __device__ __forceinline__ void ingest_pair(const void* __restrict__ raw, int p,
     if constexpr (BPP == 1) { uint16_t v; __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(raw) + p, 2); a = v & 0xFFu; b = v >> 8; }
     else { uint32_t v; __builtin_memcpy(&v, reinterpret_cast<const uint16_t*>(raw) + p, 4); a = v & 0xFFFFu; b = v >> 16; }
 }
+// Round 4: a pixel is a chain of two dependent round trips (remap entry -> taps), and with one pixel per lane a 1920x1072 frame is four rounds of the
+// resident grid: ~8 round trips end to end (15 us at 0.30 of the roofline). Now every lane owns NALO_INGEST_U pixels (stride 256 inside its workgroup's run of consecutive
+// pixels: every instruction still covers one contiguous run per wave): the U remap loads leave together, then the 4 U taps, then the stores - the whole frame is resident at once.
+#ifndef NALO_INGEST_U
+#define NALO_INGEST_U 4
+#endif
 template <int BPP, int PHOTO>
 __global__ __launch_bounds__(256) void ingest_kernel(IngestParams P) {
+    constexpr int U = NALO_INGEST_U;
     __shared__ float sG[BPP == 1 && PHOTO > 0 ? 256 : 1];
     if constexpr (BPP == 1 && PHOTO > 0) { sG[threadIdx.x] = P.G[threadIdx.x]; __syncthreads(); }
     const float* __restrict__ Gt = (BPP == 1 && PHOTO > 0) ? sG : P.G;
-    const int n = P.w * P.h, idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+    const int n = P.w * P.h, base = blockIdx.x * (256 * U) + threadIdx.x;
+    if (base >= n) return;
     auto data = [&](unsigned v, float vi) -> float {                       // PhotometricUndistorter::processFrame (Undistort.cpp:224-251) at one original pixel
         if constexpr (PHOTO == 0) return P.factor * (float)v;
         float d = Gt[v];
         if constexpr (PHOTO == 2) d *= vi;
         return d;
     };
-    float o;
+    float o[U];
     if (!P.remapXY) {
-        unsigned v;
-        if constexpr (BPP == 1) v = reinterpret_cast<const uint8_t*>(P.raw)[idx]; else v = reinterpret_cast<const uint16_t*>(P.raw)[idx];
-        o = data(v, PHOTO == 2 ? P.vinv[idx] : 1.f);
+        unsigned v[U]; float vi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + 256 * u, ii = idx < n ? idx : 0;
+            if constexpr (BPP == 1) v[u] = reinterpret_cast<const uint8_t*>(P.raw)[ii]; else v[u] = reinterpret_cast<const uint16_t*>(P.raw)[ii];
+            vi[u] = PHOTO == 2 ? P.vinv[ii] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) o[u] = data(v[u], vi[u]);
     } else {
-        const float2 r = P.remapXY[idx];
-        float xx = r.x, yy = r.y;
-        const bool outside = xx < 0;
-        if (outside) { xx = 0.f; yy = 0.f; }
-        const int xxi = (int)xx, yyi = (int)yy;
-        xx -= xxi; yy -= yyi;
-        const float xxyy = xx * yy;
-        const int p = xxi + yyi * P.wOrg;
-        unsigned v00, v10, v01, v11;
-        ingest_pair<BPP>(P.raw, p, v00, v10);
-        ingest_pair<BPP>(P.raw, p + P.wOrg, v01, v11);
-        float2 i0 = make_float2(1.f, 1.f), i1 = i0;
-        if constexpr (PHOTO == 2) { __builtin_memcpy(&i0, P.vinv + p, 8); __builtin_memcpy(&i1, P.vinv + p + P.wOrg, 8); }
-        o = xxyy * data(v11, i1.y) + (yy - xxyy) * data(v01, i1.x) + (xx - xxyy) * data(v10, i0.y) + (1 - xx - yy + xxyy) * data(v00, i0.x);
-        if (outside) o = 0.f;
+        float2 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int idx = base + 256 * u; r[u] = P.remapXY[idx < n ? idx : 0]; }
+        unsigned v00[U], v10[U], v01[U], v11[U];
+        float2 i0[U], i1[U];
+        float xx[U], yy[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xx[u] = r[u].x; yy[u] = r[u].y;
+            if (xx[u] < 0) { xx[u] = 0.f; yy[u] = 0.f; }
+            const int xxi = (int)xx[u], yyi = (int)yy[u];
+            xx[u] -= xxi; yy[u] -= yyi;
+            const int p = xxi + yyi * P.wOrg;
+            ingest_pair<BPP>(P.raw, p, v00[u], v10[u]);
+            ingest_pair<BPP>(P.raw, p + P.wOrg, v01[u], v11[u]);
+            i0[u] = make_float2(1.f, 1.f); i1[u] = i0[u];
+            if constexpr (PHOTO == 2) { __builtin_memcpy(&i0[u], P.vinv + p, 8); __builtin_memcpy(&i1[u], P.vinv + p + P.wOrg, 8); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float xxyy = xx[u] * yy[u];
+            o[u] = xxyy * data(v11[u], i1[u].y) + (yy[u] - xxyy) * data(v01[u], i1[u].x) + (xx[u] - xxyy) * data(v10[u], i0[u].y) + (1 - xx[u] - yy[u] + xxyy) * data(v00[u], i0[u].x);
+            if (r[u].x < 0) o[u] = 0.f;
+        }
     }
-    P.out_I[idx] = o;
-    if (P.mask_org || P.bgr_org) {                     // cv::resize(.., INTER_NEAREST): sx = min(floor(x * ifx), wOrg - 1)
-        const int y = idx / P.w, x = idx - y * P.w;
-        int sx = (int)floor(x * P.ifx), sy = (int)floor(y * P.ify);
-        sx = sx < P.wOrg - 1 ? sx : P.wOrg - 1; sy = sy < P.hOrg - 1 ? sy : P.hOrg - 1;
-        const int sp = sx + sy * P.wOrg;
-        if (P.mask_org) P.out_mask[idx] = (float)P.mask_org[sp] * 1.0f;
-        if (P.bgr_org) { P.out_bgr[3 * idx] = P.bgr_org[3 * sp]; P.out_bgr[3 * idx + 1] = P.bgr_org[3 * sp + 1]; P.out_bgr[3 * idx + 2] = P.bgr_org[3 * sp + 2]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int idx = base + 256 * u;
+        if (idx >= n) break;
+        P.out_I[idx] = o[u];
+        if (P.mask_org || P.bgr_org) {                     // cv::resize(.., INTER_NEAREST): sx = min(floor(x * ifx), wOrg - 1)
+            const int y = idx / P.w, x = idx - y * P.w;
+            int sx = (int)floor(x * P.ifx), sy = (int)floor(y * P.ify);
+            sx = sx < P.wOrg - 1 ? sx : P.wOrg - 1; sy = sy < P.hOrg - 1 ? sy : P.hOrg - 1;
+            const int sp = sx + sy * P.wOrg;
+            if (P.mask_org) P.out_mask[idx] = (float)P.mask_org[sp] * 1.0f;
+            if (P.bgr_org) { P.out_bgr[3 * idx] = P.bgr_org[3 * sp]; P.out_bgr[3 * idx + 1] = P.bgr_org[3 * sp + 1]; P.out_bgr[3 * idx + 2] = P.bgr_org[3 * sp + 2]; }
+        }
     }
 }
 int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOrg, int hOrg, const float* G, const float* vinv, const float2* remapXY, int photometric,
@@ -344,7 +418,7 @@ int ingest_launch(nalo_ctx* c, hipStream_t st, const void* raw, int bpp, int wOr
     P.raw = raw; P.bpp = bpp; P.wOrg = wOrg; P.hOrg = hOrg; P.w = c->w; P.h = c->h; P.G = G; P.vinv = vinv; P.remapXY = remapXY; P.photometric = photometric;
     P.factor = factor; P.mask_org = mask_org; P.bgr_org = bgr_org; P.out_I = out_I; P.out_mask = out_mask; P.out_bgr = out_bgr;
     P.ifx = 1.0 / ((double)c->w / wOrg); P.ify = 1.0 / ((double)c->h / hOrg);
-    const int n = c->w * c->h, grid = (n + 255) / 256;                   // one pixel per lane, consecutive workgroups on consecutive memory (scripts/ubench/copy.hip)
+    const int n = c->w * c->h, grid = (n + 256 * NALO_INGEST_U - 1) / (256 * NALO_INGEST_U);   // NALO_INGEST_U pixels per lane, consecutive workgroups on consecutive memory
     ProfScope ps(c, "ingest", true);                                       // dispatch-attached timestamps
 #define NALO_INGEST(B_, P_) do { if (ps.a) hipExtLaunchKernelGGL((ingest_kernel<B_, P_>), dim3(grid), dim3(256), 0, st, ps.a, ps.b, 0, P); else ingest_kernel<B_, P_><<<grid, 256, 0, st>>>(P); } while (0)
     if (bpp == 1) { if (photometric == 0) NALO_INGEST(1, 0); else if (photometric == 1) NALO_INGEST(1, 1); else NALO_INGEST(1, 2); }

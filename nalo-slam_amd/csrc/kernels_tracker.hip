@@ -20,6 +20,7 @@ struct TrkEvalParams {
     float RKi[9], t[3], Ki[9];
     float affa, affb, b0, cutoff, maxEnergy;
 };
+typedef float trk_f4 __attribute__((ext_vector_type(4)));
 constexpr int kTrkVals = 52;     // 45 upper-tri H entries + E, numTermsInE, numSaturated, numTermsInWarped, sT, sRT, sNum
 
 __device__ __forceinline__ float4 bilinear4(const float4* __restrict__ img, float x, float y, int width) {
@@ -37,8 +38,8 @@ __device__ __forceinline__ float4 bilinear4(const float4* __restrict__ img, floa
     return r;
 }
 
-__global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* __restrict__ partial) {
-    __shared__ float smem[64 * (kTrkVals + 1)];
+__global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* __restrict__ partial, unsigned* __restrict__ ticket, double* __restrict__ out, double seq) {
+    __shared__ __attribute__((aligned(16))) float smem[64 * (kTrkVals + 1)];
     float acc[kTrkVals];
 #pragma unroll
     for (int k = 0; k < kTrkVals; ++k) acc[k] = 0.f;
@@ -95,25 +96,53 @@ __global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* _
             }
         }
     }
-    block_reduce_cols<kTrkVals, 256>(acc, smem, partial + (size_t)blockIdx.x * 64);
+    // Round 4: the fp64 finish rides in this launch (it was a second, 10 us launch behind a 14 us one). A workgroup's 52 partials leave as
+    // agent-scope words, acknowledged before its ticket (the idiom of ba_reduce_kernel's tail); the workgroup that draws the last ticket sums the partials in a fixed order (fp64) and
+    // publishes them behind the sequence number the host polls.
+    __shared__ float blk[64];
+    block_reduce_cols<kTrkVals, 256>(acc, smem, blk);
+    if (threadIdx.x < kTrkVals) __hip_atomic_store(&partial[(size_t)blockIdx.x * 64 + threadIdx.x], blk[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __shared__ bool is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (!is_last) return;
+    // 13 lanes x 16 bytes cover a block's 52 partials; 19 such lane groups stride over the blocks with fourteen coherent (sc0 sc1: past this XCD's L2, where the
+    // other XCDs' write-through stores are not seen) 16-byte loads in flight each - one relaxed atomic word per lane and trip was a chain of ~130 dependent
+    // round trips (50 us). Fixed order: rows b = rg, rg + 19, ... in fp64 per group, then the 19 groups in ascending order.
+    double (*part)[kTrkVals] = reinterpret_cast<double (*)[kTrkVals]>(smem);       // 19 x 52 doubles = 7.9 KB of the 13.6 KB reduction buffer
+    const int cq = threadIdx.x % 13, rg = threadIdx.x / 13, nblocks = (int)gridDim.x;
+    if (rg < 19) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int b0 = rg; b0 < nblocks; b0 += 19 * 14) {
+            trk_f4 v[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) {
+                const int b2 = b0 + 19 * k;
+                const float* q = partial + (size_t)(b2 < nblocks ? b2 : b0) * 64 + cq * 4;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[k]) : "v"(q) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]) : : "memory");
+#pragma unroll
+            for (int k = 0; k < 14; ++k) if (b0 + 19 * k < nblocks) { a0 += (double)v[k].x; a1 += (double)v[k].y; a2 += (double)v[k].z; a3 += (double)v[k].w; }
+        }
+        part[rg][cq * 4] = a0; part[rg][cq * 4 + 1] = a1; part[rg][cq * 4 + 2] = a2; part[rg][cq * 4 + 3] = a3;
+    }
+    __syncthreads();
+    if (threadIdx.x < kTrkVals) { double t = 0; for (int k = 0; k < 19; ++k) t += part[k][threadIdx.x]; __hip_atomic_store(&out[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                // re-armed for the next (stream-ordered) launch
+        __hip_atomic_store(&out[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
-// fp64 finish: out[j] = sum_b partial[b][j]; written straight into host-mapped pinned memory
-// out = host-mapped pinned memory; out[63] carries the sequence number of this evaluation, published after the data with
-// system-scope fences so the host can poll it instead of paying a stream synchronisation per LM iteration
-__global__ __launch_bounds__(1024) void trk_finish_kernel(const float* __restrict__ partial, int nblocks, double* __restrict__ out, double seq) {
-    __shared__ double part[16][64];
-    const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
-    double s = 0;
-    if (j < kTrkVals) for (int b = g; b < nblocks; b += 16) s += (double)partial[(size_t)b * 64 + j];
-    part[g][j] = s;
-    __syncthreads();
-    if (g == 0 && j < kTrkVals) { double t = 0; for (int k = 0; k < 16; ++k) t += part[k][j]; out[j] = t; __threadfence_system(); }
-    __syncthreads();
-    if (threadIdx.x == 0) { __hip_atomic_store(&out[63], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-}
-// sharded tracker ("all-reduce of 45 + 6 floats per evaluation"): the finish kernel leaves this rank's 52 fp64 sums in DEVICE memory (out = device buffer,
-// seq unused), the caller's hook sums them over the ranks in place, and this kernel publishes the result the way trk_finish_kernel does
+// out = host-mapped pinned memory; out[63] carries the sequence number of this evaluation, published after the data so the host can poll it instead of paying a
+// stream synchronisation per LM iteration
+// sharded tracker ("all-reduce of 45 + 6 floats per evaluation"): the evaluation's last workgroup leaves this rank's 52 fp64 sums in DEVICE memory (out = device buffer,
+// seq unused), the caller's hook sums them over the ranks in place, and this kernel publishes the result the way the evaluation's tail does
 __global__ __launch_bounds__(64) void trk_publish_kernel(const double* __restrict__ src, double* __restrict__ out, double seq) {
     if (threadIdx.x < kTrkVals) __hip_atomic_store(&out[threadIdx.x], src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
@@ -136,24 +165,24 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
     int nblocks = (P.i1 - P.i0 + 255) / 256;
     nblocks = nblocks < 1 ? 1 : (nblocks > 512 ? 512 : nblocks);
     NALO_HIP(c, c->trk_partial.reserve((size_t)2048 * 64));
-    {
-        ProfScope ps(c, "trk_eval");
-        trk_eval_kernel<<<nblocks, 256, 0, c->stream>>>(P, c->trk_partial.p);
-    }
+    if (!c->trk_ticket.p) { NALO_HIP(c, c->trk_ticket.reserve(4)); NALO_HIP(c, hipMemsetAsync(c->trk_ticket.p, 0, 16, c->stream)); }
     double* dout = nullptr;
     NALO_HIP(c, hipHostGetDevicePointer((void**)&dout, c->trk_out_host, 0));
     const double seq = (double)(++c->trk_seq);
+    if (sharded) NALO_HIP(c, c->trk_shard_sums.reserve(64));
+    {
+        ProfScope ps(c, "trk_eval");
+        trk_eval_kernel<<<nblocks, 256, 0, c->stream>>>(P, c->trk_partial.p, c->trk_ticket.p, sharded ? c->trk_shard_sums.p : dout, sharded ? 0.0 : seq);
+    }
     if (sharded) {
         // every rank evaluated its share: the 52 sums meet in the hook (in place, device memory), every rank then reads the same totals and runs the same LM step
-        NALO_HIP(c, c->trk_shard_sums.reserve(64));
-        trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, c->trk_shard_sums.p, 0.0);
         if (!c->trk_hook_stream_ordered) NALO_HIP(c, hipStreamSynchronize(c->stream));
         c->trk_hook(c->trk_hook_user, c->trk_shard_sums.p, kTrkVals);
         // the same latch as the BA's call_hook (host_ba.hip): a rank whose collective failed must not take an LM step on rank-local sums - the ranks would take
         // different steps and evaluation counts, and the next collectives would mismatch or hang
         if (c->xchg_failed) return NALO_ERR_HIP;                        // message already in c->err (nalo_ba_exchange_failed / the RCCL hooks)
         trk_publish_kernel<<<1, 64, 0, c->stream>>>(c->trk_shard_sums.p, dout, seq);
-    } else trk_finish_kernel<<<1, 1024, 0, c->stream>>>(c->trk_partial.p, nblocks, dout, seq);
+    }
     NALO_HIP(c, hipGetLastError());
     if (!poll_flag(c, &c->trk_out_host[63], seq)) return NALO_ERR_HIP;
     std::memcpy(out64, c->trk_out_host, sizeof(double) * kTrkVals);

@@ -74,6 +74,7 @@ struct nalo_ctx {
     nalo::DevBuf<float> pc_u[NALO_MAX_LEVELS], pc_v[NALO_MAX_LEVELS], pc_id[NALO_MAX_LEVELS], pc_col[NALO_MAX_LEVELS];
     int pc_n[NALO_MAX_LEVELS] = {};
     nalo::DevBuf<float> trk_partial;         // [blocks][64]
+    nalo::DevBuf<unsigned> trk_ticket;       // trk_eval_kernel's arrival counter (zero between launches)
     nalo::DevBuf<double> trk_out;            // 64 doubles
     double* trk_out_host = nullptr;          // pinned, host-mapped: results + sequence flag
     unsigned long long trk_seq = 0;
