@@ -150,6 +150,22 @@ __global__ __launch_bounds__(256) void dense_count_kernel(DenseParams P) {
         o[3] = fminf(fminf(red[0][3], red[1][3]), fminf(red[2][3], red[3][3])); o[4] = fmaxf(fmaxf(red[0][4], red[1][4]), fmaxf(red[2][4], red[3][4]));
     }
 }
+// inclusive prefix minimum over the 64 lanes of a wave, in lane order, without LDS traffic: Hillis-Steele inside the rows of 16 lanes (DPP row_shr), then the row
+// tails handed on (row_bcast:15 into the rows 1 and 3, row_bcast:31 into the rows 2 and 3). Lanes without a source keep FLT_MAX, the identity. Round 4: the write
+// kernel is bound by the NUMBER of vector instructions (3 waves per SIMD of ~2600 instructions each = 13 us); the ds_bpermute shuffles (150 per wave) and their
+// address arithmetic were the largest removable part.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dn_dpp_min(float v) {
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(FLT_MAX), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+    return fminf(v, o);
+}
+__device__ __forceinline__ float dn_wave_prefix_min(float v) {
+    v = dn_dpp_min<0x111, 0xF>(v); v = dn_dpp_min<0x112, 0xF>(v); v = dn_dpp_min<0x114, 0xF>(v); v = dn_dpp_min<0x118, 0xF>(v);     // row_shr:1, 2, 4, 8
+    v = dn_dpp_min<0x142, 0xA>(v);                                                                                                  // row_bcast:15 -> rows 1, 3
+    v = dn_dpp_min<0x143, 0xC>(v);                                                                                                  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ float dn_lane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
 __global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap, int* __restrict__ ou, int* __restrict__ ov, float* __restrict__ oid, float* __restrict__ ocol,
                                                           uint8_t* __restrict__ obgr) {
     constexpr int R = kDenseChunk / 256;
@@ -161,11 +177,19 @@ __global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap
     const bool any = rx0 != INT_MAX && rx1 > rx0 && ry1 > ry0;
     const int rw = any ? rx1 - rx0 : 1, total = any ? rw * (ry1 - ry0) : 0, nb = (total + kDenseChunk - 1) / kDenseChunk;
     if (b < nb) {
-        // ---- exclusive prefix of the chunks in front: count, min x / y / z, max x (order-free folds; the in-order part happens inside the workgroup)
+        // ---- exclusive prefix of the chunks in front: count, min x / y / z, max x (order-free folds; the in-order part happens inside the workgroup).
+        // The first four strides are loaded together (a rolled loop waits for every load: three dependent L2 round trips for the last chunks of the bench's box)
         int ecnt = 0; float e1 = FLT_MAX, e2 = FLT_MAX, e3 = FLT_MAX, e4 = FLT_MIN;
-        for (int p = tid; p < b; p += 256) {
-            const float4 a = *reinterpret_cast<const float4*>(P.agg + (size_t)p * 8); const float a4 = P.agg[(size_t)p * 8 + 4];
-            ecnt += __float_as_int(a.x); e1 = fminf(e1, a.y); e2 = fminf(e2, a.z); e3 = fminf(e3, a.w); e4 = fmaxf(e4, a4);
+        {
+            float4 a[4]; float a4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int p = tid + 256 * k, pp = p < b ? p : 0; a[k] = *reinterpret_cast<const float4*>(P.agg + (size_t)pp * 8); a4[k] = P.agg[(size_t)pp * 8 + 4]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (tid + 256 * k < b) { ecnt += __float_as_int(a[k].x); e1 = fminf(e1, a[k].y); e2 = fminf(e2, a[k].z); e3 = fminf(e3, a[k].w); e4 = fmaxf(e4, a4[k]); }
+            for (int p = tid + 1024; p < b; p += 256) {
+                const float4 q = *reinterpret_cast<const float4*>(P.agg + (size_t)p * 8); const float q4 = P.agg[(size_t)p * 8 + 4];
+                ecnt += __float_as_int(q.x); e1 = fminf(e1, q.y); e2 = fminf(e2, q.z); e3 = fminf(e3, q.w); e4 = fmaxf(e4, q4);
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ecnt += __shfl_xor(ecnt, o); e1 = fminf(e1, __shfl_xor(e1, o)); e2 = fminf(e2, __shfl_xor(e2, o)); e3 = fminf(e3, __shfl_xor(e3, o)); e4 = fmaxf(e4, __shfl_xor(e4, o)); }
@@ -173,15 +197,15 @@ __global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap
         bool keep[R]; float idp[R]; int rank[R], pi[R], pj[R];
         dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp, pi, pj);
         double wy[R], wz[R];                     // world y, z of the kept points (compared as doubles against the float running minima)
+        float fyv[R], fzv[R], py[R], pz[R];      // their float values (FLT_MAX: no point) and the inclusive prefix minima over the wave in lane order
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float fy = FLT_MAX, fz = FLT_MAX; wy[r] = 0; wz[r] = 0;
-            if (keep[r]) { double m[3]; dn_world(P, pi[r], pj[r], idp[r], m); wy[r] = m[1]; wz[r] = m[2]; fy = (float)m[1]; fz = (float)m[2]; }
+            fyv[r] = FLT_MAX; fzv[r] = FLT_MAX; wy[r] = 0; wz[r] = 0;
+            if (keep[r]) { double m[3]; dn_world(P, pi[r], pj[r], idp[r], m); wy[r] = m[1]; wz[r] = m[2]; fyv[r] = (float)m[1]; fzv[r] = (float)m[2]; }
             const unsigned long long mk = __ballot(keep[r]);
-            rank[r] = __popcll(mk & ((1ull << lane) - 1ull));
-            float gy = fy, gz = fz;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { gy = fminf(gy, __shfl_xor(gy, o)); gz = fminf(gz, __shfl_xor(gz, o)); }
+            rank[r] = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            py[r] = dn_wave_prefix_min(fyv[r]); pz[r] = dn_wave_prefix_min(fzv[r]);
+            const float gy = dn_lane63(py[r]), gz = dn_lane63(pz[r]);          // the wave's minima = the last lane's prefix
             if (lane == 0) { cnt[r][wave] = __popcll(mk); gmin[r][wave][0] = gy; gmin[r][wave][1] = gz; }
         }
         __syncthreads();
@@ -196,34 +220,31 @@ __global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap
         // ---- the points in raster order; the in-order prefix minima decide who may be "the last point above the running minimum"
         int off = ecnt;
         float runy = e2, runz = e3;
-        int l1 = -1, l2 = -1; float v1 = 0.f, v2 = 0.f;
+        // output index o grows with (round, wave, lane): the last qualifying point of a wave is the highest lane of its highest round with one (two ballots per
+        // round instead of a 64-bit max reduction over the lanes)
+        unsigned long long q1 = 0ull, q2 = 0ull;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int goff = off; float gy = runy, gz = runz;                     // offset / running minima in front of this (round, wave) group
             for (int k = 0; k < wave; ++k) { goff += cnt[r][k]; gy = fminf(gy, gmin[r][k][0]); gz = fminf(gz, gmin[r][k][1]); }
-            const float fy = keep[r] ? (float)wy[r] : FLT_MAX, fz = keep[r] ? (float)wz[r] : FLT_MAX;
-            float py = fy, pz = fz;                                         // inclusive prefix minimum over the wave in lane order (lanes without a point carry FLT_MAX)
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const float ty = __shfl_up(py, o), tz = __shfl_up(pz, o); if (lane >= o) { py = fminf(py, ty); pz = fminf(pz, tz); } }
+            bool t1 = false, t2 = false;
+            const int o = goff + rank[r];
             if (keep[r]) {
                 const int i = pi[r], j = pj[r];
-                const int o = goff + rank[r];
                 if (o < cap) {
                     const int px = j + i * P.w;
                     ou[o] = j; ov[o] = i; oid[o] = idp[r]; ocol[o] = P.I0[px];                             // = dI[px][0] (makeImages keeps level 0's planar image): 4 instead of 64 bytes of sector traffic per point
                     if (P.bgr) { obgr[3 * o] = P.bgr[3 * px]; obgr[3 * o + 1] = P.bgr[3 * px + 1]; obgr[3 * o + 2] = P.bgr[3 * px + 2]; }
                 }
-                const float ry_ = fminf(gy, py), rz_ = fminf(gz, pz);       // the running minima AFTER this point's own update
-                if (wy[r] > (double)ry_) { l1 = o; v1 = fy; }
-                if (wz[r] > (double)rz_) { l2 = o; v2 = fz; }
+                const float ry_ = fminf(gy, py[r]), rz_ = fminf(gz, pz[r]);       // the running minima AFTER this point's own update
+                t1 = wy[r] > (double)ry_; t2 = wz[r] > (double)rz_;
             }
+            const unsigned long long m1 = __ballot(t1), m2 = __ballot(t2);
+            if (m1) { const int l = 63 - __clzll(m1); q1 = ((unsigned long long)(unsigned)(__builtin_amdgcn_readlane(o, l) + 1) << 32) | (unsigned)__builtin_amdgcn_readlane(__float_as_int(fyv[r]), l); }
+            if (m2) { const int l = 63 - __clzll(m2); q2 = ((unsigned long long)(unsigned)(__builtin_amdgcn_readlane(o, l) + 1) << 32) | (unsigned)__builtin_amdgcn_readlane(__float_as_int(fzv[r]), l); }
             for (int k = 0; k < 4; ++k) { off += cnt[r][k]; runy = fminf(runy, gmin[r][k][0]); runz = fminf(runz, gmin[r][k][1]); }   // this round is behind us
         }
         // the largest qualifying index of the workgroup (nearly every point qualifies: one atomic per LANE was 380 k serialised updates of two words, 88 us)
-        unsigned long long q1 = l1 >= 0 ? ((unsigned long long)(unsigned)(l1 + 1) << 32) | __float_as_uint(v1) : 0ull;
-        unsigned long long q2 = l2 >= 0 ? ((unsigned long long)(unsigned)(l2 + 1) << 32) | __float_as_uint(v2) : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t1 = __shfl_xor(q1, o), t2 = __shfl_xor(q2, o); q1 = t1 > q1 ? t1 : q1; q2 = t2 > q2 ? t2 : q2; }
         __shared__ unsigned long long sq[4][2];
         if (lane == 0) { sq[wave][0] = q1; sq[wave][1] = q2; }
         __syncthreads();

@@ -261,22 +261,26 @@ __global__ __launch_bounds__(kSweepNT) void init_sweep_kernel(int n, int nsteps,
     }
     for (int s = tid; s <= nsteps4 + 4; s += kSweepNT) soff[s] = off[s < nsteps ? s : nsteps];
     __syncthreads();
+    // (round 4: whether the lane has a point in step s travels with the record - soff[] is read when the record is requested, a group of four ahead -, and the
+    // point's own value is asked for together with its neighbours': one LDS round trip per step on the walk's critical path instead of three)
     auto load = [&](int s) {
         const int p0 = soff[s] + tid, p = p0 < n ? p0 : n - 1;
         const int4* r = rec + (size_t)p * 3;
         SweepRec R; R.a = r[0]; R.b = r[1]; R.c = r[2]; R.idp = MODE == 0 ? idp_s[p] : 0.f;
+        R.c.w = p0 < soff[s + 1];                                                   // the record's spare word: active in this step
         return R;
     };
     auto step = [&](int s, const SweepRec& R) {
-        const bool act = soff[s] + tid < soff[s + 1];
+        const bool act = R.c.w != 0;
         const int i = R.a.x;
         const int nn[10] = {R.a.y, R.a.z, R.a.w, R.b.x, R.b.y, R.b.z, R.b.w, R.c.x, R.c.y, R.c.z};
         const float inf = __builtin_inff();
-        const bool self_good = A::ld(val + i) < inf;
-        if (act && (MODE == 0 ? self_good : !self_good)) {
-            float v[10];
+        float v[10];
+        const float self = A::ld(val + i);
 #pragma unroll
-            for (int k = 0; k < 10; ++k) v[k] = A::ld(val + nn[k]);
+        for (int k = 0; k < 10; ++k) v[k] = A::ld(val + nn[k]);
+        const bool self_good = self < inf;
+        if (act && (MODE == 0 ? self_good : !self_good)) {
             if (MODE == 0) {
                 sweep_sort10(v);                                                    // the m good neighbours' values first, +inf behind them
                 if (v[2] < inf) {                                                   // nnn > 2; nth_element(idnn, idnn + nnn/2, idnn + nnn): the nnn/2-th smallest

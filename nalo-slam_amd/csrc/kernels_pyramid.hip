@@ -173,6 +173,129 @@ __device__ __forceinline__ void pyr_emit_level(const PyrLevels& P, const float* 
         pyr_store(&P.absg[LV][idx], ab);
     }
 }
+// ---- round 4: the levels 3 and 4 of a five-level pyramid in the SAME launch. They used to take a second launch over planar box values the fine tiles
+// left behind (pyr_grad_tail_kernel: 3.9 us + a kernel boundary behind a 12 us kernel, for 1/64 + 1/256 of the pixels). Now the FIRST workgroups of the one launch
+// rebuild them from level 0 on their own: a coarse tile is kCW x kCH pixels of level 3 (= 8 kCW x 8 kCH of level 0) with a halo of two level-3 pixels (one pixel of
+// level 4); a lane folds a 4 x 4 block of level 0 (four 16-byte loads) into one value of level 2 - the same 0.25f * (((a + b) + c) + d) nesting, twice -, the levels
+// 3 and 4 follow in LDS. The flat-index neighbours of the border columns (I_l(w_l - 1, y - 1) left of x = 0, I_l(0, y + 1) right of x = w_l - 1) are rebuilt the
+// same way by the border tiles: 4 (level 3) or 16 (level 4) extra level-2 values each. Read amplification (kCW + 4)(kCH + 4) / (kCW kCH) on 4 of ~25 bytes per pixel.
+#ifndef NALO_PYR_CW
+#define NALO_PYR_CW 16
+#define NALO_PYR_CH 4
+#endif
+struct PyrCoarse {
+    static constexpr int kCW = NALO_PYR_CW, kCH = NALO_PYR_CH;              // tile of level 3 (level 4: kCW / 2 x kCH / 2)
+    static constexpr int R3W = kCW + 4, R3H = kCH + 4, R2W = 2 * R3W, R2H = 2 * R3H, R4W = kCW / 2 + 2, R4H = kCH / 2 + 2;
+    static constexpr int N2 = R2W * R2H, N3 = R3W * R3H, N4 = R4W * R4H;
+    static constexpr int NX3 = 4 * kCH, NX4 = 16 * (kCH / 2);              // extra level-2 values per border side: level 3 / level 4 edge values
+    static constexpr int NX = 2 * (NX3 + NX4);
+    static_assert(N3 <= 192 && 2 * kCH <= 32 && kCH <= 32 && NX <= 256 && kCW % 2 == 0 && kCH % 2 == 0, "lane ranges of pyr_coarse_tile");
+    static constexpr int oL2 = 0, oX2 = N2, oL3 = oX2 + NX, oL4 = oL3 + N3, oE3 = oL4 + N4, oE4 = oE3 + 2 * kCH, total = oE4 + kCH;
+};
+__device__ __forceinline__ float pyr_box4(float a, float b, float c, float d) { return 0.25f * (((a + b) + c) + d); }
+// level-2 value (x2, y2) from its 4 x 4 block of level 0: four aligned 16-byte loads
+__device__ __forceinline__ void pyr_l2_load(const float* __restrict__ I0, int w0, int x2, int y2, bool ok, pyr_f4 (&r)[4]) {
+    const float* p = I0 + (ok ? (size_t)(4 * y2) * w0 + 4 * x2 : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const pyr_f4*>(p + (ok ? (size_t)k * w0 : 0));
+}
+__device__ __forceinline__ float pyr_l2_fold(const pyr_f4 (&r)[4]) {
+    const float a = pyr_box4(r[0].x, r[0].y, r[1].x, r[1].y), b = pyr_box4(r[0].z, r[0].w, r[1].z, r[1].w);
+    const float c = pyr_box4(r[2].x, r[2].y, r[3].x, r[3].y), d = pyr_box4(r[2].z, r[2].w, r[3].z, r[3].w);
+    return pyr_box4(a, b, c, d);
+}
+__device__ __forceinline__ void pyr_grad_store(const PyrLevels& P, int lv, int x, int y, float c, float left, float right, float up, float down, bool inner, const float* __restrict__ gammaB) {
+    float dx = 0.f, dy = 0.f, ab = 0.f;
+    if (inner) {                                                    // idx >= w && idx < w (h - 1)
+        dx = 0.5f * (right - left);
+        dy = 0.5f * (down - up);
+        if (!isfinite(dx)) dx = 0.f;
+        if (!isfinite(dy)) dy = 0.f;
+        ab = dx * dx + dy * dy;                                     // -ffp-contract=off: rounds as the reference's scalar code
+        if (gammaB) {                                               // HessianBlocks.h:400-406 getBGradOnly
+            int ci = (int)(c + 0.5f);
+            ci = ci < 5 ? 5 : (ci > 250 ? 250 : ci);
+            const float gw = gammaB[ci + 1] - gammaB[ci];
+            ab *= gw * gw;
+        }
+    }
+    const int idx = x + y * P.wl[lv];
+    pyr_store(&P.dI[lv][idx], c, dx, dy);
+    pyr_store(&P.absg[lv][idx], ab);
+}
+__device__ __forceinline__ void pyr_coarse_tile(const PyrLevels& P, const float* __restrict__ gammaB, int tile, float* __restrict__ lds, int tid) {
+    using C = PyrCoarse;
+    const int w0 = P.wl[0], w2 = P.wl[2], h2 = P.hl[2], w3 = P.wl[3], h3 = P.hl[3], w4 = P.wl[4], h4 = P.hl[4];
+    const int ctx = (w3 + C::kCW - 1) / C::kCW, X3 = (tile % ctx) * C::kCW, Y3 = (tile / ctx) * C::kCH, X4 = X3 >> 1, Y4 = Y3 >> 1;
+    const bool left = X3 == 0, right = X3 <= w3 - 1 && w3 - 1 < X3 + C::kCW;
+    const float* __restrict__ I0 = P.I[0];
+    // ---- level 2 of the haloed region (and of the border columns' flat-index neighbours), straight from level 0
+    constexpr int R = (C::N2 + 255) / 256;
+    pyr_f4 r[R][4]; bool ok[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int e = tid + 256 * k, x2 = 2 * X3 - 4 + e % C::R2W, y2 = 2 * Y3 - 4 + e / C::R2W;
+        ok[k] = e < C::N2 && x2 >= 0 && x2 < w2 && y2 >= 0 && y2 < h2;
+        pyr_l2_load(I0, w0, x2, y2, ok[k], r[k]);
+    }
+    pyr_f4 rx[4]; bool okx = false;
+    if ((left || right) && tid < C::NX) {                       // border tiles: extra values, [left: level 3 | level 4][right: level 3 | level 4]
+        int k = tid;
+        const bool rs = k >= C::NX3 + C::NX4;                   // right side: the neighbour of x = w_l - 1 is I_l(0, y + 1); left side: I_l(w_l - 1, y - 1) for x = 0
+        if (rs) k -= C::NX3 + C::NX4;
+        int x2, y2;
+        if (k < C::NX3) {                                       // level 3: entry = ty * 4 + (sy * 2 + sx)
+            const int ty = k >> 2, q2 = k & 3, y = Y3 + ty, x3 = rs ? 0 : w3 - 1, y3 = rs ? y + 1 : y - 1;
+            okx = (rs ? right : left) && y >= 1 && y <= h3 - 2;
+            x2 = 2 * x3 + (q2 & 1); y2 = 2 * y3 + (q2 >> 1);
+        } else {                                                // level 4: entry = ty * 16 + (level-3 sub-pixel) * 4 + (level-2 sub-pixel)
+            k -= C::NX3;
+            const int ty = k >> 4, q3 = (k >> 2) & 3, q2 = k & 3, y = Y4 + ty, x4 = rs ? 0 : w4 - 1, y4 = rs ? y + 1 : y - 1;
+            okx = (rs ? right : left) && y >= 1 && y <= h4 - 2;
+            const int x3 = 2 * x4 + (q3 & 1), y3 = 2 * y4 + (q3 >> 1);
+            x2 = 2 * x3 + (q2 & 1); y2 = 2 * y3 + (q2 >> 1);
+        }
+        pyr_l2_load(I0, w0, x2, y2, okx, rx);
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) { const int e = tid + 256 * k; if (e < C::N2) lds[C::oL2 + e] = ok[k] ? pyr_l2_fold(r[k]) : 0.f; }
+    if (tid < C::NX) lds[C::oX2 + tid] = okx ? pyr_l2_fold(rx) : 0.f;
+    __syncthreads();
+    // ---- level 3 (region), and the edge values of both levels from the extra level-2 values
+    if (tid < C::N3) {
+        const float* q = lds + C::oL2 + 2 * (tid / C::R3W) * C::R2W + 2 * (tid % C::R3W);
+        lds[C::oL3 + tid] = pyr_box4(q[0], q[1], q[C::R2W], q[C::R2W + 1]);
+    } else if (tid >= 192 && tid < 192 + 2 * C::kCH) {          // level-3 edge values: [left kCH | right kCH]
+        const int k = tid - 192, side = k >= C::kCH, ty = side ? k - C::kCH : k;
+        const float* q = lds + C::oX2 + side * (C::NX3 + C::NX4) + ty * 4;
+        lds[C::oE3 + k] = pyr_box4(q[0], q[1], q[2], q[3]);
+    } else if (tid >= 224 && tid < 224 + C::kCH) {              // level-4 edge values: [left kCH / 2 | right kCH / 2]
+        const int k = tid - 224, side = k >= C::kCH / 2, ty = side ? k - C::kCH / 2 : k;
+        const float* q = lds + C::oX2 + side * (C::NX3 + C::NX4) + C::NX3 + ty * 16;
+        lds[C::oE4 + k] = pyr_box4(pyr_box4(q[0], q[1], q[2], q[3]), pyr_box4(q[4], q[5], q[6], q[7]), pyr_box4(q[8], q[9], q[10], q[11]), pyr_box4(q[12], q[13], q[14], q[15]));
+    }
+    __syncthreads();
+    if (tid < C::N4) {                                          // ---- level 4 (region)
+        const float* q = lds + C::oL3 + 2 * (tid / C::R4W) * C::R3W + 2 * (tid % C::R4W);
+        lds[C::oL4 + tid] = pyr_box4(q[0], q[1], q[C::R3W], q[C::R3W + 1]);
+    }
+    __syncthreads();
+    // ---- texels of both levels
+    for (int t = tid; t < C::kCW * C::kCH; t += 256) {
+        const int tx = t % C::kCW, ty = t / C::kCW, x = X3 + tx, y = Y3 + ty;
+        if (x < w3 && y < h3) {
+            const float* sp = lds + C::oL3 + (ty + 2) * C::R3W + tx + 2;
+            pyr_grad_store(P, 3, x, y, sp[0], x > 0 ? sp[-1] : lds[C::oE3 + ty], x < w3 - 1 ? sp[1] : lds[C::oE3 + C::kCH + ty], sp[-C::R3W], sp[C::R3W], y >= 1 && y <= h3 - 2, gammaB);
+        }
+    }
+    for (int t = tid; t < (C::kCW / 2) * (C::kCH / 2); t += 256) {
+        const int tx = t % (C::kCW / 2), ty = t / (C::kCW / 2), x = X4 + tx, y = Y4 + ty;
+        if (x < w4 && y < h4) {
+            const float* sp = lds + C::oL4 + (ty + 1) * C::R4W + tx + 1;
+            pyr_grad_store(P, 4, x, y, sp[0], x > 0 ? sp[-1] : lds[C::oE4 + ty], x < w4 - 1 ? sp[1] : lds[C::oE4 + C::kCH / 2 + ty], sp[-C::R4W], sp[C::R4W], y >= 1 && y <= h4 - 2, gammaB);
+        }
+    }
+}
 template <int NL>
 __device__ __forceinline__ void pyr_box_level(const PyrLevels& P, float* __restrict__ lds, int l, int x0, int y0, int tid) {
     using Lay = PyrLds<NL>;
@@ -201,25 +324,33 @@ __device__ __forceinline__ void pyr_box_level(const PyrLevels& P, float* __restr
 #ifndef NALO_PYR_LD4
 #define NALO_PYR_LD4 1
 #endif
+#ifndef NALO_PYR_COARSE
+#define NALO_PYR_COARSE 1
+#endif
 template <int NL, int LV>
-__device__ __forceinline__ void pyr_walk(const PyrLevels& P, float* __restrict__ lds, const float* __restrict__ edge, const float* __restrict__ gammaB, int x0, int y0, int tid) {
+__device__ __forceinline__ void pyr_walk(const PyrLevels& P, float* __restrict__ lds, const float* __restrict__ edge, const float* __restrict__ gammaB, int x0, int y0, int tid, int Lbox) {
     if constexpr (LV <= NALO_MAX_LEVELS) {                      // step LV: emit level LV - 1 (complete since the last barrier), box level LV out of it
         if constexpr (LV - 1 < NL) pyr_emit_level<NL, LV - 1>(P, lds, edge, gammaB, x0, y0, tid);
         if constexpr (LV < NALO_MAX_LEVELS) {
-            if (LV < P.L) pyr_box_level<NL>(P, lds, LV, x0, y0, tid);
+            if (LV < Lbox) pyr_box_level<NL>(P, lds, LV, x0, y0, tid);
             __syncthreads();
-            pyr_walk<NL, LV + 1>(P, lds, edge, gammaB, x0, y0, tid);
+            pyr_walk<NL, LV + 1>(P, lds, edge, gammaB, x0, y0, tid, Lbox);
         }
     }
 }
 template <int NL>
-__global__ __launch_bounds__(256) void pyr_one_pass_kernel(PyrLevels P, const float* __restrict__ gammaB) {
+__global__ __launch_bounds__(256) void pyr_one_pass_kernel(PyrLevels P, const float* __restrict__ gammaB, int n_coarse) {
     using Lay = PyrLds<NL>;
     __shared__ __attribute__((aligned(16))) float lds[Lay::total];
     __shared__ float edge[4 * kPyrTH];                          // 2 x (TH + TH/2 + TH/4 + TH/8) <= 4 TH
     constexpr int H = Lay::H;
     const int tid = threadIdx.x, tiles_x = (P.wl[0] + kPyrTW - 1) / kPyrTW;
-    const int x0 = (blockIdx.x % tiles_x) * kPyrTW, y0 = (blockIdx.x / tiles_x) * kPyrTH;
+    if constexpr (NL == 3) {                                    // a five-level pyramid: the first n_coarse workgroups build the levels 3 and 4 (pyr_coarse_tile)
+        static_assert(Lay::total >= PyrCoarse::total, "the coarse tile's LDS image fits the fine tile's");
+        if ((int)blockIdx.x < n_coarse) { pyr_coarse_tile(P, gammaB, (int)blockIdx.x, lds, tid); return; }
+    }
+    const int bid = (int)blockIdx.x - n_coarse, Lbox = n_coarse > 0 ? NL : P.L;     // with coarse workgroups the fine tiles stop at level NL - 1 (no planar values of the levels above)
+    const int x0 = (bid % tiles_x) * kPyrTW, y0 = (bid / tiles_x) * kPyrTH;
     {                                                           // level 0 with its halo; outside the image: 0 (never used by a pixel that is written)
         constexpr int RW = Lay::rw(0), RH = Lay::rh(0);
         const int w0 = P.wl[0], h0 = P.hl[0];
@@ -274,11 +405,11 @@ __global__ __launch_bounds__(256) void pyr_one_pass_kernel(PyrLevels P, const fl
 #if NALO_PYR_EARLY
     // round 4: level l leaves for HBM while level l + 1 is being boxed out of it (both only READ level l's LDS image): the texel stores drain under the rest of
     // the LDS walk instead of forming one store phase at the end of every (lockstep) workgroup
-    pyr_walk<NL, 1>(P, lds, edge, gammaB, x0, y0, tid);
+    pyr_walk<NL, 1>(P, lds, edge, gammaB, x0, y0, tid, Lbox);
 #else
 #pragma unroll
     for (int l = 1; l < NALO_MAX_LEVELS; ++l) {                 // the box pyramid inside LDS: levels < NL over the haloed region, the ones above over the tile only
-        if (l < P.L) pyr_box_level<NL>(P, lds, l, x0, y0, tid);
+        if (l < Lbox) pyr_box_level<NL>(P, lds, l, x0, y0, tid);
         __syncthreads();
     }
     pyr_emit_level<NL, 0>(P, lds, edge, gammaB, x0, y0, tid);
@@ -490,16 +621,20 @@ int pyramid_build(nalo_ctx* c, FrameSlot& s, const float* gammaB_dev) {
     if (fused) {
         // one pass over level 0 (pyr_one_pass_kernel): every level of a pyramid of <= 4 levels, the three finest + the planar values of the rest otherwise
         const int tiles = ((c->wl[0] + kPyrTW - 1) / kPyrTW) * ((c->hl[0] + kPyrTH - 1) / kPyrTH);
-#define NALO_PYR1(NL_, E0_, E1_) do { if (ps.a) hipExtLaunchKernelGGL((pyr_one_pass_kernel<NL_>), dim3(tiles), dim3(256), 0, c->stream, E0_, E1_, 0, P, gammaB_dev); \
-                                      else pyr_one_pass_kernel<NL_><<<tiles, 256, 0, c->stream>>>(P, gammaB_dev); } while (0)
+#define NALO_PYR1(NL_, NC_, E0_, E1_) do { if (ps.a) hipExtLaunchKernelGGL((pyr_one_pass_kernel<NL_>), dim3(tiles + (NC_)), dim3(256), 0, c->stream, E0_, E1_, 0, P, gammaB_dev, (NC_)); \
+                                      else pyr_one_pass_kernel<NL_><<<tiles + (NC_), 256, 0, c->stream>>>(P, gammaB_dev, (NC_)); } while (0)
         switch (c->levels) {
-            case 2: NALO_PYR1(2, ps.a, ps.b); break;
-            case 3: NALO_PYR1(3, ps.a, ps.b); break;
-            case 4: NALO_PYR1(4, ps.a, ps.b); break;
-            default:
-                NALO_PYR1(3, ps.a, nullptr);
+            case 2: NALO_PYR1(2, 0, ps.a, ps.b); break;
+            case 3: NALO_PYR1(3, 0, ps.a, ps.b); break;
+            case 4: NALO_PYR1(4, 0, ps.a, ps.b); break;
+            default: {
+                // five levels: the levels 3 and 4 by the first workgroups of the same launch (pyr_coarse_tile; the 16-byte loads want w0 % 16 == 0, which five even levels imply)
+                const int nc = ((c->wl[3] + PyrCoarse::kCW - 1) / PyrCoarse::kCW) * ((c->hl[3] + PyrCoarse::kCH - 1) / PyrCoarse::kCH);
+                if (NALO_PYR_COARSE && c->levels == 5) { NALO_PYR1(3, nc, ps.a, ps.b); break; }
+                NALO_PYR1(3, 0, ps.a, nullptr);
                 if (ps.a) hipExtLaunchKernelGGL(pyr_grad_tail_kernel, dim3(nb - P.blk0[3]), dim3(256), 0, c->stream, nullptr, ps.b, 0, P, gammaB_dev, 3);
                 else pyr_grad_tail_kernel<<<nb - P.blk0[3], 256, 0, c->stream>>>(P, gammaB_dev, 3);
+            }
         }
 #undef NALO_PYR1
         NALO_HIP(c, hipGetLastError());

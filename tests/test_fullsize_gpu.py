@@ -296,3 +296,28 @@ def test_pyramid_six_levels_bit_exact():
         assert np.array_equal(dI, dI_ref[o:o + n]), "level %d texels differ" % lvl
         assert np.array_equal(ab, ab_ref[o:o + n])
     c.close()
+
+
+@pytest.mark.parametrize("w,h", [(1840, 880), (128, 5120), (1936, 1072)])
+def test_pyramid_five_levels_coarse_tiles_bit_exact(w, h):
+    """Five-level pyramids whose levels 3 and 4 come from the coarse workgroups of the one launch (pyr_coarse_tile, round 4): 1840x880 (level 3 = 230x110: the last coarse
+    tile column and row are partial, level 4 = 115x55 is odd), 128x5120 (level 3 = 16x640: ONE coarse tile column, every tile rebuilds both flat-index neighbours of
+    its rows) and 1936x1072 (level 3 = 242 wide: the last tile column holds two pixels); with the gamma table of CalibHessian::B, every level bit-exact."""
+    rng = np.random.RandomState(w + h)
+    img = (rng.rand(h // 16, w // 16).astype(np.float32) * 250).repeat(16, 0).repeat(16, 1) + rng.rand(h, w).astype(np.float32) * 5
+    B = (255.0 * (np.arange(256) / 255.0) ** 0.8).astype(np.float32)
+    K = (0.52 * w, 0.52 * w, (w - 1) / 2.0, (h - 1) / 2.0)
+    c = binding.Context(w, h, K, n_slots=1)
+    assert c.levels == 5
+    L = orc.lib()
+    tot = L.orc_pyr_offset(w, h, 5)
+    for gam in (None, B):
+        c.frame_upload(0, img, gammaB=gam)
+        dI_ref, ab_ref = np.zeros((tot, 3), np.float32), np.zeros(tot, np.float32)
+        L.orc_make_images(orc.fp(np.ascontiguousarray(img)), w, h, 5, orc.fp(gam) if gam is not None else None, orc.fp(dI_ref), orc.fp(ab_ref))
+        for lvl in range(5):
+            dI, ab = c.frame_download(0, lvl)
+            o, n = L.orc_pyr_offset(w, h, lvl), (w >> lvl) * (h >> lvl)
+            assert np.array_equal(dI, dI_ref[o:o + n]), "level %d texels differ (gamma %s)" % (lvl, gam is not None)
+            assert np.array_equal(ab, ab_ref[o:o + n]), "level %d absSquaredGrad differs (gamma %s)" % (lvl, gam is not None)
+    c.close()
