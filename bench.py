@@ -970,6 +970,12 @@ def stress_leg(steps=5, warmup=2):
         if n:
             ach = alg / (ms / n * 1e-3) / 1e9
             res[k] = dict(avg_us=round(ms / n * 1e3, 2), launches=n, alg_bytes=int(alg), achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
+            if k == "ba_sc":
+                # what the fused kernel really moves (counter traffic 125 MB at these sizes): 32 B of Jacobian products + the 24-B point-sum share ba_linearize leaves per
+                # residual + one more byte of state, and 116 B per point (the 56 above + the per-point sums written and the operands staged): the SURVEY 8(d) figure
+                # above prices the shares at zero
+                moved = 57.0 * R + 116.0 * P
+                res[k].update(moved_bytes=int(moved), frac_moved=round(moved / (ms / n * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
     if "ba_linearize" in res:
         res["ba_linearize"].update(measured_over="full steps (tracking + setCoarseTrackingRef + optimize), every launch", stats=lin_stats, stats_ba_only_loop=lin_ba_only)
     res["traffic"] = load_traffic("stress250k")

@@ -481,10 +481,13 @@ template <int BPP, int PHOTO>
 __global__ __launch_bounds__(256) void ingest_kernel(IngestParams P) {
     constexpr int U = NALO_INGEST_U;
     __shared__ float sG[BPP == 1 && PHOTO > 0 ? 256 : 1];
-    if constexpr (BPP == 1 && PHOTO > 0) { sG[threadIdx.x] = P.G[threadIdx.x]; __syncthreads(); }
+    // the 8-bit response table goes to LDS BEHIND the issue of the pixel loads (its own load leaves first, the LDS store and the barrier follow the taps' issue): staged
+    // in front of them it was a third round trip at the head of every workgroup
+    float g_own = 0.f;
+    if constexpr (BPP == 1 && PHOTO > 0) g_own = P.G[threadIdx.x];
+    auto stage_G = [&]() { if constexpr (BPP == 1 && PHOTO > 0) { sG[threadIdx.x] = g_own; __syncthreads(); } };
     const float* __restrict__ Gt = (BPP == 1 && PHOTO > 0) ? sG : P.G;
     const int n = P.w * P.h, base = blockIdx.x * (256 * U) + threadIdx.x;
-    if (base >= n) return;
     auto data = [&](unsigned v, float vi) -> float {                       // PhotometricUndistorter::processFrame (Undistort.cpp:224-251) at one original pixel
         if constexpr (PHOTO == 0) return P.factor * (float)v;
         float d = Gt[v];
@@ -500,6 +503,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestParams P) {
             if constexpr (BPP == 1) v[u] = reinterpret_cast<const uint8_t*>(P.raw)[ii]; else v[u] = reinterpret_cast<const uint16_t*>(P.raw)[ii];
             vi[u] = PHOTO == 2 ? P.vinv[ii] : 1.f;
         }
+        stage_G();
 #pragma unroll
         for (int u = 0; u < U; ++u) o[u] = data(v[u], vi[u]);
     } else {
@@ -521,6 +525,7 @@ __global__ __launch_bounds__(256) void ingest_kernel(IngestParams P) {
             i0[u] = make_float2(1.f, 1.f); i1[u] = i0[u];
             if constexpr (PHOTO == 2) { __builtin_memcpy(&i0[u], P.vinv + p, 8); __builtin_memcpy(&i1[u], P.vinv + p + P.wOrg, 8); }
         }
+        stage_G();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const float xxyy = xx[u] * yy[u];
