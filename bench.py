@@ -160,6 +160,12 @@ class GpuJob:
         c, W, L = self.ctx, self.win.W, self.ctx.L
         if not hasattr(self, "_trk_args"):
             self._prepare_calls()
+        if track and not upload:
+            # a1 on the HBM-resident frames: the three makeImages passes are queued ahead of the tracking calls (they do not depend on them; with host
+            # buffers the same overlap comes from nalo_frame_upload_async: the next frame's copy + pyramid run under the tracking of the current one) and ahead
+            # of the harness' snapshot restore (independent of it: the device builds the pyramids while the host rewinds the window's state)
+            for k in range(TRACKED_PER_KF):
+                c.frame_rebuild(W + k)
         c.ba_restore()
         if track:
             if upload == "raw":
@@ -168,11 +174,6 @@ class GpuJob:
             elif upload:                                                     # all three copies go to the copy stream at once: the first one is exposed,
                 for k in range(TRACKED_PER_KF):                              # the others run under the tracking of the frame before
                     c.frame_upload_async(W + k, self._pinned[k])
-            if not upload:
-                # a1 on the HBM-resident frames: the three makeImages passes are queued ahead of the tracking calls (they do not depend on them; with host
-                # buffers the same overlap comes from nalo_frame_upload_async: the next frame's copy + pyramid run under the tracking of the current one)
-                for k in range(TRACKED_PER_KF):
-                    c.frame_rebuild(W + k)
             for k in range(TRACKED_PER_KF):
                 self._T[:] = self._T0[k]; self._aff[:] = 0
                 c._ck(L.nalo_trk_track(c.h_, W + k, *self._trk_args, c.levels - 1, *self._trk_tail))

@@ -4,6 +4,7 @@
 // block only holds points of one host (blk_host[b]). One residual slot per (target t, point d): arrays are
 // [W][Ppad], t-major, so a wave reads consecutive points of one target: coalesced.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
@@ -78,7 +79,10 @@ struct XadArg { float v[4 + 8 * 64]; };
 // inputs - the step {xc, xAd}, the precalc records - and then the sequence number. What it saves per Gauss-Newton iteration is the launch latency of the two
 // kernels on the critical path (the device starts ~1.5 us after the host's store instead of 5-6 us after its launch call). 0xFFFFFFFF = cancelled: the kernel returns
 // without touching anything (the host's error paths), as it does when the bound expires (and then raises err).
-struct GateBlock { unsigned x_seq, p_seq, err, pad[13]; float x[4 + NALO_MAX_WINDOW * NALO_MAX_WINDOW * 8]; };
+// (the payload starts on its own 128-byte line: a gated kernel's first look at a flag is a cached scalar load made BEFORE the host writes the payload, and a device
+// cache line that held both would hand the payload's loads the bytes of the iteration before)
+struct GateBlock { unsigned x_seq, p_seq, err, pad[29]; float x[4 + NALO_MAX_WINDOW * NALO_MAX_WINDOW * 8]; };
+static_assert(offsetof(GateBlock, x) == 128, "flags and payload of the gate block on separate cache lines");
 constexpr unsigned kGateCancel = 0xFFFFFFFFu;
 struct GateArg { const unsigned* flag; unsigned* err; const float* x; unsigned want; };
 __device__ __forceinline__ bool gate_wait(const unsigned* flag, unsigned want, unsigned* err) {      // one lane; true = the inputs are there

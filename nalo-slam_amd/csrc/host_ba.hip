@@ -534,6 +534,10 @@ static int prelaunch_iteration(nalo_ctx* c) {
         NALO_HIP(c, hipHostGetDevicePointer((void**)&w.gate_d, w.gate_h, 0));
     }
     if (w.pre_pos + 1 - 4 > w.pre_synced || !w.pre_map_dev[0]) return NALO_OK;    // the ring slot of the next records may still have readers: this iteration launches the ordinary way
+    // a cancelled pass (prelaunch_cancel) leaves kGateCancel in both words and nothing waiting on them (it drained the stream): a kernel enqueued now must find
+    // them merely closed
+    if (w.gate_h->x_seq == kGateCancel) __atomic_store_n(&w.gate_h->x_seq, 0u, __ATOMIC_RELEASE);
+    if (w.gate_h->p_seq == kGateCancel) __atomic_store_n(&w.gate_h->p_seq, 0u, __ATOMIC_RELEASE);
     if (++w.gate_x_seq == kGateCancel) w.gate_x_seq = 1;
     if (++w.gate_p_seq == kGateCancel) w.gate_p_seq = 1;
     {

@@ -77,24 +77,49 @@ __device__ __forceinline__ void dn_world(const DenseParams& P, int i, int j, flo
     for (int q = 0; q < 3; ++q) m[q] = P.c2w[q * 4] * (double)c0 + P.c2w[q * 4 + 1] * (double)c1 + P.c2w[q * 4 + 2] * (double)c2 + P.c2w[q * 4 + 3];
 }
 // which pixels of this lane's R rounds are kept (MapPoint.cpp:366-380); the mask loads are issued together, an out-of-range lane reads pixel (rx0, ry0) and drops it
+// Round 4: the chunks run over the CANDIDATES of the box in raster order - the pixels with (i % 3 == 0 || j % 3 == 0), MapPoint.cpp:366 -, not over all its pixels:
+// both kernels are bound by the number of vector instructions they issue, and 4 of 9 lanes spent theirs on pixels that can never be kept. A band of three rows
+// starting at a row i = 0 (mod 3) holds rw candidates (the whole first row) + cj + cj (the columns j = 0 (mod 3) of the other two); the virtual bands start at
+// i0 = ry0 - ry0 % 3, `pre` candidates of the first band lie above the box.
+struct DnMap {
+    int rx0, rw, cj, j0, i0, B, pre, total; DnDiv dv;
+    __device__ __forceinline__ DnMap(int rx0_, int rx1, int ry0, int ry1, bool any) {
+        rx0 = any ? rx0_ : 0; rw = any ? rx1 - rx0 : 1;
+        j0 = rx0 + (3 - rx0 % 3) % 3;
+        cj = any && j0 < rx1 ? (rx1 - 1 - j0) / 3 + 1 : 0;
+        B = rw + 2 * cj;
+        const int m = any ? ry0 % 3 : 0;
+        i0 = (any ? ry0 : 0) - m;
+        pre = m == 0 ? 0 : (m == 1 ? rw : rw + cj);
+        const int nrows = any ? ry1 - i0 : 0, full = nrows / 3, r = nrows - 3 * full;
+        total = any ? full * B + (r >= 1 ? rw : 0) + (r >= 2 ? cj : 0) - pre : 0;
+        dv = DnDiv{B, total + pre < (1 << 24) ? 1.0f / (float)B : 0.f};
+    }
+    __device__ __forceinline__ void at(int e, int& i, int& j) const {         // candidate e (0 <= e < total) -> pixel (i, j)
+        int band, rem; dn_divmod(dv, e + pre, band, rem);
+        i = i0 + 3 * band;
+        if (rem < rw) j = rx0 + rem;
+        else if (rem < rw + cj) { i += 1; j = j0 + 3 * (rem - rw); }
+        else { i += 2; j = j0 + 3 * (rem - rw - cj); }
+    }
+};
+// which candidates of this lane's R rounds are kept (MapPoint.cpp:366-380); the mask loads are issued together, an out-of-range lane reads candidate 0 and drops it
 template <int R>
-__device__ __forceinline__ void dn_keep(const DenseParams& P, int b, int tid, int rx0, int ry0, int rw, int total, bool (&keep)[R], float (&idp)[R], int (&pi)[R], int (&pj)[R]) {
+__device__ __forceinline__ void dn_keep(const DenseParams& P, const DnMap& M, int b, int tid, bool (&keep)[R], float (&idp)[R], int (&pi)[R], int (&pj)[R]) {
     float mv[R];
-    const DnDiv dv{rw, total < (1 << 24) ? 1.0f / (float)rw : 0.f};
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int e = b * kDenseChunk + r * 256 + tid, ee = e < total ? e : 0;
-        int q, m; dn_divmod(dv, ee, q, m);
-        pi[r] = ry0 + q; pj[r] = rx0 + m;
+        const int e = b * kDenseChunk + r * 256 + tid;
+        M.at(e < M.total ? e : 0, pi[r], pj[r]);
         mv[r] = P.mask[pj[r] + pi[r] * P.w];
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = b * kDenseChunk + r * 256 + tid;
         keep[r] = false; idp[r] = 0.f;
-        if (e < total) {
+        if (e < M.total) {
             const int i = pi[r], j = pj[r];
-            if (mv[r] == P.pcolor && (i % 3 == 0 || j % 3 == 0)) {
+            if (mv[r] == P.pcolor) {                                                                                  // (i % 3 == 0 || j % 3 == 0) holds for every candidate
                 const float ddepth = P.p0 * (j * P.fxi - P.cx * P.fxi) + P.p1 * (i * P.fyi - P.cy * P.fyi) + P.p2;   // MapPoint.cpp:377
                 if (ddepth != 0.f) { const float depth = -P.p3 / ddepth; if (depth != 0.f) { idp[r] = 1.f / depth; keep[r] = true; } }
             }
@@ -125,10 +150,11 @@ __global__ __launch_bounds__(256) void dense_count_kernel(DenseParams P) {
     const int ry0 = min(min(sr[0][2], sr[1][2]), min(sr[2][2], sr[3][2])), ry1 = max(max(sr[0][3], sr[1][3]), max(sr[2][3], sr[3][3]));
     if (b == 0 && tid == 0) { P.rect[0] = rx0; P.rect[1] = rx1; P.rect[2] = ry0; P.rect[3] = ry1; P.last[0] = 0ull; P.last[1] = 0ull; P.n_out[0] = 0; }
     const bool any = rx0 != INT_MAX && rx1 > rx0 && ry1 > ry0;
-    const int rw = any ? rx1 - rx0 : 1, total = any ? rw * (ry1 - ry0) : 0, nb = (total + kDenseChunk - 1) / kDenseChunk;
+    const DnMap M(rx0, rx1, ry0, ry1, any);
+    const int nb = (M.total + kDenseChunk - 1) / kDenseChunk;
     if (b >= nb) return;
     bool keep[R]; float idp[R]; int pi[R], pj[R];
-    dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp, pi, pj);
+    dn_keep<R>(P, M, b, tid, keep, idp, pi, pj);
     int cnt = 0;
     float mnx = FLT_MAX, mny = FLT_MAX, mnz = FLT_MAX, mxx = FLT_MIN;
 #pragma unroll
@@ -175,7 +201,8 @@ __global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const int rx0 = P.rect[0], rx1 = P.rect[1], ry0 = P.rect[2], ry1 = P.rect[3];
     const bool any = rx0 != INT_MAX && rx1 > rx0 && ry1 > ry0;
-    const int rw = any ? rx1 - rx0 : 1, total = any ? rw * (ry1 - ry0) : 0, nb = (total + kDenseChunk - 1) / kDenseChunk;
+    const DnMap M(rx0, rx1, ry0, ry1, any);
+    const int nb = (M.total + kDenseChunk - 1) / kDenseChunk;
     if (b < nb) {
         // ---- exclusive prefix of the chunks in front: count, min x / y / z, max x (order-free folds; the in-order part happens inside the workgroup).
         // The first four strides are loaded together (a rolled loop waits for every load: three dependent L2 round trips for the last chunks of the bench's box)
@@ -195,7 +222,7 @@ __global__ __launch_bounds__(256) void dense_write_kernel(DenseParams P, int cap
         for (int o = 32; o > 0; o >>= 1) { ecnt += __shfl_xor(ecnt, o); e1 = fminf(e1, __shfl_xor(e1, o)); e2 = fminf(e2, __shfl_xor(e2, o)); e3 = fminf(e3, __shfl_xor(e3, o)); e4 = fmaxf(e4, __shfl_xor(e4, o)); }
         if (lane == 0) { red[wave][0] = __int_as_float(ecnt); red[wave][1] = e1; red[wave][2] = e2; red[wave][3] = e3; red[wave][4] = e4; }
         bool keep[R]; float idp[R]; int rank[R], pi[R], pj[R];
-        dn_keep<R>(P, b, tid, rx0, ry0, rw, total, keep, idp, pi, pj);
+        dn_keep<R>(P, M, b, tid, keep, idp, pi, pj);
         double wy[R], wz[R];                     // world y, z of the kept points (compared as doubles against the float running minima)
         float fyv[R], fzv[R], py[R], pz[R];      // their float values (FLT_MAX: no point) and the inclusive prefix minima over the wave in lane order
 #pragma unroll

@@ -319,4 +319,6 @@ def test_error_between_a_prelaunch_and_its_gates_leaves_nothing_spinning(tmp_pat
         runs[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert runs["plain"]["first"] == "no error"
     assert "between a pre-launch and its gates" in runs["cancel"]["first"]
-    assert runs["cancel"]["rmse_after"] == runs["plain"]["rmse_after"] and np.array_equal(np.asarray(runs["cancel"]["w2c_after"]), np.asarray(runs["plain"]["w2c_after"]))
+    assert runs["cancel"]["rmse_after"] == runs["plain"]["rmse_after"], (runs["cancel"]["rmse_after"], runs["plain"]["rmse_after"])
+    d = np.abs(np.asarray(runs["cancel"]["w2c_after"]) - np.asarray(runs["plain"]["w2c_after"])).max()
+    assert d == 0, "window poses after restore + optimize differ by %.3e between the cancelled and the plain process" % d
