@@ -1043,7 +1043,7 @@ def frontend_legs(rounds=30):
     L = c.levels
     alg_pyr = 4.0 * w * h + 16.0 * w * h * sum(0.25 ** l for l in range(L))
     res["pyramid"] = timed("pyramid", lambda: c.frame_rebuild(1), alg_pyr)
-    res["pyramid"]["note"] = "one pass over level 0 for the levels 0-2 (LDS tiles with halo) + one small launch for the gradients of the levels >= 3; 4wh in + 16 B per pixel of every level out"
+    res["pyramid"]["note"] = "ONE launch: fine tiles (64x16, LDS with halo) for the levels 0-2, coarse workgroups of the same launch rebuild the levels 3-4 from level 0; 4wh in + 16 B per pixel of every level out"
     # ---- dense map
     import ctypes as C
     cap = w * h
@@ -1060,8 +1060,8 @@ def frontend_legs(rounds=30):
     dm()
     bbox_px = int((rect[1] - rect[0]) * (rect[3] - rect[2]))
     res["dense_map"] = timed("dense_map", dm, 11.0 * bbox_px + 24.0 * n.value, n_rounds=10)
-    res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="three launches (row extents, chunk counts, ordered write; kernels_dense.hip), no atomics per lane and no look-back: every workgroup folds the "
-                            "chunk aggregates in front of it; the accept test of MapPoint.cpp:403 (the reference's order-dependent maxy / maxz) rides along; the D2H copy of the point list is not in avg_us")
+    res["dense_map"].update(bbox_px=bbox_px, points_out=int(n.value), note="row extents (dense_bbox scope) + two launches (chunk counts, ordered write; kernels_dense.hip) over the candidate pixels (i % 3 == 0 || j % 3 == 0) of the box, "
+                            "no atomics per lane and no look-back: every workgroup folds the chunk aggregates in front of it; the accept test of MapPoint.cpp:403 (the reference's order-dependent maxy / maxz) rides along; the D2H copy of the point list is not in avg_us")
     res["dense_bbox"] = timed("dense_bbox", dm, 4.0 * (w - 4) * (h - 4), n_rounds=10)
     # ---- raw-frame ingest (photometric undistortion + remap fused in front of makeImages): an 8-bit sensor frame slightly larger than the rectified image
     wo, ho = w + 64, h + 48
@@ -1077,7 +1077,7 @@ def frontend_legs(rounds=30):
                              "at 1 B/px (%.2f MB) instead of 4 B/px; avg_us is the kernel, the call also pays the copy and the pyramid" % (wo * ho / 1e6))
     c.close()
     # HBM traffic per launch from the committed counter passes (profiles/traffic_r04.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of scripts/diag/frontend_prof.py)
-    for leg, keys in (("pyramid", ("fe_pyramid", "fe_pyramid_tail")), ("ingest", ("fe_ingest",)), ("dense_map", ("fe_dense_rows", "fe_dense_count", "fe_dense_write")),
+    for leg, keys in (("pyramid", ("fe_pyramid",)), ("ingest", ("fe_ingest",)), ("dense_map", ("fe_dense_count", "fe_dense_write")),
                       ("trk_eval_250k", ("fe_trk_eval",)), ("trk_eval_full_density", ("fe_trk_eval",))):
         if isinstance(res.get(leg), dict):
             t = [load_traffic(k2) for k2 in keys]
