@@ -99,5 +99,6 @@ def test_make_map_box_phases_and_ragged_boxes():
         if n_o:
             assert acc.value == acc_o[0]
             assert np.array_equal(ou[:n_o], pu[:n_o]) and np.array_equal(ov[:n_o], pv[:n_o]), (y0, y1, x0, x1)
-            assert np.allclose(oid[:n_o], pid[:n_o], rtol=2e-6) and np.array_equal(oc[:n_o], pc[:n_o]) and np.array_equal(ob[:n_o], pb[:n_o])
+            # (the full-frame box crosses the plane's horizon row, where the plane depth cancels to ~0: an absolute floor beside the relative bound of the test above)
+            assert np.allclose(oid[:n_o], pid[:n_o], rtol=2e-6, atol=2e-7) and np.array_equal(oc[:n_o], pc[:n_o]) and np.array_equal(ob[:n_o], pb[:n_o]), (y0, y1, x0, x1)
     ctx.close()
