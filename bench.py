@@ -155,6 +155,9 @@ class GpuJob:
         self._trk_tail = (self._mr.ctypes.data_as(dp), self._lr.ctypes.data_as(dp), self._lf.ctypes.data_as(dp), C.byref(self._ok), C.byref(self._ne))
         self._ref = [np.ascontiguousarray(x, np.float32) for x in self.trk]
         self._ref_args = tuple(x.ctypes.data_as(fp) for x in self._ref)
+        # the inputs of setCoarseTrackingRef are constants of the synthetic keyframe: resident in HBM before the timed region like the frames themselves (the contract's
+        # "inputs already resident"); the legs that time host buffers (with_frame_uploads, with_raw_frame_uploads) hand the four arrays over per keyframe instead
+        self.ctx.trk_ref_upload(*self._ref)
 
     def step(self, track=True, upload=False, keep=False):
         c, W, L = self.ctx, self.win.W, self.ctx.L
@@ -188,7 +191,10 @@ class GpuJob:
         if track:
             # a2 for the new keyframe: setCoarseTrackingRef FOLLOWS the optimisation, as in makeKeyFrame (FullSystem.cpp:1404) - the next step's frames are tracked
             # against it (its inputs are constants of the synthetic keyframe here; in the reference they are the optimised window's residuals)
-            c._ck(L.nalo_trk_set_ref(c.h_, W - 1, len(self._ref[0]), *self._ref_args))
+            if upload:
+                c._ck(L.nalo_trk_set_ref(c.h_, W - 1, len(self._ref[0]), *self._ref_args))
+            else:
+                c._ck(L.nalo_trk_set_ref_resident(c.h_, W - 1))
         return rm
 
 

@@ -135,6 +135,12 @@ int nalo_trk_make_k(nalo_ctx* ctx, float fx, float fy, float cx, float cy);
  * per-level point clouds pc_u/pc_v/pc_idepth/pc_color in raster order. */
 int nalo_trk_set_ref(nalo_ctx* ctx, int slot_ref, int n, const float* Ku, const float* Kv,
                      const float* new_idepth, const float* HdiF);
+/* The same with the four input arrays RESIDENT on the device (round 4): nalo_trk_ref_upload copies them into a block the context owns (one pinned staging copy + one
+ * H2D copy, as nalo_trk_set_ref does on every call) and nalo_trk_set_ref_resident runs makeCoarseDepthL0 (CoarseTracker.cpp:382-538) from that block - for a caller whose
+ * inputs do not change between calls, or who fills them ahead of time: the per-keyframe call then pays no host copy, no staging and no copy packet in front of its kernels.
+ * The block stays valid until the next nalo_trk_ref_upload; nalo_trk_set_ref leaves it untouched. Results are those of nalo_trk_set_ref on the same arrays, bit for bit. */
+int nalo_trk_ref_upload(nalo_ctx* ctx, int n, const float* Ku, const float* Kv, const float* new_idepth, const float* HdiF);
+int nalo_trk_set_ref_resident(nalo_ctx* ctx, int slot_ref);
 /* direct injection of one level's point cloud (synthetic stress windows) */
 int nalo_trk_set_pc(nalo_ctx* ctx, int slot_ref, int lvl, int n, const float* u, const float* v,
                     const float* idepth, const float* color);

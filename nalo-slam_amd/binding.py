@@ -27,7 +27,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 EXPORTS = [
     "nalo_create", "nalo_destroy", "nalo_last_error", "nalo_levels", "nalo_sync", "nalo_stream",
     "nalo_frame_upload", "nalo_frame_upload_raw", "nalo_frame_upload_raw_async", "nalo_undist_set", "nalo_frame_upload_async", "nalo_frame_wait", "nalo_host_alloc", "nalo_host_free", "nalo_frame_rebuild", "nalo_frame_download",
-    "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_append_plane_points", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track", "nalo_trk_last_evals", "nalo_trk_set_shard",
+    "nalo_trk_make_k", "nalo_trk_set_ref", "nalo_trk_ref_upload", "nalo_trk_set_ref_resident", "nalo_trk_set_pc", "nalo_trk_get_pc", "nalo_trk_append_plane_points", "nalo_trk_get_depth", "nalo_trk_eval", "nalo_trk_track", "nalo_trk_last_evals", "nalo_trk_set_shard",
     "nalo_ba_set_window", "nalo_ba_set_points", "nalo_ba_set_residuals", "nalo_ba_set_prior", "nalo_ba_get_prior",
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_set_prior_carry", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_plane_scale_fix", "nalo_ba_sw_gray_optimize", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_constants", "nalo_constants_device", "nalo_ba_get_frames", "nalo_ba_get_points",
@@ -87,6 +87,8 @@ def load():
     L.nalo_frame_download.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp]
     L.nalo_trk_make_k.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
     L.nalo_trk_set_ref.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]
+    L.nalo_trk_ref_upload.argtypes = [vp, C.c_int, c_fp, c_fp, c_fp, c_fp]
+    L.nalo_trk_set_ref_resident.argtypes = [vp, C.c_int]
     L.nalo_trk_set_pc.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]
     L.nalo_trk_get_pc.argtypes = [vp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp]
     L.nalo_trk_get_depth.argtypes = [vp, C.c_int, c_fp, c_fp]
@@ -295,6 +297,14 @@ class Context:
     def trk_set_ref(self, slot, Ku, Kv, new_idepth, HdiF):
         a = [np.ascontiguousarray(x, np.float32) for x in (Ku, Kv, new_idepth, HdiF)]
         self._ck(self.L.nalo_trk_set_ref(self.h_, slot, len(a[0]), *[_f(x) for x in a]))
+
+    def trk_ref_upload(self, Ku, Kv, new_idepth, HdiF):
+        """the inputs of setCoarseTrackingRef resident on the device (nalo_trk_ref_upload); trk_set_ref_resident(slot) then builds the reference from them"""
+        a = [np.ascontiguousarray(x, np.float32) for x in (Ku, Kv, new_idepth, HdiF)]
+        self._ck(self.L.nalo_trk_ref_upload(self.h_, len(a[0]), *[_f(x) for x in a]))
+
+    def trk_set_ref_resident(self, slot):
+        self._ck(self.L.nalo_trk_set_ref_resident(self.h_, slot))
 
     def trk_set_pc(self, slot, lvl, u, v, idepth, color):
         a = [np.ascontiguousarray(x, np.float32) for x in (u, v, idepth, color)]

@@ -73,7 +73,7 @@ void nalo_destroy(nalo_ctx* c) {
         c->trk_idepth[l].release(); c->trk_wsum[l].release(); c->trk_wbak[l].release();
         c->pc_u[l].release(); c->pc_v[l].release(); c->pc_id[l].release(); c->pc_col[l].release();
     }
-    c->dense_lb.release(); c->trk_partial.release(); c->trk_ticket.release(); c->trk_out.release(); c->lm_partial.release(); c->trk_shard_sums.release(); c->scan_tmp.release(); c->trk_cnt.release(); c->upload_tmp.release();
+    c->dense_lb.release(); c->trk_partial.release(); c->trk_ticket.release(); c->ref_res.release(); c->trk_out.release(); c->lm_partial.release(); c->trk_shard_sums.release(); c->scan_tmp.release(); c->trk_cnt.release(); c->upload_tmp.release();
     if (c->trk_out_host) (void)hipHostFree(c->trk_out_host);
     if (c->pinned_f) (void)hipHostFree(c->pinned_f);
     if (c->imm_host) (void)hipHostFree(c->imm_host);
@@ -349,6 +349,32 @@ int nalo_trk_set_ref(nalo_ctx* c, int slot_ref, int n, const float* Ku, const fl
     float* dev[4] = {};
     if (n > 0) { int rc = upload4(c, n, Ku, Kv, new_idepth, HdiF, dev); if (rc) return rc; }
     return trk_build_ref(c, n, dev[0], dev[1], dev[2], dev[3]);
+}
+
+int nalo_trk_ref_upload(nalo_ctx* c, int n, const float* Ku, const float* Kv, const float* new_idepth, const float* HdiF) {
+    if (!c || n < 0 || (n > 0 && (!Ku || !Kv || !new_idepth || !HdiF))) return fail(c, NALO_ERR_ARG, "nalo_trk_ref_upload: bad argument");
+    NALO_HIP(c, hipSetDevice(c->device));
+    c->ref_res_n = -1;
+    if (n > 0) {
+        float* dev[4] = {};
+        int rc = upload4(c, n, Ku, Kv, new_idepth, HdiF, dev); if (rc) return rc;                  // pinned staging + ONE H2D copy into the shared scratch ...
+        NALO_HIP(c, c->ref_res.reserve((size_t)4 * n));
+        NALO_HIP(c, hipMemcpyAsync(c->ref_res.p, dev[0], (size_t)4 * n * 4, hipMemcpyDeviceToDevice, c->stream));   // ... and from there into the block that stays
+        NALO_HIP(c, hipStreamSynchronize(c->stream));                                              // the staging buffers are free again when this returns
+    }
+    c->ref_res_n = n;
+    return NALO_OK;
+}
+int nalo_trk_set_ref_resident(nalo_ctx* c, int slot_ref) {
+    if (!c || slot_ref < 0 || slot_ref >= (int)c->slots.size()) return fail(c, NALO_ERR_ARG, "nalo_trk_set_ref_resident: bad argument");
+    if (!c->slots[slot_ref].valid) return fail(c, NALO_ERR_STATE, "nalo_trk_set_ref_resident: reference slot has no pyramid");
+    if (c->ref_res_n < 0) return fail(c, NALO_ERR_STATE, "nalo_trk_set_ref_resident: no resident inputs (nalo_trk_ref_upload)");
+    NALO_HIP(c, hipSetDevice(c->device));
+    HostTimer ht(c, "trk_set_ref");
+    c->slot_ref = slot_ref;
+    const size_t n = (size_t)c->ref_res_n;
+    const float* b = c->ref_res.p;
+    return trk_build_ref(c, c->ref_res_n, b, b + n, b + 2 * n, b + 3 * n);
 }
 
 int nalo_trk_set_pc(nalo_ctx* c, int slot_ref, int lvl, int n, const float* u, const float* v, const float* idepth, const float* color) {

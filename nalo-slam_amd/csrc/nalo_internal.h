@@ -75,6 +75,7 @@ struct nalo_ctx {
     int pc_n[NALO_MAX_LEVELS] = {};
     nalo::DevBuf<float> trk_partial;         // [blocks][64]
     nalo::DevBuf<unsigned> trk_ticket;       // trk_eval_kernel's arrival counter (zero between launches)
+    nalo::DevBuf<float> ref_res; int ref_res_n = -1;   // nalo_trk_ref_upload: {Ku, Kv, new_idepth, HdiF} of the tracking reference, resident (n = -1: none)
     nalo::DevBuf<double> trk_out;            // 64 doubles
     double* trk_out_host = nullptr;          // pinned, host-mapped: results + sequence flag
     unsigned long long trk_seq = 0;

@@ -52,6 +52,36 @@ def test_coarse_depth_and_point_clouds(ctx, small_window):
         assert rel_err(ib, ia) < 1e-6 and rel_err(wb, wa) < 1e-6
 
 
+def test_resident_reference_inputs_equal_the_host_arrays(small_window):
+    """nalo_trk_ref_upload + nalo_trk_set_ref_resident (round 4: the per-keyframe call without host copy, staging and copy packet): clouds and depth maps of every level
+    are those of nalo_trk_set_ref on the same arrays bit for bit, repeatedly (other users of the shared staging in between), and the call refuses to run without an upload"""
+    win = small_window
+    Ku, Kv, nid, hdi = tracker_inputs(win)
+    a = binding.Context(win.w, win.h, win.K, n_slots=win.W + 1)
+    b = binding.Context(win.w, win.h, win.K, n_slots=win.W + 1)
+    for c in (a, b):
+        for i in range(win.W + 1):
+            c.frame_upload(i, win.images[i])
+    with pytest.raises(RuntimeError):
+        b.trk_set_ref_resident(win.W - 1)
+    a.trk_set_ref(win.W - 1, Ku, Kv, nid, hdi)
+    b.trk_ref_upload(Ku, Kv, nid, hdi)
+    for rep in range(3):
+        b.trk_set_ref_resident(win.W - 1)
+        for l in range(win.levels):
+            pa, pb = a.trk_get_pc(l), b.trk_get_pc(l)
+            assert all(np.array_equal(x, y) for x, y in zip(pa, pb)), "level %d (repeat %d)" % (l, rep)
+            da, db = a.trk_get_depth(l), b.trk_get_depth(l)
+            assert np.array_equal(da[0], db[0]) and np.array_equal(da[1], db[1])
+        b.frame_upload(win.W, win.images[win.W])                       # the shared staging buffers are used by someone else in between
+        b.trk_set_ref(win.W - 1, Ku[:100], Kv[:100], nid[:100], hdi[:100])   # and the host-array call leaves the resident block alone
+    T0 = orc.se3_exp(orc.se3_log(true_rel_pose(win, win.W - 1, win.W)) * 0.9)
+    a.trk_set_ref(win.W - 1, Ku, Kv, nid, hdi); b.trk_set_ref_resident(win.W - 1)
+    ra, rb = a.trk_track(win.W, T0, [0, 0], [0, 0], [1, 1], win.levels - 1), b.trk_track(win.W, T0, [0, 0], [0, 0], [1, 1], win.levels - 1)
+    assert ra[0] == rb[0] and np.array_equal(np.asarray(ra[1]), np.asarray(rb[1]))
+    a.close(); b.close()
+
+
 def test_scatter_collisions_are_summed_in_residual_order(ctx, small_window):
     """a2 step 1 with MANY residuals on the same pixels (3 .. 40 hits): the reference adds them serially in residual order; the device redoes every pixel with
     >= 3 hits in ascending index (trk_scatter_fix_kernel), so level 0's idepth / weightSums equal the oracle's BIT FOR BIT and repeat exactly"""
