@@ -1042,8 +1042,8 @@ def frontend_legs(rounds=30):
         def ev():
             st[0] = c.trk_eval(1, 0, T_rel, [1.0, 0.0], 0.0, 20.0)[0]
         r = timed("trk_eval", ev, 64.0 * len(u))
-        r.update(points=int(len(u)), residuals_in=int(st[0][1]), note="64 B/point = 16 B point record + four 12-B bilinear taps counted uncached; the launch also "
-                 "needs a finish kernel and a host poll (not in avg_us): %s" % ("spec size, 16 MB: 2 us at 8 TB/s, launch-latency bound by construction" if n_pts else "asymptote of the kernel"))
+        r.update(points=int(len(u)), residuals_in=int(st[0][1]), note="64 B/point = 16 B point record + four 12-B bilinear taps counted uncached; avg_us holds the evaluation AND its fp64 finish "
+                 "(one launch since round 4: the last workgroup sums the block partials; round 3 reported the evaluation alone, 14.0 us, beside a 9.9 us finish launch): %s" % ("spec size, 16 MB: 2 us at 8 TB/s, launch-latency bound by construction" if n_pts else "asymptote of the kernel"))
         res[name] = r
     # ---- pyramid
     L = c.levels
