@@ -419,7 +419,9 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
             if (lane == 0) S.evals_lvl[S.lvl] += 1;
             // sums (52 doubles) -> stats6 and this lane's entry of the scaled H / b (CoarseTracker.cpp:1040-1046, 869-884)
             const double E = sums[45], nE = sums[46], nSat = sums[47], nW = sums[48], sT = sums[49], sRT = sums[50], sN = sums[51];
-            const double st[6] = {E, nE, sT / (sN + 0.1), 0, sRT / (sN + 0.1), (double)((float)nSat / (float)nE)};
+            // (round 4: the three fp64 divisions an evaluation does not need are off wave 0's path - the two flow indicators are divided when a level ends, from the
+            // sums kept meanwhile; the accepted estimate's E / nE is kept as a quotient instead of being divided again at every later test; same operands, same bits)
+            const double st[6] = {E, nE, sT, sN, sRT, E / nE};
             const double inv = 1.0 / (double)(((long)nW + 3) & ~3L);
             const int hr = lane >> 3, hc = lane & 7, lo = hr < hc ? hr : hc, hi = hr < hc ? hc : hr;
             const double Hval = sums[lo * 9 - lo * (lo - 1) / 2 + (hi - lo)] * inv * lm_scale(hr) * lm_scale(hc);     // upper-triangular index of the 9x9
@@ -432,10 +434,10 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
             bool store_H = false, take_T = false;
             if (phase == 0) {
                 store_H = true;
-                if (st[5] > 0.6 && lcr < 50) { lcr *= 2; next_action = 0; }                      // :1106-1113
+                if ((double)((float)nSat / (float)nE) > 0.6 && lcr < 50) { lcr *= 2; next_action = 0; }   // :1106-1113
                 else { lambda = 0.01f; it = 0; brk = 0; next_action = 1; }
             } else {
-                const bool accept = (st[0] / st[1]) < (ro[0] / ro[1]);                           // :1186
+                const bool accept = st[5] < ro[5];                                               // :1186 (resNew[0] / resNew[1]) < (resOld[0] / resOld[1])
                 if (accept) { store_H = true; take_T = true; lambda *= 0.5f; }                   // :1202-1209
                 else { lambda *= 4; if (lambda < lambdaExtrapolationLimit) lambda = lambdaExtrapolationLimit; }
                 it++;
@@ -493,8 +495,8 @@ __global__ __launch_bounds__(kLmThreads) void trk_lm_kernel(TrkLmParams P) {
             }
             if (next_action == 0) lm_prepare_eval(S, P, lvl, lcr, T, aff0, aff1, lane == 0);
             if (next_action == 2) {                                                              // level finished (:1225-1235)
-                const double lr = (double)sqrtf((float)(ro[0] / ro[1]));
-                if (lane == 0) { S.lastRes[lvl] = lr; S.flow[0] = ro[2]; S.flow[1] = ro[3]; S.flow[2] = ro[4]; }
+                const double lr = (double)sqrtf((float)ro[5]);
+                if (lane == 0) { S.lastRes[lvl] = lr; S.flow[0] = ro[2] / (ro[3] + 0.1); S.flow[1] = 0; S.flow[2] = ro[4] / (ro[3] + 0.1); }
                 if (P.has_minres && lr > 1.5 * P.minRes[lvl]) { good = 0; done = 1; }
                 else {
                     int next = lvl - 1;
