@@ -147,6 +147,44 @@ def test_track_round_trip_full_size(full_window):
     assert abs(aff[0]) < 0.02 and abs(aff[1]) < 2.0
 
 
+def test_fused_eval_many_workgroups_full_size(full_window):
+    """nalo_trk_eval at 1920x1072 with 200 k and 131 073 level-0 points: 512 (the cap) and 513 -> 512 workgroups publish their partials and the one that draws the last
+    ticket sums them (fourteen 16-byte coherent loads in flight per lane, rows clamped at the tail: round 4) - energy, counts and the 8x8 system against the oracle's
+    evaluation of the same cloud, and bit-identical from call to call (the order of the fp64 sums is fixed, whichever workgroup comes last)"""
+    win, _ = full_window
+    W, w, h = win.W, win.w, win.h
+    c = binding.Context(w, h, win.K, n_slots=2)
+    c.frame_upload(0, win.images[W - 1]); c.frame_upload(1, win.images[W])
+    dI_ref, _ = orc.make_images(win.images[W - 1], c.levels)
+    dI_new, _ = orc.make_images(win.images[W], c.levels)
+    T = orc.se3_exp(orc.se3_log(true_rel_pose(win, W - 1, W)) * 0.9)
+    aff = np.array([0.98, 1.5], np.float32)
+    d0 = win.depth[W - 1]
+    rng = np.random.RandomState(2)
+    for n_pts in (200000, 131073):
+        idx = np.sort(rng.permutation(np.unique(rng.randint(4, h - 4, 3 * n_pts) * w + rng.randint(4, w - 4, 3 * n_pts)))[:n_pts])
+        u, v = idx % w, idx // w
+        ok = np.isfinite(d0[v, u]); u, v = u[ok], v[ok]
+        pc = (u.astype(np.float32), v.astype(np.float32), (1.0 / d0[v, u]).astype(np.float32), win.images[W - 1][v, u].astype(np.float32))
+        c.trk_set_pc(0, 0, *pc)
+        trk = orc.Tracker(w, h, c.levels, win.K)
+        trk.set_pc(dI_ref, 0, *pc)
+        orc.lib().orc_set_sum_mode(0)
+        # cutoff far above every residual: among 2e5 residuals one or two sit within an fp32 rounding of a finite cutoff, and a residual that saturates on one side only
+        # moves b by its whole contribution - that decision is the small test's subject (test_tracker_gpu), the sums over many workgroups are this one's
+        CUT = 1e9
+        st_o = trk.calc_res(dI_new, 0, T, aff, CUT)
+        H_o, b_o = trk.calc_gs(0, float(aff[0]), 0.3)
+        st, H, b = c.trk_eval(1, 0, T, aff, 0.3, CUT)
+        assert st[1] == st_o[1] and st[1] > 0.5 * len(u), (st[1], st_o[1])                 # same inlier count
+        assert abs(st[0] - st_o[0]) / st_o[0] < 2e-6 and st[5] == st_o[5] == 0
+        assert rel_err(H, H_o) < 2e-5 and rel_err(b, b_o) < 2e-5
+        for _ in range(3):
+            st2, H2, b2 = c.trk_eval(1, 0, T, aff, 0.3, CUT)
+            assert np.array_equal(st2, st) and np.array_equal(H2, H) and np.array_equal(b2, b)
+    c.close()
+
+
 # ------------------------------------------------------------------------------------------------ edge cases
 def test_empty_tracker_reference():
     win = synth.make_window(w=320, h=240, W=3, P=60, seed=2, n_extra=1)
