@@ -38,8 +38,14 @@ __device__ __forceinline__ float4 bilinear4(const float4* __restrict__ img, floa
     return r;
 }
 
-__global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* __restrict__ partial, unsigned* __restrict__ ticket, double* __restrict__ out, double seq) {
-    __shared__ __attribute__((aligned(16))) float smem[64 * (kTrkVals + 1)];
+#ifndef NALO_TRK_EVAL_NT
+#define NALO_TRK_EVAL_NT 512
+#endif
+constexpr int kTrkEvalNT = NALO_TRK_EVAL_NT;      // lanes per workgroup of the evaluation. 256 -> 512 (round 4, same box): half as many grid-stride rounds at 250 k points and half as many
+                                                  // partial rows for the last workgroup: 21.0 -> 19.0 us at 250 k points, 40.0 -> 35.7 us at full density (1920x1072)
+constexpr int kTrkEvalNG = kTrkEvalNT / 13;        // lane groups of the last workgroup's sum: 13 lanes x 16 bytes = one block's 52 partials
+__global__ __launch_bounds__(kTrkEvalNT) void trk_eval_kernel(TrkEvalParams P, float* __restrict__ partial, unsigned* __restrict__ ticket, double* __restrict__ out, double seq) {
+    __shared__ __attribute__((aligned(16))) float smem[(kTrkEvalNT / 4) * (kTrkVals + 1)];
     float acc[kTrkVals];
 #pragma unroll
     for (int k = 0; k < kTrkVals; ++k) acc[k] = 0.f;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* _
     // agent-scope words, acknowledged before its ticket (the idiom of ba_reduce_kernel's tail); the workgroup that draws the last ticket sums the partials in a fixed order (fp64) and
     // publishes them behind the sequence number the host polls.
     __shared__ float blk[64];
-    block_reduce_cols<kTrkVals, 256>(acc, smem, blk);
+    block_reduce_cols<kTrkVals, kTrkEvalNT>(acc, smem, blk);
     if (threadIdx.x < kTrkVals) __hip_atomic_store(&partial[(size_t)blockIdx.x * 64 + threadIdx.x], blk[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __shared__ bool is_last;
@@ -108,29 +114,30 @@ __global__ __launch_bounds__(256) void trk_eval_kernel(TrkEvalParams P, float* _
     if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
     __syncthreads();
     if (!is_last) return;
-    // 13 lanes x 16 bytes cover a block's 52 partials; 19 such lane groups stride over the blocks with fourteen coherent (sc0 sc1: past this XCD's L2, where the
+    // 13 lanes x 16 bytes cover a block's 52 partials; kTrkEvalNG (19 of a 256-lane workgroup) such lane groups stride over the blocks with fourteen coherent (sc0 sc1: past this XCD's L2, where the
     // other XCDs' write-through stores are not seen) 16-byte loads in flight each - one relaxed atomic word per lane and trip was a chain of ~130 dependent
-    // round trips (50 us). Fixed order: rows b = rg, rg + 19, ... in fp64 per group, then the 19 groups in ascending order.
-    double (*part)[kTrkVals] = reinterpret_cast<double (*)[kTrkVals]>(smem);       // 19 x 52 doubles = 7.9 KB of the 13.6 KB reduction buffer
+    // round trips (50 us). Fixed order: rows b = rg, rg + NG, ... in fp64 per group, then the groups in ascending order.
+    double (*part)[kTrkVals] = reinterpret_cast<double (*)[kTrkVals]>(smem);       // NG x 52 doubles (7.9 KB of the 13.6 KB reduction buffer at 256 lanes)
     const int cq = threadIdx.x % 13, rg = threadIdx.x / 13, nblocks = (int)gridDim.x;
-    if (rg < 19) {
+    static_assert(kTrkEvalNG * kTrkVals * 2 <= (kTrkEvalNT / 4) * (kTrkVals + 1), "the groups' fp64 sums fit the reduction buffer");
+    if (rg < kTrkEvalNG) {
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-        for (int b0 = rg; b0 < nblocks; b0 += 19 * 14) {
+        for (int b0 = rg; b0 < nblocks; b0 += kTrkEvalNG * 14) {
             trk_f4 v[14];
 #pragma unroll
             for (int k = 0; k < 14; ++k) {
-                const int b2 = b0 + 19 * k;
+                const int b2 = b0 + kTrkEvalNG * k;
                 const float* q = partial + (size_t)(b2 < nblocks ? b2 : b0) * 64 + cq * 4;
                 asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[k]) : "v"(q) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]) : : "memory");
 #pragma unroll
-            for (int k = 0; k < 14; ++k) if (b0 + 19 * k < nblocks) { a0 += (double)v[k].x; a1 += (double)v[k].y; a2 += (double)v[k].z; a3 += (double)v[k].w; }
+            for (int k = 0; k < 14; ++k) if (b0 + kTrkEvalNG * k < nblocks) { a0 += (double)v[k].x; a1 += (double)v[k].y; a2 += (double)v[k].z; a3 += (double)v[k].w; }
         }
         part[rg][cq * 4] = a0; part[rg][cq * 4 + 1] = a1; part[rg][cq * 4 + 2] = a2; part[rg][cq * 4 + 3] = a3;
     }
     __syncthreads();
-    if (threadIdx.x < kTrkVals) { double t = 0; for (int k = 0; k < 19; ++k) t += part[k][threadIdx.x]; __hip_atomic_store(&out[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+    if (threadIdx.x < kTrkVals) { double t = 0; for (int k = 0; k < kTrkEvalNG; ++k) t += part[k][threadIdx.x]; __hip_atomic_store(&out[threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -162,7 +169,7 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
     for (int i = 0; i < 9; ++i) { P.RKi[i] = RKi[i]; P.Ki[i] = Ki[i]; }
     for (int i = 0; i < 3; ++i) P.t[i] = t[i];
     P.affa = affa; P.affb = affb; P.b0 = b0; P.cutoff = cutoff; P.maxEnergy = maxEnergy;
-    int nblocks = (P.i1 - P.i0 + 255) / 256;
+    int nblocks = (P.i1 - P.i0 + kTrkEvalNT - 1) / kTrkEvalNT;
     nblocks = nblocks < 1 ? 1 : (nblocks > 512 ? 512 : nblocks);
     NALO_HIP(c, c->trk_partial.reserve((size_t)2048 * 64));
     if (!c->trk_ticket.p) { NALO_HIP(c, c->trk_ticket.reserve(4)); NALO_HIP(c, hipMemsetAsync(c->trk_ticket.p, 0, 16, c->stream)); }
@@ -172,7 +179,7 @@ int trk_eval_launch(nalo_ctx* c, int slot_new, int lvl, const float RKi[9], cons
     if (sharded) NALO_HIP(c, c->trk_shard_sums.reserve(64));
     {
         ProfScope ps(c, "trk_eval");
-        trk_eval_kernel<<<nblocks, 256, 0, c->stream>>>(P, c->trk_partial.p, c->trk_ticket.p, sharded ? c->trk_shard_sums.p : dout, sharded ? 0.0 : seq);
+        trk_eval_kernel<<<nblocks, kTrkEvalNT, 0, c->stream>>>(P, c->trk_partial.p, c->trk_ticket.p, sharded ? c->trk_shard_sums.p : dout, sharded ? 0.0 : seq);
     }
     if (sharded) {
         // every rank evaluated its share: the 52 sums meet in the hook (in place, device memory), every rank then reads the same totals and runs the same LM step
