@@ -132,8 +132,9 @@ __global__ __launch_bounds__(256) void pixsel_cells_kernel(PixSelArgs P, uint8_t
 }
 
 // exclusive scan of n byte flags (single workgroup: contiguous runs per thread, wave shuffles, 16 wave totals)
-__global__ __launch_bounds__(1024) void pixsel_scan_bytes_kernel(const uint8_t* __restrict__ f, int n, int* __restrict__ out) {
+__global__ __launch_bounds__(1024) void pixsel_scan_bytes_kernel(const uint8_t* __restrict__ f, int n, int* __restrict__ out, int* __restrict__ zero8) {
     __shared__ int wtot[16];
+    if (zero8 && threadIdx.x < 8) zero8[threadIdx.x] = 0;          // the counters of the selection pass behind this launch (was a fill launch of its own)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, per = (n + 1023) / 1024, a = min(tid * per, n), b = min(a + per, n);
     int s = 0;
     for (int i = a; i < b; ++i) s += f[i];
@@ -146,8 +147,9 @@ __global__ __launch_bounds__(1024) void pixsel_scan_bytes_kernel(const uint8_t* 
     for (int k = 0; k < wave; ++k) base += wtot[k];
     for (int i = a; i < b; ++i) { out[i] = base; base += f[i]; }
 }
-__global__ __launch_bounds__(1024) void pixsel_scan_ints_kernel(int* __restrict__ v, int n, int* __restrict__ total) {       // in place, exclusive; n <= 1024 * per
+__global__ __launch_bounds__(1024) void pixsel_scan_ints_kernel(int* __restrict__ v, int n, int* __restrict__ total, int* __restrict__ zero1) {       // in place, exclusive; n <= 1024 * per
     __shared__ int wtot[16];
+    if (zero1 && threadIdx.x == 0) *zero1 = 0;                     // the compaction's kept counter (was a fill launch of its own)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, per = (n + 1023) / 1024, a = min(tid * per, n), b = min(a + per, n);
     int s = 0;
     for (int i = a; i < b; ++i) s += v[i];
@@ -305,9 +307,8 @@ static int pixsel_select_dev(nalo_ctx* c, PixSel* p, int slot, int pot, float th
     uint8_t *flags = p->has.p, *other = p->sel.p;
     for (int round = 0;; ++round) {
         if (round > A.nslots) return fail(c, NALO_ERR_STATE, "nalo_pixsel_select: the selection did not reach its fixed point");
-        pixsel_scan_bytes_kernel<<<1, 1024, 0, c->stream>>>(flags, A.nslots, p->pre.p);
+        pixsel_scan_bytes_kernel<<<1, 1024, 0, c->stream>>>(flags, A.nslots, p->pre.p, p->cnt.p);
         NALO_HIP(c, hipMemsetAsync(p->map.p, 0, npx, c->stream));
-        NALO_HIP(c, hipMemsetAsync(p->cnt.p, 0, 8 * sizeof(int), c->stream));
         cells(true, flags, other);
         NALO_HIP(c, hipMemcpyAsync(p->host, p->cnt.p, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         NALO_HIP(c, hipStreamSynchronize(c->stream));
@@ -319,17 +320,19 @@ static int pixsel_select_dev(nalo_ctx* c, PixSel* p, int slot, int pot, float th
     return NALO_OK;
 }
 // compaction (+ optional sub-selection) and the host copies: list -> pinned, map_out filled from the list
-static int pixsel_fetch(nalo_ctx* c, PixSel* p, int charTH, float* map_out, int* kept) {
+// expect: the number of selected pixels the caller already knows (n2 + n3 + n4 of the selection pass), or < 0: the list then travels with the counters, ONE completion
+// round trip instead of two (round 4)
+static int pixsel_fetch(nalo_ctx* c, PixSel* p, int charTH, float* map_out, int* kept, int expect = -1) {
     const int npx = c->w * c->h, nch = (npx + kChunk - 1) / kChunk;
     pixsel_count_kernel<<<nch, 256, 0, c->stream>>>(p->map.p, npx, p->chunk.p);
-    pixsel_scan_ints_kernel<<<1, 1024, 0, c->stream>>>(p->chunk.p, nch, p->cnt.p + 4);
-    NALO_HIP(c, hipMemsetAsync(p->cnt.p + 5, 0, sizeof(int), c->stream));
+    pixsel_scan_ints_kernel<<<1, 1024, 0, c->stream>>>(p->chunk.p, nch, p->cnt.p + 4, p->cnt.p + 5);
     pixsel_compact_kernel<<<nch, 256, 0, c->stream>>>(p->map.p, npx, p->chunk.p, p->rp.p, charTH, p->list.p, p->cnt.p);
     NALO_HIP(c, hipMemcpyAsync(p->host, p->cnt.p, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (expect > 0) NALO_HIP(c, hipMemcpyAsync(p->host + 16, p->list.p, (size_t)expect * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     NALO_HIP(c, hipStreamSynchronize(c->stream));
     const int total = p->host[4];
     if (kept) *kept = p->host[5];
-    if (total > 0) {
+    if (total > 0 && total != expect) {                     // no expectation, or not the count the device found (never seen): the list at its real length
         NALO_HIP(c, hipMemcpyAsync(p->host + 16, p->list.p, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         NALO_HIP(c, hipStreamSynchronize(c->stream));
     }
@@ -404,7 +407,7 @@ int nalo_pixsel_select(nalo_ctx* c, int slot, int pot, float thFactor, float* ma
     if (p->hist_slot != slot) return fail(c, NALO_ERR_STATE, "nalo_pixsel_select: nalo_pixsel_make_hists has not run on this frame (PixelSelector::gradHistFrame)");
     ProfScope ps(c, "pixsel");
     rc = pixsel_select_dev(c, p, slot, pot, thFactor, n); if (rc) return rc;
-    return pixsel_fetch(c, p, -1, map_out, nullptr);
+    return pixsel_fetch(c, p, -1, map_out, nullptr, n[0] + n[1] + n[2]);
 }
 
 int nalo_pixsel_make_maps(nalo_ctx* c, int slot, float density, int recursionsLeft, float thFactor, int* currentPotential, float* map_out, int* numHaveSub) {
@@ -430,7 +433,7 @@ int nalo_pixsel_make_maps(nalo_ctx* c, int slot, float density, int recursionsLe
     }
     const bool sub = quotia < 0.95;
     int kept = 0;
-    rc = pixsel_fetch(c, p, sub ? (int)(unsigned char)(255 * quotia) : -1, map_out, &kept); if (rc) return rc;
+    rc = pixsel_fetch(c, p, sub ? (int)(unsigned char)(255 * quotia) : -1, map_out, &kept, (int)numHave); if (rc) return rc;
     *numHaveSub = sub ? kept : (int)numHave;
     *currentPotential = ideal;
     return NALO_OK;
