@@ -419,6 +419,11 @@ int nalo_imm_resident_get(nalo_ctx* ctx, float* idepth_min, float* idepth_max, i
 int nalo_imm_optimize(nalo_ctx* ctx, int n, const int* host, const float* u, const float* v, const float* color, const float* weights,
                       const float* energyTH, const float* idepth_min, const float* idepth_max, int minObs,
                       int* result, float* idepth_out, uint8_t* res_in);
+/* The same for points of the device-resident set (nalo_imm_resident_set, kept up to date by nalo_imm_resident_trace): sel[n] = their indices in that set (NULL: all of
+ * them, n = the set's size). Pattern colours, weights, energyTH, host frame (host_idx must index the window's frames) and the inverse-depth interval [idepth_min,
+ * idepth_max] - as the device's last trace left it, FullSystem.cpp:700-760 activates right after traceNewCoarse - are read on the device; 4 bytes per point cross PCIe
+ * on the way down instead of 88. Outputs as nalo_imm_optimize. */
+int nalo_imm_resident_optimize(nalo_ctx* ctx, int n, const int* sel, int minObs, int* result, float* idepth_out, uint8_t* res_in);
 
 /* ------------------------------------------------------------------------------------------------
  * the two-frame initialiser's Gauss-Newton pass.

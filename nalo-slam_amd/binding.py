@@ -32,7 +32,7 @@ EXPORTS = [
     "nalo_ba_linearize", "nalo_ba_accumulate", "nalo_ba_accumulate_sc", "nalo_ba_solve_system", "nalo_ba_backup_state",
     "nalo_ba_do_step", "nalo_ba_optimize", "nalo_ba_marginalize_points", "nalo_ba_marginalize_frame", "nalo_ba_set_prior_carry", "nalo_ba_calc_l_energy", "nalo_ba_calc_m_energy", "nalo_ba_plane_scale_fix", "nalo_ba_sw_gray_optimize", "nalo_ba_optimize_stats", "nalo_get_settings", "nalo_set_settings", "nalo_constants", "nalo_constants_device", "nalo_ba_get_frames", "nalo_ba_get_points",
     "nalo_ba_get_residuals", "nalo_ba_get_idepth_zero", "nalo_ba_get_acc13", "nalo_ba_counts", "nalo_ba_set_allreduce", "nalo_ba_set_allreduce_mode", "nalo_ba_set_allreduce_side", "nalo_ba_exchange_failed", "nalo_side_stream", "nalo_rccl_unique_id", "nalo_ba_rccl_init", "nalo_ba_set_rccl_comm", "nalo_ba_rccl_ranks", "nalo_shard_points", "nalo_ba_snapshot", "nalo_ba_restore",
-    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_init_set_state", "nalo_init_set_points", "nalo_init_get_carried", "nalo_init_sweep", "nalo_dist_make_map", "nalo_pixsel_make_hists",
+    "nalo_imm_create", "nalo_imm_trace", "nalo_imm_optimize", "nalo_imm_resident_set", "nalo_imm_resident_optimize", "nalo_imm_resident_trace", "nalo_imm_resident_get", "nalo_init_calc_res_and_gs", "nalo_init_do_step", "nalo_init_set_first", "nalo_init_track_frame", "nalo_init_get_state", "nalo_init_get_points", "nalo_init_set_state", "nalo_init_set_points", "nalo_init_get_carried", "nalo_init_sweep", "nalo_dist_make_map", "nalo_pixsel_make_hists",
     "nalo_pixsel_set_random", "nalo_pixsel_select", "nalo_pixsel_make_maps", "nalo_pixsel_make_maps_lidar", "nalo_pixsel_get_selected",
     "nalo_dense_make_map", "nalo_profile_enable", "nalo_profile_select", "nalo_profile_reset", "nalo_profile_get", "nalo_profile_samples", "nalo_profile_sample", "nalo_hbm_calibrate",
 ]
@@ -161,6 +161,7 @@ def load():
     L.nalo_imm_resident_trace.argtypes = [vp, C.c_int, C.c_int, c_fp, c_fp, c_fp]
     L.nalo_imm_resident_get.argtypes = [vp, c_fp, c_fp, c_ip, c_fp, c_fp, c_fp]
     L.nalo_imm_optimize.argtypes = [vp, C.c_int, c_ip, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, c_ip, c_fp, c_u8p]
+    L.nalo_imm_resident_optimize.argtypes = [vp, C.c_int, c_ip, C.c_int, c_ip, c_fp, c_u8p]
     L.nalo_ba_restore.argtypes = [vp]
     L.nalo_dense_make_map.argtypes = [vp, C.c_int, c_fp, C.c_float, c_dp, C.c_int, c_ip, c_ip, c_ip, c_fp, c_fp, c_u8p, c_ip, c_ip]
     L.nalo_profile_enable.argtypes = [vp, C.c_int]
@@ -734,6 +735,16 @@ class Context:
         hi = np.ascontiguousarray(host, np.int32)
         res, idp, rin = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, self.W), np.uint8)
         self._ck(self.L.nalo_imm_optimize(self.h_, n, _i(hi), *[_f(x) for x in a], int(min_obs), _i(res), _f(idp), _u8(rin)))
+        return res, idp, rin
+
+    def imm_resident_optimize(self, sel, min_obs, n_all=None):
+        """optimizeImmaturePoint for points of the device-resident set: sel = their indices (None: all n_all of them)"""
+        if sel is None:
+            n, sp = int(n_all), None
+        else:
+            si = np.ascontiguousarray(sel, np.int32); n, sp = len(si), _i(si)
+        res, idp, rin = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, self.W), np.uint8)
+        self._ck(self.L.nalo_imm_resident_optimize(self.h_, n, sp, int(min_obs), _i(res), _f(idp), _u8(rin)))
         return res, idp, rin
 
     def ba_snapshot(self):

@@ -1608,6 +1608,48 @@ int nalo_imm_optimize(nalo_ctx* c, int n, const int* host, const float* u, const
     return NALO_OK;
 }
 
+// The same for points of the DEVICE-RESIDENT set (nalo_imm_resident_set / _trace, round 4): the caller names them by index, their pattern, weights, host frame and -
+// as the device's last trace left them - inverse-depth interval are read where they are. Per call 4 bytes per point go down instead of 88, the results come back as
+// in nalo_imm_optimize. sel == NULL: all resident points, n = their number.
+int nalo_imm_resident_optimize(nalo_ctx* c, int n, const int* sel, int minObs, int* result, float* idepth_out, uint8_t* res_in) {
+    if (!c || !c->ba || c->ba->W < 2) return fail(c, NALO_ERR_STATE, "nalo_imm_resident_optimize: set the window first (nalo_ba_set_window)");
+    if (n < 0 || (n > 0 && (!result || !idepth_out || !res_in))) return fail(c, NALO_ERR_ARG, "nalo_imm_resident_optimize: bad argument");
+    if (n == 0) return NALO_OK;
+    BAWindow& w = *c->ba;
+    const int W = w.W;
+    if (c->imm_res_n <= 0) return fail(c, NALO_ERR_STATE, "nalo_imm_resident_optimize: no resident points (nalo_imm_resident_set)");
+    if (c->imm_res_maxhost >= W) return fail(c, NALO_ERR_ARG, "nalo_imm_resident_optimize: a resident point's host_idx is outside the window");
+    if (!sel && n != c->imm_res_n) return fail(c, NALO_ERR_ARG, "nalo_imm_resident_optimize: sel == NULL means all resident points");
+    if (sel) for (int i = 0; i < n; ++i) if (sel[i] < 0 || sel[i] >= c->imm_res_n) return fail(c, NALO_ERR_ARG, "nalo_imm_resident_optimize: index outside the resident set");
+    NALO_HIP(c, hipSetDevice(c->device));
+    HostTimer ht(c, "imm_optimize");
+    // words: [0, n) sel | [n, n + 14 W^2) Rt aff | outputs: result(n) idepth(n) res_in(n*W bytes)
+    const size_t N = (size_t)n, PW = (size_t)W * W, out0 = N + 14 * PW, outw = 2 * N + (N * W + 3) / 4;
+    int rc = imm_stage(c, out0 + outw); if (rc) return rc;
+    float* hst = c->imm_host;
+    if (sel) std::memcpy(hst, sel, N * 4);
+    float* Rt = hst + N; float* af = Rt + 12 * PW;
+    for (int h = 0; h < W; ++h) for (int t = 0; t < W; ++t) {               // FrameFramePrecalc::set (HessianBlocks.cpp:203-221) at the current states
+        const HostFrame &hf = w.frames[h], &tf = w.frames[t];
+        const SE3 ll = tf.PRE_worldToCam * hf.PRE_camToWorld;
+        float* o = Rt + (size_t)(h * W + t) * 12;
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) o[i * 3 + j] = (float)ll.R(i, j); o[9 + i] = (float)ll.t(i); }
+        double a[2];
+        aff_from_to(hf.ab_exposure, tf.ab_exposure, hf.state_scaled[6], hf.state_scaled[7], tf.state_scaled[6], tf.state_scaled[7], a);
+        af[(h * W + t) * 2] = (float)a[0]; af[(h * W + t) * 2 + 1] = (float)a[1];
+    }
+    float* d = c->imm_dev.p;
+    NALO_HIP(c, hipMemcpyAsync(d, hst, out0 * 4, hipMemcpyHostToDevice, c->stream));
+    const float K[4] = {w.c_scaledf[0], w.c_scaledf[1], w.c_scaledf[2], w.c_scaledf[3]};
+    rc = imm_optimize_resident_launch(c, w.dev.img, W, K, d + N, d + N + 12 * PW, n, sel ? (const int*)d : nullptr, c->imm_res.p, (size_t)c->imm_res_n, minObs,
+                                      (int*)(d + out0), d + out0 + N, (uint8_t*)(d + out0 + 2 * N));
+    if (rc) return rc;
+    NALO_HIP(c, hipMemcpyAsync(hst + out0, d + out0, outw * 4, hipMemcpyDeviceToHost, c->stream));
+    NALO_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(result, hst + out0, N * 4); std::memcpy(idepth_out, hst + out0 + N, N * 4); std::memcpy(res_in, hst + out0 + 2 * N, N * W);
+    return NALO_OK;
+}
+
 int nalo_ba_snapshot(nalo_ctx* c) {
     NALO_BA_READY("nalo_ba_snapshot")
     const size_t N = w.Ppad, NS = (size_t)w.W * N;

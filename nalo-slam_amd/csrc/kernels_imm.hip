@@ -238,6 +238,7 @@ struct ImmOptParams {
     float fx, fy, cx, cy;
     const float *Rt, *aff;                           // [W*W][12] = PRE_RTll | PRE_tTll, [W*W][2] = PRE_aff_mode, index host*W + target
     const int* host; const float *u, *v, *color, *weights, *energyTH, *idmin, *idmax;
+    const int* sel;                                  // NULL: point p reads entry p of the input arrays; else entry sel[p] (the device-resident set, nalo_imm_resident_optimize)
     int* result; float* idepth_out; uint8_t* res_in;
 };
 
@@ -305,16 +306,17 @@ __global__ __launch_bounds__(256) void imm_optimize8_kernel(ImmOptParams P) {
     const int p = blockIdx.x * kImmGroups + tid;
     if (p >= P.n) return;
     double* en = en_s + tid; double* nen = nen_s + tid;
-    const int W = P.W, hf = P.host[p], nres = W - 1;
-    const float color_l = P.color[p * 8 + l], weight_l = P.weights[p * 8 + l];
-    const float u = P.u[p], v = P.v[p], energyTH = P.energyTH[p];
+    const int q = P.sel ? P.sel[p] : p;                                        // where the point's inputs are; the outputs are indexed by p
+    const int W = P.W, hf = P.host[q], nres = W - 1;
+    const float color_l = P.color[(size_t)q * 8 + l], weight_l = P.weights[(size_t)q * 8 + l];
+    const float u = P.u[q], v = P.v[q], energyTH = P.energyTH[q];
     unsigned st = 0, nst = 0;                                                  // state = IN (0) for every residual; newState = OUTLIER
     for (int i = 0; i < nres; ++i) { en[i * kImmGroups] = 0; nen[i * kImmGroups] = 0; nst |= (unsigned)IRS_OUTLIER << (2 * i); }
     if (l == 0) for (int t = 0; t < W; ++t) P.res_in[(size_t)p * W + t] = 0;
     if (l == 0) P.idepth_out[p] = NAN;
     auto tgt = [&](int i) { return i < hf ? i : i + 1; };                      // residual i <-> the i-th frame that is not the host
     float lastEnergy = 0, lastHdd = 0, lastbd = 0;
-    float currentIdepth = (P.idmax[p] + P.idmin[p]) * 0.5f;
+    float currentIdepth = (P.idmax[q] + P.idmin[q]) * 0.5f;
     for (int i = 0; i < nres; ++i) {
         // `float += double`: formed in double, rounded once (FullSystemOptPoint.cpp:79)
         lastEnergy = (float)((double)lastEnergy + imm_linearize8(P, hf, tgt(i), u, v, color_l, weight_l, l, energyTH, 1000.f, st, nst, en, nen, i, lastHdd, lastbd, currentIdepth));
@@ -496,6 +498,24 @@ int imm_trace_launch(nalo_ctx* c, const float4* dI, int n, const float* base /* 
     if (n > 0) {
         ProfScope ps(c, "imm_trace");
         imm_trace8_kernel<<<(n + 31) / 32, 256, 0, c->stream>>>(P);
+    }
+    NALO_HIP(c, hipGetLastError());
+    return NALO_OK;
+}
+// the resident set's layout (nalo_imm_resident_set): u | v | color8 | weights8 | gradH3 | energyTH | host | idmin | idmax | ..., N entries each; sel picks n of them
+int imm_optimize_resident_launch(nalo_ctx* c, const float4* const* dI, int W, const float K[4], const float* Rt, const float* aff, int n, const int* sel, const float* res, size_t N,
+                                 int minObs, int* result, float* idepth_out, uint8_t* res_in) {
+    ImmOptParams P;
+    std::memset(&P, 0, sizeof(P));
+    for (int i = 0; i < W; ++i) P.dI[i] = dI[i];
+    P.W = W; P.w = c->w; P.h = c->h; P.n = n; P.minObs = minObs;
+    P.fx = K[0]; P.fy = K[1]; P.cx = K[2]; P.cy = K[3];
+    P.Rt = Rt; P.aff = aff; P.sel = sel;
+    P.u = res; P.v = res + N; P.color = res + 2 * N; P.weights = res + 10 * N; P.energyTH = res + 21 * N; P.host = (const int*)(res + 22 * N); P.idmin = res + 23 * N; P.idmax = res + 24 * N;
+    P.result = result; P.idepth_out = idepth_out; P.res_in = res_in;
+    if (n > 0) {
+        ProfScope ps(c, "imm_optimize");
+        imm_optimize8_kernel<<<(n + kImmGroups - 1) / kImmGroups, 256, 0, c->stream>>>(P);
     }
     NALO_HIP(c, hipGetLastError());
     return NALO_OK;

@@ -170,6 +170,8 @@ struct ProfScope {               // HIP-event bracket on the ctx stream (only wh
 int imm_create_launch(nalo_ctx* c, const float4* dI, int n, const int* u, const int* v, float* color, float* weights, float* gradH, float* energyTH);
 int imm_trace_launch(nalo_ctx* c, const float4* dI, int n, const float* base, const int* host_idx, const float* KRKi, const float* Kt, const float* aff,
                      float* idmin, float* idmax, int* status, float* quality, float* lastUV, float* lastInterval);
+int imm_optimize_resident_launch(nalo_ctx* c, const float4* const* dI, int W, const float K[4], const float* Rt, const float* aff, int n, const int* sel, const float* res, size_t N,
+                                 int minObs, int* result, float* idepth_out, uint8_t* res_in);
 int imm_optimize_launch(nalo_ctx* c, const float4* const* dI, int W, const float K[4], const float* Rt, const float* aff, int n, const int* host, const float* base,
                         int minObs, int* result, float* idepth_out, uint8_t* res_in);
 int dist_make_launch(nalo_ctx* c, const float4* pt_geo, const uint8_t* pt_flags, const int* blk_host, int Ppad, int frame, const float* KRKi, const float* Kt, uint8_t* seed, float* out);

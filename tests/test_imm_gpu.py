@@ -127,6 +127,15 @@ def test_optimize_bit_exact_and_recovers_truth(scene):
     err0 = np.abs(mid[act] - idt[act]) / idt[act]
     err1 = np.abs(idp[act] - idt[act]) / idt[act]
     assert np.median(err1) < 0.25 * np.median(err0)        # three GN steps pull the 5 % error to about 1 %
+    # the same points through the device-resident set (nalo_imm_resident_optimize, round 4): all of them, then a shuffled subset named by index - bit for bit the staged call
+    c.imm_resident_set(uf, vf, color, weights, gradH, eth, host, idmin, idmax, np.zeros(n, np.int32), np.zeros(n, np.float32))
+    res_r, idp_r, rin_r = c.imm_resident_optimize(None, 1, n_all=n)
+    assert eq(res_r, res) and eq(idp_r, idp) and eq(rin_r, rin)
+    sel = np.random.RandomState(8).permutation(n)[:n // 3].astype(np.int32)
+    res_s, idp_s, rin_s = c.imm_resident_optimize(sel, 1)
+    assert eq(res_s, res[sel]) and eq(idp_s, idp[sel]) and eq(rin_s, rin[sel])
+    with pytest.raises(RuntimeError):
+        c.imm_resident_optimize(np.array([n], np.int32), 1)                          # an index outside the resident set
 
 
 def test_distance_map_exact(scene):
