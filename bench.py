@@ -500,6 +500,7 @@ def main():
     prof.update({k: job.ctx.profile_get(k) for k in ("ba_sc", "ba_reduce", "ba_resub", "trk_eval", "trk_lm", "pyramid")})
     job.evals = evals_timed
     out = None
+    cpu_legs_pending, cpu_baseline_legs = False, None          # rank 0 of a default run: the CPU baseline legs are run behind the GPU legs
     if rank == 0:
         # roofline of the dominant kernel (ba_linearize): algorithmic bytes per launch:
         #   424*R + 104*P  = R*(8 state/energy + 8px*4taps*12 B + 32 B JpJdF write) + P*(80 B point + 24 B Hdd/bd/Hcd write)
@@ -602,7 +603,6 @@ def main():
                 out["cpu_baseline_all_cores"].update(cpu_model=info["model"], physical_cores=info["physical_cores"], usable_cpus=info["usable_cpus"])
             except Exception as e:
                 out["cpu_baseline"] = {"error": repr(e)}
-        cpu_legs_pending = False
         if not args.no_cpu_baseline and world == 1:
             if do_track:
                 out["pose_delta_vs_oracle"] = pose_delta_vs_oracle(job, win, st6, trk)
@@ -713,7 +713,7 @@ def main():
                     out["roofline"].update(measured_copy_GBs=round(hbm_copy, 1), measured_triad_GBs=round(hbm_triad, 1), frac_of_measured_copy=round(sl["achieved_GBs"] / hbm_copy, 4),
                                            measured_note="nalo_hbm_calibrate in this run: copy = 2 x 1 GiB / t, triad = 3 x 1 GiB / t, 10 passes, HIP events")
         watchdog.cancel()
-    if rank == 0 and locals().get("cpu_legs_pending"):
+    if rank == 0 and cpu_legs_pending:
         cpu_baseline_legs()
     if rank == 0:
         print(json.dumps(out), flush=True)
