@@ -1144,7 +1144,7 @@ def init_leg(w=1224, h=368, frames=3, cpu=True):
     return res
 
 
-def imm_leg(per_host=1500, rounds=5, cpu=True):
+def imm_leg(per_host=1500, rounds=20, cpu=True):
     """traceOn for setting_desiredImmatureDensity = 1500 immature points per host x 8 hosts against a new KITTI-sized
     frame, then optimizeImmaturePoint for the same points. Kernel time from HIP events, call time includes the PCIe staging of the
     caller-owned point arrays; the CPU figure is the oracle's fast build on one thread (the reference chunks 50 points per thread)."""
@@ -1228,7 +1228,7 @@ def imm_leg(per_host=1500, rounds=5, cpu=True):
     return res
 
 
-def pixsel_leg(rounds=10, cpu=True):
+def pixsel_leg(rounds=50, cpu=True):
     """SURVEY 8(f) rank 3: PixelSelector::makeMaps (makeHists + select + sub-selection, the per-keyframe candidate selection of makeNewTraces) on a
     KITTI-sized frame, setting_desiredImmatureDensity = 1500. Call time = everything between the C-ABI call and the filled w*h float map on the host
     (what the reference's caller gets); kernel time from HIP events. The CPU figure is the oracle's fast build on one thread."""
