@@ -573,6 +573,7 @@ static void prelaunch_cancel(nalo_ctx* c) {
 // misc_only: the caller wants the per-bin {count, energy} and the threshold, not the systems: finish the partials, skip the stitch, publish the tail
 static int stitch_and_fetch(nalo_ctx* c, bool want_top, bool want_sc, bool th_to_host = false, bool misc_only = false) {
     BAWindow& w = *c->ba;
+    if (w.ad_pending && !misc_only) { int ra = upload_adjoints(c); if (ra) return ra; }   // the stitch (and a large window's back-substitution behind it) reads the device copy of the adjoints
     const int n1 = w.n1, NPL = w.NPL, W = w.W;
     const size_t blk = (size_t)n1 * n1;
     bool did = false;
@@ -1174,13 +1175,13 @@ static int optimize_epilogue(nalo_ctx* c, double* rmse) {
     const double nsz[10] = {0, 0, 0, 0, 0, 0, nf.state[6], nf.state[7], 0, 0};
     nf.evalPT = nf.PRE_worldToCam;
     frame_set_state(nf, nsz); frame_set_state_zero(nf, nsz);
-    int rc = set_adjoints(c, true); if (rc) return rc;                      // the device copy of the adjoints follows the fetch below (round 4: the copy packet and its event stood ~25 us between the last
-    rc = set_precalc(c); if (rc) return rc;                                 // linearisation of the loop and this one; nothing in the epilogue reads them)
+    int rc = set_adjoints(c, true); if (rc) return rc;                      // host tables only: the device copy follows when somebody stitches (round 4: the copy packet and its event stood ~25 us
+    rc = set_precalc(c); if (rc) return rc;                                 // between the last linearisation of the loop and this one; nothing in the epilogue reads the adjoints)
     rc = linearize_async(c, 0, 1); if (rc) return rc;                       // :562 linearizeAll(true)
     w.pt_acc_on_read = false;                                               // the per-point sums stay those of the last solve
     rc = stitch_and_fetch(c, true, false, true, true); if (rc) return rc;  // energy, residual count and the threshold: no stitch
     { const float th = tail_th(w); rc = check_th(c, th); if (rc) return rc; nf.frameEnergyTH = th; }
-    rc = upload_adjoints(c); if (rc) return rc;
+    // (the device copy of the adjoints is brought up to date by whoever stitches next - stitch_and_fetch -, or by the next set_adjoints: the epilogue has no reader for it)
     double e = 0; int nres = 0; misc_totals(w, &e, &nres);
     // the reference reports sqrt(E / (patternNum * resInA)) with resInA from the last accumulateAF (the last solve)
     if (rmse) *rmse = std::sqrt((float)(e / (kPatternNum * (double)w.resInA)));
