@@ -216,42 +216,57 @@ __global__ __launch_bounds__(256) void trk_scatter_kernel(const float* __restric
 // the lowest remaining index first (the pixel's count word is reused as the "next index allowed" gate). Usually the list is empty and pass 2 is one read.
 // (The list used to be built by the single workgroup itself, striding all n residuals: 530 us at n = 250 000.)
 constexpr int kScatterFixCap = 4096;
-__global__ __launch_bounds__(256) void trk_scatter_hot_kernel(const float* __restrict__ Ku, const float* __restrict__ Kv, int n, int w0, int h0, const int* __restrict__ cnt,
-                                                              int* __restrict__ list /* [kScatterFixCap] + counter */) {
+template <int NT>
+__device__ __forceinline__ void trk_scatter_fix_body(const float* __restrict__ Ku, const float* __restrict__ Kv, const float* __restrict__ nid, const float* __restrict__ HdiF,
+                                                     int n, int w0, int h0, float* __restrict__ idepth, float* __restrict__ wsum, int* __restrict__ cnt, int* __restrict__ glist, int* list);
+// Round 4: ONE launch for both passes (the fix pass was a launch of its own, 4.6 us for what is almost always one read): every workgroup lists its residuals on hot pixels
+// (agent-scope stores, acknowledged before its ticket), the workgroup that draws the last ticket runs the fix.
+__global__ __launch_bounds__(256) void trk_scatter_hot_kernel(const float* __restrict__ Ku, const float* __restrict__ Kv, const float* __restrict__ nid, const float* __restrict__ HdiF,
+                                                              int n, int w0, int h0, float* __restrict__ idepth, float* __restrict__ wsum, int* __restrict__ cnt,
+                                                              int* __restrict__ list /* [kScatterFixCap] + counter + ticket */) {
+    __shared__ int slist[kScatterFixCap];
+    __shared__ int is_last;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int u = (int)(Ku[i] + 0.5f), v = (int)(Kv[i] + 0.5f);
-    if (u < 0 || v < 0 || u >= w0 || v >= h0) return;
-    if (__hip_atomic_load(cnt + u + w0 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 3) {       // written by the scatter's atomics: read at L2
-        const int at = atomicAdd(list + kScatterFixCap, 1);
-        if (at < kScatterFixCap) list[at] = i;
+    if (i < n) {
+        const int u = (int)(Ku[i] + 0.5f), v = (int)(Kv[i] + 0.5f);
+        if (!(u < 0 || v < 0 || u >= w0 || v >= h0) && __hip_atomic_load(cnt + u + w0 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 3) {       // written by the scatter's atomics: read at L2
+            const int at = atomicAdd(list + kScatterFixCap, 1);
+            if (at < kScatterFixCap) __hip_atomic_store(list + at, i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = __hip_atomic_fetch_add((unsigned*)(list + kScatterFixCap + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (!is_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(list + kScatterFixCap + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ticket re-armed for the next (stream-ordered) call
+    trk_scatter_fix_body<256>(Ku, Kv, nid, HdiF, n, w0, h0, idepth, wsum, cnt, list, slist);
 }
-__global__ __launch_bounds__(1024) void trk_scatter_fix_kernel(const float* __restrict__ Ku, const float* __restrict__ Kv, const float* __restrict__ nid, const float* __restrict__ HdiF,
-                                                               int n, int w0, int h0, float* __restrict__ idepth, float* __restrict__ wsum, int* __restrict__ cnt, int* __restrict__ glist) {
-    __shared__ int list[kScatterFixCap];
+template <int NT>
+__device__ __forceinline__ void trk_scatter_fix_body(const float* __restrict__ Ku, const float* __restrict__ Kv, const float* __restrict__ nid, const float* __restrict__ HdiF,
+                                                     int n, int w0, int h0, float* __restrict__ idepth, float* __restrict__ wsum, int* __restrict__ cnt, int* __restrict__ glist, int* list) {
     const int tid = threadIdx.x;
     const int total = __hip_atomic_load(glist + kScatterFixCap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (total == 0) return;
     __syncthreads();
     if (tid == 0) __hip_atomic_store(glist + kScatterFixCap, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // re-armed for the next (stream-ordered) call
-    for (int k = tid; k < total && k < kScatterFixCap; k += 1024) list[k] = __hip_atomic_load(glist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = tid; k < total && k < kScatterFixCap; k += NT) list[k] = __hip_atomic_load(glist + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int m = total;
     if (m == 0 || m > kScatterFixCap) return;            // (more than 4096 colliding residuals — never seen —: the atomic sums stay)
-    for (int k = tid; k < m; k += 1024) {
+    for (int k = tid; k < m; k += NT) {
         const int i = list[k], p = (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f);
         // every access to the pixel's words below goes to L2 (atomics / agent-scope loads): the atomics of the scatter and of the gate bypass this CU's L1,
         // a plain load could return a stale line
         atomicExch(idepth + p, 0.f); atomicExch(wsum + p, 0.f); atomicExch(cnt + p, 0x7fffffff);       // gate = lowest listed index of the pixel, found next
     }
     __syncthreads();
-    for (int k = tid; k < m; k += 1024) { const int i = list[k]; atomicMin(cnt + (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f), i); }
+    for (int k = tid; k < m; k += NT) { const int i = list[k]; atomicMin(cnt + (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f), i); }
     __syncthreads();
     // rounds: a listed residual adds itself when the gate of its pixel shows its index, then passes the gate to the next listed index of that pixel
     for (int round = 0; round < m; ++round) {
         bool any = false;
-        for (int k = tid; k < m; k += 1024) {
+        for (int k = tid; k < m; k += NT) {
             const int i = list[k];
             if (i < 0) continue;
             const int p = (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f);
@@ -264,9 +279,9 @@ __global__ __launch_bounds__(1024) void trk_scatter_fix_kernel(const float* __re
         __syncthreads();
         if (!__syncthreads_or(any)) break;
         // next gate per pixel: the lowest not-yet-added listed index
-        for (int k = tid; k < m; k += 1024) { const int i = list[k]; if (i < 0) { const int j = -1 - i, p = (int)(Ku[j] + 0.5f) + w0 * (int)(Kv[j] + 0.5f); atomicCAS(cnt + p, j, 0x7fffffff); } }
+        for (int k = tid; k < m; k += NT) { const int i = list[k]; if (i < 0) { const int j = -1 - i, p = (int)(Ku[j] + 0.5f) + w0 * (int)(Kv[j] + 0.5f); atomicCAS(cnt + p, j, 0x7fffffff); } }
         __syncthreads();
-        for (int k = tid; k < m; k += 1024) { const int i = list[k]; if (i >= 0) atomicMin(cnt + (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f), i); }
+        for (int k = tid; k < m; k += NT) { const int i = list[k]; if (i >= 0) atomicMin(cnt + (int)(Ku[i] + 0.5f) + w0 * (int)(Kv[i] + 0.5f), i); }
         __syncthreads();
     }
 }
@@ -283,7 +298,7 @@ struct TrkLevels {
 __global__ __launch_bounds__(256) void trk_zero2_kernel(float* __restrict__ a, float* __restrict__ b, int* __restrict__ cnt, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { a[i] = 0.f; b[i] = 0.f; cnt[i] = 0; }
-    if (i == 0) cnt[n + kScatterFixCap] = 0;                       // the hot list's counter (trk_scatter_hot_kernel)
+    if (i == 0) { cnt[n + kScatterFixCap] = 0; cnt[n + kScatterFixCap + 1] = 0; }   // the hot list's counter and the ticket of trk_scatter_hot_kernel
 }
 // step 2 (:408-433): 2x2 SUM pyramid, every level from one pass over level 0. A block owns a 32x32 level-0 tile = 16x16 level-1 pixels, and
 // walks up through LDS (8x8, 4x4, 2x2, 1); each parent is a + b + c + d of its four children in the reference's order, so the values
@@ -515,8 +530,7 @@ int trk_build_ref(nalo_ctx* c, int n, const float* dKu, const float* dKv, const 
     trk_zero2_kernel<<<(n0 + 255) / 256, 256, 0, c->stream>>>(P.id[0], P.ws[0], c->trk_cnt.p, n0);
     if (n > 0) {
         trk_scatter_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(dKu, dKv, dId, dHdi, n, c->wl[0], c->hl[0], P.id[0], P.ws[0], c->trk_cnt.p);
-        trk_scatter_hot_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(dKu, dKv, n, c->wl[0], c->hl[0], c->trk_cnt.p, c->trk_cnt.p + n0);
-        trk_scatter_fix_kernel<<<1, 1024, 0, c->stream>>>(dKu, dKv, dId, dHdi, n, c->wl[0], c->hl[0], P.id[0], P.ws[0], c->trk_cnt.p, c->trk_cnt.p + n0);
+        trk_scatter_hot_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(dKu, dKv, dId, dHdi, n, c->wl[0], c->hl[0], P.id[0], P.ws[0], c->trk_cnt.p, c->trk_cnt.p + n0);
     }
     if (L > 1) trk_sum_down_all_kernel<<<((c->wl[1] + 15) / 16) * ((c->hl[1] + 15) / 16), 256, 0, c->stream>>>(P);
     for (int l = 0; l <= L; ++l) P.blk0[l] = dil0[l];
