@@ -67,6 +67,7 @@ struct BADev {
     int sc_bpw, sc_groups;                      // blocks per group (1 when sc_split > 1), total groups
     // settings (nalo_set_settings): setting_affineOptModeA / B < 0 zero JabF[0] / JabF[1] (Residuals.cpp:241-242)
     int fix_a, fix_b;
+    int reset_oob;                              // 1: the pass starts from resetOOB'ed residuals (the first linearisation of optimize(), FullSystemOptimize.cpp:412-429): state = IN, energies 0
     int no_th;                                  // 1: this pass does not feed setNewFrameEnergyTH (the re-run that applies an accepted step, setting_forceAceptStep = false)
     double* noapply_E;                          // [nblocks*lin_sub][W] energy partials of a linearisation that is NOT applied (FIX = 2)
 };

@@ -193,6 +193,7 @@ __device__ __forceinline__ void lin_setup(const BADev& B, const LinWhere& w, Lin
     R.en = B.rs_energy[w.si];
     R.state = R.st & RS_STATE_MASK;
     if (MODE == 2) { R.en.x = 0.f; R.en.y = 0.f; R.state = 0; R.st &= ~RS_LINEARIZED; }            // resetOOB + isLinearized=false (FullSystem.cpp:978-981)
+    else if (B.reset_oob) { R.en.x = 0.f; R.en.y = 0.f; R.state = 0; }                             // resetOOB of every active residual at the start of optimize() (FullSystemOptimize.cpp:412-429): was a launch of its own
     R.energy = R.en.x;
     if (R.state == 1) { R.newState = 1; return; }                                                   // Residuals.cpp:82-83
     const float pu = R.pu, pv = R.pv, idepth = R.idepth, idz = R.idz;
